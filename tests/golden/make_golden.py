@@ -1,0 +1,320 @@
+"""Generates the committed golden vectors by running the REAL reference (imported from
+/root/reference on CPU through oracle/ref_harness.py).  Development-container only.
+
+    python tests/golden/make_golden.py small            # F2 quantizers, F3 layers, F4 blocks  (seconds)
+    python tests/golden/make_golden.py schema           # F1 ckpt schema + F6 loader side effects
+    python tests/golden/make_golden.py unet c1|c2|c3    # F5 full SD UNet, 64x64 latents (minutes each)
+    python tests/golden/make_golden.py ddim [steps]     # F5 N-step DDIM final latent (tens of minutes)
+    DIFFUSERS_REWRITE=sdxl python tests/golden/make_golden.py unet xl   # SDXL (separate process)
+
+Fixtures are DATA: seeded inputs and the reference's outputs (``.pt`` files of plain tensors +
+JSON).  Full-UNet inputs are not stored — they are regenerated from ``dgq_amd.synth`` (name-keyed).
+"""
+import json
+import os
+import sys
+import time
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from oracle import ref_harness as rh          # noqa: E402
+from dgq_amd import synth                      # noqa: E402
+from tests.golden import recipes               # noqa: E402
+
+torch.set_grad_enabled(False)
+
+
+def g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def save(name, obj):
+    torch.save(obj, os.path.join(HERE, name))
+    print("wrote", name)
+
+
+# --------------------------------------------------------------------------------------- F2
+def make_quantizers(ref):
+    out = {}
+    # UniformAffineQuantizer inference branch incl. exact .5 ties, clamp edges, z outside [0, 2^b-1]
+    for bits in (4, 6, 8):
+        for tag, delta, zp in (("pos", 0.05, 3.0), ("negz", 0.031, -7.0), ("bigz", 0.02, float(2 ** bits + 9))):
+            x = torch.randn(4, 33, generator=g(bits * 10 + len(tag))) * (delta * 2 ** bits / 3)
+            ties = (torch.arange(-8, 8, dtype=torch.float32) + 0.5) * delta      # exact half steps
+            x = torch.cat([x.flatten(), ties, torch.tensor([0.0, -0.0, 1e-9, 1e6, -1e6])])
+            q = ref.ql.UniformAffineQuantizer(bits=bits)
+            q.delta, q.zero_point, q.init = torch.tensor(delta), torch.tensor(zp), True
+            out["uaq_b%d_%s" % (bits, tag)] = dict(x=x, delta=q.delta, zp=q.zero_point, bits=bits, y=q(x))
+    # broadcast layouts (1,1,X) and (1,X,1)
+    x = torch.randn(2, 12, 20, generator=g(5))
+    for tag, shp in (("lastdim", (1, 1, 20)), ("dim1", (1, 12, 1))):
+        d = 0.01 + 0.05 * torch.rand(shp, generator=g(6))
+        z = torch.round(128 + 40 * torch.randn(shp, generator=g(7)))
+        q = ref.ql.UniformAffineQuantizer(bits=8)
+        q.delta, q.zero_point, q.init = d, z, True
+        out["uaq_bcast_" + tag] = dict(x=x, delta=d, zp=z, bits=8, y=q(x))
+    # per-channel minmax init (quant_layer.py:253-264) incl. all-positive / all-negative / constant rows
+    w = torch.randn(9, 3, 3, 3, generator=g(8)) * 0.2
+    w[0] = w[0].abs() + 0.01
+    w[1] = -w[1].abs() - 0.01
+    w[2] = 0.0
+    w[3] = -1e-10        # (+1e-10 makes the reference itself raise TypeError at quant_layer.py:37)
+    for bits in (4, 8):
+        q = ref.ql.UniformAffineQuantizer(bits=bits, channel_wise=True)
+        y = q(w)
+        out["minmax_ch_b%d" % bits] = dict(w=w, bits=bits, delta=q.delta.clone(), zp=q.zero_point.clone(), y=y)
+    # scalar minmax (activation self-init) and always_zero
+    x = torch.randn(3, 50, generator=g(9)) * 2 + 0.3
+    q = ref.ql.UniformAffineQuantizer(bits=8, leaf_param=True)
+    y = q(x)
+    out["minmax_scalar"] = dict(x=x, bits=8, delta=q.delta.data.clone(), zp=torch.as_tensor(q.zero_point).clone(), y=y)
+    p = torch.softmax(torch.randn(2, 4, 10, 10, generator=g(10)) * 3, -1)
+    q = ref.ql.UniformAffineQuantizer(bits=8, always_zero=True)
+    y = q(p)
+    out["minmax_always_zero"] = dict(x=p, bits=8, delta=torch.as_tensor(q.delta).clone(), y=y)
+    # AdaRound hard rounding
+    w = torch.randn(6, 16, generator=g(11)) * 0.1
+    uq = ref.ql.UniformAffineQuantizer(bits=4, channel_wise=True)
+    uq(w)
+    ar = ref.ar.AdaRoundQuantizer(uq, w, rmode=ref.ar.RMODE.LEARNED_HARD_SIGMOID)
+    alpha = torch.randn(6, 16, generator=g(12))
+    ar.alpha = torch.nn.Parameter(alpha)
+    out["adaround_b4"] = dict(w=w, delta=uq.delta.clone(), zp=uq.zero_point.clone(), alpha=alpha, bits=4, y=ar(w))
+    # T2ILogQuantizer: zeros, x>δ, real-time, a∈{6,8}
+    p = torch.softmax(torch.randn(2, 3, 9, 17, generator=g(13)) * 4, -1)
+    p[0, 0, 0, :3] = 0.0
+    for bits in (6, 8):
+        q = ref.qlt.T2ILogQuantizer(bits=bits, real_time=True)
+        out["logq_rt_b%d" % bits] = dict(x=p, bits=bits, y=q(p))
+        q = ref.qlt.T2ILogQuantizer(bits=bits, real_time=False)
+        y = q(p)
+        out["logq_static_b%d" % bits] = dict(x=p, bits=bits, delta=q.delta.clone(), y=y)
+        q = ref.qlt.T2ILogQuantizer(bits=bits, real_time=False)
+        q.delta, q.init = torch.tensor(0.05), True      # x > δ  → negative log2 → clamps to code 0
+        out["logq_fixed_b%d" % bits] = dict(x=p, bits=bits, delta=q.delta.clone(), y=q(p))
+    save("f2_quantizers.pt", out)
+
+
+# --------------------------------------------------------------------------------------- F3
+def make_layers(ref):
+    """QuantLayer Linear & Conv (3x3 s1, 3x3 s2 p1, 1x1) x act-param layout x W{4,8} x A{6,8} x G{1,8,16}.
+    Inputs come from tests/golden/recipes.py (name-keyed, regenerated by the tests); only the
+    reference's weight-quantizer params and outputs are stored."""
+    import torch.nn as nn
+    out = {}
+    for case in recipes.f3_cases():
+        inp = recipes.f3_inputs(case)
+        wq = {"bits": case["wbits"], "channel_wise": True, "scaler": ref.ql.Scaler.MINMAX}
+        aq = {"bits": case.get("abits", 8), "channel_wise": False, "scaler": ref.ql.Scaler.MINMAX,
+              "leaf_param": True}
+        if case["kind"] == "linear":
+            layer = nn.Linear(inp["w"].shape[1], inp["w"].shape[0])
+        else:
+            layer = nn.Conv2d(inp["w"].shape[1], inp["w"].shape[0], case["k"], case["stride"], case["padding"])
+        layer.weight.data, layer.bias.data = inp["w"].clone(), inp["b"].clone()
+        ql = ref.ql.QuantLayer(layer, dict(wq), dict(aq))
+        state = case["state"]
+        ql.set_quant_state(state != "fp", state == "wa")
+        ql(inp["x"])                                             # self-init quantizers
+        rec = {}
+        if state == "wa":
+            ql.aqtizer.delta.data, ql.aqtizer.zero_point = inp["adelta"], inp["azp"]
+            if case["kind"] == "conv" and case["layout"] != "scalar":
+                ql.use_group_num = True                          # what calibration.py:268-291 does
+        if state != "fp":
+            rec["wdelta"], rec["wzp"] = ql.wqtizer.delta.clone(), ql.wqtizer.zero_point.clone()
+        rec["y"] = ql(inp["x"]).clone()
+        out[case["name"]] = rec
+    save("f3_layers.pt", out)
+
+
+# --------------------------------------------------------------------------------------- F4
+def make_blocks(ref):
+    """Attention_forward self/cross with start_peak on/off inside QuantBasicTransformerBlock (hidden 64;
+    the reference hard-codes 8 heads & ctx 768, sd.py:243-245) and QuantResnetBlock2D (temb 1280)."""
+    import torch.nn as nn
+    out = {}
+    for case in recipes.f4_tblock_cases():
+        inp = recipes.f4_tblock_inputs(case)
+        abits = case["abits"]
+        wq = {"bits": 4, "channel_wise": True, "scaler": ref.ql.Scaler.MINMAX}
+        aq = {"bits": abits, "channel_wise": False, "scaler": ref.ql.Scaler.MINMAX, "leaf_param": True}
+        sm = {"softmax_a_bit": abits, "t2i_log_quant": case["log"], "t2i_real_time": case["rt"],
+              "t2i_start_peak": case["sp"], "log_max_1": False}
+        blk = ref.dr.BasicTransformerBlock(recipes.F4_HIDDEN)
+        blk.load_state_dict(inp["fp_sd"])
+        for name, mod in list(blk.named_modules()):              # QuantModel.quant_module by hand
+            for cname, child in list(mod.named_children()):
+                if isinstance(child, nn.Linear):
+                    setattr(mod, cname, ref.ql.QuantLayer(child, dict(wq), dict(aq)))
+        qb = ref.qb.QuantBasicTransformerBlock(blk, dict(aq), sm)
+        qb.set_quant_state(True, True)
+        qb(inp["x"], inp["ctx"])                                 # self-init every quantizer (scalars)
+        act = {}
+        for name, mod in qb.named_modules():
+            if isinstance(mod, ref.ql.UniformAffineQuantizer) and "aqtizer" in name and mod.delta is not None:
+                if name in inp["act_override"]:
+                    d, z = inp["act_override"][name]
+                    mod.delta.data = d
+                    mod.zero_point = z
+                act[name] = (torch.as_tensor(mod.delta.data).clone(),
+                             torch.as_tensor(mod.zero_point).clone().float())
+        wqp = {name: (m.wqtizer.delta.clone(), m.wqtizer.zero_point.clone())
+               for name, m in qb.named_modules() if isinstance(m, ref.ql.QuantLayer)}
+        out["tblock_" + case["name"]] = dict(act=act, wq=wqp, y=qb(inp["x"], inp["ctx"]).clone())
+    # ResNet block 64 -> 96 (shortcut), 10x10, grouped conv inputs
+    inp = recipes.f4_resnet_inputs()
+    rb = ref.dr.ResnetBlock2D(64, 96, conv_shortcut=True)
+    rb.load_state_dict(inp["fp_sd"])
+    wq = {"bits": 4, "channel_wise": True, "scaler": ref.ql.Scaler.MINMAX}
+    aq = {"bits": 8, "channel_wise": False, "scaler": ref.ql.Scaler.MINMAX, "leaf_param": True}
+    for cname, child in list(rb.named_children()):
+        if isinstance(child, (nn.Linear, nn.Conv2d)):
+            setattr(rb, cname, ref.ql.QuantLayer(child, dict(wq), dict(aq)))
+    qr = ref.qb.QuantResnetBlock2D(rb, dict(aq))
+    qr.set_quant_state(True, True)
+    qr(inp["x"], inp["temb"])
+    act = {}
+    for name in ("conv1", "conv2", "conv_shortcut", "time_emb_proj"):
+        ql = getattr(qr, name)
+        if name in inp["act_override"]:
+            ql.aqtizer.delta.data, ql.aqtizer.zero_point = inp["act_override"][name]
+            ql.use_group_num = True
+        act[name] = (torch.as_tensor(ql.aqtizer.delta.data).clone(),
+                     torch.as_tensor(ql.aqtizer.zero_point).clone().float())
+    wqp = {n: (getattr(qr, n).wqtizer.delta.clone(), getattr(qr, n).wqtizer.zero_point.clone())
+           for n in ("conv1", "conv2", "conv_shortcut", "time_emb_proj")}
+    out["resnet_w4a8g8"] = dict(act=act, wq=wqp, y=qr(inp["x"], inp["temb"]).clone())
+    save("f4_blocks.pt", out)
+
+
+# --------------------------------------------------------------------------------------- F5
+UNET_CFG = {
+    # name: (wbits, abits, use_aq, G, log, rt, sp, time_aware, steps, timesteps)
+    "c1": dict(wbits=8, abits=8, use_aq=False, G=1, log=False, rt=False, sp=False, time_aware=False, steps=50,
+               ts=(981,)),
+    "c2": dict(wbits=4, abits=8, use_aq=True, G=16, log=True, rt=True, sp=True, time_aware=True, steps=50,
+               ts=(981, 481)),
+    "c3": dict(wbits=4, abits=6, use_aq=True, G=8, log=True, rt=True, sp=True, time_aware=True, steps=50,
+               ts=(981, 21)),
+    "c2u": dict(wbits=4, abits=8, use_aq=True, G=1, log=False, rt=False, sp=False, time_aware=True, steps=50,
+                ts=(981,)),
+}
+
+
+def build_ref_unet_qnn(ref, arch, c, res, batch, slots, path=None):
+    path = path or "/tmp/golden_%s_%s_r%d.pth" % (arch, "w%da%dg%d" % (c["wbits"], c["abits"], c["G"]), res)
+    if not os.path.exists(path):
+        synth.write_cali_ckpt(path, arch, c["wbits"], c["abits"], c["G"], num_slots=slots, seed=0, batch=batch,
+                              res=res, start_peak=c["sp"], uniform_softmax=(c["use_aq"] and not c["log"]),
+                              with_act=c["use_aq"])
+    fp_sd = synth.synth_state_dict(arch, 0)
+    unet = ref.dr.UNet2DConditionModel()
+    unet.load_state_dict(fp_sd)
+    sm = {"softmax_a_bit": c["abits"], "t2i_log_quant": c["log"], "t2i_real_time": c["rt"],
+          "t2i_start_peak": c["sp"], "log_max_1": False}
+    a = synth.ARCH[arch]
+    init = [torch.randn(1, 4, res, res), torch.randint(0, 1000, (1,)), torch.randn(1, 77, a["ctx_dim"])]
+    if arch == "sdxl":
+        # get_qmodel's positional adaptor (load_qmodel_util.py:6-18)
+        of = unet.forward
+        unet.forward = lambda s, t, e, te=None, ti=None, **kw: of(
+            s, t, e, kw.pop("added_cond_kwargs", None) or {"text_embeds": te, "time_ids": ti}, **kw)
+        init += [torch.randn(1, 1280), torch.randn(1, 6)]
+    qnn = rh.build_reference_qnn(ref, c["wbits"], c["abits"], c["use_aq"], sm, path, tuple(init),
+                                 use_group=c["G"] > 1, time_aware=c["time_aware"] and c["use_aq"],
+                                 num_inference_steps=c["steps"], unet=unet)
+    return qnn, path
+
+
+def make_unet(ref, arch, name, res=None, batch=2):
+    c = UNET_CFG[name if name in UNET_CFG else "c2"]
+    if name == "xl":
+        c = dict(wbits=4, abits=8, use_aq=True, G=16, log=True, rt=True, sp=True, time_aware=True, steps=4,
+                 ts=(999, 249))
+        batch = 1
+    res = res or synth.ARCH[arch]["sample_size"]
+    need_slots = 1 + max((1000 - t) // (1000 // c["steps"]) for t in c["ts"]) if c["time_aware"] else 1
+    t0 = time.time()
+    qnn, path = build_ref_unet_qnn(ref, arch, c, res, batch, need_slots)
+    print("reference qnn ready in %.0fs" % (time.time() - t0))
+    inp = synth.synth_inputs(arch, batch, 1, res)
+    outs = {}
+    for t in c["ts"]:
+        t0 = time.time()
+        if arch == "sdxl":
+            y = qnn(inp["sample"], torch.tensor(t), inp["encoder_hidden_states"],
+                    added_cond_kwargs={"text_embeds": inp["text_embeds"], "time_ids": inp["time_ids"]})[0]
+        else:
+            y = qnn(inp["sample"], torch.tensor(t), inp["encoder_hidden_states"])[0]
+        print("t=%d  %.1fs  absmax %.4f" % (t, time.time() - t0, y.abs().max().item()))
+        outs[t] = y.clone()
+    meta = dict(c)
+    meta.update(arch=arch, res=res, batch=batch, seed=0, input_seed=1)
+    save("f5_unet_%s_%s_r%d.pt" % (arch, name, res), dict(meta=meta, outputs=outs))
+
+
+def make_ddim(ref, steps=50, res=64, name="c2"):
+    """C2: SD W4A8 G16, N-step DDIM, CFG 7.5, final latent."""
+    from oracle import dgq_oracle as orc
+    c = dict(UNET_CFG[name])
+    c["steps"] = steps
+    qnn, path = build_ref_unet_qnn(ref, "sd", c, res, 2, steps,
+                                   path="/tmp/golden_sd_ddim%d_%s_r%d.pth" % (steps, name, res))
+    lat = synth.named_randn("latent", (1, 4, res, res), 1)
+    ctx = synth.named_randn("ctx", (2, 77, 768), 2)
+
+    def fn(x, t, ctx):
+        t0 = time.time()
+        y = qnn(x, torch.tensor(t), ctx)[0]
+        print("  t=%d %.1fs" % (t, time.time() - t0), flush=True)
+        return y
+    out = orc.denoise_loop(fn, lat, ctx, steps, guidance=7.5)
+    meta = dict(c)
+    meta.update(arch="sd", res=res, guidance=7.5)
+    save("f5_ddim%d_sd_%s_r%d.pt" % (steps, name, res), dict(meta=meta, final_latent=out))
+
+
+# --------------------------------------------------------------------------------------- F1/F6
+def make_schema(ref, arch):
+    res = 16
+    c = UNET_CFG["c2"]
+    qnn, path = build_ref_unet_qnn(ref, arch, dict(c, steps=2), res, 2, 2,
+                                   path="/tmp/golden_schema_%s.pth" % arch)
+    ck = torch.load(path)
+    schema = {k: {kk: [list(v.shape), str(v.dtype)] for kk, v in d.items()} for k, d in ck.items()}
+    side = {}
+    for name, m in qnn.named_modules():
+        if isinstance(m, ref.ql.QuantLayer):
+            side[name] = dict(use_group_num=bool(m.use_group_num), use_wq=bool(m.use_wq), use_aq=bool(m.use_aq),
+                              disable_aq=bool(m.disable_aq), adelta_shape=(list(m.aqtizer.delta.shape)
+                                                                          if m.aqtizer.delta is not None else None))
+    slots = {str(t): int((1000 - t) // (1000 // n)) for n in (50, 25, 4) for t in
+             ([int(i * (1000 // n)) + 1 for i in range(n)] if n != 4 else (999, 749, 499, 249))}
+    with open(os.path.join(HERE, "f1_f6_schema_%s.json" % arch), "w") as f:
+        json.dump(dict(n_weight_keys=len(ck["weight"]), n_act_keys=len(ck["act_0"]), schema_res=res,
+                       act0=schema["act_0"], weight={k: v for k, v in list(schema["weight"].items())},
+                       loader_side_effects=side, slots=slots), f)
+    print("wrote schema", arch)
+
+
+if __name__ == "__main__":
+    what = sys.argv[1]
+    arch = os.environ.get("DIFFUSERS_REWRITE", "sd")
+    ref = rh.import_reference(arch)
+    if what == "small":
+        make_quantizers(ref)
+        make_layers(ref)
+        make_blocks(ref)
+    elif what == "schema":
+        make_schema(ref, arch)
+    elif what == "unet":
+        res = int(sys.argv[3]) if len(sys.argv) > 3 else None
+        make_unet(ref, arch, sys.argv[2], res=res)
+    elif what == "ddim":
+        make_ddim(ref, int(sys.argv[2]) if len(sys.argv) > 2 else 50,
+                  int(sys.argv[3]) if len(sys.argv) > 3 else 64)

@@ -1,0 +1,156 @@
+"""CPU: the oracle restatement against the golden vectors produced by the REAL reference
+(tests/golden/make_golden.py).  This is what pins the oracle."""
+import os
+
+import pytest
+import torch
+
+from oracle import dgq_oracle as orc
+from tests.golden import recipes
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    return torch.load(os.path.join(GOLD, name), map_location="cpu")
+
+
+def same(a, b):
+    assert a.shape == b.shape
+    assert torch.equal(a, b), "max abs diff %g" % (a - b).abs().max().item()
+
+
+# ------------------------------------------------------------------------------------------ F2
+def test_f2_uniform_affine():
+    f2 = load("f2_quantizers.pt")
+    n = 0
+    for k, v in f2.items():
+        if k.startswith("uaq_"):
+            same(orc.uaq(v["x"], v["delta"], v["zp"], v["bits"]), v["y"])
+            n += 1
+    assert n == 11
+
+
+def test_f2_minmax_init():
+    f2 = load("f2_quantizers.pt")
+    for bits in (4, 8):
+        v = f2["minmax_ch_b%d" % bits]
+        d, z = orc.minmax_channel(v["w"], bits)
+        same(d, v["delta"])
+        same(z, v["zp"])
+        same(orc.uaq(v["w"], d, z, bits), v["y"])
+    v = f2["minmax_scalar"]
+    d, z = orc.minmax_scalar(v["x"], 8)
+    same(d, v["delta"])
+    same(z, v["zp"].float())
+    same(orc.uaq(v["x"], d, z, 8), v["y"])
+    v = f2["minmax_always_zero"]
+    d, z = orc.minmax_scalar(v["x"], 8, always_zero=True)
+    same(d, v["delta"].float())
+    same(orc.uaq(v["x"], d, z, 8), v["y"])
+
+
+def test_f2_vectorised_minmax_matches():
+    """dgq_amd.synth.channel_minmax (vectorised) == the reference's per-channel python loop."""
+    from dgq_amd.synth import channel_minmax
+    f2 = load("f2_quantizers.pt")
+    for bits in (4, 8):
+        v = f2["minmax_ch_b%d" % bits]
+        d, z = channel_minmax(v["w"], bits)
+        same(d, v["delta"])
+        same(z, v["zp"])
+
+
+def test_f2_adaround():
+    v = load("f2_quantizers.pt")["adaround_b4"]
+    same(orc.adaround_hard(v["w"], v["delta"], v["zp"], v["alpha"], 4), v["y"])
+
+
+def test_f2_log_quant():
+    f2 = load("f2_quantizers.pt")
+    for bits in (6, 8):
+        v = f2["logq_rt_b%d" % bits]
+        same(orc.log_quant(v["x"], v["x"].max(), bits), v["y"])
+        v = f2["logq_static_b%d" % bits]
+        d = orc.log_quant_init_delta(v["x"], bits)
+        same(d, v["delta"])
+        same(orc.log_quant(v["x"], d, bits), v["y"])
+        v = f2["logq_fixed_b%d" % bits]
+        same(orc.log_quant(v["x"], v["delta"], bits), v["y"])
+
+
+# ------------------------------------------------------------------------------------------ F3
+def oracle_layer(case, inp, gold):
+    cfg = orc.OracleConfig(wbits=case["wbits"], abits=case.get("abits", 8), use_wq=case["state"] != "fp",
+                           use_aq=case["state"] == "wa", use_group=True)
+    w = {"model.l.w": inp["w"], "model.l.b": inp["b"]}
+    if case["state"] != "fp":
+        w["model.l.wqtizer.delta"], w["model.l.wqtizer.zero_point"] = gold["wdelta"], gold["wzp"]
+    ck = {"weight": w}
+    if case["state"] == "wa":
+        ck["act_0"] = {"model.l.aqtizer.delta": inp["adelta"], "model.l.aqtizer.zero_point": inp["azp"]}
+    om = orc.OracleModel(ck, cfg)
+    if case["kind"] == "linear":
+        return om.linear("l", inp["x"])
+    return om.conv("l", inp["x"], case["stride"], case["padding"])
+
+
+@pytest.mark.parametrize("case", recipes.f3_cases(), ids=lambda c: c["name"])
+def test_f3_layers(case):
+    gold = load("f3_layers.pt")[case["name"]]
+    inp = recipes.f3_inputs(case)
+    y = oracle_layer(case, inp, gold)
+    same(y, gold["y"])
+    if case["state"] != "fp":      # weight-quantizer self-init restated
+        d, z = orc.minmax_channel(inp["w"], case["wbits"])
+        same(d, gold["wdelta"])
+        same(z, gold["wzp"])
+
+
+# ------------------------------------------------------------------------------------------ F4
+def block_ckpt(fp_sd, gold, prefix="blk"):
+    w = {}
+    for k, v in fp_sd.items():
+        path, leaf = k.rsplit(".", 1)
+        if path in gold["wq"]:
+            w["model.%s.%s.%s" % (prefix, path, "w" if leaf == "weight" else "b")] = v
+        else:
+            w["model.%s.%s" % (prefix, k)] = v
+    for path, (d, z) in gold["wq"].items():
+        w["model.%s.%s.wqtizer.delta" % (prefix, path)] = d
+        w["model.%s.%s.wqtizer.zero_point" % (prefix, path)] = z
+    act = {}
+    for name, (d, z) in gold["act"].items():
+        act["model.%s.%s.delta" % (prefix, name)] = d
+        act["model.%s.%s.zero_point" % (prefix, name)] = z
+    return {"weight": w, "act_0": act}
+
+
+@pytest.mark.parametrize("case", recipes.f4_tblock_cases(), ids=lambda c: c["name"])
+def test_f4_transformer_block(case):
+    gold = load("f4_blocks.pt")["tblock_" + case["name"]]
+    inp = recipes.f4_tblock_inputs(case)
+    cfg = orc.OracleConfig(wbits=4, abits=case["abits"], t2i_log_quant=case["log"], t2i_real_time=case["rt"],
+                           t2i_start_peak=case["sp"], use_group=True)
+    om = orc.OracleModel(block_ckpt(inp["fp_sd"], gold), cfg)
+    y = om.transformer_block("blk", inp["x"], inp["ctx"], heads=8)
+    same(y, gold["y"])
+
+
+def test_f4_resnet_block():
+    gold = load("f4_blocks.pt")["resnet_w4a8g8"]
+    inp = recipes.f4_resnet_inputs()
+    cfg = orc.OracleConfig(wbits=4, abits=8, use_group=True)
+    ck = block_ckpt(inp["fp_sd"], gold)
+    for name in list(gold["act"]):      # conv/linear aqtizers are keyed '<layer>.aqtizer' in a real ckpt
+        ck["act_0"]["model.blk.%s.aqtizer.delta" % name] = ck["act_0"].pop("model.blk.%s.delta" % name)
+        ck["act_0"]["model.blk.%s.aqtizer.zero_point" % name] = ck["act_0"].pop("model.blk.%s.zero_point" % name)
+    om = orc.OracleModel(ck, cfg)
+    same(om.resnet("blk", inp["x"], inp["temb"]), gold["y"])
+
+
+# ------------------------------------------------------------------------------------------ misc
+def test_slot_formula():
+    assert [orc.slot_for_timestep(t, 50) for t in (981, 961, 21, 1)] == [0, 1, 48, 49]
+    assert [orc.slot_for_timestep(t, 4) for t in (999, 749, 499, 249)] == [0, 1, 2, 3]
+    assert orc.DDIM(50).timesteps[:3] == [981, 961, 941] and orc.DDIM(50).timesteps[-1] == 1
