@@ -1,0 +1,76 @@
+"""ctypes binding of libdgq_hip.so (include/dgq_hip.h).  There is NO fallback: if the shared
+library is missing or a call fails, the product raises."""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libdgq_hip.so")
+
+_vp, _i, _f, _i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64
+
+# name -> argtypes; every function returns int except dgq_last_error
+SIGNATURES = {
+    "dgq_version": [],
+    "dgq_quantize_weight": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp],
+    "dgq_pack_w4": [_vp, _i, _i, _vp, _i, _vp, _vp],
+    "dgq_unpack_w4": [_vp, _i, _i, _vp, _vp],
+    "dgq_pack_w8": [_vp, _i, _i, _vp, _i, _vp, _vp],
+    "dgq_quant_act": [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _vp],
+    "dgq_gemm_wxa8": [_vp, _vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
+    "dgq_fakequant_rows": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp],
+    "dgq_max_f32": [_vp, _i64, _i, _i, _vp, _vp],
+    "dgq_logquant_f32": [_vp, _vp, _i64, _i, _i, _vp, _i, _vp],
+}
+
+_lib = None
+
+
+def load():
+    """Loads the shared library (no GPU needed for loading / symbol checks)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "dgq_amd: %s not found — build it with `make -C dgq_amd/csrc` (or __graft_entry__.build()); "
+                "there is no CPU fallback" % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, args in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.argtypes = args
+            fn.restype = ctypes.c_int
+        lib.dgq_last_error.argtypes = []
+        lib.dgq_last_error.restype = ctypes.c_char_p
+        _lib = lib
+    return _lib
+
+
+def last_error():
+    return load().dgq_last_error().decode()
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError("%s failed (%d): %s" % (what, rc, last_error()))
+
+
+DTYPE_CODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
+
+
+def ptr(t):
+    if t is None:
+        return None
+    assert t.is_cuda, "dgq_amd kernels need device tensors (no CPU path)"
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise RuntimeError("dgq_amd: no GPU visible — the quantized path runs only through the HIP kernels "
+                           "(no CPU fallback)")
+    load()

@@ -1,0 +1,47 @@
+// Internal helpers shared by the HIP translation units of libdgq_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <hip/hip_bf16.h>
+#include <stdint.h>
+#include "../../include/dgq_hip.h"
+
+void dgq_set_error(const char* fmt, ...);
+
+#define DGQ_CHECK_ARG(cond, ...)            \
+    do {                                    \
+        if (!(cond)) {                      \
+            dgq_set_error(__VA_ARGS__);     \
+            return DGQ_EINVAL;              \
+        }                                   \
+    } while (0)
+
+static inline int dgq_launch_status(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        dgq_set_error("%s: %s", what, hipGetErrorString(e));
+        return DGQ_ELAUNCH;
+    }
+    return DGQ_OK;
+}
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float dgq_to_float(float v) { return v; }
+__device__ __forceinline__ float dgq_to_float(__half v) { return __half2float(v); }
+__device__ __forceinline__ float dgq_to_float(__hip_bfloat16 v) { return __bfloat162float(v); }
+
+template <typename T> __device__ __forceinline__ T dgq_from_float(float v);
+template <> __device__ __forceinline__ float dgq_from_float<float>(float v) { return v; }
+template <> __device__ __forceinline__ __half dgq_from_float<__half>(float v) { return __float2half(v); }
+template <> __device__ __forceinline__ __hip_bfloat16 dgq_from_float<__hip_bfloat16>(float v) { return __float2bfloat16(v); }
+
+// One affine quantisation step exactly as the reference evaluates it in fp32
+// (quant_layer.py:297): true division, round-half-even, add zero point, clamp.
+__device__ __forceinline__ float dgq_affine_code(float x, float delta, float zp, float qmax) {
+    float t = __fdiv_rn(x, delta);
+    float r = rintf(t);
+    float u = r + zp;
+    return fminf(fmaxf(u, 0.0f), qmax);
+}

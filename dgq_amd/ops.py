@@ -1,0 +1,202 @@
+"""Thin Python wrappers, one per C-ABI entry point of libdgq_hip.so, plus the per-layer objects
+(`PackedWeight`, `ActBinding`) that own the device-resident tables.  No arithmetic happens in Python on the
+hot path: a quantized layer call is `dgq_quant_act` + `dgq_gemm_wxa8`."""
+import ctypes
+from typing import Optional
+
+import torch
+
+from . import _lib
+from .plan import ActLayout, natural_kperm, round_up, KTILE, act_offset
+
+_c = ctypes
+
+
+def _lib_call(name, *args):
+    _lib.check(getattr(_lib.load(), name)(*args), name)
+
+
+# ------------------------------------------------------------------------------------------ weights
+def quantize_weight(w: torch.Tensor, delta: torch.Tensor, zp: torch.Tensor, alpha: Optional[torch.Tensor], bits: int):
+    """Integer codes (uint8 [N][K_ref]) of wqtizer(w); K_ref = w.view(N,-1) order."""
+    _lib.require_gpu()
+    N = w.shape[0]
+    w2 = w.detach().reshape(N, -1).contiguous().float()
+    K = w2.shape[1]
+    d = delta.detach().reshape(-1).contiguous().float()
+    z = zp.detach().reshape(-1).contiguous().float()
+    assert d.numel() == N and z.numel() == N, "weight quantizer must be per output channel"
+    a = alpha.detach().reshape(N, -1).contiguous().float() if alpha is not None else None
+    codes = torch.empty((N, K), dtype=torch.uint8, device=w.device)
+    _lib_call("dgq_quantize_weight", _lib.ptr(w2), _lib.ptr(d), _lib.ptr(z), _lib.ptr(a), N, K, bits,
+              _lib.ptr(codes), _lib.stream())
+    return codes
+
+
+def pack_weight(codes: torch.Tensor, kperm: Optional[torch.Tensor], Kp: int, bits: int):
+    N, K = codes.shape
+    kp = kperm.to(codes.device, torch.int32).contiguous() if kperm is not None else None
+    if bits == 4:
+        out = torch.empty((N, Kp // 2), dtype=torch.uint8, device=codes.device)
+        _lib_call("dgq_pack_w4", _lib.ptr(codes), N, K, _lib.ptr(kp), Kp, _lib.ptr(out), _lib.stream())
+    elif bits == 8:
+        out = torch.empty((N, Kp), dtype=torch.int8, device=codes.device)
+        _lib_call("dgq_pack_w8", _lib.ptr(codes), N, K, _lib.ptr(kp), Kp, _lib.ptr(out), _lib.stream())
+    else:
+        raise NotImplementedError("weight bits %d: the HIP path implements W4 and W8" % bits)
+    return out
+
+
+def unpack_w4(packed: torch.Tensor, Kp: int):
+    N = packed.shape[0]
+    out = torch.empty((N, Kp), dtype=torch.uint8, device=packed.device)
+    _lib_call("dgq_unpack_w4", _lib.ptr(packed), N, Kp, _lib.ptr(out), _lib.stream())
+    return out
+
+
+class PackedWeight:
+    """One quantized layer's weight, frozen to integer codes once (the reference re-derives them from fp32
+    ``w`` on every call, quant_layer.py:642-643)."""
+
+    def __init__(self, w, delta, zp, alpha, bias, bits, C, taps):
+        self.bits, self.C, self.taps = bits, C, taps
+        self.N = w.shape[0]
+        self.K = C * taps
+        dev = w.device
+        self.codes = quantize_weight(w, delta, zp, alpha, bits)           # [N][K_ref] u8
+        woff = 0.0 if bits == 4 else 128.0
+        self.alpha = delta.detach().reshape(-1).float().contiguous().to(dev)
+        self.zp_true = zp.detach().reshape(-1).float().contiguous().to(dev)
+        self.zw = (self.zp_true - woff).contiguous()                       # zero point in the stored code domain
+        self.bias = (bias.detach().float().contiguous().to(dev) if bias is not None
+                     else torch.zeros(self.N, device=dev))
+        self._natural = None
+        self._vn = None
+
+    def natural(self):
+        if self._natural is None:
+            perm = natural_kperm(self.C, self.taps)
+            self._natural = (pack_weight(self.codes, perm, perm.numel(), self.bits), perm.numel())
+        return self._natural
+
+    def centered(self):
+        """(q − z) as float64 [N][K_ref] — load-time helper for the epilogue constants."""
+        return self.codes.double() - self.zp_true.double()[:, None]
+
+    def vn(self):
+        if self._vn is None:
+            self._vn = self.centered().sum(dim=1).float().contiguous()
+        return self._vn
+
+
+class ActBinding:
+    """Device-resident tables of one (layer, timestep-slot) activation quantizer."""
+
+    def __init__(self, layout: ActLayout, pw: PackedWeight, abits: int):
+        dev = pw.codes.device
+        self.mode, self.abits, self.offset = layout.mode, abits, act_offset(abits)
+        self.pw = pw
+        if layout.mode == "perK":
+            self.Kp = layout.Kp
+            self.ksrc = layout.ksrc.to(dev)
+            self.cdelta = layout.cdelta.to(dev)
+            self.czp = layout.czp.to(dev)
+            self.cflush = layout.cflush.to(dev)
+            self.wpacked = pack_weight(pw.codes, layout.kperm, layout.Kp, pw.bits)
+            U = (pw.centered() @ layout.kcoef.to(dev)).float()             # Σ_k δ_k(o − z_k)(qw − zw)
+            self.gamma = (pw.bias + pw.alpha * U).contiguous()
+            self.n_groups = layout.n_groups
+        else:
+            self.wpacked, self.Kp = pw.natural()
+            self.ksrc = None
+            self.mdelta = layout.mdelta.to(dev).contiguous()
+            self.mzp = layout.mzp.to(dev).contiguous()
+            self.L = layout.L
+            self.gamma = pw.bias
+            self.vn = pw.vn()
+
+
+# ------------------------------------------------------------------------------------------ hot path
+def quant_act(x_cl: torch.Tensor, B, H, W, C, kh, kw, stride, pad, ab: ActBinding):
+    """x_cl: contiguous channels-last storage [B][H][W][C] (any fp dtype). Returns (codes, rowsum, M)."""
+    Ho = (H + 2 * pad - kh) // stride + 1
+    Wo = (W + 2 * pad - kw) // stride + 1
+    M = B * Ho * Wo
+    codes = torch.empty((M, ab.Kp), dtype=torch.int8, device=x_cl.device)
+    rowsum = torch.empty((M,), dtype=torch.float32, device=x_cl.device)
+    per_m = 0 if ab.mode == "perK" else 1
+    delta = ab.cdelta if ab.mode == "perK" else ab.mdelta
+    zp = ab.czp if ab.mode == "perK" else ab.mzp
+    L = 1 if ab.mode == "perK" else ab.L
+    _lib_call("dgq_quant_act", _lib.ptr(x_cl), _lib.DTYPE_CODE[x_cl.dtype], B, H, W, C, kh, kw, stride, pad,
+              _lib.ptr(ab.ksrc), ab.Kp, per_m, _lib.ptr(delta), _lib.ptr(zp), L, ab.abits,
+              _lib.ptr(codes), _lib.ptr(rowsum), _lib.stream())
+    return codes, rowsum, M
+
+
+def gemm_wxa8(codes, rowsum, M, ab: ActBinding, out_dtype, out: Optional[torch.Tensor] = None):
+    pw = ab.pw
+    if out is None:
+        out = torch.empty((M, pw.N), dtype=out_dtype, device=codes.device)
+    per_m = 0 if ab.mode == "perK" else 1
+    _lib_call("dgq_gemm_wxa8", _lib.ptr(codes), _lib.ptr(rowsum), M, ab.Kp, _lib.ptr(ab.wpacked), pw.bits, pw.N,
+              per_m,
+              _lib.ptr(ab.cdelta) if not per_m else None, _lib.ptr(ab.cflush) if not per_m else None,
+              _lib.ptr(ab.mdelta) if per_m else None, _lib.ptr(ab.mzp) if per_m else None,
+              ab.L if per_m else 1, _c.c_float(ab.offset),
+              _lib.ptr(pw.alpha), _lib.ptr(pw.zw), _lib.ptr(ab.gamma), _lib.ptr(ab.vn) if per_m else None,
+              _lib.ptr(out), _lib.DTYPE_CODE[out.dtype], out.stride(0), _lib.stream())
+    return out
+
+
+def quant_linear(x: torch.Tensor, ab: ActBinding):
+    """x [..., K] -> [..., N]."""
+    K = x.shape[-1]
+    x2 = x.reshape(-1, K)
+    if not x2.is_contiguous():
+        x2 = x2.contiguous()
+    rows = x2.shape[0]
+    codes, rowsum, M = quant_act(x2, rows, 1, 1, K, 1, 1, 1, 0, ab)
+    y = gemm_wxa8(codes, rowsum, M, ab, x.dtype)
+    return y.view(*x.shape[:-1], ab.pw.N)
+
+
+def quant_conv2d(x: torch.Tensor, ab: ActBinding, kh, kw, stride, pad):
+    """x logical NCHW (any strides; made channels-last) -> logical NCHW output in channels-last storage."""
+    B, C, H, W = x.shape
+    xc = x.contiguous(memory_format=torch.channels_last)
+    x_store = xc.permute(0, 2, 3, 1)                  # [B,H,W,C] view over the same storage, contiguous
+    codes, rowsum, M = quant_act(x_store, B, H, W, C, kh, kw, stride, pad, ab)
+    y = gemm_wxa8(codes, rowsum, M, ab, x.dtype)
+    Ho = (H + 2 * pad - kh) // stride + 1
+    Wo = (W + 2 * pad - kw) // stride + 1
+    return y.view(B, Ho, Wo, ab.pw.N).permute(0, 3, 1, 2)
+
+
+# ------------------------------------------------------------------------------------------ attention side
+def fakequant_rows(x2d: torch.Tensor, T, D, mode, delta, zp, skip, bits, out=None):
+    """x2d [rows][C] contiguous; see dgq_fakequant_rows."""
+    assert x2d.is_contiguous()
+    rows, C = x2d.shape
+    out = x2d if out is None else out
+    _lib_call("dgq_fakequant_rows", _lib.ptr(x2d), _lib.ptr(out), _lib.DTYPE_CODE[x2d.dtype], rows, C, T, D, mode,
+              _lib.ptr(delta), _lib.ptr(zp), skip, bits, _lib.stream())
+    return out
+
+
+def max_f32(p: torch.Tensor, skip_cols=0):
+    assert p.is_contiguous() and p.dtype == torch.float32
+    S = p.shape[-1]
+    rows = p.numel() // S
+    out = torch.zeros((1,), dtype=torch.float32, device=p.device)
+    _lib_call("dgq_max_f32", _lib.ptr(p), rows, S, skip_cols, _lib.ptr(out), _lib.stream())
+    return out
+
+
+def logquant_f32(p: torch.Tensor, delta: torch.Tensor, bits, skip_cols=0, out=None):
+    assert p.is_contiguous() and p.dtype == torch.float32
+    S = p.shape[-1]
+    rows = p.numel() // S
+    out = p if out is None else out
+    _lib_call("dgq_logquant_f32", _lib.ptr(p), _lib.ptr(out), rows, S, skip_cols, _lib.ptr(delta), bits, _lib.stream())
+    return out

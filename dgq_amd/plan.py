@@ -1,0 +1,135 @@
+"""Host-side planning for the W4A8 GEMM: how DGQ's per-timestep activation-quantizer tables
+(``delta`` / ``zero_point`` of ``UniformAffineQuantizer``, shapes per SURVEY.md §5.4) are turned into
+the K permutation, 64-wide chunk tables and epilogue vectors the HIP kernels consume.
+
+Pure CPU/torch index arithmetic (no kernels) so it is unit-tested without a GPU.
+
+K orders:
+  * reference order  k_ref = c·(kh·kw) + tap     (``w.view(N,-1)`` / ``F.unfold`` row order, quant_layer.py:557,634)
+  * natural physical kp = tap·C + c               (channels-last friendly; used for per-M / scalar scales)
+  * grouped physical: DGQ groups (= distinct (δ,z) pairs, arbitrary channel sets, quant_layer.py:405-418)
+    made contiguous, each padded with zero codes to a multiple of 64 (one MFMA_I32_16x16x64_I8 slice can
+    then be scaled by a single δ), whole K padded to a multiple of 128 (the GEMM's K tile).
+"""
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+KCHUNK = 64
+KTILE = 128
+
+
+def round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+def natural_kperm(C: int, taps: int):
+    """kperm[kp] -> k_ref for the natural physical order, padded with -1 to a multiple of KTILE."""
+    K = C * taps
+    kp = torch.arange(K)
+    tap, c = kp // C, kp % C
+    perm = torch.full((round_up(K, KTILE),), -1, dtype=torch.int32)
+    perm[:K] = (c * taps + tap).to(torch.int32)
+    return perm
+
+
+@dataclass
+class ActLayout:
+    """What one activation quantizer looks like to the kernels."""
+    mode: str                       # 'scalar' | 'perM' | 'perK'
+    # perM / scalar
+    mdelta: Optional[torch.Tensor] = None     # [L] f32
+    mzp: Optional[torch.Tensor] = None
+    L: int = 1
+    # perK
+    kperm: Optional[torch.Tensor] = None      # [Kp] int32: k_ref or -1   (weight packing)
+    ksrc: Optional[torch.Tensor] = None       # [Kp] int32: (tap<<16)|c or -1 (activation gather)
+    cdelta: Optional[torch.Tensor] = None     # [Kp/64] f32
+    czp: Optional[torch.Tensor] = None
+    cflush: Optional[torch.Tensor] = None     # [Kp/64] u8
+    kcoef: Optional[torch.Tensor] = None      # [K] f64 in k_ref order: δ_k·(offset − z_k), for U[n]
+    Kp: int = 0
+    n_groups: int = 0
+
+
+def classify_act_params(delta: torch.Tensor, kind: str):
+    """Which axis a ckpt (δ,z) pair addresses.
+    kind 'linear': input [B,T,K]; (1,1,K) -> perK, (1,T,1) -> perM, () -> scalar.
+    kind 'conv'  : quantizer sees unfolded [B, C·kh·kw, L]; (1,K,1) -> perK, (1,1,L) -> perM."""
+    if delta.dim() == 0 or delta.numel() == 1:
+        return "scalar"
+    if delta.dim() != 3 or delta.shape[0] != 1:
+        raise ValueError("unsupported activation-quantizer shape %s" % (tuple(delta.shape),))
+    if kind == "linear":
+        if delta.shape[1] == 1:
+            return "perK"
+        if delta.shape[2] == 1:
+            return "perM"
+    else:
+        if delta.shape[2] == 1:
+            return "perK"
+        if delta.shape[1] == 1:
+            return "perM"
+    raise ValueError("unsupported activation-quantizer shape %s for %s" % (tuple(delta.shape), kind))
+
+
+def plan_act(delta: torch.Tensor, zp: torch.Tensor, kind: str, C: int, taps: int, abits: int) -> ActLayout:
+    """delta/zp as stored in the cali_ckpt (CPU tensors)."""
+    delta = delta.detach().float().cpu()
+    zp = torch.as_tensor(zp).detach().float().cpu()
+    mode = classify_act_params(delta, kind)
+    if mode == "scalar":
+        return ActLayout("scalar", mdelta=delta.reshape(1).clone(), mzp=zp.reshape(1).clone(), L=1)
+    if mode == "perM":
+        d = delta.reshape(-1).clone()
+        z = zp.reshape(-1).expand_as(d).clone() if zp.numel() == 1 else zp.reshape(-1).clone()
+        return ActLayout("perM", mdelta=d, mzp=z, L=d.numel())
+    # ---- perK: group = distinct (δ,z) pair
+    K = C * taps
+    d = delta.reshape(-1)
+    z = zp.reshape(-1)
+    if d.numel() != K or z.numel() != K:
+        raise ValueError("per-K activation table has %d entries, layer has K=%d" % (d.numel(), K))
+    pairs = torch.stack([d, z], dim=1)
+    uniq, inv = torch.unique(pairs, dim=0, return_inverse=True)
+    G = uniq.shape[0]
+    k_ref = torch.arange(K)
+    c_of, tap_of = k_ref // taps, k_ref % taps
+    # sort by (group, tap, c): members of a group stay close in memory (channels-last gather)
+    key = (inv.long() * taps + tap_of) * C + c_of
+    order = torch.argsort(key)
+    counts = torch.bincount(inv, minlength=G)
+    padded = ((counts + KCHUNK - 1) // KCHUNK) * KCHUNK
+    Kp = round_up(int(padded.sum()), KTILE)
+    kperm = torch.full((Kp,), -1, dtype=torch.int32)
+    ksrc = torch.full((Kp,), -1, dtype=torch.int32)
+    nch = Kp // KCHUNK
+    cdelta = torch.ones(nch)
+    czp = torch.zeros(nch)
+    cflush = torch.zeros(nch, dtype=torch.uint8)
+    pos, src = 0, 0
+    for g in range(G):
+        n = int(counts[g])
+        ks = order[src:src + n]
+        kperm[pos:pos + n] = ks.to(torch.int32)
+        ksrc[pos:pos + n] = ((tap_of[ks] << 16) | c_of[ks]).to(torch.int32)
+        c0, c1 = pos // KCHUNK, (pos + int(padded[g])) // KCHUNK
+        cdelta[c0:c1] = uniq[g, 0]
+        czp[c0:c1] = uniq[g, 1]
+        cflush[c1 - 1] = 1
+        pos += int(padded[g])
+        src += n
+    if pos < Kp:                       # tail chunk added to reach the K tile: all-zero codes
+        cdelta[pos // KCHUNK:] = uniq[G - 1, 0]
+        czp[pos // KCHUNK:] = uniq[G - 1, 1]
+        cflush[-1] = 1
+    offset = 128.0 if abits == 8 else 0.0
+    kcoef = d.double() * (offset - z.double())
+    return ActLayout("perK", kperm=kperm, ksrc=ksrc, cdelta=cdelta, czp=czp, cflush=cflush, kcoef=kcoef, Kp=Kp,
+                     n_groups=G)
+
+
+def act_offset(abits: int) -> float:
+    """Code offset that maps activation codes into int8: q∈[0,255] -> s=q−128 for A8, none below."""
+    return 128.0 if abits == 8 else 0.0

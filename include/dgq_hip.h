@@ -1,0 +1,115 @@
+/* dgq_hip.h — C ABI of libdgq_hip.so: the MI355X (gfx950) kernels behind DGQ's quantized-UNet path.
+ *
+ * The reference (ugonfor/DGQ) has NO FFI: its per-layer operator boundary is the Python method
+ * QuantLayer.forward (quant/quant_layer.py:626-661) and the attention-side quantizer calls in
+ * Attention.Attention_forward (diffusers_rewrite/sd.py:151-207).  Each entry point below names the
+ * reference code it replaces.  Conventions:
+ *   - plain C types only: raw DEVICE pointers, ints, floats and a hipStream_t passed as void*;
+ *   - the caller owns every buffer; the library never allocates, frees or keeps device pointers;
+ *   - every launch is asynchronous on `stream`; no host synchronisation, safe under hipGraph capture;
+ *   - return 0 on success, a negative DGQ_E* otherwise (message via dgq_last_error()); no exceptions,
+ *     no abort().
+ * dtype codes for floating tensors: 0 = f32, 1 = f16, 2 = bf16.
+ */
+#ifndef DGQ_HIP_H
+#define DGQ_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DGQ_OK 0
+#define DGQ_EINVAL (-1)   /* bad shape / alignment / argument */
+#define DGQ_EUNSUPPORTED (-2)
+#define DGQ_ELAUNCH (-3)  /* HIP reported a launch error */
+
+#define DGQ_F32 0
+#define DGQ_F16 1
+#define DGQ_BF16 2
+
+#define DGQ_KCHUNK 64     /* K granularity of one MFMA_I32_16x16x64_I8 slice = DGQ group padding */
+#define DGQ_KTILE 128     /* Kp (padded, permuted K) must be a multiple of this */
+
+int dgq_version(void);
+const char* dgq_last_error(void);
+
+/* ---- weights (load time) -------------------------------------------------------------------------
+ * dgq_quantize_weight: integer codes of wqtizer(self.w) — UniformAffineQuantizer.forward
+ * (quant_layer.py:295-299: clamp(rne(w/δ)+z, 0, 2^b−1)) or, when alpha != NULL, AdaRoundQuantizer hard
+ * mode (adaptive_rounding.py:51,58-70: clamp(floor(w/δ)+(α≥0)+z, 0, 2^b−1)).  The reference recomputes
+ * these on EVERY forward (quant_layer.py:642-643); here they are computed once.
+ * w [N][K] f32, delta/zp [N] f32, alpha [N][K] f32 or NULL, codes [N][K] u8. */
+int dgq_quantize_weight(const float* w, const float* delta, const float* zp, const float* alpha,
+                        int N, int K, int bits, uint8_t* codes, void* stream);
+
+/* dgq_pack_w4: codes u8 [N][K] (values 0..15) -> packed [N][Kp/2] bytes.  kperm [Kp] gives for each
+ * packed position the source k (or -1 = zero padding); NULL = identity (Kp == K).  Layout per 8
+ * consecutive kp: one 32-bit word, byte j holds kp+j in its low nibble and kp+4+j in its high nibble,
+ * so that (word & 0x0F0F0F0F) and ((word >> 4) & 0x0F0F0F0F) are 4 consecutive int8 each. */
+int dgq_pack_w4(const uint8_t* codes, int N, int K, const int32_t* kperm, int Kp, uint8_t* packed, void* stream);
+/* exact inverse (test hook for the "bit-exact int4 unpack" requirement): out [N][Kp] u8 */
+int dgq_unpack_w4(const uint8_t* packed, int N, int Kp, uint8_t* out, void* stream);
+/* W8: out[n][kp] = (int8)(codes[n][kperm[kp]] - 128), 0 for padding */
+int dgq_pack_w8(const uint8_t* codes, int N, int K, const int32_t* kperm, int Kp, int8_t* packed, void* stream);
+
+/* ---- activations: quantise-on-load pre-pass ------------------------------------------------------
+ * Replaces `x = self.aqtizer(x)` (quant_layer.py:640-641 -> :295-299) and, for grouped convs, the
+ * F.unfold that precedes it (quant_layer.py:630-638): writes int8 codes s = q − offset of the (implicit)
+ * unfolded operand, row-major [M][Kp], in the permuted/padded K order of the packed weight, plus one
+ * float per row.
+ *
+ * x is a channels-last tensor [B][H][W][C] (a Linear input [B,T,K] is B=B·T... H=W=1, C=K); geometry
+ * (kh,kw,stride,pad) as the conv; M = B·Ho·Wo.  Source of packed position kp:
+ *   ksrc == NULL : natural order kp = tap·C + c   (tap = dh·kw + dw)
+ *   ksrc != NULL : ksrc[kp] = c + C·tap, or -1 for padding.
+ * Quantiser parameters:
+ *   per_m == 0 : cdelta/czp [Kp/64] — one (δ,z) per 64-wide chunk (DGQ groups are chunk aligned);
+ *                rowsum[m] = Σ_kp δ(kp)·s[m,kp]
+ *   per_m == 1 : mdelta/mzp [L] indexed by (m % L) (L=1: scalar quantiser);
+ *                rowsum[m] = Σ_kp s[m,kp]  (exact integer in f32)
+ * bits: activation bits (8 -> offset 128, <8 -> offset 0).  Out-of-image taps read 0.0 and are
+ * quantised like any value (F.unfold pads before the quantizer). */
+int dgq_quant_act(const void* x, int x_dtype, int B, int H, int W, int C,
+                  int kh, int kw, int stride, int pad,
+                  const int32_t* ksrc, int Kp,
+                  int per_m, const float* delta, const float* zp, int L,
+                  int bits, int8_t* codes, float* rowsum, void* stream);
+
+/* ---- the hot kernel: W4A8 / W8A8 MFMA GEMM with fused dequantisation ------------------------------
+ * Replaces F.linear / `w.view(N,-1) @ unfolded` / F.conv2d on fake-quantised operands
+ * (quant_layer.py:652-659, :562).  Integer identity, s = qx − offset, zw' = zw − woff:
+ *   per_m == 0: y[m,n] = alpha[n]·( Σ_chunks cdelta[c]·Σ_{k∈c} s[m,k]·qw'[n,k]  −  zw[n]·rowsum[m] ) + gamma[n]
+ *   per_m == 1: y[m,n] = alpha[n]·mdelta[m%L]·( Σ_k s·qw' − zw[n]·rowsum[m] + (offset − mzp[m%L])·vn[n] ) + gamma[n]
+ * codes [M][Kp] int8; wpacked: w_bits==4 -> [N][Kp/2] (dgq_pack_w4), w_bits==8 -> [N][Kp] int8;
+ * alpha = δw, zw = zero point in the stored code domain (zw − 8·0 for W4: unsigned nibbles; zw − 128 for W8);
+ * gamma = bias (+ alpha·U for per_m==0, U[n] = Σ_k δx_k(offset − zx_k)(qw'[n,k] − zw[n]), precomputed per slot);
+ * vn[n] = Σ_k qw'[n,k] − K·zw[n].  y [M][ldy] of y_dtype.  cflush[c] != 0 marks the last chunk of a group. */
+int dgq_gemm_wxa8(const int8_t* codes, const float* rowsum, int M, int Kp,
+                  const void* wpacked, int w_bits, int N,
+                  int per_m, const float* cdelta, const uint8_t* cflush,
+                  const float* mdelta, const float* mzp, int L, float offset,
+                  const float* alpha, const float* zw, const float* gamma, const float* vn,
+                  void* y, int y_dtype, int ldy, void* stream);
+
+/* ---- attention-side quantizers --------------------------------------------------------------------
+ * dgq_fakequant_rows: aqtizer_q/k/v (sd.py:174-182,199 -> quant_layer.py:295-299) applied on the
+ * projection output viewed as [rows][C] (row = b·T + t, col = h·D + d): y = δ·(clamp(rne(x/δ)+z,0,2^b−1) − z).
+ *   mode 0: scalar (delta[0]);  mode 1: per token, index (row % T) − skip;  mode 2: per head-dim, index col % D.
+ * Tokens t < skip are copied unquantised (start_peak bypass of token 0, sd.py:176-180). In-place allowed. */
+int dgq_fakequant_rows(const void* x, void* y, int dtype, int rows, int C, int T, int D,
+                       int mode, const float* delta, const float* zp, int skip, int bits, void* stream);
+
+/* dgq_max_f32: out[0] = max over p[rows][S] excluding columns < skip_cols (real-time δ = x.max(),
+ * quant_layer_text.py:96-97). `out` must be pre-set to 0 by the caller; probabilities are >= 0. */
+int dgq_max_f32(const float* p, int64_t rows, int S, int skip_cols, float* out, void* stream);
+/* dgq_logquant_f32: T2ILogQuantizer.forward (quant_layer_text.py:101-105) on softmax probabilities,
+ * y = δ·2^(−clamp(rne(−log2(p/δ)),0,2^b−1)), δ read from device memory; columns < skip_cols are copied
+ * (start_peak, sd.py:191-195). In-place allowed. */
+int dgq_logquant_f32(const float* p, float* y, int64_t rows, int S, int skip_cols, const float* delta,
+                     int bits, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
