@@ -1,0 +1,8 @@
+"""Mirror of the reference's ``quant`` package surface for the inference path."""
+from .quant_layer import (Scaler, QMODE, StraightThrough, UniformAffineQuantizer, QuantLayer, minmax)
+from .quant_layer_text import T2ILogQuantizer
+from .adaptive_rounding import AdaRoundQuantizer, RMODE
+from .quant_block import BaseQuantBlock, QuantResnetBlock2D, QuantBasicTransformerBlock, b2qb
+from .quant_model import QuantModel
+from .calibration import load_cali_model
+from .load_qmodel_util import get_qmodel

@@ -1,0 +1,48 @@
+"""``get_qmodel`` — mirror of quant/load_qmodel_util.py:28-72 (the function src/inference_qmodel.py:91 calls)."""
+import torch
+
+from .calibration import load_cali_model
+from .quant_block import QuantBasicTransformerBlock
+from .quant_model import QuantModel, QMODE  # noqa: F401  (QMODE re-exported like the reference)
+from .quant_layer import QMODE as _QMODE
+
+
+def setup_pipe_to_calibrate(model_type, pipe):
+    """SDXL: the calibration forward takes (text_embeds, time_ids) positionally (load_qmodel_util.py:6-18)."""
+    pipe.unet.float()
+    if model_type == "sdxl":
+        def forward(self, sample, timesteps, encoder_hidden_states, text_embeds=None, time_ids=None, **kwargs):
+            ack = kwargs.pop("added_cond_kwargs", None) or {"text_embeds": text_embeds, "time_ids": time_ids}
+            return self.original_forward(sample, timesteps, encoder_hidden_states, ack, **kwargs)
+        setattr(pipe.unet, "original_forward", pipe.unet.forward)
+        setattr(pipe.unet, "forward", forward.__get__(pipe.unet))
+
+
+def setup_pipe_to_inference(model_type, qnn):
+    if model_type == "sdxl":
+        setattr(qnn.model, "forward", qnn.model.original_forward)
+        delattr(qnn.model, "original_forward")
+
+
+def get_qmodel(model_type, pipe, ckpt_path, wq_params, use_aq, aq_params, softmax_aq_params,
+               use_group, num_inference_steps, time_aware_aqtizer, device="cuda"):
+    setup_pipe_to_calibrate(model_type, pipe)
+    qnn = QuantModel(model=pipe.unet, wq_params=wq_params, aq_params=aq_params, softmax_aq_params=softmax_aq_params,
+                     aq_mode=[_QMODE.NORMAL.value, _QMODE.QDIFF.value], tib_recon=False).to(device).eval()
+    if model_type == "sd":
+        cali_data = (torch.randn(1, 4, 64, 64), torch.randint(0, 1000, (1,)), torch.randn(1, 77, 768))
+    elif model_type == "sdxl":
+        cali_data = (torch.randn(1, 4, 128, 128), torch.randint(0, 1000, (1,)), torch.randn(1, 77, 2048),
+                     torch.randn(1, 1280), torch.randn(1, 6))
+    else:
+        raise ValueError(f"Unknown model type: {model_type}")
+    load_cali_model(qnn, init_data=cali_data, use_aq=use_aq, path=ckpt_path, time_aware_aqtizer=time_aware_aqtizer,
+                    num_inference_steps=num_inference_steps, use_group=use_group)
+    qnn.disable_out_quantization()
+    if use_aq:       # softmax quantization is performed on float32 (load_qmodel_util.py:63-68)
+        for _, module in qnn.named_modules():
+            if isinstance(module, QuantBasicTransformerBlock):
+                module.attn1.use_aq = True
+                module.attn2.use_aq = True
+    setup_pipe_to_inference(model_type, qnn)
+    return qnn

@@ -1,0 +1,194 @@
+"""Block wrappers — mirror of the reference's ``quant/quant_block.py``.
+
+``QuantBasicTransformerBlock`` (quant_block.py:121-186) attaches ``aqtizer_{q,k,v,w}`` to both attentions and
+owns the quantized attention forward (the reference swaps in ``Attention.Attention_forward``,
+diffusers_rewrite/sd.py:151-207); ``QuantResnetBlock2D`` (quant_block.py:79-119) re-hosts the resnet
+submodules.  Wrapping is by duck-typing, so both this package's UNet and the reference's
+``diffusers_rewrite`` UNet classes are accepted.
+"""
+from typing import Dict
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+from .quant_layer import QuantLayer, UniformAffineQuantizer, StraightThrough
+from .quant_layer_text import T2ILogQuantizer
+
+
+class BaseQuantBlock(nn.Module):
+    def __init__(self, aq_params: dict = {}) -> None:
+        super().__init__()
+        self.use_wq = False
+        self.use_aq = False
+        self.act_func = StraightThrough()
+        self.ignore_recon = False
+
+    def set_quant_state(self, use_wq: bool = False, use_aq: bool = False) -> None:
+        """quant_block.py:25-33: QuantLayers follow both flags; attentions only ``use_aq``."""
+        for m in self.modules():
+            if isinstance(m, QuantLayer):
+                m.set_quant_state(use_wq=use_wq, use_aq=use_aq)
+            if hasattr(m, "aqtizer_q") and hasattr(m, "to_q"):
+                m.use_aq = use_aq
+
+
+class QuantResnetBlock2D(BaseQuantBlock):
+    def __init__(self, resnet: nn.Module, aq_params: dict = {}) -> None:
+        super().__init__(aq_params)
+        self.norm1 = resnet.norm1
+        self.conv1 = resnet.conv1
+        self.time_emb_proj = resnet.time_emb_proj
+        self.norm2 = resnet.norm2
+        self.dropout = resnet.dropout
+        self.conv2 = resnet.conv2
+        self.nonlinearity = resnet.nonlinearity
+        self.conv_shortcut = resnet.conv_shortcut
+
+    def forward(self, input_tensor, temb):
+        h = self.conv1(F.silu(self.norm1(input_tensor)))
+        h = h + self.time_emb_proj(F.silu(temb))[:, :, None, None]
+        h = self.conv2(F.silu(self.norm2(h)))
+        if self.conv_shortcut is not None:
+            input_tensor = self.conv_shortcut(input_tensor)
+        return input_tensor + h
+
+
+def _qparams(q: UniformAffineQuantizer, dev):
+    """(mode, δ, z) of an attention-side quantizer for dgq_fakequant_rows on the [B·T, H·D] layout:
+    () -> scalar; (1,T,1) -> per token; (1,1,D) -> per head-dim (quant_layer.py:311-313, 391-402)."""
+    d = q.delta.detach()
+    z = torch.as_tensor(q.zero_point).detach()
+    cache = getattr(q, "_dev_cache", None)
+    key = (d.data_ptr(), d._version, z.data_ptr() if z.numel() else 0, z._version, str(dev))
+    if cache is not None and cache[0] == key:
+        return cache[1]
+    if d.numel() == 1:
+        mode = 0
+    elif d.dim() == 3 and d.shape[2] == 1:
+        mode = 1
+    elif d.dim() == 3 and d.shape[1] == 1:
+        mode = 2
+    else:
+        raise NotImplementedError("attention quantizer δ shape %s" % (tuple(d.shape),))
+    dd = d.reshape(-1).float().to(dev).contiguous()
+    zz = z.reshape(-1).float().to(dev)
+    zz = (zz.expand_as(dd) if zz.numel() == 1 else zz).contiguous()
+    q._dev_cache = (key, (mode, dd, zz))
+    return mode, dd, zz
+
+
+class QuantBasicTransformerBlock(BaseQuantBlock):
+    def __init__(self, tran: nn.Module, aq_params: dict = {}, softmax_aq_params: dict = {}) -> None:
+        super().__init__(aq_params)
+        self.norm1 = tran.norm1
+        self.attn1 = tran.attn1
+        self.norm2 = tran.norm2
+        self.attn2 = tran.attn2
+        self.norm3 = tran.norm3
+        self.ff = tran.ff
+        for attn in (self.attn1, self.attn2):
+            attn.aqtizer_q = UniformAffineQuantizer(**aq_params)
+            attn.aqtizer_k = UniformAffineQuantizer(**aq_params)
+            attn.aqtizer_v = UniformAffineQuantizer(**aq_params)
+        aq_params_w = dict(aq_params)
+        aq_params_w["bits"] = softmax_aq_params["softmax_a_bit"]
+        aq_params_w["symmetric"] = False
+        aq_params_w["always_zero"] = True
+        if softmax_aq_params["t2i_log_quant"]:
+            aq_params_w["real_time"] = softmax_aq_params["t2i_real_time"]
+            aq_params_w["log_max_1"] = softmax_aq_params["log_max_1"]
+            self.attn1.aqtizer_w = T2ILogQuantizer(**aq_params_w)
+            self.attn2.aqtizer_w = T2ILogQuantizer(**aq_params_w)
+        else:
+            self.attn1.aqtizer_w = UniformAffineQuantizer(**aq_params_w)
+            self.attn2.aqtizer_w = UniformAffineQuantizer(**aq_params_w)
+        if softmax_aq_params["t2i_start_peak"]:
+            self.attn2.start_peak = True                       # only ever set on attn2 (quant_block.py:157-158)
+        self.attn1.use_aq = False
+        self.attn2.use_aq = False
+        self.attn1.forward = lambda hidden_states, encoder_hidden_states=None, _a=self.attn1: \
+            quant_attention_forward(_a, hidden_states, encoder_hidden_states)
+        self.attn2.forward = lambda hidden_states, encoder_hidden_states=None, _a=self.attn2: \
+            quant_attention_forward(_a, hidden_states, encoder_hidden_states)
+
+    def forward(self, x, encoder_hidden_states=None):
+        x = x + self.attn1(self.norm1(x))
+        x = x + self.attn2(self.norm2(x), encoder_hidden_states=encoder_hidden_states)
+        return x + self.ff(self.norm3(x))
+
+
+def quant_attention_forward(attn, hidden_states, encoder_hidden_states=None):
+    """Quantized attention (replaces Attention.Attention_forward, sd.py:151-207).
+
+    q/k/v quantizers run in place on the projection outputs in their [B·T, H·D] layout (a per-token or
+    per-head-dim table addresses the same elements as the reference's [B,H,T,D] broadcast); the start-peak
+    bypass of key token 0 / probability column 0 (sd.py:176-180,191-195) is a ``skip`` argument of the kernels
+    instead of slice + concat."""
+    start_peak = bool(getattr(attn, "start_peak", False))
+    src = hidden_states if encoder_hidden_states is None else encoder_hidden_states
+    q = attn.to_q(hidden_states)
+    k = attn.to_k(src)
+    v = attn.to_v(src)
+    b, t, c = q.shape
+    s = k.shape[1]
+    H, D = attn.num_heads, attn.head_dim
+    use_aq = bool(getattr(attn, "use_aq", False))
+    if use_aq:
+        dev = q.device
+        for name, ten, ntok, skip in (("aqtizer_q", q, t, 0), ("aqtizer_k", k, s, 1 if start_peak else 0),
+                                      ("aqtizer_v", v, s, 0)):
+            qz = getattr(attn, name)
+            if not qz.init:                                          # first-forward scalar self-init
+                view = ten.view(b, ntok, H, D)
+                qz.init_from(view[:, skip:] if skip else view)
+            mode, dd, zz = _qparams(qz, dev)
+            ten2 = ten.contiguous().view(b * ntok, c)
+            ops.fakequant_rows(ten2, ntok, D, mode, dd, zz, skip, qz.bits)
+            if name == "aqtizer_q":
+                q = ten2.view(b, ntok, c)
+            elif name == "aqtizer_k":
+                k = ten2.view(b, ntok, c)
+            else:
+                v = ten2.view(b, ntok, c)
+    qh = q.view(b, t, H, D).transpose(1, 2)
+    kh = k.view(b, s, H, D).transpose(1, 2)
+    vh = v.view(b, s, H, D).transpose(1, 2)
+    scores = torch.matmul(qh, kh.transpose(-2, -1)) * attn.scale
+    p = torch.softmax(scores, dim=-1)
+    del scores
+    if use_aq:
+        p = p.float().contiguous()                                    # softmax quantisation in fp32 (sd.py:189)
+        wq = attn.aqtizer_w
+        skip = 1 if start_peak else 0
+        if isinstance(wq, T2ILogQuantizer):
+            if wq.real_time:
+                delta = ops.max_f32(p, skip)
+            else:
+                if not wq.init:
+                    wq.forward(p.clone(), skip)                       # quantile search on first use
+                delta = wq.delta.detach().reshape(1).float().to(p.device)
+            ops.logquant_f32(p, delta, wq.bits, skip)
+        else:
+            if not wq.init:
+                wq.init_from(p[..., skip:] if skip else p)
+            dd = wq.delta.detach().reshape(1).float().to(p.device)
+            zz = torch.as_tensor(wq.zero_point).detach().reshape(1).float().to(p.device)
+            if skip:
+                pv = p.view(-1, s)
+                # column bypass is not a row/token skip: quantise all, then restore column 0
+                col0 = pv[:, 0].clone()
+                ops.fakequant_rows(pv, 1, s, 0, dd, zz, 0, wq.bits)
+                pv[:, 0] = col0
+            else:
+                ops.fakequant_rows(p.view(-1, s), 1, s, 0, dd, zz, 0, wq.bits)
+        p = p.to(vh.dtype)
+    o = torch.matmul(p, vh).transpose(1, 2).reshape(b, t, c)
+    for layer in attn.to_out:
+        o = layer(o)
+    return o
+
+
+def b2qb() -> Dict[str, type]:
+    return {"ResnetBlock2D": QuantResnetBlock2D, "BasicTransformerBlock": QuantBasicTransformerBlock}

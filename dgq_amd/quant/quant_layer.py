@@ -1,0 +1,378 @@
+"""Host-side mirror of the reference's ``quant/quant_layer.py`` operator interface, executing on MI355X.
+
+Same public names and argument meaning (``Scaler``, ``UniformAffineQuantizer``, ``QuantLayer``, ``QMODE``,
+``StraightThrough``), different execution model:
+
+  reference (quant_layer.py:626-661)                      here
+  ---------------------------------------------------    -----------------------------------------------------
+  fake-quant weights from fp32 on EVERY call (:642-643)   integer codes frozen once -> int4/int8 packed in HBM
+  F.unfold materialises im2col in fp32 (:630-638)         gather + quantise straight to int8 codes (dgq_quant_act)
+  6 elementwise fp passes per activation (:297-299)       fused into that single pre-pass
+  fp32 F.linear / matmul / F.conv2d (:562,:659)           V_MFMA_I32_16X16X64_I8 GEMM, dequant in the epilogue
+  ~750 host->device δ/z copies per step when time-aware   all timestep slots resident on the device
+
+There is no CPU execution path: a quantized forward on a CPU tensor raises.
+"""
+import logging
+from enum import Enum
+from typing import List, Optional, Union
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+from ..plan import plan_act
+
+logger = logging.getLogger(__name__)
+
+
+class StraightThrough(nn.Module):
+    def forward(self, x):
+        return x
+
+
+def minmax(x: torch.Tensor, symmetric: bool = False, level: int = 256, always_zero: bool = False):
+    """Scalar min/max scale initialiser — same arithmetic as quant_layer.py:22-38 (python-double range,
+    δ clamped to ≥1e-8, z = rne(−min/δ))."""
+    x_min, x_max = min(x.min().item(), 0.0), max(x.max().item(), 0.0)
+    delta = torch.tensor(float(x_max - x_min) / (level - 1))
+    if symmetric:
+        m = max(abs(x_min), x_max)
+        x_min, x_max = -m, m
+        delta = torch.tensor(float(x_max - x_min) / (level - 2))
+    if always_zero:
+        delta = torch.tensor(float(x_max) / (level - 1))
+    if delta < 1e-8:
+        delta = torch.tensor(1e-8)
+    if symmetric or always_zero:
+        zero_point = torch.tensor(0.0)
+    else:
+        zero_point = torch.round(-torch.tensor(float(x_min)) / delta)
+    return delta.to(device=x.device, dtype=x.dtype), zero_point.to(device=x.device, dtype=x.dtype)
+
+
+def _calibration_only(name):
+    def f(*a, **k):
+        raise NotImplementedError(
+            "Scaler.%s is a calibration-time scale search (quant/quant_layer.py); the inference path "
+            "only needs MINMAX (src/inference_qmodel.py:73-81)" % name)
+    f.__name__ = name.lower()
+    return f
+
+
+class Scaler(Enum):
+    """Same member names as the reference enum (quant_layer.py:187-193)."""
+    MINMAX = minmax
+    MSE = _calibration_only("MSE")
+    KL = _calibration_only("KL")
+    HIST = _calibration_only("HIST")
+    OMSE = _calibration_only("OMSE")
+    LOGMINMAX = _calibration_only("LOGMINMAX")
+
+
+QMODE = Enum("QMODE", ("QDIFF", "NORMAL", "PTQD"))
+
+
+def channel_minmax(w: torch.Tensor, level: int):
+    """Vectorised per-output-channel ``minmax`` (what quant_layer.py:253-264 computes with a python loop
+    over channels — the dominant cost of the reference's load)."""
+    flat = w.detach().reshape(w.shape[0], -1)
+    mn = torch.clamp(flat.min(dim=1)[0], max=0.0).double()
+    mx = torch.clamp(flat.max(dim=1)[0], min=0.0).double()
+    delta = ((mx - mn) / float(level - 1)).float()
+    delta = torch.where(delta < 1e-8, torch.full_like(delta, 1e-8), delta)
+    zp = torch.round(-mn.float() / delta)
+    shape = (-1,) + (1,) * (w.dim() - 1)
+    return delta.view(shape), zp.view(shape)
+
+
+class UniformAffineQuantizer(nn.Module):
+    """δ·(clamp(rne(x/δ)+z, 0, 2^b−1) − z)  — quant_layer.py:216-299 (inference branch)."""
+
+    def __init__(self, bits: int = 8, symmetric: bool = False, channel_wise: bool = False,
+                 scaler: Scaler = Scaler.MINMAX, leaf_param: bool = False, always_zero: bool = False,
+                 quant_emb: bool = False) -> None:
+        super().__init__()
+        if symmetric:
+            raise NotImplementedError("symmetric quantizers are not used by the DGQ inference path")
+        self.level = 2 ** bits
+        self.symmetric = symmetric
+        self.channel_wise = channel_wise
+        self.scaler = scaler
+        self.leaf_param = leaf_param
+        if leaf_param:
+            self.x_min, self.x_max = None, None
+        self.running_stat = False
+        self.always_zero = always_zero
+        self.delta = None
+        self.zero_point = None
+        self.init = False
+        self.quant_emb = quant_emb
+        self.group_num = -1
+
+    @property
+    def bits(self):
+        return int(self.level).bit_length() - 1
+
+    # -- initialisation -------------------------------------------------------------------------
+    def _init_quantization_param(self, x: torch.Tensor, channel_wise: bool = False):
+        if channel_wise:
+            return channel_minmax(x, self.level)
+        if self.leaf_param:
+            self.x_min, self.x_max = x.data.min(), x.data.max()
+        return self.scaler(x, self.symmetric, self.level, self.always_zero)
+
+    def init_from(self, x: torch.Tensor):
+        delta, zp = self._init_quantization_param(x, self.channel_wise)
+        self.delta = nn.Parameter(delta) if self.leaf_param else delta
+        self.zero_point = zp
+        self.init = True
+
+    # -- forward --------------------------------------------------------------------------------
+    def layout(self, x: torch.Tensor):
+        """(x2d, mode, T, D) for dgq_fakequant_rows given this quantizer's δ shape and a contiguous x:
+        scalar; (1,1,X) = last dim; (1,X,1) = second-to-last dim (token); [N,1(,1,1)] = dim 0 (weights)."""
+        d = self.delta
+        C = x.shape[-1]
+        if d.numel() == 1:
+            return x.view(-1, C), 0, 1, C
+        if d.dim() == x.dim() and d.shape[0] == x.shape[0] and d.numel() == x.shape[0]:   # per output channel
+            return x.view(x.shape[0], -1), 1, x.shape[0], x[0].numel()
+        if d.dim() == 3 and d.shape[0] == 1 and d.shape[1] == 1 and d.shape[2] == C:
+            return x.view(-1, C), 2, 1, C
+        if d.dim() == 3 and d.shape[0] == 1 and d.shape[2] == 1 and x.dim() >= 2 and d.shape[1] == x.shape[-2]:
+            return x.view(-1, C), 1, x.shape[-2], C
+        raise NotImplementedError("quantizer δ shape %s on input %s" % (tuple(d.shape), tuple(x.shape)))
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if not self.init:
+            self.init_from(x)
+        if self.running_stat or self.group_num != -1:
+            raise NotImplementedError("activation-statistics collection is calibration-time (SURVEY.md §8(f)-1)")
+        if not x.is_cuda:
+            raise RuntimeError("dgq_amd: quantizers execute on the GPU only (no CPU fallback)")
+        xc = x.contiguous()
+        x2d, mode, T, D = self.layout(xc)
+        d = self.delta.detach().reshape(-1).float().to(x.device)
+        z = torch.as_tensor(self.zero_point).detach().reshape(-1).float().to(x.device)
+        if z.numel() == 1 and d.numel() > 1:
+            z = z.expand_as(d).contiguous()
+        out = torch.empty_like(xc)
+        ops.fakequant_rows(x2d, T, D, mode, d, z, 0, self.bits, out=out.view(x2d.shape))
+        return out
+
+    def bitwidth_refactor(self, bits: int = 8) -> None:
+        self.level = 2 ** bits
+
+    def extra_repr(self) -> str:
+        return "level=%d, channel_wise=%s, leaf_param=%s, always_zero=%s" % (
+            self.level, self.channel_wise, self.leaf_param, self.always_zero)
+
+    def half(self):
+        super().half()
+        if self.delta is not None and not isinstance(self.delta, nn.Parameter):
+            self.delta = self.delta.half()
+        if torch.is_tensor(self.zero_point) and not isinstance(self.zero_point, nn.Parameter):
+            self.zero_point = self.zero_point.half()
+        return self
+
+    def float(self):
+        super().float()
+        if self.delta is not None and not isinstance(self.delta, nn.Parameter):
+            self.delta = self.delta.float()
+        if torch.is_tensor(self.zero_point) and not isinstance(self.zero_point, nn.Parameter):
+            self.zero_point = self.zero_point.float()
+        return self
+
+
+class SlotRef:
+    """Shared by every layer of one QuantModel: which timestep slot's activation tables are live
+    (time-aware mode, calibration.py:297-312). ``None`` = use the quantizer modules' own δ/z."""
+
+    def __init__(self):
+        self.slot = None
+
+
+class QuantLayer(nn.Module):
+    """Drop-in for the reference's QuantLayer (quant_layer.py:577-702) around nn.Linear / nn.Conv2d."""
+
+    QMAP = {nn.Conv2d: F.conv2d, nn.Linear: F.linear}
+
+    def __init__(self, layer: Union[nn.Conv2d, nn.Linear], wq_params: dict = {}, aq_params: dict = {},
+                 disable_aq: bool = False, aq_mode: List[int] = [QMODE.QDIFF.value], quant_emb: bool = False) -> None:
+        super().__init__()
+        self.wq_params = dict(wq_params)
+        self.aq_params = dict(aq_params)
+        self.fwd_kwargs = {}
+        self.is_conv = isinstance(layer, nn.Conv2d)
+        if self.is_conv:
+            if layer.groups != 1 or layer.dilation != (1, 1):
+                raise NotImplementedError("grouped/dilated convolutions do not occur in the SD/SDXL UNets")
+            self.fwd_kwargs = dict(stride=layer.stride, padding=layer.padding, dilation=layer.dilation,
+                                   groups=layer.groups)
+        self.kwd_func = self.QMAP[type(layer)]
+        self.w = layer.weight
+        self.original_w = self.w.data.clone()
+        self.b = None
+        self.original_b = None
+        if layer.bias is not None:
+            self.b = layer.bias
+            self.original_b = self.b.data.clone()
+        self.use_wq = False
+        self.use_aq = False
+        self.disable_aq = disable_aq
+        self.aq_mode = aq_mode
+        self.quant_emb = quant_emb
+        self.wq_params["quant_emb"] = quant_emb
+        self.wqtizer = UniformAffineQuantizer(**self.wq_params)
+        self.aqtizer = UniformAffineQuantizer(**self.aq_params)
+        self.split = 0
+        self.act_func = StraightThrough()
+        self.ignore_recon = False
+        self.extra_repr = layer.extra_repr
+        self.use_group_num = False
+        # device-side state (not part of the state-dict)
+        self._pw = None
+        self._pw_key = None
+        self._wdq = None
+        self._bindings = {}
+        self._act_tables = {}            # slot -> (δ, z) CPU tensors from the cali_ckpt
+        self._slot_ref: Optional[SlotRef] = None
+
+    # -- geometry ---------------------------------------------------------------------------------
+    @property
+    def in_channels(self):
+        return self.w.shape[1]
+
+    @property
+    def taps(self):
+        return self.w.shape[2] * self.w.shape[3] if self.is_conv else 1
+
+    # -- weights ------------------------------------------------------------------------------------
+    def _weight_key(self):
+        q = self.wqtizer
+        alpha = getattr(q, "alpha", None)
+        return (self.w.data_ptr(), self.w._version, str(self.w.device),
+                q.delta.data_ptr() if torch.is_tensor(q.delta) else None,
+                q.delta._version if torch.is_tensor(q.delta) else None,
+                q.zero_point._version if torch.is_tensor(q.zero_point) else None,
+                alpha._version if alpha is not None else None,
+                self.b._version if self.b is not None else None)
+
+    def packed_weight(self) -> ops.PackedWeight:
+        """Freeze the weight to integer codes (once; re-done only if a parameter was modified)."""
+        q = self.wqtizer
+        if not q.init:
+            q.init_from(self.w.data)
+        key = self._weight_key()
+        if self._pw is None or key != self._pw_key:
+            dev = self.w.device
+            self._pw = ops.PackedWeight(self.w.data.float(), q.delta.data.to(dev), torch.as_tensor(q.zero_point).data.to(dev),
+                                        getattr(q, "alpha", None), self.b.data if self.b is not None else None,
+                                        q.bits, self.in_channels, self.taps)
+            self._pw_key = key
+            self._bindings = {}
+            self._wdq = None
+        return self._pw
+
+    def dequantized_weight(self, dtype):
+        """δ·(q − z) as a tensor: weight-only mode feeds it to the library GEMM/conv."""
+        pw = self.packed_weight()
+        if self._wdq is None or self._wdq.dtype != dtype:
+            w = (pw.alpha[:, None] * (pw.codes.float() - pw.zp_true[:, None])).view(self.w.shape)
+            self._wdq = w.to(dtype)
+            if self.is_conv:
+                self._wdq = self._wdq.contiguous(memory_format=torch.channels_last)
+        return self._wdq
+
+    # -- activation tables ----------------------------------------------------------------------------
+    def set_act_table(self, slot, delta, zero_point):
+        self._act_tables[slot] = (delta, zero_point)
+        self._bindings.pop(slot, None)
+
+    def _binding(self) -> ops.ActBinding:
+        pw = self.packed_weight()
+        slot = self._slot_ref.slot if self._slot_ref is not None else None
+        if slot is not None and slot in self._act_tables:
+            key = slot
+            if key not in self._bindings:
+                d, z = self._act_tables[slot]
+                lay = plan_act(d, z, "conv" if self.is_conv else "linear", self.in_channels, self.taps, self.aqtizer.bits)
+                self._bindings[key] = ops.ActBinding(lay, pw, self.aqtizer.bits)
+            return self._bindings[key]
+        a = self.aqtizer
+        d = a.delta
+        z = torch.as_tensor(a.zero_point)
+        key = ("live", d.data_ptr(), d._version, z.data_ptr() if z.numel() else 0, z._version)
+        if key not in self._bindings:
+            self._bindings = {k: v for k, v in self._bindings.items() if not (isinstance(k, tuple) and k[0] == "live")}
+            lay = plan_act(d.data, z.data, "conv" if self.is_conv else "linear", self.in_channels, self.taps, a.bits)
+            self._bindings[key] = ops.ActBinding(lay, pw, a.bits)
+        return self._bindings[key]
+
+    # -- forward ----------------------------------------------------------------------------------------
+    def forward(self, x: torch.Tensor, split: int = 0) -> torch.Tensor:
+        quant_act = self.use_aq and not self.disable_aq
+        if not self.use_wq:
+            w = self.original_w.to(device=x.device, dtype=x.dtype)
+            b = self.original_b.to(device=x.device, dtype=x.dtype) if self.original_b is not None else None
+            if quant_act:
+                x = self.aqtizer(x)
+            if self.is_conv:
+                return F.conv2d(x, w, b, stride=self.fwd_kwargs["stride"], padding=self.fwd_kwargs["padding"])
+            return F.linear(x, w, b)
+        if not x.is_cuda:
+            raise RuntimeError("dgq_amd.QuantLayer: the quantized path runs only through the HIP kernels on the GPU "
+                               "(no CPU fallback); got a %s tensor" % x.device)
+        if not quant_act:
+            w = self.dequantized_weight(x.dtype)
+            b = self.b.to(x.dtype) if self.b is not None else None
+            if self.is_conv:
+                return F.conv2d(x, w, b, stride=self.fwd_kwargs["stride"], padding=self.fwd_kwargs["padding"])
+            return F.linear(x, w, b)
+        if not self.aqtizer.init and not (self._slot_ref is not None and self._slot_ref.slot in self._act_tables):
+            self.aqtizer.init_from(x)           # first-forward self-initialisation (quant_layer.py:274-278)
+        ab = self._binding()
+        if self.is_conv:
+            kh, kw = self.w.shape[2], self.w.shape[3]
+            return ops.quant_conv2d(x, ab, kh, kw, self.fwd_kwargs["stride"][0], self.fwd_kwargs["padding"][0])
+        return ops.quant_linear(x, ab)
+
+    # -- state switches (quant_layer.py:663-686) -----------------------------------------------------------
+    def set_quant_state(self, use_wq: bool = False, use_aq: bool = False) -> None:
+        self.use_wq = use_wq if not self.ignore_recon else False
+        self.use_aq = use_aq if not self.ignore_recon else False
+
+    def set_running_stat(self, running_stat: bool) -> None:
+        if running_stat:
+            raise NotImplementedError("running statistics are calibration-time (SURVEY.md §8(f)-1)")
+        self.aqtizer.running_stat = False
+
+    def set_group_num(self, group_num: int = 1) -> None:
+        raise NotImplementedError("DGQ activation calibration (set_group_num/done_group_num) is the producer side "
+                                  "of the cali_ckpt — SURVEY.md §8(f)-1, not part of the inference path")
+
+    def done_group_num(self, group_num, mode) -> None:
+        self.set_group_num(group_num)
+
+    def half(self):
+        super().half()
+        self.original_w = self.original_w.half()
+        if self.original_b is not None:
+            self.original_b = self.original_b.half()
+        return self
+
+    def float(self):
+        super().float()
+        self.original_w = self.original_w.float()
+        if self.original_b is not None:
+            self.original_b = self.original_b.float()
+        return self
+
+    def _apply(self, fn, *a, **k):
+        super()._apply(fn, *a, **k)
+        self.original_w = fn(self.original_w)
+        if self.original_b is not None:
+            self.original_b = fn(self.original_b)
+        return self

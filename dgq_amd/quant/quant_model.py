@@ -1,0 +1,144 @@
+"""QuantModel — mirror of the reference's ``quant/quant_model.py:18-205``: recursively wraps every
+nn.Linear / nn.Conv2d into a QuantLayer and every ResnetBlock2D / BasicTransformerBlock into its Quant block,
+keeps the ``config`` shim the diffusers pipeline reads, the state switches, ``half/float`` and ``device``."""
+from typing import List
+
+import torch
+import torch.nn as nn
+
+from .adaptive_rounding import AdaRoundQuantizer
+from .quant_block import BaseQuantBlock, QuantBasicTransformerBlock, QuantResnetBlock2D, b2qb
+from .quant_layer import QMODE, QuantLayer, SlotRef, StraightThrough, UniformAffineQuantizer
+from .quant_layer_text import T2ILogQuantizer
+
+
+class CFG:
+    in_channels = 0
+    sample_size = 0
+    time_cond_proj_dim = 0
+    addition_time_embed_dim = 0
+
+
+def _cfg_get(cfg, name, default=None):
+    if isinstance(cfg, dict):
+        return cfg.get(name, default)
+    return getattr(cfg, name, default)
+
+
+class QuantModel(nn.Module):
+    def __init__(self, model: nn.Module, wq_params: dict = {}, aq_params: dict = {}, softmax_aq_params: dict = {},
+                 cali: bool = True, tib_recon: bool = False, **kwargs) -> None:
+        super().__init__()
+        if tib_recon:
+            raise NotImplementedError("tib_recon is reconstruction-time (quant_model.py:52-64); inference uses False")
+        self.model = model
+        self.config = CFG()                                           # for the diffusers pipeline
+        self.config.in_channels = _cfg_get(model.config, "in_channels")
+        self.config.sample_size = _cfg_get(model.config, "sample_size")
+        self.config.time_cond_proj_dim = _cfg_get(model.config, "time_cond_proj_dim")
+        if _cfg_get(model.config, "addition_time_embed_dim") is not None:
+            self.config.addition_time_embed_dim = _cfg_get(model.config, "addition_time_embed_dim")
+        self.tib_recon = tib_recon
+        self.B = b2qb()
+        self.slot_ref = SlotRef()
+        self.quant_module(self.model, wq_params, aq_params, aq_mode=kwargs.get("aq_mode", [QMODE.NORMAL.value]),
+                          prev_name=None)
+        self.quant_block(self.model, wq_params, aq_params, softmax_aq_params)
+        self.time_aware = None          # set by load_cali_model(time_aware_aqtizer=True)
+
+    # -- module surgery (quant_model.py:66-103) ------------------------------------------------------------
+    def quant_module(self, module: nn.Module, wq_params: dict = {}, aq_params: dict = {},
+                     aq_mode: List[int] = [QMODE.NORMAL.value], prev_name: str = None) -> None:
+        for name, child in module.named_children():
+            if isinstance(child, tuple(QuantLayer.QMAP.keys())):
+                ql = QuantLayer(child, wq_params, aq_params, aq_mode=aq_mode)
+                ql._slot_ref = self.slot_ref
+                setattr(module, name, ql)
+            elif isinstance(child, StraightThrough):
+                continue
+            else:
+                self.quant_module(child, wq_params, aq_params, aq_mode=aq_mode, prev_name=name)
+
+    def quant_block(self, module: nn.Module, wq_params: dict = {}, aq_params: dict = {},
+                    softmax_aq_params: dict = {}) -> None:
+        for name, child in module.named_children():
+            cls = self.B.get(child.__class__.__name__)
+            if cls is QuantBasicTransformerBlock:
+                setattr(module, name, cls(child, aq_params, softmax_aq_params))
+            elif cls is QuantResnetBlock2D:
+                setattr(module, name, cls(child, aq_params))
+            else:
+                self.quant_block(child, wq_params, aq_params, softmax_aq_params)
+
+    # -- state switches ----------------------------------------------------------------------------------------
+    def set_quant_state(self, use_wq: bool = False, use_aq: bool = False) -> None:
+        for m in self.model.modules():
+            if isinstance(m, (BaseQuantBlock, QuantLayer)):
+                m.set_quant_state(use_wq=use_wq, use_aq=use_aq)
+
+    def disable_out_quantization(self) -> None:
+        """conv_in / conv_out stay floating point (quant_model.py:118-124)."""
+        self.model.conv_in.use_wq = False
+        self.model.conv_in.disable_aq = True
+        self.model.conv_out.use_wq = False
+        self.model.conv_out.disable_aq = True
+
+    def forward(self, sample, timesteps, encoder_hidden_states, *args, **kwargs):
+        if self.time_aware is not None:
+            # time-aware activation tables (calibration.py:297-312): the reference re-copies ~750 δ/z tensors
+            # host->device here; every slot is already device-resident, so this only flips an index.
+            t = timesteps if not torch.is_tensor(timesteps) else (timesteps if timesteps.dim() == 0 else timesteps[0])
+            n = self.time_aware["num_inference_steps"]
+            slot = int((1000 - int(t)) // (1000 // n))
+            self.activate_slot(slot)
+        return self.model(sample, timesteps, encoder_hidden_states, *args, **kwargs)
+
+    def activate_slot(self, slot: int):
+        ta = self.time_aware
+        if slot not in ta["slots"]:
+            raise KeyError("cali_ckpt has no 'act_%d' (needs act_0..act_%d for %d inference steps)"
+                           % (slot, ta["num_inference_steps"] - 1, ta["num_inference_steps"]))
+        if self.slot_ref.slot == slot:
+            return
+        self.slot_ref.slot = slot
+        for q, table in ta["attn"]:                 # attention-side quantizers: swap the (device) tensors
+            d, z = table[slot]
+            q.delta.data = d
+            q.zero_point.data = z
+
+    # -- calibration-time API (producer side) -----------------------------------------------
+    def set_group_num(self, group_num: int = 1) -> None:
+        raise NotImplementedError("DGQ activation calibration is not part of the inference path (SURVEY.md §8(f)-1)")
+
+    def done_group_num(self, group_num, mode) -> None:
+        self.set_group_num(group_num)
+
+    def set_running_stat(self, running_stat: bool = False) -> None:
+        if running_stat:
+            raise NotImplementedError("running statistics are calibration-time (SURVEY.md §8(f)-1)")
+
+    def synchorize_activation_statistics(self):
+        raise NotImplementedError("multi-GPU calibration is disabled in the reference too (src/quantize_weight.py:214)")
+
+    # -- dtype / device ---------------------------------------------------------------------------------------
+    def half(self):
+        super().half()
+        for m in self.model.modules():
+            if isinstance(m, (AdaRoundQuantizer, UniformAffineQuantizer, QuantLayer)):
+                m.half()
+        return self
+
+    def float(self):
+        super().float()
+        for m in self.model.modules():
+            if isinstance(m, (AdaRoundQuantizer, UniformAffineQuantizer, QuantLayer)):
+                m.float()
+        return self
+
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+    @property
+    def dtype(self):
+        return next(self.parameters()).dtype
