@@ -255,7 +255,28 @@ def make_unet(ref, arch, name, res=None, batch=2):
         outs[t] = y.clone()
     meta = dict(c)
     meta.update(arch=arch, res=res, batch=batch, seed=0, input_seed=1)
-    save("f5_unet_%s_%s_r%d.pt" % (arch, name, res), dict(meta=meta, outputs=outs))
+    blob = dict(meta=meta, outputs=outs)
+    if c["use_aq"]:
+        # The same reference code on the same inputs with ONE BLAS thread: only the fp32 summation order inside
+        # the GEMMs changes.  The difference to `outputs` is the reference's own sensitivity to rounding — the
+        # scale against which any other implementation's end-to-end deviation has to be read.
+        nt = torch.get_num_threads()
+        torch.set_num_threads(1)
+        outs1 = {}
+        for t in c["ts"]:
+            t0 = time.time()
+            if arch == "sdxl":
+                y = qnn(inp["sample"], torch.tensor(t), inp["encoder_hidden_states"],
+                        added_cond_kwargs={"text_embeds": inp["text_embeds"], "time_ids": inp["time_ids"]})[0]
+            else:
+                y = qnn(inp["sample"], torch.tensor(t), inp["encoder_hidden_states"])[0]
+            rel = ((y - outs[t]).norm() / outs[t].norm()).item()
+            print("1-thread t=%d  %.1fs  rel-L2 vs %d-thread run: %.4g" % (t, time.time() - t0, nt, rel))
+            outs1[t] = y.clone()
+        torch.set_num_threads(nt)
+        blob["outputs_1thread"] = outs1
+        blob["meta"]["threads"] = nt
+    save("f5_unet_%s_%s_r%d.pt" % (arch, name, res), blob)
 
 
 def make_ddim(ref, steps=50, res=64, name="c2"):
