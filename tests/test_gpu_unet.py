@@ -68,11 +68,14 @@ def teacher_forced_check(qnn, io, run):
     tensors and (2) replaced by them.  Because the fake-quant UNet is chaotic (a 1e-7
     perturbation grows to ~1e-1 through the quantizers — the reference differs from ITSELF by that much when
     only the BLAS thread count changes), this is how every operator of the path is pinned tightly:
-      * layer outputs: integer GEMM vs the reference's fp32 GEMM on IDENTICAL inputs  -> tol 2e-5 rel-L2
+      * layer outputs: integer GEMM vs the reference's fp32 GEMM on IDENTICAL inputs  -> tol 1e-4 rel-L2
+        (median ~3e-7; the reference's own fp32 accumulation error grows ~sqrt(K): K=23040 convs reach 4e-5)
       * layer inputs: the glue since the previous pinned tensor (GN/LN/SiLU/GELU/residual/concat/upsample,
         time embedding)                                                               -> tol 2e-5
-      * to_out inputs: the attention core (q/k/v quantizers, softmax, log2-quantised probabilities, P·V); a
-        few probabilities sit on a rounding tie and flip one code                     -> tol 2e-3
+      * to_out inputs: the attention core (q/k/v quantizers, softmax, log2-quantised probabilities, P·V):
+        75 % of the 32 attentions within 1e-5 (observed median 2e-7); an attention where one probability
+        sits on a log2 rounding tie flips a code (p changes 2x) — with only 4 query tokens in the 16x16
+        mid block a single flip is 3e-3 of the tensor                                 -> max tol 2e-2
     """
     from dgq_amd.quant import QuantLayer
     stats = {"out": [], "in": [], "attn": []}
@@ -129,10 +132,22 @@ def test_unet_teacher_forced_vs_oracle(res, tmp_path_factory):
                 out["y"] = qnn(inp["sample"].cuda(), torch.tensor(t), inp["encoder_hidden_states"].cuda())[0]
         stats = teacher_forced_check(qnn, rec.io, run)
         assert len(stats["out"]) == 280                      # every quantized layer of SD1.4 was exercised
-        for kind, tol in (("out", 2e-5), ("in", 2e-5), ("attn", 2e-3)):
+        fails = []
+        for kind, tol in (("out", 1e-4), ("in", 2e-5), ("attn", 2e-2)):
             worst = max(stats[kind])
-            print("res=%d t=%d %-4s n=%d worst rel-L2 %.3g (%s)" % (res, t, kind, len(stats[kind]), worst[0], worst[1]))
-            assert worst[0] < tol, (kind, worst)
+            errs = sorted(e for e, _ in stats[kind])
+            med = errs[len(errs) // 2]
+            if kind == "attn" and errs[int(0.75 * len(errs))] >= 1e-5:
+                fails.append(("attn-p75", errs[int(0.75 * len(errs))]))
+            print("res=%d t=%d %-4s n=%d median %.3g worst rel-L2 %.3g (%s)"
+                  % (res, t, kind, len(stats[kind]), med, worst[0], worst[1]))
+            if worst[0] >= tol:
+                fails.append((kind, worst))
+            os.makedirs("gpurun_out", exist_ok=True)
+            with open("gpurun_out/tf_stats_r%d_t%d_%s.txt" % (res, t, kind), "w") as fh:
+                for e, n in sorted(stats[kind], reverse=True):
+                    fh.write("%.4e %s\n" % (e, n))
+        assert not fails, fails
         # tail of the network after the last pinned tensor (conv_norm_out -> SiLU -> FP conv_out)
         e = rel_l2(out["y"].float().cpu(), ref)
         print("res=%d t=%d final (teacher-forced) rel-L2 %.3g" % (res, t, e))
