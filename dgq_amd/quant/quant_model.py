@@ -106,6 +106,20 @@ class QuantModel(nn.Module):
             q.delta.data = d
             q.zero_point.data = z
 
+    def prepare_slots(self, slots=None):
+        """Plan + upload the activation tables (and per-slot permuted weight copies) of the given timestep
+        slots ahead of time, so the first forward of a slot does no host work."""
+        if self.time_aware is None:
+            return
+        slots = sorted(self.time_aware["slots"]) if slots is None else slots
+        prev = self.slot_ref.slot
+        for s in slots:
+            self.slot_ref.slot = s
+            for m in self.model.modules():
+                if isinstance(m, QuantLayer) and m.use_wq and m.use_aq and not m.disable_aq and s in m._act_tables:
+                    m._binding()
+        self.slot_ref.slot = prev
+
     # -- calibration-time API (producer side, SURVEY.md §8(f)-1) -----------------------------------------------
     def set_group_num(self, group_num: int = 1) -> None:
         raise NotImplementedError("DGQ activation calibration is not part of the inference path (SURVEY.md §8(f)-1)")

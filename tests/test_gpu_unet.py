@@ -22,25 +22,8 @@ def rel_l2(a, b):
 
 
 def build_qnn(arch, c, res, batch, slots, tmpdir):
-    from dgq_amd.diffusers_rewrite import UNet2DConditionModel
-    from dgq_amd.quant import get_qmodel, Scaler
-    path = os.path.join(tmpdir, "ck_%s_w%da%dg%d_r%d.pth" % (arch, c["wbits"], c["abits"], c["G"], res))
-    if not os.path.exists(path):
-        synth.write_cali_ckpt(path, arch, c["wbits"], c["abits"], c["G"], num_slots=slots, seed=0, batch=batch, res=res,
-                              start_peak=c["sp"], uniform_softmax=(c["use_aq"] and not c["log"]), with_act=c["use_aq"])
-    unet = UNet2DConditionModel(arch)
-    synth.load_synth_weights(unet, arch, 0)
-    pipe = types.SimpleNamespace(unet=unet)
-    wq = {"bits": c["wbits"], "channel_wise": True, "scaler": Scaler.MINMAX}
-    aq = {"bits": c["abits"], "channel_wise": False, "scaler": Scaler.MINMAX, "leaf_param": c["use_aq"]}
-    sm = {"softmax_a_bit": c["abits"], "t2i_log_quant": c["log"], "t2i_real_time": c["rt"],
-          "t2i_start_peak": c["sp"], "log_max_1": False}
-    qnn = get_qmodel(arch, pipe, path, wq, c["use_aq"], aq, sm, c["G"] > 1, c["steps"],
-                     c["time_aware"] and c["use_aq"])
-    qnn.float()
-    qnn = qnn.cuda()
-    qnn.disable_out_quantization()
-    return qnn, path
+    from dgq_amd.runtime import build_synthetic_qnn
+    return build_synthetic_qnn(arch, c, res, batch, slots, ckpt_dir=tmpdir)
 
 
 C2 = dict(wbits=4, abits=8, use_aq=True, G=16, log=True, rt=True, sp=True, time_aware=True, steps=50)
