@@ -33,6 +33,14 @@ ARCH = {
         up=(("plain", 0, True), ("xattn", 1, True), ("xattn", 1, True), ("xattn", 1, False)),
         addition_time_embed_dim=None, add_in=None,
     ),
+    # a miniature of the SD layout (same block kinds, conv projections, 8 heads) for fast tests
+    "tiny": dict(
+        sample_size=16, ctx_dim=64, heads=8, head_dim=None, proj="conv", mid_layers=1,
+        block_out=(64, 128),
+        down=(("xattn", 1, True), ("plain", 0, False)),
+        up=(("plain", 0, True), ("xattn", 1, False)),
+        addition_time_embed_dim=None, add_in=None, temb_dim=128,
+    ),
     "sdxl": dict(
         sample_size=128, ctx_dim=2048, heads=None, head_dim=64, proj="linear", mid_layers=10,
         block_out=(320, 640, 1280),
@@ -213,7 +221,7 @@ class _Stage(nn.Module):
 
     def __init__(self, res_io, tf_layers, a, sampler=None):
         super().__init__()
-        self.resnets = nn.ModuleList([ResnetBlock2D(i, o) for i, o in res_io])
+        self.resnets = nn.ModuleList([ResnetBlock2D(i, o, a.get("temb_dim", 1280)) for i, o in res_io])
         if tf_layers:
             n_att = len(res_io) if sampler != "mid" else len(res_io) - 1
             self.attentions = nn.ModuleList(
@@ -274,10 +282,11 @@ class UNet2DConditionModel(nn.Module):
         bo = a["block_out"]
         self.conv_in = nn.Conv2d(4, bo[0], 3, 1, 1)
         self.time_proj = Timesteps(bo[0])
-        self.time_embedding = TimestepEmbedding(bo[0], 1280)
+        td = a.get("temb_dim", 1280)
+        self.time_embedding = TimestepEmbedding(bo[0], td)
         if a["add_in"]:
             self.add_time_proj = Timesteps(a["addition_time_embed_dim"])
-            self.add_embedding = TimestepEmbedding(a["add_in"], 1280)
+            self.add_embedding = TimestepEmbedding(a["add_in"], td)
         # skip-channel bookkeeping: every down resnet output and every downsampler output is a skip
         skip_ch = [bo[0]]
         downs, cin = [], bo[0]

@@ -62,7 +62,7 @@ int dgq_pack_w8(const uint8_t* codes, int N, int K, const int32_t* kperm, int Kp
  * x is a channels-last tensor [B][H][W][C] (a Linear input [B,T,K] is B=B·T... H=W=1, C=K); geometry
  * (kh,kw,stride,pad) as the conv; M = B·Ho·Wo.  Source of packed position kp:
  *   ksrc == NULL : natural order kp = tap·C + c   (tap = dh·kw + dw)
- *   ksrc != NULL : ksrc[kp] = c + C·tap, or -1 for padding.
+ *   ksrc != NULL : ksrc[kp] = (tap << 16) | c, or -1 for padding (zero code).
  * Quantiser parameters:
  *   per_m == 0 : cdelta/czp [Kp/64] — one (δ,z) per 64-wide chunk (DGQ groups are chunk aligned);
  *                rowsum[m] = Σ_kp δ(kp)·s[m,kp]

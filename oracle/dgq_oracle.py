@@ -105,6 +105,18 @@ def slot_for_timestep(t, num_inference_steps):
     return int((1000 - int(t)) // (1000 // num_inference_steps))
 
 
+# (n transformer layers, has down/up-sampler) per block; the same tables as the reference's two model files
+# (sd.py:493-544, sdxl.py:505-556) plus a miniature of the SD layout for fast tests.
+ORACLE_ARCH = {
+    "sd": dict(bo=(320, 640, 1280, 1280), down=((1, True), (1, True), (1, True), (0, False)),
+               up=((0, True), (1, True), (1, True), (1, False)), proj="conv", heads=lambda c: 8, mid=1),
+    "sdxl": dict(bo=(320, 640, 1280), down=((0, True), (2, True), (10, False)),
+                 up=((10, True), (2, True), (0, False)), proj="linear", heads=lambda c: c // 64, mid=10),
+    "tiny": dict(bo=(64, 128), down=((1, True), (0, False)), up=((0, True), (1, False)), proj="conv",
+                 heads=lambda c: 8, mid=1),
+}
+
+
 class OracleConfig:
     def __init__(self, arch="sd", wbits=4, abits=8, use_wq=True, use_aq=True, softmax_bits=None,
                  t2i_log_quant=False, t2i_real_time=False, t2i_start_peak=False,
@@ -330,17 +342,14 @@ class OracleModel:
         cfg = self.cfg
         if cfg.use_aq and cfg.time_aware:
             self.act = self.ck["act_%d" % slot_for_timestep(t, cfg.num_inference_steps)]
+        A = ORACLE_ARCH[cfg.arch]
         xl = cfg.arch == "sdxl"
         tt = torch.as_tensor(t).reshape(-1).expand(sample.shape[0])
-        emb = self.time_embed("time_embedding", self.timesteps_embedding(tt, 320))
+        emb = self.time_embed("time_embedding", self.timesteps_embedding(tt, A["bo"][0]))
         if xl:
             te = self.timesteps_embedding(time_ids.flatten(), 256).reshape(text_embeds.shape[0], -1)
             emb = emb + self.time_embed("add_embedding", torch.cat([text_embeds, te], dim=-1))
-        bo = (320, 640, 1280) if xl else (320, 640, 1280, 1280)
-        down = ((0, True), (2, True), (10, False)) if xl else ((1, True), (1, True), (1, True), (0, False))
-        up = ((10, True), (2, True), (0, False)) if xl else ((0, True), (1, True), (1, True), (1, False))
-        proj = "linear" if xl else "conv"
-        heads = (lambda c: c // 64) if xl else (lambda c: 8)
+        bo, down, up, proj, heads = A["bo"], A["down"], A["up"], A["proj"], A["heads"]
         h = self.fp_conv("conv_in", sample)
         skips = [h]
         for i, ((nl, has_down), c) in enumerate(zip(down, bo)):
@@ -353,7 +362,7 @@ class OracleModel:
                 h = self.conv("down_blocks.%d.downsamplers.0.conv" % i, h, 2, 1)
                 skips.append(h)
         h = self.resnet("mid_block.resnets.0", h, emb)
-        h = self.transformer2d("mid_block.attentions.0", h, ctx, 10 if xl else 1, heads(1280), proj)
+        h = self.transformer2d("mid_block.attentions.0", h, ctx, A["mid"], heads(bo[-1]), proj)
         h = self.resnet("mid_block.resnets.1", h, emb)
         for i, ((nl, has_up), c) in enumerate(zip(up, reversed(bo))):
             for j in range(3):
