@@ -18,7 +18,9 @@ SIGNATURES = {
     "dgq_unpack_w4": [_vp, _i, _i, _vp, _vp],
     "dgq_pack_w8": [_vp, _i, _i, _vp, _i, _vp, _vp],
     "dgq_quant_act": [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _vp],
-    "dgq_gemm_wxa8": [_vp, _vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
+    "dgq_gemm_wxa8": [_vp, _vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _vp, _i, _i,
+                      _vp, ctypes.c_size_t, _vp],
+    "dgq_gemm_workspace_bytes": [_i, _i, _i],
     "dgq_fakequant_rows": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp],
     "dgq_max_f32": [_vp, _i64, _i, _i, _vp, _vp],
     "dgq_logquant_f32": [_vp, _vp, _i64, _i, _i, _vp, _i, _vp],
@@ -39,7 +41,7 @@ def load():
         for name, args in SIGNATURES.items():
             fn = getattr(lib, name)
             fn.argtypes = args
-            fn.restype = ctypes.c_int
+            fn.restype = ctypes.c_size_t if name == "dgq_gemm_workspace_bytes" else ctypes.c_int
         lib.dgq_last_error.argtypes = []
         lib.dgq_last_error.restype = ctypes.c_char_p
         _lib = lib

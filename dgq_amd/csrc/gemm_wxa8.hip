@@ -1,20 +1,32 @@
 // W4A8 / W8A8 GEMM on V_MFMA_I32_16X16X64_I8 with DGQ per-group dequantisation fused in.
 //
-//   A  = int8 activation codes [M][Kp]  (from dgq_quant_act; K already permuted so each DGQ group is a run of
-//        64-wide chunks)
-//   W  = int4 packed [N][Kp/2] (nibbles -> int8 on the way into LDS) or int8 [N][Kp]
+//   A  = int8 activation codes [M][Kp]  (from dgq_quant_act; K already permuted so that each DGQ group is a run
+//        of 64-wide chunks)
+//   W  = int4 packed [N][Kp/2]  or int8 [N][Kp]
 //   Y  = fp [M][N]
 //
-// Tiling (wave64, gfx950): 128x128 block tile, BK = 128 (two MFMA K-slices), 256 threads = 2x2 waves,
-// each wave owns 64x64 = 4x4 MFMA tiles: 64 int32 accumulators + (per-K mode) 64 fp32 accumulators.
-// LDS: double-buffered A and W tiles of 128 rows x 128 B, 16-byte chunks XOR-swizzled with (row>>1)&7 so
-// that every ds_read_b128 lane group covers all 64 banks once.  Global->register prefetch of tile t+1
-// overlaps the MFMAs of tile t; one barrier per K step.
+// Tiling (wave64, gfx950): 128x128 block tile, BK = 128 (two MFMA K-slices), 256 threads = 2x2 waves, each wave
+// owns 64x64 = 4x4 MFMA tiles: 64 int32 accumulators + (per-K mode) 64 fp32 accumulators.
+//
+// Operand staging is LDS-DMA only (global_load_lds_dwordx4: no staging VGPRs, no ds_write — ds_write_b128 runs at
+// ~79 B/clk/CU and was the bottleneck of the register-staged version): a 3-stage LDS ring, tile t+2 is issued
+// before the MFMAs of tile t, a counted s_waitcnt vmcnt leaves it in flight across the (raw) barrier.
+// LDS images are lane-linear per DMA instruction, so the bank swizzle is applied to the per-lane SOURCE address
+// and to the ds_read address (cdna guide rule 21):
+//   A / int8-W tile: 128-byte rows, 16-byte chunk c stored at c ^ ((row>>1)&7)   -> conflict-free ds_read_b128
+//   int4-W tile    : 64-byte rows (packed), 8-byte slot s stored at s ^ (((row>>2)&3)<<1) -> conflict-free ds_read_b64
+// int4 weights stay packed in LDS (half the LDS bytes) and are widened to int8 in registers right after the
+// ds_read: (w & 0x0F0F0F0F), ((w>>4) & 0x0F0F0F0F) — the dgq_pack_w4 nibble order makes those 4 consecutive k each.
+//
+// Small grids (most SD1.4 layers give 10..192 tiles on 256 CUs) use deterministic split-K: grid.z slices of the
+// K-tile range write fp32 partial slabs [S][M][N] to a caller-provided workspace; splitk_epilogue_kernel sums
+// them in a fixed order and applies the dequantisation epilogue (no float atomics: results are bit-reproducible).
 #include "dgq_common.h"
 
 #define BM 128
 #define BN 128
 #define BK 128
+#define STAGES 3
 
 struct GemmParams {
     const int8_t* codes;
@@ -33,87 +45,99 @@ struct GemmParams {
     const float* vn;
     void* y;
     int ldy;
+    float* slab;          // split-K partials [S][M][N] (nullptr when S == 1)
+    int splits;
+    int tiles_per_split;  // K tiles (of BK) per split
 };
 
-__device__ __forceinline__ int swz(int row, int chunk) { return row * BK + ((chunk ^ ((row >> 1) & 7)) << 4); }
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// LDS-DMA of 16 B per lane: LDS[lds_addr + lane*16] <- *gsrc.  Issued from inline asm on purpose: with the builtin
+// hipcc treats the DMA as an LDS store that every later ds_read may alias and drains it with s_waitcnt vmcnt(0)
+// before the first ds_read of each K step; here the ring is ordered by hand (counted vmcnt + barrier below).
+// M0 carries the wave-uniform LDS base and is written in the same statement that uses it (cdna guide §5.7).
+__device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_addr) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_addr)
+                 : "memory");
+}
+
+template <bool PER_M>
+__device__ __forceinline__ float dgq_epilogue(const GemmParams& p, float acc, int m, int n, float al, float zw, float ga,
+                                              float vn) {
+    const float rs = p.rowsum[m];
+    if (PER_M) {
+        const int li = m % p.L;
+        const float md = p.mdelta[li], mz = p.mzp[li];
+        return al * (md * acc - zw * (md * rs) + (md * (p.offset - mz)) * vn) + ga;
+    }
+    return al * (acc - zw * rs) + ga;
+}
 
 template <int WBITS, bool PER_M, typename TOut>
 __global__ __launch_bounds__(256, 2) void gemm_wxa8_kernel(GemmParams p) {
-    __shared__ __attribute__((aligned(16))) uint8_t smem[2 * 2 * BM * BK];   // [buf][A|W][128][128]
-    uint8_t* sA = smem;
-    uint8_t* sW = smem + 2 * BM * BK;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    constexpr int A_BYTES = BM * BK;                       // 16 KiB
+    constexpr int W_ROW = (WBITS == 4) ? BK / 2 : BK;      // bytes per n-row per stage
+    constexpr int W_BYTES = BN * W_ROW;
+    constexpr int STAGE_BYTES = A_BYTES + W_BYTES;
+    constexpr int A_DMA = A_BYTES / 1024 / 4;              // DMA instructions per wave per tile (1 KiB each)
+    constexpr int W_DMA = W_BYTES / 1024 / 4;
+    constexpr int DMA_PER_TILE = A_DMA + W_DMA;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wid = tid >> 6;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wave_m = wid >> 1, wave_n = wid & 1;
     const int n0 = blockIdx.x * BN;
     const int m0 = blockIdx.y * BM;
-    const int nk = p.Kp / BK;
+    const int nk_total = p.Kp / BK;
+    const int kt_begin = blockIdx.z * p.tiles_per_split;
+    const int kt_end = min(nk_total, kt_begin + p.tiles_per_split);
+    const int nk = kt_end - kt_begin;
 
-    uint4 ra[4];
-    uint4 rw[WBITS == 4 ? 2 : 4];
-
-    auto load_tile = [&](int kt) {
-        const int k0 = kt * BK;
+    // per-lane global source pointers of this wave's DMA pieces (k offset added per tile)
+    const int8_t* a_src[A_DMA];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int id = tid + 256 * i;
-            int row = id >> 3, c = id & 7;
-            int m = m0 + row;
-            ra[i] = (m < p.M) ? *reinterpret_cast<const uint4*>(p.codes + (int64_t)m * p.Kp + k0 + 16 * c)
-                              : make_uint4(0, 0, 0, 0);
-        }
-        if (WBITS == 4) {
+    for (int i = 0; i < A_DMA; ++i) {
+        const int blk = wid * A_DMA + i;                   // 1 KiB = 8 rows of 128 B
+        const int row = blk * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        const int m = min(m0 + row, p.M - 1);
+        a_src[i] = p.codes + (int64_t)m * p.Kp + 16 * c;
+    }
+    const uint8_t* w_src[W_DMA];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                int id = tid + 256 * i;
-                int row = id >> 2, pc = id & 3;
-                int n = n0 + row;
-                rw[i] = (n < p.N) ? *reinterpret_cast<const uint4*>(p.wpacked + (int64_t)n * (p.Kp / 2) + k0 / 2 + 16 * pc)
-                                  : make_uint4(0, 0, 0, 0);
-            }
+    for (int i = 0; i < W_DMA; ++i) {
+        const int blk = wid * W_DMA + i;
+        if (WBITS == 4) {                                  // 1 KiB = 16 rows of 64 B
+            const int row = blk * 16 + (lane >> 2);
+            const int c = (lane & 3) ^ ((row >> 2) & 3);
+            const int n = min(n0 + row, p.N - 1);
+            w_src[i] = p.wpacked + (int64_t)n * (p.Kp / 2) + 16 * c;
         } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                int id = tid + 256 * i;
-                int row = id >> 3, c = id & 7;
-                int n = n0 + row;
-                rw[i] = (n < p.N) ? *reinterpret_cast<const uint4*>(p.wpacked + (int64_t)n * p.Kp + k0 + 16 * c)
-                                  : make_uint4(0, 0, 0, 0);
-            }
+            const int row = blk * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ ((row >> 1) & 7);
+            const int n = min(n0 + row, p.N - 1);
+            w_src[i] = p.wpacked + (int64_t)n * p.Kp + 16 * c;
         }
-    };
+    }
 
-    auto store_tile = [&](int buf) {
-        uint8_t* a = sA + buf * BM * BK;
-        uint8_t* w = sW + buf * BN * BK;
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(lptr_t)smem;
+    auto issue_tile = [&](int kt, int stage) {
+        const uint32_t sa = lds_base + stage * STAGE_BYTES;
+        const uint32_t sw = sa + A_BYTES;
+        const int64_t ka = (int64_t)kt * BK;
+        const int64_t kw = (WBITS == 4) ? ka / 2 : ka;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int id = tid + 256 * i;
-            int row = id >> 3, c = id & 7;
-            *reinterpret_cast<uint4*>(a + swz(row, c)) = ra[i];
-        }
-        if (WBITS == 4) {
+        for (int i = 0; i < A_DMA; ++i)
+            glds16(a_src[i] + ka, __builtin_amdgcn_readfirstlane(sa + (wid * A_DMA + i) * 1024));
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                int id = tid + 256 * i;
-                int row = id >> 2, pc = id & 3;
-                uint4 v = rw[i];
-                // int4 -> int8: low nibbles = 4 consecutive k, high nibbles = the next 4 (dgq_pack_w4 layout)
-                uint4 c0 = make_uint4(v.x & 0x0F0F0F0Fu, (v.x >> 4) & 0x0F0F0F0Fu, v.y & 0x0F0F0F0Fu, (v.y >> 4) & 0x0F0F0F0Fu);
-                uint4 c1 = make_uint4(v.z & 0x0F0F0F0Fu, (v.z >> 4) & 0x0F0F0F0Fu, v.w & 0x0F0F0F0Fu, (v.w >> 4) & 0x0F0F0F0Fu);
-                *reinterpret_cast<uint4*>(w + swz(row, 2 * pc)) = c0;
-                *reinterpret_cast<uint4*>(w + swz(row, 2 * pc + 1)) = c1;
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                int id = tid + 256 * i;
-                int row = id >> 3, c = id & 7;
-                *reinterpret_cast<uint4*>(w + swz(row, c)) = rw[i];
-            }
-        }
+        for (int i = 0; i < W_DMA; ++i)
+            glds16(w_src[i] + kw, __builtin_amdgcn_readfirstlane(sw + (wid * W_DMA + i) * 1024));
     };
 
     v4i acc[4][4];
@@ -127,27 +151,82 @@ __global__ __launch_bounds__(256, 2) void gemm_wxa8_kernel(GemmParams p) {
         }
 
     const int fr = lane & 15, fq = lane >> 4;
+    // ds_read byte offsets inside a stage (h = K half adds its chunk index below)
+    int a_off[4][2], w_off[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = wave_m * 64 + i * 16 + fr;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) a_off[i][h] = row * BK + (((4 * h + fq) ^ ((row >> 1) & 7)) << 4);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = wave_n * 64 + j * 16 + fr;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (WBITS == 4) w_off[j][h] = row * W_ROW + (((4 * h + fq) ^ (((row >> 2) & 3) << 1)) << 3);
+            else w_off[j][h] = row * BK + (((4 * h + fq) ^ ((row >> 1) & 7)) << 4);
+        }
+    }
 
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
-    int cur = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) load_tile(kt + 1);
-        const uint8_t* a = sA + cur * BM * BK;
-        const uint8_t* w = sW + cur * BN * BK;
+    // prologue: two tiles in flight first, then (while they fly) stage everything the epilogue needs into LDS with
+    // ordinary loads: per-chunk scales (+δ = flush after this chunk, −δ = keep accumulating), per-row and
+    // per-column dequantisation vectors.  A VMEM load inside the main loop would make hipcc drain the DMA ring with
+    // vmcnt(0), and dependent global loads in the epilogue cost ~1 us each on a lone wave — both avoided this way.
+    if (nk > 0) issue_tile(kt_begin, 0);
+    if (nk > 1) issue_tile(kt_begin + 1, 1);
+    float* vtab = reinterpret_cast<float*>(smem + STAGES * STAGE_BYTES);   // [7][128]: R0 R1 R2 | alpha zw gamma vn
+    float* ctab = vtab + 7 * 128;
+    {
+        const bool final_ep = (p.splits == 1);
+        if (final_ep) {
+            if (tid < 128) {
+                const int m = min(m0 + tid, p.M - 1);
+                const float rs = p.rowsum[m];
+                float r0 = 1.0f, r1 = rs, r2 = 0.0f;
+                if (PER_M) {
+                    const int li = m % p.L;
+                    const float md = p.mdelta[li], mz = p.mzp[li];
+                    r0 = md; r1 = md * rs; r2 = md * (p.offset - mz);
+                }
+                vtab[tid] = r0; vtab[128 + tid] = r1; vtab[256 + tid] = r2;
+            } else {
+                const int c = tid - 128;
+                const int n = min(n0 + c, p.N - 1);
+                vtab[384 + c] = p.alpha[n]; vtab[512 + c] = p.zw[n]; vtab[640 + c] = p.gamma[n];
+                vtab[768 + c] = PER_M ? p.vn[n] : 0.0f;
+            }
+        }
+        if (!PER_M) {
+            for (int c = tid; c < 2 * nk; c += 256) {
+                const int chunk = kt_begin * 2 + c;
+                const float d = p.cdelta[chunk];
+                ctab[c] = (p.cflush[chunk] || c == 2 * nk - 1) ? d : -d;
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // DMA tiles 0,1 + the staging loads/stores
+    __builtin_amdgcn_s_barrier();
+
+    for (int t = 0; t < nk; ++t) {
+        const int stage = t % STAGES;
+        if (t + 2 < nk) issue_tile(kt_begin + t + 2, (t + 2) % STAGES);
+        const uint8_t* sa = smem + stage * STAGE_BYTES;
+        const uint8_t* sw = sa + A_BYTES;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             v4i af[4], bf[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                int row = wave_m * 64 + i * 16 + fr;
-                af[i] = *reinterpret_cast<const v4i*>(a + swz(row, 4 * h + fq));
-            }
+            for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const v4i*>(sa + a_off[i][h]);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                int row = wave_n * 64 + j * 16 + fr;
-                bf[j] = *reinterpret_cast<const v4i*>(w + swz(row, 4 * h + fq));
+                if (WBITS == 4) {
+                    const uint2 v = *reinterpret_cast<const uint2*>(sw + w_off[j][h]);
+                    bf[j] = (v4i){(int)(v.x & 0x0F0F0F0Fu), (int)((v.x >> 4) & 0x0F0F0F0Fu),
+                                  (int)(v.y & 0x0F0F0F0Fu), (int)((v.y >> 4) & 0x0F0F0F0Fu)};
+                } else {
+                    bf[j] = *reinterpret_cast<const v4i*>(sw + w_off[j][h]);
+                }
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -155,9 +234,10 @@ __global__ __launch_bounds__(256, 2) void gemm_wxa8_kernel(GemmParams p) {
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[i], bf[j], acc[i][j], 0, 0, 0);
             if (!PER_M) {
-                const int chunk = kt * 2 + h;
-                if (p.cflush[chunk]) {          // wave-uniform: last chunk of a DGQ group
-                    const float sc = p.cdelta[chunk];
+                // wave-uniform: > 0 on the last chunk of a DGQ group or of this K split
+                const float sc = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(
+                    __builtin_bit_cast(int, ctab[2 * t + h])));
+                if (sc > 0.0f) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -169,50 +249,172 @@ __global__ __launch_bounds__(256, 2) void gemm_wxa8_kernel(GemmParams p) {
                 }
             }
         }
-        if (kt + 1 < nk) store_tile(cur ^ 1);
-        __syncthreads();
-        cur ^= 1;
+        // tile t+1 must have landed (this wave's pieces) before anyone reads it; tile t+2 may stay in flight
+        if (t + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_TILE) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
     }
 
-    // epilogue: C/D layout of the 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + reg
-    TOut* y = reinterpret_cast<TOut*>(p.y);
+    // epilogue.  The MFMA C/D layout (col = lane&15, row = (lane>>4)*4 + reg) would give 4-byte stores in 64-byte
+    // runs; measured, that store pattern (not the MFMAs) bounded every small-K layer (~1 TB/s).  Each wave
+    // therefore transposes its 64x64 fp32 tile through the (now idle) LDS ring and writes 16 bytes per lane, 256
+    // contiguous bytes per row.  Row stride 68 floats: conflict-free ds_write_b32, near conflict-free ds_read_b128.
+    constexpr int EP_LD = 68;
+    float* ep = reinterpret_cast<float*>(smem) + wid * 64 * EP_LD;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int n = n0 + wave_n * 64 + j * 16 + fr;
-        if (n >= p.N) continue;
-        const float al = p.alpha[n], zw = p.zw[n], ga = p.gamma[n];
-        const float vn = PER_M ? p.vn[n] : 0.0f;
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = m0 + wave_m * 64 + i * 16 + fq * 4 + r;
-                if (m >= p.M) continue;
-                const float rs = p.rowsum[m];
-                float out;
-                if (PER_M) {
-                    const int li = m % p.L;
-                    const float md = p.mdelta[li], mz = p.mzp[li];
-                    out = al * md * ((float)acc[i][j][r] - zw * rs + (p.offset - mz) * vn) + ga;
-                } else {
-                    out = al * (accf[i][j][r] - zw * rs) + ga;
-                }
-                y[(int64_t)m * p.ldy + n] = dgq_from_float<TOut>(out);
+            for (int r = 0; r < 4; ++r)
+                ep[(i * 16 + fq * 4 + r) * EP_LD + j * 16 + fr] = PER_M ? (float)acc[i][j][r] : accf[i][j][r];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // same-wave LDS round trip: no barrier needed
+    const int c4 = (lane & 15) * 4;                          // 4 consecutive n per lane
+    const int nb = n0 + wave_n * 64 + c4;
+    const bool vec_ok = (nb + 3 < p.N);
+    if (p.splits > 1) {
+        float* slab = p.slab + (int64_t)blockIdx.z * p.M * p.N;
+        const bool al16 = ((p.N & 3) == 0);
+#pragma unroll 4
+        for (int rr = 0; rr < 16; ++rr) {
+            const int row = rr * 4 + (lane >> 4);
+            const int m = m0 + wave_m * 64 + row;
+            if (m >= p.M || nb >= p.N) continue;
+            const float4 v = *reinterpret_cast<const float4*>(ep + row * EP_LD + c4);
+            float* dst = slab + (int64_t)m * p.N + nb;
+            if (vec_ok && al16) {
+                *reinterpret_cast<float4*>(dst) = v;
+            } else {
+                const float e[4] = {v.x, v.y, v.z, v.w};
+                for (int k = 0; k < 4 && nb + k < p.N; ++k) dst[k] = e[k];
             }
         }
+        return;
+    }
+    TOut* y = reinterpret_cast<TOut*>(p.y);
+    const float* vc = vtab + 384 + wave_n * 64 + c4;
+    const float4 al = *reinterpret_cast<const float4*>(vc);
+    const float4 zw = *reinterpret_cast<const float4*>(vc + 128);
+    const float4 ga = *reinterpret_cast<const float4*>(vc + 256);
+    const float4 vn = *reinterpret_cast<const float4*>(vc + 384);
+    const bool st_vec = vec_ok && ((p.ldy * (int)sizeof(TOut)) % 16 == 0) &&
+                        ((reinterpret_cast<uintptr_t>(p.y) & 15) == 0) && (sizeof(TOut) == 4 || (p.ldy & 3) == 0);
+#pragma unroll 4
+    for (int rr = 0; rr < 16; ++rr) {
+        const int row = rr * 4 + (lane >> 4);
+        const int m = m0 + wave_m * 64 + row;
+        if (m >= p.M || nb >= p.N) continue;
+        const float4 v = *reinterpret_cast<const float4*>(ep + row * EP_LD + c4);
+        const float* vr = vtab + wave_m * 64 + row;
+        const float r0 = vr[0], r1 = vr[128], r2 = vr[256];
+        // y = alpha·(R0·acc − zw·R1 + R2·vn) + gamma   (per-K: R0 = 1, R1 = rowsum, R2 = 0)
+        float o[4];
+        o[0] = al.x * (r0 * v.x - zw.x * r1 + r2 * vn.x) + ga.x;
+        o[1] = al.y * (r0 * v.y - zw.y * r1 + r2 * vn.y) + ga.y;
+        o[2] = al.z * (r0 * v.z - zw.z * r1 + r2 * vn.z) + ga.z;
+        o[3] = al.w * (r0 * v.w - zw.w * r1 + r2 * vn.w) + ga.w;
+        TOut* dst = y + (int64_t)m * p.ldy + nb;
+        if (st_vec) {
+            if (sizeof(TOut) == 4) {
+                *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+            } else {
+                TOut t[4] = {dgq_from_float<TOut>(o[0]), dgq_from_float<TOut>(o[1]), dgq_from_float<TOut>(o[2]),
+                             dgq_from_float<TOut>(o[3])};
+                *reinterpret_cast<uint2*>(dst) = *reinterpret_cast<const uint2*>(t);
+            }
+        } else {
+            for (int k = 0; k < 4 && nb + k < p.N; ++k) dst[k] = dgq_from_float<TOut>(o[k]);
+        }
+    }
+}
+
+// Deterministic split-K combine + dequantisation epilogue: one thread per 4 consecutive n.
+template <bool PER_M, typename TOut>
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(GemmParams p) {
+    const int n4 = (p.N + 3) / 4;
+    const int64_t total = (int64_t)p.M * n4;
+    TOut* y = reinterpret_cast<TOut*>(p.y);
+    const int64_t slab_stride = (int64_t)p.M * p.N;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int m = (int)(i / n4);
+        const int nb = (int)(i - (int64_t)m * n4) * 4;
+        float a[4] = {0.f, 0.f, 0.f, 0.f};
+        const bool full = (nb + 3 < p.N) && ((p.N & 3) == 0);
+        for (int s = 0; s < p.splits; ++s) {
+            const float* src = p.slab + s * slab_stride + (int64_t)m * p.N + nb;
+            if (full) {
+                const float4 v = *reinterpret_cast<const float4*>(src);
+                a[0] += v.x; a[1] += v.y; a[2] += v.z; a[3] += v.w;
+            } else {
+                for (int e = 0; e < 4 && nb + e < p.N; ++e) a[e] += src[e];
+            }
+        }
+        for (int e = 0; e < 4 && nb + e < p.N; ++e) {
+            const int n = nb + e;
+            const float out = dgq_epilogue<PER_M>(p, a[e], m, n, p.alpha[n], p.zw[n], p.gamma[n], PER_M ? p.vn[n] : 0.0f);
+            y[(int64_t)m * p.ldy + n] = dgq_from_float<TOut>(out);
+        }
+    }
+}
+
+template <int WBITS, bool PER_M, typename TOut>
+static void launch_one(const GemmParams& p, hipStream_t st) {
+    constexpr int lds_stages = STAGES * (BM * BK + BN * ((WBITS == 4) ? BK / 2 : BK));
+    constexpr int lds_max = lds_stages + 7 * 128 * 4 + 8192;    // + epilogue vectors + per-chunk scales (<= 2048 chunks)
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_wxa8_kernel<WBITS, PER_M, TOut>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+        attr_set = true;
+    }
+    const int lds = lds_stages + 7 * 128 * 4 + (PER_M ? 0 : ((2 * p.tiles_per_split * 4 + 15) & ~15));
+    dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, p.splits), block(256);
+    hipLaunchKernelGGL((gemm_wxa8_kernel<WBITS, PER_M, TOut>), grid, block, lds, st, p);
+    if (p.splits > 1) {
+        int64_t total = (int64_t)p.M * ((p.N + 3) / 4);
+        int g = (int)((total + 255) / 256);
+        if (g > 4096) g = 4096;
+        hipLaunchKernelGGL((splitk_epilogue_kernel<PER_M, TOut>), dim3(g), dim3(256), 0, st, p);
     }
 }
 
 template <int WBITS, bool PER_M>
 static int launch_gemm(const GemmParams& p, int y_dtype, hipStream_t st) {
-    dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM), block(256);
     switch (y_dtype) {
-        case DGQ_F32: hipLaunchKernelGGL((gemm_wxa8_kernel<WBITS, PER_M, float>), grid, block, 0, st, p); break;
-        case DGQ_F16: hipLaunchKernelGGL((gemm_wxa8_kernel<WBITS, PER_M, __half>), grid, block, 0, st, p); break;
-        case DGQ_BF16: hipLaunchKernelGGL((gemm_wxa8_kernel<WBITS, PER_M, __hip_bfloat16>), grid, block, 0, st, p); break;
+        case DGQ_F32: launch_one<WBITS, PER_M, float>(p, st); break;
+        case DGQ_F16: launch_one<WBITS, PER_M, __half>(p, st); break;
+        case DGQ_BF16: launch_one<WBITS, PER_M, __hip_bfloat16>(p, st); break;
         default: dgq_set_error("dgq_gemm_wxa8: unknown y dtype %d", y_dtype); return DGQ_EINVAL;
     }
     return dgq_launch_status("dgq_gemm_wxa8");
+}
+
+// K split factor from a small cost model (all times in us; constants measured on MI355X, tools/bench_gemm.py):
+//   a resident block retires one 128x128x128 K tile in ~0.6 us with 2 blocks/CU (0.35 us alone on its CU),
+//   512 block slots; a split adds S·M·N·4 B of slab writes + reads at ~3 TB/s and a ~2 us combine launch.
+static int choose_splits(int M, int N, int Kp, size_t ws_bytes) {
+    const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    const int nk = Kp / BK;
+    if (nk < 4) return 1;
+    const double slab_bytes = (double)M * N * 4.0;
+    double best_t = 1e30;
+    int best = 1;
+    for (int s = 1; s <= 32 && s * 2 <= nk; ++s) {
+        if (s > 1 && slab_bytes * s > (double)ws_bytes) break;
+        const int tps = (nk + s - 1) / s;
+        const long blocks = (long)tiles * ((nk + tps - 1) / tps);
+        const long waves = (blocks + 511) / 512;
+        const double per_tile = blocks <= 256 ? 0.35 : 0.6;
+        double t = waves * (tps * per_tile + 1.5);
+        if (s > 1) t += 2.0 + 2.0 * slab_bytes * s / 3.0e6;
+        if (t < best_t) { best_t = t; best = s; }
+    }
+    return best;
+}
+
+extern "C" size_t dgq_gemm_workspace_bytes(int M, int N, int Kp) {
+    const int s = choose_splits(M, N, Kp, (size_t)-1);
+    return s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
 }
 
 extern "C" int dgq_gemm_wxa8(const int8_t* codes, const float* rowsum, int M, int Kp,
@@ -220,13 +422,15 @@ extern "C" int dgq_gemm_wxa8(const int8_t* codes, const float* rowsum, int M, in
                              int per_m, const float* cdelta, const uint8_t* cflush,
                              const float* mdelta, const float* mzp, int L, float offset,
                              const float* alpha, const float* zw, const float* gamma, const float* vn,
-                             void* y, int y_dtype, int ldy, void* stream) {
+                             void* y, int y_dtype, int ldy, void* workspace, size_t workspace_bytes, void* stream) {
     DGQ_CHECK_ARG(codes && rowsum && wpacked && alpha && zw && gamma && y, "dgq_gemm_wxa8: null pointer");
     DGQ_CHECK_ARG(M > 0 && N > 0 && Kp > 0 && Kp % DGQ_KTILE == 0, "dgq_gemm_wxa8: bad shape M=%d N=%d Kp=%d", M, N, Kp);
     DGQ_CHECK_ARG(w_bits == 4 || w_bits == 8, "dgq_gemm_wxa8: w_bits=%d unsupported", w_bits);
     DGQ_CHECK_ARG(ldy >= N, "dgq_gemm_wxa8: ldy < N");
+    DGQ_CHECK_ARG(Kp / DGQ_KCHUNK <= 2048, "dgq_gemm_wxa8: Kp=%d too large (max %d)", Kp, 2048 * DGQ_KCHUNK);
     DGQ_CHECK_ARG((reinterpret_cast<uintptr_t>(codes) & 15) == 0 && (reinterpret_cast<uintptr_t>(wpacked) & 15) == 0,
                   "dgq_gemm_wxa8: codes/wpacked must be 16-byte aligned");
+    DGQ_CHECK_ARG(!workspace || (reinterpret_cast<uintptr_t>(workspace) & 15) == 0, "dgq_gemm_wxa8: workspace alignment");
     if (per_m) {
         DGQ_CHECK_ARG(mdelta && mzp && vn && L >= 1, "dgq_gemm_wxa8: per_m needs mdelta/mzp/vn/L");
     } else {
@@ -237,6 +441,12 @@ extern "C" int dgq_gemm_wxa8(const int8_t* codes, const float* rowsum, int M, in
     p.wpacked = reinterpret_cast<const uint8_t*>(wpacked);
     p.cdelta = cdelta; p.cflush = cflush; p.mdelta = mdelta; p.mzp = mzp; p.L = per_m ? L : 1; p.offset = offset;
     p.alpha = alpha; p.zw = zw; p.gamma = gamma; p.vn = vn; p.y = y; p.ldy = ldy;
+    p.splits = workspace ? choose_splits(M, N, Kp, workspace_bytes) : 1;
+    p.slab = p.splits > 1 ? reinterpret_cast<float*>(workspace) : nullptr;
+    const int nk = Kp / BK;
+    p.tiles_per_split = (nk + p.splits - 1) / p.splits;
+    p.splits = (nk + p.tiles_per_split - 1) / p.tiles_per_split;      // no empty split
+    if (p.splits == 1) p.slab = nullptr;
     hipStream_t st = (hipStream_t)stream;
     if (w_bits == 4) return per_m ? launch_gemm<4, true>(p, y_dtype, st) : launch_gemm<4, false>(p, y_dtype, st);
     return per_m ? launch_gemm<8, true>(p, y_dtype, st) : launch_gemm<8, false>(p, y_dtype, st);

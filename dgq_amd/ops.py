@@ -134,8 +134,21 @@ def quant_act(x_cl: torch.Tensor, B, H, W, C, kh, kw, stride, pad, ab: ActBindin
     return codes, rowsum, M
 
 
+_WORKSPACE = {}
+WORKSPACE_BYTES = 256 << 20
+
+
+def workspace(device):
+    """Persistent split-K scratch (caller-owned, per device): the library never allocates."""
+    key = str(device)
+    if key not in _WORKSPACE:
+        _WORKSPACE[key] = torch.empty(WORKSPACE_BYTES, dtype=torch.uint8, device=device)
+    return _WORKSPACE[key]
+
+
 def gemm_wxa8(codes, rowsum, M, ab: ActBinding, out_dtype, out: Optional[torch.Tensor] = None):
     pw = ab.pw
+    ws = workspace(codes.device)
     if out is None:
         out = torch.empty((M, pw.N), dtype=out_dtype, device=codes.device)
     per_m = 0 if ab.mode == "perK" else 1
@@ -145,7 +158,7 @@ def gemm_wxa8(codes, rowsum, M, ab: ActBinding, out_dtype, out: Optional[torch.T
               _lib.ptr(ab.mdelta) if per_m else None, _lib.ptr(ab.mzp) if per_m else None,
               ab.L if per_m else 1, _c.c_float(ab.offset),
               _lib.ptr(pw.alpha), _lib.ptr(pw.zw), _lib.ptr(ab.gamma), _lib.ptr(ab.vn) if per_m else None,
-              _lib.ptr(out), _lib.DTYPE_CODE[out.dtype], out.stride(0), _lib.stream())
+              _lib.ptr(out), _lib.DTYPE_CODE[out.dtype], out.stride(0), _lib.ptr(ws), ws.numel(), _lib.stream())
     return out
 
 

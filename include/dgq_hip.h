@@ -13,6 +13,7 @@
  */
 #ifndef DGQ_HIP_H
 #define DGQ_HIP_H
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -90,7 +91,12 @@ int dgq_gemm_wxa8(const int8_t* codes, const float* rowsum, int M, int Kp,
                   int per_m, const float* cdelta, const uint8_t* cflush,
                   const float* mdelta, const float* mzp, int L, float offset,
                   const float* alpha, const float* zw, const float* gamma, const float* vn,
-                  void* y, int y_dtype, int ldy, void* stream);
+                  void* y, int y_dtype, int ldy, void* workspace, size_t workspace_bytes, void* stream);
+/* Small tile grids are split along K (deterministic: fp32 partial slabs [S][M][N] in the caller's `workspace`,
+ * summed in a fixed order by a second kernel). dgq_gemm_workspace_bytes returns what the preferred split of a
+ * shape needs; with workspace == NULL (or too small) fewer / no splits are used — results do not depend on it
+ * beyond fp32 summation order. */
+size_t dgq_gemm_workspace_bytes(int M, int N, int Kp);
 
 /* ---- attention-side quantizers --------------------------------------------------------------------
  * dgq_fakequant_rows: aqtizer_q/k/v (sd.py:174-182,199 -> quant_layer.py:295-299) applied on the

@@ -76,7 +76,9 @@ def test_gemm_exact_integer(dev):
     from dgq_amd import _lib, ops
     from dgq_amd.plan import ActLayout
     g = torch.Generator().manual_seed(1)
-    for (M, N, Kp, wbits) in ((200, 136, 384, 4), (64, 320, 128, 4), (130, 72, 256, 8)):
+    ws = ops.workspace(dev)
+    for (M, N, Kp, wbits) in ((200, 136, 384, 4), (64, 320, 128, 4), (130, 72, 256, 8), (100, 200, 2048, 4),
+                              (300, 136, 1024, 8), (2, 320, 1280, 4)):      # the last three take the split-K path
         s = torch.randint(-16, 16, (M, Kp), generator=g, dtype=torch.int32)
         s[::7, ::13] = -128            # int8 extremes, sparsely (keeps every fp32 step exact)
         s[3::11, 5::17] = 127
@@ -114,7 +116,7 @@ def test_gemm_exact_integer(dev):
         rc = lib.dgq_gemm_wxa8(_lib.ptr(codes), _lib.ptr(rs), M, Kp, _lib.ptr(wp), wbits, N, 0,
                                _lib.ptr(cdg), _lib.ptr(flg), None, None, 1, ctypes.c_float(128.0),
                                _lib.ptr(al), _lib.ptr(zwg), _lib.ptr(ga), None,
-                               _lib.ptr(y), 0, N, _lib.stream())
+                               _lib.ptr(y), 0, N, _lib.ptr(ws), ws.numel(), _lib.stream())
         _lib.check(rc, "dgq_gemm_wxa8")
         torch.cuda.synchronize()
         assert torch.equal(y.cpu().double(), expect), (M, N, Kp, wbits, (y.cpu().double() - expect).abs().max())
@@ -132,7 +134,7 @@ def test_gemm_exact_integer(dev):
         rc = lib.dgq_gemm_wxa8(_lib.ptr(codes), _lib.ptr(rs), M, Kp, _lib.ptr(wp), wbits, N, 1,
                                None, None, _lib.ptr(mdg), _lib.ptr(mzg), L, ctypes.c_float(128.0),
                                _lib.ptr(al), _lib.ptr(zwg), _lib.ptr(ga), _lib.ptr(vng),
-                               _lib.ptr(y), 0, N, _lib.stream())
+                               _lib.ptr(y), 0, N, _lib.ptr(ws), ws.numel(), _lib.stream())
         _lib.check(rc, "dgq_gemm_wxa8")
         torch.cuda.synchronize()
         got = y.cpu().double()

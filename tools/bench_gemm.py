@@ -1,0 +1,71 @@
+"""GEMM microbenchmark (GPU box): dgq_gemm_wxa8 on representative SD1.4 / SDXL shapes,
+back-to-back launches timed with HIP events on the launch stream; prints algorithmic TOP/s and the fraction
+of the dense int8 MFMA peak (5000 TOP/s).   usage: python tools/bench_gemm.py [iters]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from dgq_amd import ops, synth
+from dgq_amd.plan import plan_act
+
+dev = torch.device("cuda:0")
+iters = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+PEAK = 5000.0
+# (name, M, N, C, taps, mode)
+SHAPES = [
+    ("sd conv3x3 64x64 320->320", 8192, 320, 320, 9, "perK"),
+    ("sd conv3x3 32x32 640->640", 2048, 640, 640, 9, "perK"),
+    ("sd conv3x3 16x16 1280->1280", 512, 1280, 1280, 9, "perK"),
+    ("sd conv3x3 8x8 2560->1280", 128, 1280, 2560, 9, "perK"),
+    ("sd conv3x3 16x16 2560->1280", 512, 1280, 2560, 9, "perK"),
+    ("sd conv3x3 64x64 960->320", 8192, 320, 960, 9, "perM"),
+    ("sd geglu 64x64 320->2560", 8192, 2560, 320, 1, "perK"),
+    ("sd geglu 32x32 640->5120", 2048, 5120, 640, 1, "perK"),
+    ("sd geglu 16x16 1280->10240", 512, 10240, 1280, 1, "perK"),
+    ("sd ff.2 64x64 1280->320", 8192, 320, 1280, 1, "perK"),
+    ("sd to_q 64x64 320->320", 8192, 320, 320, 1, "perM"),
+    ("sd to_q 16x16 1280->1280", 512, 1280, 1280, 1, "perK"),
+    ("sd to_k ctx 768->320", 154, 320, 768, 1, "perK"),
+    ("xl geglu 32x32 1280->10240 (B=1)", 1024, 10240, 1280, 1, "perK"),
+    ("xl geglu 64x64 640->5120 (B=1)", 4096, 5120, 640, 1, "perK"),
+    ("xl ff.2 32x32 5120->1280", 1024, 1280, 5120, 1, "perK"),
+    ("big 8192x8192x8192 perM", 8192, 8192, 8192, 1, "perM"),
+    ("big 8192x8192x8192 perK g16", 8192, 8192, 8192, 1, "perK"),
+]
+print("%-40s %6s %6s %6s  %9s %9s %7s" % ("shape", "M", "N", "K", "us", "TOP/s", "frac"))
+for name, M, N, C, taps, mode in SHAPES:
+    K = C * taps
+    g = torch.Generator().manual_seed(0)
+    w = torch.randn(N, K, generator=g) * 0.05
+    wd, wz = synth.channel_minmax(w, 4)
+    pw = ops.PackedWeight(w.to(dev), wd.to(dev), wz.to(dev), None, torch.zeros(N, device=dev), 4, C, taps)
+    if mode == "perK":
+        d, z = synth._group_params(K, 16, 8, "bench|" + name, 0)
+        lay = plan_act(d.view(1, -1, 1) if taps > 1 else d.view(1, 1, -1), z.view(1, -1, 1) if taps > 1 else z.view(1, 1, -1),
+                       "conv" if taps > 1 else "linear", C, taps, 8)
+    else:
+        d, z = synth._group_params(64, 16, 8, "bench|" + name, 0)
+        lay = plan_act(d.view(1, 1, -1) if taps > 1 else d.view(1, -1, 1), z.view(1, 1, -1) if taps > 1 else z.view(1, -1, 1),
+                       "conv" if taps > 1 else "linear", C, taps, 8)
+    ab = ops.ActBinding(lay, pw, 8)
+    codes = torch.randint(-128, 128, (M, ab.Kp), dtype=torch.int8, device=dev)
+    rowsum = torch.randn(M, device=dev)
+    out = torch.empty(M, N, device=dev)
+    for _ in range(3):
+        ops.gemm_wxa8(codes, rowsum, M, ab, torch.float32, out)
+    torch.cuda.synchronize()
+    # capture `iters` launches in a hipGraph so that host launch overhead (python + ctypes ~15 us/call) is excluded
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        for _ in range(iters):
+            ops.gemm_wxa8(codes, rowsum, M, ab, torch.float32, out)
+    graph.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    graph.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / iters
+    tops = 2.0 * M * N * K / (us * 1e-6) / 1e12
+    print("%-40s %6d %6d %6d  %9.1f %9.1f %6.1f%%  Kp=%d" % (name, M, N, K, us, tops, 100 * tops / PEAK, ab.Kp))
+    del pw, ab, codes, out
