@@ -24,6 +24,7 @@ SIGNATURES = {
     "dgq_fakequant_rows": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp],
     "dgq_max_f32": [_vp, _i64, _i, _i, _vp, _vp],
     "dgq_logquant_f32": [_vp, _vp, _i64, _i, _i, _vp, _i, _vp],
+    "dgq_attention_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _vp, _i, _vp, _vp, _vp],
 }
 
 _lib = None

@@ -1,0 +1,243 @@
+// Fused attention with quantised softmax — replaces, for one attention call of Attention.Attention_forward
+// (diffusers_rewrite/sd.py:183-201):
+//     scores = (q @ k^T) * scale ; p = softmax(scores) (fp32) ; p = aqtizer_w(p) [column 0 bypassed under
+//     start_peak] ; o = p @ v
+// without materialising the [B,H,T,S] probabilities (1 GB per SD self-attention at 64x64 in the reference).
+//
+// T2ILogQuantizer in real-time mode (quant_layer_text.py:96-105) needs δ = max over the WHOLE probability tensor
+// before any element can be quantised, so the kernel pair is two-pass:
+//   pass 1  attn_stats : per query row m = max_s score, l = Σ_s exp(score − m) (online), and the row's largest
+//                        probability outside the bypassed column, exp(m' − m)/l; a grid-wide max of those is δ
+//                        (atomicMax on the bit pattern: values are positive floats);
+//   pass 2  attn_pv    : recomputes the scores tile by tile, forms p = exp(score − m)/l with the FINAL m, l (no online
+//                        rescaling), quantises and accumulates o += p̂·v.
+// log2 quantiser in the log domain:  −log2(p/δ) = (m − score)·log2(e) + log2(l) + log2(δ)  → code = clamp(rne(·), 0,
+// 2^b−1), p̂ = ldexp(δ, −code) (exact power of two times δ, as the reference's 2**(−code)·δ).
+//
+// All arithmetic is fp32 like the reference: the matrix products run on the exact fp32 MFMA
+// (V_MFMA_F32_32X32X2_F32 = a k-ordered fmaf chain, 64 FLOP/clk/SIMD).  Work decomposition (wave64):
+//   block = 4 waves = 128 query rows of one (batch, head); each wave owns 32 rows; key/value tiles of 32 rows are
+//   staged once per block in LDS.  The score tile is computed TRANSPOSED (S^T = K·Q^T: A = K tile, B = Q) so that a
+//   lane's column is its query row: all softmax statistics are in-register (16 keys per lane; lanes l and l+32 hold
+//   the two key halves of the same query), and the S^T accumulator is directly the B operand of O^T = V^T · P^T
+//   (cdna guide §3 "accumulator tile as the next MFMA's operand"): register r holds key (r&3)+8(r>>2) in lanes 0-31
+//   and that key + 4 in lanes 32-63 — exactly the k = 0/1 pair of the 32x32x2 instruction.
+#include "dgq_common.h"
+
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+#define ATT_QROWS 128      // query rows per block
+#define ATT_KT 32          // keys per tile
+#define LOG2E 1.4426950408889634f
+
+struct AttnParams {
+    const float* q;
+    const float* k;
+    const float* v;
+    float* o;
+    int B, H, T, S;
+    float scale;
+    int mode;              // 0: no quantiser, 1: log2 real-time δ, 2: log2 static δ, 3: uniform (δ, z = 0)
+    int skip;              // leading key columns that bypass the quantiser (start-peak)
+    float qmax;
+    float* stats;          // [B*H][T][2] : m, l
+    float* delta;          // device scalar
+};
+
+__device__ __forceinline__ int key_of(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+template <int D>
+__device__ __forceinline__ void load_tile(float* dst, const float* src, int rows_valid, int row_stride, int tid) {
+    // dst [ATT_KT][D+1] ; src row-major with `row_stride` floats between consecutive keys
+    constexpr int LD = D + 1;
+    for (int i = tid; i < ATT_KT * D; i += 256) {
+        const int r = i / D, c = i - r * D;
+        dst[r * LD + c] = (r < rows_valid) ? src[(int64_t)r * row_stride + c] : 0.0f;
+    }
+}
+
+// S^T tile (32 keys x 32 queries per wave): acc[r] = score(key_of(r,h), query lane&31), unscaled
+template <int D>
+__device__ __forceinline__ v16f score_tile(const float* ks, const float (&qreg)[D / 2], int lane) {
+    constexpr int LD = D + 1;
+    v16f acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    const float* kp = ks + (lane & 31) * LD + (lane >> 5);
+#pragma unroll
+    for (int kk = 0; kk < D / 2; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(kp[2 * kk], qreg[kk], acc, 0, 0, 0);
+    return acc;
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void attn_stats_kernel(AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int LD = D + 1;
+    float* ks = lds;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, h32 = lane >> 5;
+    const int bh = blockIdx.y, b = bh / p.H, hd = bh - b * p.H;
+    const int HD = p.H * D;
+    const int t = blockIdx.x * ATT_QROWS + wid * 32 + (lane & 31);
+    const int tq = min(t, p.T - 1);
+    float qreg[D / 2];
+    {
+        const float* qp = p.q + ((int64_t)(b * p.T + tq) * p.H + hd) * D + h32;
+#pragma unroll
+        for (int kk = 0; kk < D / 2; ++kk) qreg[kk] = qp[2 * kk];
+    }
+    float m = -INFINITY, l = 0.0f, m2 = -INFINITY;      // m2: max over keys >= skip
+    for (int s0 = 0; s0 < p.S; s0 += ATT_KT) {
+        __syncthreads();
+        load_tile<D>(ks, p.k + ((int64_t)(b * p.S + s0) * p.H + hd) * D, min(ATT_KT, p.S - s0), HD, tid);
+        __syncthreads();
+        v16f acc = score_tile<D>(ks, qreg, lane);
+        float tmax = -INFINITY, tmax2 = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int s = s0 + key_of(r, h32);
+            const float sc = (s < p.S) ? acc[r] * p.scale : -INFINITY;
+            acc[r] = sc;
+            tmax = fmaxf(tmax, sc);
+            if (s >= p.skip) tmax2 = fmaxf(tmax2, sc);
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        tmax2 = fmaxf(tmax2, __shfl_xor(tmax2, 32, 64));
+        const float mn = fmaxf(m, tmax);
+        float part = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) part += expf(acc[r] - mn);
+        part += __shfl_xor(part, 32, 64);
+        l = l * expf(m - mn) + part;
+        m = mn;
+        m2 = fmaxf(m2, tmax2);
+    }
+    if (t < p.T && h32 == 0) {
+        float* st = p.stats + ((int64_t)bh * p.T + t) * 2;
+        st[0] = m;
+        st[1] = l;
+    }
+    if (p.mode == 1) {
+        float pm = (t < p.T) ? expf(m2 - m) / l : 0.0f;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) pm = fmaxf(pm, __shfl_xor(pm, o, 64));
+        if (lane == 0) atomicMax(reinterpret_cast<int*>(p.delta), __float_as_int(pm));
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void attn_pv_kernel(AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int LD = D + 1;
+    constexpr int NDT = (D + 31) / 32;                 // 32-wide d tiles of O^T
+    float* ks = lds;
+    float* vs = lds + ATT_KT * LD;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, h32 = lane >> 5;
+    const int bh = blockIdx.y, b = bh / p.H, hd = bh - b * p.H;
+    const int HD = p.H * D;
+    const int t = blockIdx.x * ATT_QROWS + wid * 32 + (lane & 31);
+    const int tq = min(t, p.T - 1);
+    float qreg[D / 2];
+    {
+        const float* qp = p.q + ((int64_t)(b * p.T + tq) * p.H + hd) * D + h32;
+#pragma unroll
+        for (int kk = 0; kk < D / 2; ++kk) qreg[kk] = qp[2 * kk];
+    }
+    const float m = p.stats[((int64_t)bh * p.T + tq) * 2], l = p.stats[((int64_t)bh * p.T + tq) * 2 + 1];
+    const float delta = (p.mode != 0) ? p.delta[0] : 1.0f;
+    const float c0 = log2f(l) + log2f(delta);           // −log2(p/δ) = (m − score)·log2e + c0
+    const float inv_l = 1.0f / l;
+    v16f oacc[NDT];
+#pragma unroll
+    for (int j = 0; j < NDT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[j][r] = 0.0f;
+
+    for (int s0 = 0; s0 < p.S; s0 += ATT_KT) {
+        __syncthreads();
+        const int valid = min(ATT_KT, p.S - s0);
+        load_tile<D>(ks, p.k + ((int64_t)(b * p.S + s0) * p.H + hd) * D, valid, HD, tid);
+        load_tile<D>(vs, p.v + ((int64_t)(b * p.S + s0) * p.H + hd) * D, valid, HD, tid);
+        __syncthreads();
+        v16f acc = score_tile<D>(ks, qreg, lane);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int s = s0 + key_of(r, h32);
+            const float sc = acc[r] * p.scale;
+            float ph;
+            if (s >= p.S) {
+                ph = 0.0f;
+            } else if (p.mode == 0 || s < p.skip) {
+                ph = expf(sc - m) * inv_l;               // unquantised probability (bypassed column / FP attention)
+            } else if (p.mode == 3) {
+                const float pr = expf(sc - m) * inv_l;   // uniform, always_zero: δ·clamp(rne(p/δ), 0, 2^b−1)
+                ph = delta * fminf(fmaxf(rintf(__fdiv_rn(pr, delta)), 0.0f), p.qmax);
+            } else {
+                float code = rintf((m - sc) * LOG2E + c0);
+                code = fminf(fmaxf(code, 0.0f), p.qmax);
+                ph = ldexpf(delta, -(int)code);
+            }
+            acc[r] = ph;
+        }
+        // O^T[d, t] += Σ_s V^T[d, s] · P^T[s, t]: register r of acc is the B operand of k-step r
+#pragma unroll
+        for (int j = 0; j < NDT; ++j) {
+            const int d = j * 32 + (lane & 31);
+            const float* vp = vs + (4 * h32) * LD + min(d, D - 1);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int srow = (r & 3) + 8 * (r >> 2);
+                const float a = (d < D) ? vp[srow * LD] : 0.0f;
+                oacc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, acc[r], oacc[j], 0, 0, 0);
+            }
+        }
+    }
+    // O^T tile j: lane holds query t = lane&31 (column), rows d = j*32 + (r&3) + 8(r>>2) + 4*h32
+    if (t < p.T) {
+        float* op = p.o + ((int64_t)(b * p.T + t) * p.H + hd) * D;
+#pragma unroll
+        for (int j = 0; j < NDT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int d = j * 32 + key_of(r, h32);
+                if (d < D) op[d] = oacc[j][r];
+            }
+    }
+}
+
+template <int D>
+static int launch_attn(const AttnParams& p, hipStream_t st) {
+    dim3 grid((p.T + ATT_QROWS - 1) / ATT_QROWS, p.B * p.H), block(256);
+    const int lds1 = ATT_KT * (D + 1) * sizeof(float), lds2 = 2 * lds1;
+    hipLaunchKernelGGL((attn_stats_kernel<D>), grid, block, lds1, st, p);
+    hipLaunchKernelGGL((attn_pv_kernel<D>), grid, block, lds2, st, p);
+    return dgq_launch_status("dgq_attention_f32");
+}
+
+extern "C" int dgq_attention_f32(const float* q, const float* k, const float* v, float* o, int B, int H, int T, int S,
+                                 int D, float scale, int mode, int skip, const float* delta_in, int bits,
+                                 float* stats_ws, float* delta_ws, void* stream) {
+    DGQ_CHECK_ARG(q && k && v && o && stats_ws && delta_ws, "dgq_attention_f32: null pointer");
+    DGQ_CHECK_ARG(B > 0 && H > 0 && T > 0 && S > 0, "dgq_attention_f32: bad shape");
+    DGQ_CHECK_ARG(mode >= 0 && mode <= 3 && skip >= 0 && skip < S && bits >= 2 && bits <= 8, "dgq_attention_f32: bad mode");
+    DGQ_CHECK_ARG(mode < 2 || delta_in, "dgq_attention_f32: static modes need delta");
+    hipStream_t st = (hipStream_t)stream;
+    AttnParams p;
+    p.q = q; p.k = k; p.v = v; p.o = o; p.B = B; p.H = H; p.T = T; p.S = S; p.scale = scale; p.mode = mode; p.skip = skip;
+    p.qmax = (float)((1 << bits) - 1); p.stats = stats_ws; p.delta = delta_ws;
+    if (mode == 1) {
+        if (hipMemsetAsync(delta_ws, 0, sizeof(float), st) != hipSuccess) { dgq_set_error("dgq_attention_f32: memset"); return DGQ_ELAUNCH; }
+    } else if (mode >= 2) {
+        if (hipMemcpyAsync(delta_ws, delta_in, sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) {
+            dgq_set_error("dgq_attention_f32: memcpy"); return DGQ_ELAUNCH;
+        }
+    }
+    switch (D) {
+        case 8: return launch_attn<8>(p, st);
+        case 16: return launch_attn<16>(p, st);
+        case 40: return launch_attn<40>(p, st);
+        case 64: return launch_attn<64>(p, st);
+        case 80: return launch_attn<80>(p, st);
+        case 160: return launch_attn<160>(p, st);
+        default: dgq_set_error("dgq_attention_f32: head_dim %d not instantiated (8,16,40,64,80,160)", D); return DGQ_EUNSUPPORTED;
+    }
+}

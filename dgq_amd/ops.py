@@ -213,3 +213,19 @@ def logquant_f32(p: torch.Tensor, delta: torch.Tensor, bits, skip_cols=0, out=No
     out = p if out is None else out
     _lib_call("dgq_logquant_f32", _lib.ptr(p), _lib.ptr(out), rows, S, skip_cols, _lib.ptr(delta), bits, _lib.stream())
     return out
+
+
+ATTN_HEAD_DIMS = (8, 16, 40, 64, 80, 160)
+
+
+def attention_f32(q, k, v, H, D, scale, mode, skip, delta, bits):
+    """q [B,T,H*D], k/v [B,S,H*D] fp32 contiguous -> o [B,T,H*D]; see dgq_attention_f32."""
+    assert q.dtype == torch.float32 and q.is_contiguous() and k.is_contiguous() and v.is_contiguous()
+    B, T, _ = q.shape
+    S = k.shape[1]
+    o = torch.empty_like(q)
+    stats = torch.empty((B * H * T * 2,), dtype=torch.float32, device=q.device)
+    dws = torch.empty((1,), dtype=torch.float32, device=q.device)
+    _lib_call("dgq_attention_f32", _lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(o), B, H, T, S, D,
+              _c.c_float(scale), mode, skip, _lib.ptr(delta), bits, _lib.ptr(stats), _lib.ptr(dws), _lib.stream())
+    return o

@@ -152,6 +152,29 @@ def quant_attention_forward(attn, hidden_states, encoder_hidden_states=None):
                 k = ten2.view(b, ntok, c)
             else:
                 v = ten2.view(b, ntok, c)
+    if q.dtype == torch.float32 and D in ops.ATTN_HEAD_DIMS and q.is_cuda:
+        # fused two-pass attention (dgq_attention_f32): probabilities are never materialised
+        mode, delta, bits = 0, None, 8
+        skip = 1 if (start_peak and use_aq) else 0
+        if use_aq:
+            wq = attn.aqtizer_w
+            bits = wq.bits
+            if isinstance(wq, T2ILogQuantizer):
+                if wq.real_time:
+                    mode = 1
+                else:
+                    if not wq.init:
+                        _init_static_softmax_delta(attn, wq, q, k, b, t, s, H, D, skip)
+                    mode, delta = 2, wq.delta.detach().reshape(1).float().to(q.device)
+            else:
+                if not wq.init:
+                    _init_static_softmax_delta(attn, wq, q, k, b, t, s, H, D, skip)
+                mode, delta = 3, wq.delta.detach().reshape(1).float().to(q.device)
+        o = ops.attention_f32(q.contiguous(), k.contiguous(), v.contiguous(), H, D, float(attn.scale), mode, skip,
+                              delta, bits)
+        for layer in attn.to_out:
+            o = layer(o)
+        return o
     qh = q.view(b, t, H, D).transpose(1, 2)
     kh = k.view(b, s, H, D).transpose(1, 2)
     vh = v.view(b, s, H, D).transpose(1, 2)
@@ -188,6 +211,21 @@ def quant_attention_forward(attn, hidden_states, encoder_hidden_states=None):
     for layer in attn.to_out:
         o = layer(o)
     return o
+
+
+def _init_static_softmax_delta(attn, wq, q, k, b, t, s, H, D, skip):
+    """First-use initialisation of a static softmax quantizer (T2ILogQuantizer quantile search,
+    quant_layer_text.py:49-76, or always_zero min/max): materialises the probabilities once, at load time only."""
+    qh = q.view(b, t, H, D).transpose(1, 2)
+    kh = k.view(b, s, H, D).transpose(1, 2)
+    p = torch.softmax(torch.matmul(qh, kh.transpose(-2, -1)) * attn.scale, dim=-1).float()
+    view = p[..., skip:] if skip else p
+    if isinstance(wq, T2ILogQuantizer):
+        d = wq._init_quantization_param(view.contiguous())
+        wq.delta = nn.Parameter(d) if wq.leaf_param else d
+        wq.init = True
+    else:
+        wq.init_from(view)
 
 
 def b2qb() -> Dict[str, type]:

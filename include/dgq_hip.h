@@ -115,6 +115,18 @@ int dgq_max_f32(const float* p, int64_t rows, int S, int skip_cols, float* out, 
 int dgq_logquant_f32(const float* p, float* y, int64_t rows, int S, int skip_cols, const float* delta,
                      int bits, void* stream);
 
+/* dgq_attention_f32: the attention core of Attention.Attention_forward (sd.py:183-201) without materialising the
+ * probabilities:  o = aqtizer_w(softmax((q·kᵀ)·scale)) · v, all fp32 (exact fp32 MFMA).
+ * q [B][T][H·D], k/v [B][S][H·D], o [B][T][H·D] (the projection layout: no head transposes).
+ * mode 0: no quantiser; 1: T2ILogQuantizer real-time (δ = max probability over the whole [B,H,T,S≥skip] tensor,
+ *         quant_layer_text.py:96-105, found by a first statistics pass); 2: T2ILogQuantizer with δ = delta_in[0];
+ *         3: UniformAffineQuantizer always_zero with δ = delta_in[0] (quant_block.py:145-156).
+ * skip = 1 bypasses key column 0 (start_peak, sd.py:191-195).  stats_ws: B·H·T·2 floats, delta_ws: 1 float
+ * (caller-owned scratch).  head_dim D ∈ {8,16,40,64,80,160}. */
+int dgq_attention_f32(const float* q, const float* k, const float* v, float* o, int B, int H, int T, int S, int D,
+                      float scale, int mode, int skip, const float* delta_in, int bits,
+                      float* stats_ws, float* delta_ws, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -231,3 +231,40 @@ def test_fakequant_rows_and_logquant(dev):
         v = f2["logq_fixed_b%d" % bits]
         y = ops.logquant_f32(v["x"].to(dev).contiguous(), v["delta"].reshape(1).to(dev), bits).cpu()
         assert (y != v["y"]).float().mean().item() < 1e-3
+
+
+# ------------------------------------------------------------------------------------------ fused attention
+@pytest.mark.parametrize("D,T,S,H", [(40, 200, 200, 2), (8, 70, 77, 8), (16, 130, 40, 3), (64, 96, 77, 2),
+                                     (80, 257, 257, 2), (160, 64, 77, 2)])
+@pytest.mark.parametrize("mode,skip", [(0, 0), (1, 0), (1, 1), (2, 0), (3, 1)])
+def test_fused_attention_vs_reference_formulas(D, T, S, H, mode, skip, dev):
+    """dgq_attention_f32 against the materialised reference sequence of sd.py:183-201 evaluated with torch on the
+    CPU (scores·scale -> softmax -> aqtizer_w with column bypass -> @ v).  FP mode within 1e-5; quantised modes
+    allow isolated one-code flips of a probability that sits on a rounding tie (rel-L2 < 2e-3)."""
+    from dgq_amd import ops
+    g = torch.Generator().manual_seed(D * 1000 + T + mode)
+    B, bits = 2, 8
+    q = torch.randn(B, T, H * D, generator=g)
+    k = torch.randn(B, S, H * D, generator=g)
+    v = torch.randn(B, S, H * D, generator=g)
+    scale = D ** -0.5
+    qh, kh, vh = (x.view(B, -1, H, D).transpose(1, 2) for x in (q, k, v))
+    p = torch.softmax(torch.matmul(qh, kh.transpose(-2, -1)) * scale, dim=-1)
+    delta = None
+    if mode == 1:
+        pq = orc.log_quant(p[..., skip:], p[..., skip:].max(), bits)
+    elif mode == 2:
+        delta = torch.tensor([0.37 * float(p.max())])
+        pq = orc.log_quant(p[..., skip:], delta[0], bits)
+    elif mode == 3:
+        delta = torch.tensor([float(p.max()) / 255.0])
+        pq = orc.uaq(p[..., skip:], delta[0], torch.tensor(0.0), bits)
+    else:
+        pq = p[..., skip:]
+    pf = torch.cat([p[..., :skip], pq], dim=-1) if skip else pq
+    ref = torch.matmul(pf, vh).transpose(1, 2).reshape(B, T, H * D)
+    o = ops.attention_f32(q.to(dev), k.to(dev), v.to(dev), H, D, scale, mode, skip,
+                          delta.to(dev) if delta is not None else None, bits)
+    torch.cuda.synchronize()
+    err = rel_l2(o.cpu(), ref)
+    assert err < (1e-5 if mode == 0 else 2e-3), err
