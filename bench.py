@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one hipGraph per timestep slot")
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "fp16", "bf16"],
                     help="inter-layer activation dtype (fp32 = the reference's default .float() mode)")
     args = ap.parse_args()
@@ -74,6 +75,8 @@ def main():
         qnn.to(torch.bfloat16)
     adt = {"fp32": torch.float32, "fp16": torch.float16, "bf16": torch.bfloat16}[args.dtype]
     qnn.prepare_slots(slots)
+    if not args.no_graph:
+        qnn.enable_graphs(True)
 
     # this rank's prompt (seeded by rank: rank-sliced prompt list), resident on the device
     lat = synth.named_randn("latent", (1, 4, 64, 64), 1 + rank).to(dev, adt)
@@ -82,12 +85,15 @@ def main():
 
     def one_step(x, t):
         inp = torch.cat([x, x], dim=0)
-        eps = qnn(inp, torch.tensor(t), ctx)[0]
+        eps = qnn(inp, t, ctx)[0]
         e_u, e_c = eps.chunk(2)
         return sch.step(e_u + guidance * (e_c - e_u), t, x)
 
     x = lat
     with torch.no_grad():
+        if not args.no_graph:
+            for t in sorted(set(timesteps), reverse=True):     # capture one graph per slot used (amortised over images)
+                one_step(lat, t)
         for t in timesteps[:W]:
             x = one_step(x, t)
         torch.cuda.synchronize()
@@ -123,9 +129,12 @@ def main():
             algo_bytes.append(M * ab.pw.K / max(1, ab.pw.taps) + ab.pw.N * ab.pw.K / 2 + M * ab.pw.N * y.element_size())
             return y
         ops.gemm_wxa8 = timed
+        graphs_were = qnn._graphs
+        qnn._graphs = None                                  # eager: the events bracket each launch
         with torch.no_grad():
             one_step(lat, timesteps[W])
         torch.cuda.synchronize()
+        qnn._graphs = graphs_were
         ops.gemm_wxa8 = orig
         gemm_ms = sum(a.elapsed_time(b) for a, b in events)
         tops = sum(algo_ops) / (gemm_ms * 1e-3) / 1e12

@@ -31,6 +31,7 @@
 struct GemmParams {
     const int8_t* codes;
     const float* rowsum;
+    int rowsum_parts;
     int M, Kp, N;
     const uint8_t* wpacked;
     const float* cdelta;
@@ -68,7 +69,8 @@ __device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_addr) {
 template <bool PER_M>
 __device__ __forceinline__ float dgq_epilogue(const GemmParams& p, float acc, int m, int n, float al, float zw, float ga,
                                               float vn) {
-    const float rs = p.rowsum[m];
+    float rs = 0.0f;
+    for (int j = 0; j < p.rowsum_parts; ++j) rs += p.rowsum[(int64_t)j * p.M + m];
     if (PER_M) {
         const int li = m % p.L;
         const float md = p.mdelta[li], mz = p.mzp[li];
@@ -182,7 +184,8 @@ __global__ __launch_bounds__(256, 2) void gemm_wxa8_kernel(GemmParams p) {
         if (final_ep) {
             if (tid < 128) {
                 const int m = min(m0 + tid, p.M - 1);
-                const float rs = p.rowsum[m];
+                float rs = 0.0f;
+                for (int j = 0; j < p.rowsum_parts; ++j) rs += p.rowsum[(int64_t)j * p.M + m];
                 float r0 = 1.0f, r1 = rs, r2 = 0.0f;
                 if (PER_M) {
                     const int li = m % p.L;
@@ -417,7 +420,7 @@ extern "C" size_t dgq_gemm_workspace_bytes(int M, int N, int Kp) {
     return s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
 }
 
-extern "C" int dgq_gemm_wxa8(const int8_t* codes, const float* rowsum, int M, int Kp,
+extern "C" int dgq_gemm_wxa8(const int8_t* codes, const float* rowsum, int rowsum_parts, int M, int Kp,
                              const void* wpacked, int w_bits, int N,
                              int per_m, const float* cdelta, const uint8_t* cflush,
                              const float* mdelta, const float* mzp, int L, float offset,
@@ -426,6 +429,7 @@ extern "C" int dgq_gemm_wxa8(const int8_t* codes, const float* rowsum, int M, in
     DGQ_CHECK_ARG(codes && rowsum && wpacked && alpha && zw && gamma && y, "dgq_gemm_wxa8: null pointer");
     DGQ_CHECK_ARG(M > 0 && N > 0 && Kp > 0 && Kp % DGQ_KTILE == 0, "dgq_gemm_wxa8: bad shape M=%d N=%d Kp=%d", M, N, Kp);
     DGQ_CHECK_ARG(w_bits == 4 || w_bits == 8, "dgq_gemm_wxa8: w_bits=%d unsupported", w_bits);
+    DGQ_CHECK_ARG(rowsum_parts >= 1 && rowsum_parts <= 64, "dgq_gemm_wxa8: rowsum_parts=%d", rowsum_parts);
     DGQ_CHECK_ARG(ldy >= N, "dgq_gemm_wxa8: ldy < N");
     DGQ_CHECK_ARG(Kp / DGQ_KCHUNK <= 2048, "dgq_gemm_wxa8: Kp=%d too large (max %d)", Kp, 2048 * DGQ_KCHUNK);
     DGQ_CHECK_ARG((reinterpret_cast<uintptr_t>(codes) & 15) == 0 && (reinterpret_cast<uintptr_t>(wpacked) & 15) == 0,
@@ -437,7 +441,7 @@ extern "C" int dgq_gemm_wxa8(const int8_t* codes, const float* rowsum, int M, in
         DGQ_CHECK_ARG(cdelta && cflush, "dgq_gemm_wxa8: per-K mode needs cdelta/cflush");
     }
     GemmParams p;
-    p.codes = codes; p.rowsum = rowsum; p.M = M; p.Kp = Kp; p.N = N;
+    p.codes = codes; p.rowsum = rowsum; p.rowsum_parts = rowsum_parts; p.M = M; p.Kp = Kp; p.N = N;
     p.wpacked = reinterpret_cast<const uint8_t*>(wpacked);
     p.cdelta = cdelta; p.cflush = cflush; p.mdelta = mdelta; p.mzp = mzp; p.L = per_m ? L : 1; p.offset = offset;
     p.alpha = alpha; p.zw = zw; p.gamma = gamma; p.vn = vn; p.y = y; p.ldy = ldy;

@@ -1,57 +1,60 @@
 // Activation quantise-on-load pre-pass: channels-last fp tensor -> int8 codes of the (implicit) unfolded
-// operand in the packed weight's K order, + one float per row.  HBM-bound; one wave per output row,
-// 16 consecutive kp (one 16-byte store) per lane per iteration, exact fp32 division per element.
+// operand in the packed weight's K order, + one float per row.  HBM-bound; one wave per output row, 4 consecutive
+// kp (one packed dword) per lane per 256-wide step; rounding bit-identical to fp32 true division (see below).
 #include "dgq_common.h"
 
 struct QuantActParams {
     const void* x;
     int B, H, W, C, kh, kw, stride, pad, Ho, Wo;
-    const int32_t* ksrc;      // [Kp] (tap<<16 | c) or -1, or NULL (natural order kp = tap*C + c)
+    const int32_t* ksrc;      // [Kp] (dh<<24 | dw<<16 | c) or -1, or NULL (natural order kp = tap*C + c)
     int Kp, K;
     const float* delta;       // per_m: [L]; else [Kp/64]
     const float* zp;
     int L;
     float qmax, offset;
     int8_t* codes;
-    float* rowsum;
+    float* rowsum;            // [ksplits][M] partial sums (the GEMM epilogue adds them in a fixed order)
     int M;
+    int kp_per_split;         // multiple of 256
 };
 
 template <typename TIn>
-__device__ __forceinline__ void load16(const TIn* p, float (&v)[16]);
-
+__device__ __forceinline__ void load4(const TIn* p, float (&v)[4]);
 template <>
-__device__ __forceinline__ void load16<float>(const float* p, float (&v)[16]) {
-    const float4* q = reinterpret_cast<const float4*>(p);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        float4 t = q[i];
-        v[4 * i] = t.x; v[4 * i + 1] = t.y; v[4 * i + 2] = t.z; v[4 * i + 3] = t.w;
-    }
+__device__ __forceinline__ void load4<float>(const float* p, float (&v)[4]) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
 }
 template <>
-__device__ __forceinline__ void load16<__half>(const __half* p, float (&v)[16]) {
-    const uint4* q = reinterpret_cast<const uint4*>(p);
+__device__ __forceinline__ void load4<__half>(const __half* p, float (&v)[4]) {
+    const uint2 t = *reinterpret_cast<const uint2*>(p);
+    const __half* h = reinterpret_cast<const __half*>(&t);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        uint4 t = q[i];
-        const __half* h = reinterpret_cast<const __half*>(&t);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[8 * i + j] = __half2float(h[j]);
-    }
+    for (int j = 0; j < 4; ++j) v[j] = __half2float(h[j]);
 }
 template <>
-__device__ __forceinline__ void load16<__hip_bfloat16>(const __hip_bfloat16* p, float (&v)[16]) {
-    const uint4* q = reinterpret_cast<const uint4*>(p);
+__device__ __forceinline__ void load4<__hip_bfloat16>(const __hip_bfloat16* p, float (&v)[4]) {
+    const uint2 t = *reinterpret_cast<const uint2*>(p);
+    const uint16_t* h = reinterpret_cast<const uint16_t*>(&t);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        uint4 t = q[i];
-        const uint16_t* h = reinterpret_cast<const uint16_t*>(&t);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[8 * i + j] = __uint_as_float(((uint32_t)h[j]) << 16);
-    }
+    for (int j = 0; j < 4; ++j) v[j] = __uint_as_float(((uint32_t)h[j]) << 16);
 }
 
+// clamp(rne(x/δ)+z, 0, qmax) with the reference's exact semantics (true division, quant_layer.py:297) at the cost
+// of a multiply: t = x·fl(1/δ) differs from the real quotient q by < |q|·1.2e-7, and so does the correctly rounded
+// fl(q); whenever t is farther than |t|·2.4e-7 from every half-integer, rint(t) == rint(fl(x/δ)).  Only lanes
+// inside that band (probability ~5e-5 per element) take the IEEE division.
+__device__ __forceinline__ float dgq_affine_code_fast(float x, float delta, float inv_delta, float zp, float qmax) {
+    const float t = x * inv_delta;
+    float r = rintf(t);
+    const float dist = fabsf(fabsf(t - r) - 0.5f);
+    if (dist <= fabsf(t) * 2.4e-7f + 1e-30f || !(fabsf(t) < 3.0e6f)) r = rintf(__fdiv_rn(x, delta));
+    return fminf(fmaxf(r + zp, 0.0f), qmax);
+}
+
+// One wave per output row; each lane owns 4 consecutive kp per 256-wide step (one packed dword), so that the
+// table read (int4), the gathered loads (lane stride 16 B within a (group, tap) run) and the code store (256 B per
+// wave instruction) are all coalesced.  The 4 kp of a lane share one 64-wide chunk, hence one (δ, z).
 template <typename TIn, bool HAS_TABLE, bool PER_M>
 __global__ __launch_bounds__(256) void quant_act_kernel(QuantActParams p) {
     const int lane = threadIdx.x & 63;
@@ -63,78 +66,86 @@ __global__ __launch_bounds__(256) void quant_act_kernel(QuantActParams p) {
     const int l = row - b * L;
     const int ho = l / p.Wo, wo = l - ho * p.Wo;
     const int hbase = ho * p.stride - p.pad, wbase = wo * p.stride - p.pad;
-    const int64_t img = (int64_t)b * p.H * p.W;
-    float md = 1.0f, mz = 0.0f;
+    const TIn* img = x + (int64_t)b * p.H * p.W * p.C;
+    float md = 1.0f, mz = 0.0f, minv = 1.0f;
     if (PER_M) {
-        int li = row % p.L;
+        const int li = row % p.L;
         md = p.delta[li];
         mz = p.zp[li];
+        minv = 1.0f / md;
     }
+    const int ioff = (int)p.offset;
     float partial = 0.0f;
-    int8_t* out = p.codes + (int64_t)row * p.Kp;
-    for (int kp0 = lane * 16; kp0 < p.Kp; kp0 += 64 * 16) {
-        float d = md, z = mz;
+    uint32_t* out = reinterpret_cast<uint32_t*>(p.codes + (int64_t)row * p.Kp);
+    // K range of this wave (blockIdx.y): low-M layers would otherwise leave the chip empty (M=512: 2 waves per CU)
+    const int k_begin = blockIdx.y * p.kp_per_split;
+    const int k_end = min(p.Kp, k_begin + p.kp_per_split);
+    // natural order: (tap, c) of the lane's first element, advanced by 256 per step without divisions
+    int ntap = 0, nc = 0;
+    if (!HAS_TABLE) {
+        const int k0 = k_begin + lane * 4;
+        ntap = k0 / p.C;
+        nc = k0 - ntap * p.C;
+    }
+#pragma unroll 2
+    for (int kp0 = k_begin + lane * 4; kp0 < k_end; kp0 += 256) {
+        float d = md, z = mz, inv = minv;
         if (!PER_M) {
             d = p.delta[kp0 >> 6];
             z = p.zp[kp0 >> 6];
+            inv = 1.0f / d;
         }
-        float v[16];
-        bool valid[16];
+        float v[4];
+        bool valid[4];
         if (!HAS_TABLE) {
-            // natural order: 16 | C, so the 16 elements share one tap and are contiguous in c
-            bool in_k = kp0 < p.K;
-            int tap = in_k ? kp0 / p.C : 0;
-            int c = kp0 - tap * p.C;
-            int dh = tap / p.kw, dw = tap - dh * p.kw;
-            int hi = hbase + dh, wi = wbase + dw;
-            bool inb = in_k && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
+            // natural order kp = tap*C + c ; 4 | C, so the lane's 4 elements are contiguous channels of one tap
+            const bool in_k = kp0 < p.K;
+            const int dh = ntap / p.kw, dw = ntap - dh * p.kw;
+            const int hi = hbase + dh, wi = wbase + dw;
+            const bool inb = in_k && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
             if (inb) {
-                load16<TIn>(x + ((img + (int64_t)hi * p.W + wi) * p.C + c), v);
+                load4<TIn>(img + ((int64_t)hi * p.W + wi) * p.C + nc, v);
             } else {
 #pragma unroll
-                for (int j = 0; j < 16; ++j) v[j] = 0.0f;
+                for (int j = 0; j < 4; ++j) v[j] = 0.0f;
             }
 #pragma unroll
-            for (int j = 0; j < 16; ++j) valid[j] = in_k;
+            for (int j = 0; j < 4; ++j) valid[j] = in_k;
+            nc += 256;
+            while (nc >= p.C) { nc -= p.C; ++ntap; }
         } else {
-            int idx[16];
-            const int4* t4 = reinterpret_cast<const int4*>(p.ksrc + kp0);
+            const int4 t = *reinterpret_cast<const int4*>(p.ksrc + kp0);
+            const int idx[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                int4 t = t4[i];
-                idx[4 * i] = t.x; idx[4 * i + 1] = t.y; idx[4 * i + 2] = t.z; idx[4 * i + 3] = t.w;
-            }
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                int e = idx[j];
+            for (int j = 0; j < 4; ++j) {
+                const int e = idx[j];
                 valid[j] = e >= 0;
-                int tap = (e >> 16) & 0x7FFF, c = e & 0xFFFF;
-                int dh = tap / p.kw, dw = tap - dh * p.kw;
-                int hi = hbase + dh, wi = wbase + dw;
-                bool inb = valid[j] && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
-                v[j] = inb ? dgq_to_float(x[(img + (int64_t)hi * p.W + wi) * p.C + c]) : 0.0f;
+                const int hi = hbase + ((e >> 24) & 0x7F), wi = wbase + ((e >> 16) & 0xFF), c = e & 0xFFFF;
+                const bool inb = valid[j] && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
+                v[j] = inb ? dgq_to_float(img[((int64_t)hi * p.W + wi) * p.C + c]) : 0.0f;
             }
         }
-        uint32_t w4[4] = {0, 0, 0, 0};
+        uint32_t w = 0;
         int ssum = 0;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            float q = dgq_affine_code(v[j], d, z, p.qmax);
-            int s = valid[j] ? ((int)q - (int)p.offset) : 0;
+        for (int j = 0; j < 4; ++j) {
+            const float q = dgq_affine_code_fast(v[j], d, inv, z, p.qmax);
+            const int s = valid[j] ? ((int)q - ioff) : 0;
             ssum += s;
-            w4[j >> 2] |= ((uint32_t)(s & 0xFF)) << (8 * (j & 3));
+            w |= ((uint32_t)(s & 0xFF)) << (8 * j);
         }
         partial += PER_M ? (float)ssum : d * (float)ssum;
-        *reinterpret_cast<uint4*>(out + kp0) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+        out[kp0 >> 2] = w;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) partial += __shfl_down(partial, o, 64);
-    if (lane == 0) p.rowsum[row] = partial;
+    if (lane == 0) p.rowsum[(int64_t)blockIdx.y * p.M + row] = partial;
 }
 
 template <typename TIn>
 static void launch_quant_act(const QuantActParams& p, bool table, bool per_m, hipStream_t st) {
-    dim3 grid((p.M + 3) / 4), block(256);
+    const int ks = (p.Kp + p.kp_per_split - 1) / p.kp_per_split;
+    dim3 grid((p.M + 3) / 4, ks), block(256);
     if (table) {
         if (per_m) hipLaunchKernelGGL((quant_act_kernel<TIn, true, true>), grid, block, 0, st, p);
         else hipLaunchKernelGGL((quant_act_kernel<TIn, true, false>), grid, block, 0, st, p);
@@ -144,21 +155,28 @@ static void launch_quant_act(const QuantActParams& p, bool table, bool per_m, hi
     }
 }
 
+extern "C" int dgq_quant_act_parts(int Kp, int ksplits) {
+    if (ksplits < 1) ksplits = 1;
+    const int per = (((Kp + ksplits - 1) / ksplits) + 255) / 256 * 256;
+    return (Kp + per - 1) / per;
+}
+
 extern "C" int dgq_quant_act(const void* x, int x_dtype, int B, int H, int W, int C,
                              int kh, int kw, int stride, int pad,
                              const int32_t* ksrc, int Kp,
                              int per_m, const float* delta, const float* zp, int L,
-                             int bits, int8_t* codes, float* rowsum, void* stream) {
+                             int bits, int8_t* codes, float* rowsum, int ksplits, void* stream) {
     DGQ_CHECK_ARG(x && delta && zp && codes && rowsum, "dgq_quant_act: null pointer");
     DGQ_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && kh > 0 && kw > 0 && stride > 0 && pad >= 0,
                   "dgq_quant_act: bad geometry");
-    DGQ_CHECK_ARG(kh * kw <= 0x7FFF && C <= 0xFFFF, "dgq_quant_act: kernel/channel count out of range");
+    DGQ_CHECK_ARG(kh <= 0x7F && kw <= 0xFF && C <= 0xFFFF, "dgq_quant_act: kernel/channel count out of range");
     DGQ_CHECK_ARG(Kp > 0 && Kp % DGQ_KTILE == 0, "dgq_quant_act: Kp=%d must be a multiple of %d", Kp, DGQ_KTILE);
     DGQ_CHECK_ARG(bits >= 2 && bits <= 8, "dgq_quant_act: bits=%d", bits);
     DGQ_CHECK_ARG(!per_m || L >= 1, "dgq_quant_act: per_m needs L >= 1");
+    DGQ_CHECK_ARG(ksplits >= 1 && ksplits <= 64, "dgq_quant_act: ksplits=%d", ksplits);
     int K = C * kh * kw;
     if (!ksrc) {
-        DGQ_CHECK_ARG(C % 16 == 0, "dgq_quant_act: natural K order needs C %% 16 == 0 (C=%d)", C);
+        DGQ_CHECK_ARG(C % 4 == 0, "dgq_quant_act: natural K order needs C %% 4 == 0 (C=%d)", C);
         DGQ_CHECK_ARG(Kp >= K, "dgq_quant_act: natural K order needs Kp >= K");
     }
     int Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W + 2 * pad - kw) / stride + 1;
@@ -169,6 +187,7 @@ extern "C" int dgq_quant_act(const void* x, int x_dtype, int B, int H, int W, in
     p.qmax = (float)((1 << bits) - 1);
     p.offset = bits == 8 ? 128.0f : 0.0f;
     p.codes = codes; p.rowsum = rowsum; p.M = B * Ho * Wo;
+    p.kp_per_split = (((Kp + ksplits - 1) / ksplits) + 255) / 256 * 256;
     hipStream_t st = (hipStream_t)stream;
     switch (x_dtype) {
         case DGQ_F32: launch_quant_act<float>(p, ksrc != nullptr, per_m != 0, st); break;

@@ -117,20 +117,27 @@ class ActBinding:
 
 
 # ------------------------------------------------------------------------------------------ hot path
+def act_ksplits(M, Kp):
+    """K splits of the activation pre-pass: aim for >= 8192 waves (one per row x split) on low-M layers."""
+    ks = max(1, min(16, 8192 // max(M, 1), Kp // 512))
+    return _lib.load().dgq_quant_act_parts(Kp, ks)
+
+
 def quant_act(x_cl: torch.Tensor, B, H, W, C, kh, kw, stride, pad, ab: ActBinding):
-    """x_cl: contiguous channels-last storage [B][H][W][C] (any fp dtype). Returns (codes, rowsum, M)."""
+    """x_cl: contiguous channels-last storage [B][H][W][C] (any fp dtype). Returns (codes, rowsum[parts][M], M)."""
     Ho = (H + 2 * pad - kh) // stride + 1
     Wo = (W + 2 * pad - kw) // stride + 1
     M = B * Ho * Wo
+    parts = act_ksplits(M, ab.Kp)
     codes = torch.empty((M, ab.Kp), dtype=torch.int8, device=x_cl.device)
-    rowsum = torch.empty((M,), dtype=torch.float32, device=x_cl.device)
+    rowsum = torch.empty((parts, M), dtype=torch.float32, device=x_cl.device)
     per_m = 0 if ab.mode == "perK" else 1
     delta = ab.cdelta if ab.mode == "perK" else ab.mdelta
     zp = ab.czp if ab.mode == "perK" else ab.mzp
     L = 1 if ab.mode == "perK" else ab.L
     _lib_call("dgq_quant_act", _lib.ptr(x_cl), _lib.DTYPE_CODE[x_cl.dtype], B, H, W, C, kh, kw, stride, pad,
               _lib.ptr(ab.ksrc), ab.Kp, per_m, _lib.ptr(delta), _lib.ptr(zp), L, ab.abits,
-              _lib.ptr(codes), _lib.ptr(rowsum), _lib.stream())
+              _lib.ptr(codes), _lib.ptr(rowsum), parts, _lib.stream())
     return codes, rowsum, M
 
 
@@ -152,7 +159,8 @@ def gemm_wxa8(codes, rowsum, M, ab: ActBinding, out_dtype, out: Optional[torch.T
     if out is None:
         out = torch.empty((M, pw.N), dtype=out_dtype, device=codes.device)
     per_m = 0 if ab.mode == "perK" else 1
-    _lib_call("dgq_gemm_wxa8", _lib.ptr(codes), _lib.ptr(rowsum), M, ab.Kp, _lib.ptr(ab.wpacked), pw.bits, pw.N,
+    parts = rowsum.shape[0] if rowsum.dim() == 2 else 1
+    _lib_call("dgq_gemm_wxa8", _lib.ptr(codes), _lib.ptr(rowsum), parts, M, ab.Kp, _lib.ptr(ab.wpacked), pw.bits, pw.N,
               per_m,
               _lib.ptr(ab.cdelta) if not per_m else None, _lib.ptr(ab.cflush) if not per_m else None,
               _lib.ptr(ab.mdelta) if per_m else None, _lib.ptr(ab.mzp) if per_m else None,

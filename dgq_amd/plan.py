@@ -44,7 +44,7 @@ class ActLayout:
     L: int = 1
     # perK
     kperm: Optional[torch.Tensor] = None      # [Kp] int32: k_ref or -1   (weight packing)
-    ksrc: Optional[torch.Tensor] = None       # [Kp] int32: (tap<<16)|c or -1 (activation gather)
+    ksrc: Optional[torch.Tensor] = None       # [Kp] int32: (dh<<24)|(dw<<16)|c or -1 (activation gather)
     cdelta: Optional[torch.Tensor] = None     # [Kp/64] f32
     czp: Optional[torch.Tensor] = None
     cflush: Optional[torch.Tensor] = None     # [Kp/64] u8
@@ -74,8 +74,10 @@ def classify_act_params(delta: torch.Tensor, kind: str):
     raise ValueError("unsupported activation-quantizer shape %s for %s" % (tuple(delta.shape), kind))
 
 
-def plan_act(delta: torch.Tensor, zp: torch.Tensor, kind: str, C: int, taps: int, abits: int) -> ActLayout:
-    """delta/zp as stored in the cali_ckpt (CPU tensors)."""
+def plan_act(delta: torch.Tensor, zp: torch.Tensor, kind: str, C: int, taps: int, abits: int, kw: int = 0) -> ActLayout:
+    """delta/zp as stored in the cali_ckpt (CPU tensors). ``kw``: kernel width (default: square kernel)."""
+    if kw <= 0:
+        kw = int(round(taps ** 0.5))
     delta = delta.detach().float().cpu()
     zp = torch.as_tensor(zp).detach().float().cpu()
     mode = classify_act_params(delta, kind)
@@ -113,7 +115,7 @@ def plan_act(delta: torch.Tensor, zp: torch.Tensor, kind: str, C: int, taps: int
         n = int(counts[g])
         ks = order[src:src + n]
         kperm[pos:pos + n] = ks.to(torch.int32)
-        ksrc[pos:pos + n] = ((tap_of[ks] << 16) | c_of[ks]).to(torch.int32)
+        ksrc[pos:pos + n] = (((tap_of[ks] // kw) << 24) | ((tap_of[ks] % kw) << 16) | c_of[ks]).to(torch.int32)
         c0, c1 = pos // KCHUNK, (pos + int(padded[g])) // KCHUNK
         cdelta[c0:c1] = uniq[g, 0]
         czp[c0:c1] = uniq[g, 1]

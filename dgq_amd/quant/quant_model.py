@@ -45,6 +45,8 @@ class QuantModel(nn.Module):
                           prev_name=None)
         self.quant_block(self.model, wq_params, aq_params, softmax_aq_params)
         self.time_aware = None          # set by load_cali_model(time_aware_aqtizer=True)
+        self._graphs = None
+        self._graph_pool = None
 
     # -- module surgery (quant_model.py:66-103) ------------------------------------------------------------
     def quant_module(self, module: nn.Module, wq_params: dict = {}, aq_params: dict = {},
@@ -84,6 +86,7 @@ class QuantModel(nn.Module):
         self.model.conv_out.disable_aq = True
 
     def forward(self, sample, timesteps, encoder_hidden_states, *args, **kwargs):
+        slot = None
         if self.time_aware is not None:
             # time-aware activation tables (calibration.py:297-312): the reference re-copies ~750 δ/z tensors
             # host->device here; every slot is already device-resident, so this only flips an index.
@@ -91,7 +94,52 @@ class QuantModel(nn.Module):
             n = self.time_aware["num_inference_steps"]
             slot = int((1000 - int(t)) // (1000 // n))
             self.activate_slot(slot)
+        if self._graphs is not None and torch.is_tensor(sample) and sample.is_cuda and not args:
+            return self._graph_forward(slot, sample, timesteps, encoder_hidden_states, kwargs)
         return self.model(sample, timesteps, encoder_hidden_states, *args, **kwargs)
+
+    # -- hipGraph replay of a whole denoise step -------------------------------------------------------------------
+    def enable_graphs(self, enabled: bool = True):
+        """Capture one hipGraph per (timestep slot, input signature) and replay it afterwards: a step is ~1400 kernel
+        launches, which eager Python issues slower than the GPU executes them.  Every kernel of this package takes
+        its stream explicitly and neither allocates nor synchronises, so the whole forward is capturable."""
+        self._graphs = {} if enabled else None
+        self._graph_pool = None
+        return self
+
+    def _graph_forward(self, slot, sample, timesteps, ehs, kwargs):
+        ack = kwargs.get("added_cond_kwargs")
+        extra = {k: v for k, v in kwargs.items() if k != "added_cond_kwargs"}
+        tval = int(timesteps if not torch.is_tensor(timesteps) else (timesteps if timesteps.dim() == 0 else timesteps[0]))
+        key = (slot, tuple(sample.shape), sample.dtype, tuple(ehs.shape),
+               tuple(sorted((k, tuple(v.shape)) for k, v in ack.items())) if ack else None)
+        ent = self._graphs.get(key)
+        if ent is None:
+            dev = sample.device
+            st = dict(sample=sample.clone(), ehs=ehs.clone(), t=torch.full((1,), tval, dtype=torch.int64, device=dev),
+                      ack={k: v.clone() for k, v in ack.items()} if ack else None)
+            kw = dict(extra)
+            if st["ack"] is not None:
+                kw["added_cond_kwargs"] = st["ack"]
+            with torch.no_grad():
+                self.model(st["sample"], st["t"], st["ehs"], **kw)          # eager warm-up: lazy inits, caches
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                if self._graph_pool is None:
+                    self._graph_pool = torch.cuda.graph_pool_handle()
+                with torch.cuda.graph(g, pool=self._graph_pool):
+                    out = self.model(st["sample"], st["t"], st["ehs"], **kw)
+            ent = (g, st, out)
+            self._graphs[key] = ent
+        g, st, out = ent
+        st["sample"].copy_(sample)
+        st["ehs"].copy_(ehs)
+        st["t"].fill_(tval)
+        if ack:
+            for k, v in ack.items():
+                st["ack"][k].copy_(v)
+        g.replay()
+        return [o.clone() for o in out]
 
     def activate_slot(self, slot: int):
         ta = self.time_aware

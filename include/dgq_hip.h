@@ -63,19 +63,22 @@ int dgq_pack_w8(const uint8_t* codes, int N, int K, const int32_t* kperm, int Kp
  * x is a channels-last tensor [B][H][W][C] (a Linear input [B,T,K] is B=B·T... H=W=1, C=K); geometry
  * (kh,kw,stride,pad) as the conv; M = B·Ho·Wo.  Source of packed position kp:
  *   ksrc == NULL : natural order kp = tap·C + c   (tap = dh·kw + dw)
- *   ksrc != NULL : ksrc[kp] = (tap << 16) | c, or -1 for padding (zero code).
+ *   ksrc != NULL : ksrc[kp] = (dh << 24) | (dw << 16) | c, or -1 for padding (zero code).
  * Quantiser parameters:
  *   per_m == 0 : cdelta/czp [Kp/64] — one (δ,z) per 64-wide chunk (DGQ groups are chunk aligned);
  *                rowsum[m] = Σ_kp δ(kp)·s[m,kp]
  *   per_m == 1 : mdelta/mzp [L] indexed by (m % L) (L=1: scalar quantiser);
  *                rowsum[m] = Σ_kp s[m,kp]  (exact integer in f32)
  * bits: activation bits (8 -> offset 128, <8 -> offset 0).  Out-of-image taps read 0.0 and are
- * quantised like any value (F.unfold pads before the quantizer). */
+ * quantised like any value (F.unfold pads before the quantizer).
+ * ksplits >= 1 splits every row's K range over that many waves (low-M layers); rowsum then has
+ * dgq_quant_act_parts(Kp, ksplits) x M entries ([part][m]) which dgq_gemm_wxa8 adds in a fixed order. */
 int dgq_quant_act(const void* x, int x_dtype, int B, int H, int W, int C,
                   int kh, int kw, int stride, int pad,
                   const int32_t* ksrc, int Kp,
                   int per_m, const float* delta, const float* zp, int L,
-                  int bits, int8_t* codes, float* rowsum, void* stream);
+                  int bits, int8_t* codes, float* rowsum, int ksplits, void* stream);
+int dgq_quant_act_parts(int Kp, int ksplits);
 
 /* ---- the hot kernel: W4A8 / W8A8 MFMA GEMM with fused dequantisation ------------------------------
  * Replaces F.linear / `w.view(N,-1) @ unfolded` / F.conv2d on fake-quantised operands
@@ -86,7 +89,7 @@ int dgq_quant_act(const void* x, int x_dtype, int B, int H, int W, int C,
  * alpha = δw, zw = zero point in the stored code domain (zw − 8·0 for W4: unsigned nibbles; zw − 128 for W8);
  * gamma = bias (+ alpha·U for per_m==0, U[n] = Σ_k δx_k(offset − zx_k)(qw'[n,k] − zw[n]), precomputed per slot);
  * vn[n] = Σ_k qw'[n,k] − K·zw[n].  y [M][ldy] of y_dtype.  cflush[c] != 0 marks the last chunk of a group. */
-int dgq_gemm_wxa8(const int8_t* codes, const float* rowsum, int M, int Kp,
+int dgq_gemm_wxa8(const int8_t* codes, const float* rowsum, int rowsum_parts, int M, int Kp,
                   const void* wpacked, int w_bits, int N,
                   int per_m, const float* cdelta, const uint8_t* cflush,
                   const float* mdelta, const float* mzp, int L, float offset,

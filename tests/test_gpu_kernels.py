@@ -113,7 +113,7 @@ def test_gemm_exact_integer(dev):
         import ctypes
         t = lambda x: x.to(dev).contiguous()
         cdg, flg, al, zwg, ga, rs = t(gscale), t(fl), t(alpha), t(zw), t(gamma), t(rowsum)
-        rc = lib.dgq_gemm_wxa8(_lib.ptr(codes), _lib.ptr(rs), M, Kp, _lib.ptr(wp), wbits, N, 0,
+        rc = lib.dgq_gemm_wxa8(_lib.ptr(codes), _lib.ptr(rs), 1, M, Kp, _lib.ptr(wp), wbits, N, 0,
                                _lib.ptr(cdg), _lib.ptr(flg), None, None, 1, ctypes.c_float(128.0),
                                _lib.ptr(al), _lib.ptr(zwg), _lib.ptr(ga), None,
                                _lib.ptr(y), 0, N, _lib.ptr(ws), ws.numel(), _lib.stream())
@@ -131,7 +131,7 @@ def test_gemm_exact_integer(dev):
             acc1 - zw[None, :].double() * rowsum[:, None].double()
             + (128.0 - mz[mi][:, None].double()) * vn[None, :].double()) + gamma[None, :].double()
         mdg, mzg, vng = t(md), t(mz), t(vn)
-        rc = lib.dgq_gemm_wxa8(_lib.ptr(codes), _lib.ptr(rs), M, Kp, _lib.ptr(wp), wbits, N, 1,
+        rc = lib.dgq_gemm_wxa8(_lib.ptr(codes), _lib.ptr(rs), 1, M, Kp, _lib.ptr(wp), wbits, N, 1,
                                None, None, _lib.ptr(mdg), _lib.ptr(mzg), L, ctypes.c_float(128.0),
                                _lib.ptr(al), _lib.ptr(zwg), _lib.ptr(ga), _lib.ptr(vng),
                                _lib.ptr(y), 0, N, _lib.ptr(ws), ws.numel(), _lib.stream())

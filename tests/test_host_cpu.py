@@ -62,7 +62,7 @@ def test_plan_perK_groups_are_chunk_aligned_permutation():
         assert torch.all(d[ks] == lay.cdelta[c]) and torch.all(z[ks] == lay.czp[c])
     # ksrc decodes to the same (c, tap) as kperm's reference index k = c*taps + tap
     m = lay.kperm >= 0
-    cc, tt = lay.ksrc[m] & 0xFFFF, lay.ksrc[m] >> 16
+    cc, tt = lay.ksrc[m] & 0xFFFF, (lay.ksrc[m] >> 24) * 3 + ((lay.ksrc[m] >> 16) & 0xFF)
     assert torch.equal((cc * taps + tt).int(), lay.kperm[m])
     assert int(lay.cflush[-1]) == 1 and int(lay.cflush.sum()) >= lay.n_groups
     # every group's last chunk is flagged: chunks between flags share one scale
