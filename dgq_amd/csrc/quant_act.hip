@@ -185,7 +185,7 @@ extern "C" int dgq_quant_act(const void* x, int x_dtype, int B, int H, int W, in
     p.x = x; p.B = B; p.H = H; p.W = W; p.C = C; p.kh = kh; p.kw = kw; p.stride = stride; p.pad = pad;
     p.Ho = Ho; p.Wo = Wo; p.ksrc = ksrc; p.Kp = Kp; p.K = K; p.delta = delta; p.zp = zp; p.L = per_m ? L : 1;
     p.qmax = (float)((1 << bits) - 1);
-    p.offset = bits == 8 ? 128.0f : 0.0f;
+    p.offset = (float)(1 << (bits - 1));
     p.codes = codes; p.rowsum = rowsum; p.M = B * Ho * Wo;
     p.kp_per_split = (((Kp + ksplits - 1) / ksplits) + 255) / 256 * 256;
     hipStream_t st = (hipStream_t)stream;

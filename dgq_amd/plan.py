@@ -126,12 +126,13 @@ def plan_act(delta: torch.Tensor, zp: torch.Tensor, kind: str, C: int, taps: int
         cdelta[pos // KCHUNK:] = uniq[G - 1, 0]
         czp[pos // KCHUNK:] = uniq[G - 1, 1]
         cflush[-1] = 1
-    offset = 128.0 if abits == 8 else 0.0
+    offset = act_offset(abits)
     kcoef = d.double() * (offset - z.double())
     return ActLayout("perK", kperm=kperm, ksrc=ksrc, cdelta=cdelta, czp=czp, cflush=cflush, kcoef=kcoef, Kp=Kp,
                      n_groups=G)
 
 
 def act_offset(abits: int) -> float:
-    """Code offset that maps activation codes into int8: q∈[0,255] -> s=q−128 for A8, none below."""
-    return 128.0 if abits == 8 else 0.0
+    """Code offset o = 2^(b−1): q ∈ [0, 2^b−1] -> s = q − o ∈ [−2^(b−1), 2^(b−1)−1] fits int8 for every b ≤ 8, and
+    centred codes keep the fp32 epilogue free of the cancellation an all-positive operand would cause."""
+    return float(2 ** (abits - 1))

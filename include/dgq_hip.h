@@ -69,7 +69,7 @@ int dgq_pack_w8(const uint8_t* codes, int N, int K, const int32_t* kperm, int Kp
  *                rowsum[m] = Σ_kp δ(kp)·s[m,kp]
  *   per_m == 1 : mdelta/mzp [L] indexed by (m % L) (L=1: scalar quantiser);
  *                rowsum[m] = Σ_kp s[m,kp]  (exact integer in f32)
- * bits: activation bits (8 -> offset 128, <8 -> offset 0).  Out-of-image taps read 0.0 and are
+ * bits: activation bits b; code offset = 2^(b-1) (s = q − 2^(b−1) is a centred int8).  Out-of-image taps read 0.0 and are
  * quantised like any value (F.unfold pads before the quantizer).
  * ksplits >= 1 splits every row's K range over that many waves (low-M layers); rowsum then has
  * dgq_quant_act_parts(Kp, ksplits) x M entries ([part][m]) which dgq_gemm_wxa8 adds in a fixed order. */

@@ -186,7 +186,7 @@ def test_f3_layers_vs_reference(case, dev):
         codes, rowsum, M = ops.quant_act(xc, x.shape[0], x.shape[2], x.shape[3], C, case["k"], case["k"],
                                          case["stride"], case["padding"], ab)
     torch.cuda.synchronize()
-    off = 128 if case["abits"] == 8 else 0
+    off = 2 ** (case["abits"] - 1)
     if lay.mode == "perK":
         kperm = lay.kperm
     else:

@@ -80,7 +80,9 @@ def test_plan_layout_classification_and_natural_order():
     assert lay.mode == "perM" and lay.L == 24
     lay = plan_act(torch.rand(1, 1, 100) + 0.1, torch.zeros(1, 1, 100), "conv", 32, 9, 8)
     assert lay.mode == "perM" and lay.L == 100
-    assert plan_act(torch.rand(1, 1, 64) + 0.1, torch.zeros(1, 1, 64), "linear", 64, 1, 6).mode == "perK"
+    d6 = torch.rand(1, 1, 64) + 0.1
+    lay6 = plan_act(d6, torch.full((1, 1, 64), 7.0), "linear", 64, 1, 6)
+    assert lay6.mode == "perK" and torch.allclose(lay6.kcoef, d6.reshape(-1).double() * (32.0 - 7.0))
     p = natural_kperm(32, 9)
     assert p.numel() == 384 and p[0] == 0 and p[1] == 9 and p[32] == 1 and int(p[288]) == -1
     with pytest.raises(ValueError):
