@@ -26,7 +26,6 @@
 #define BM 128
 #define BN 128
 #define BK 128
-#define STAGES 3
 
 struct GemmParams {
     const int8_t* codes;
@@ -79,8 +78,8 @@ __device__ __forceinline__ float dgq_epilogue(const GemmParams& p, float acc, in
     return al * (acc - zw * rs) + ga;
 }
 
-template <int WBITS, bool PER_M, typename TOut>
-__global__ __launch_bounds__(256, 2) void gemm_wxa8_kernel(GemmParams p) {
+template <int WBITS, bool PER_M, typename TOut, int STAGES>
+__global__ __launch_bounds__(256, (STAGES <= 3 ? 2 : 1)) void gemm_wxa8_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr int A_BYTES = BM * BK;                       // 16 KiB
     constexpr int W_ROW = (WBITS == 4) ? BK / 2 : BK;      // bytes per n-row per stage
@@ -175,8 +174,9 @@ __global__ __launch_bounds__(256, 2) void gemm_wxa8_kernel(GemmParams p) {
     // ordinary loads: per-chunk scales (+δ = flush after this chunk, −δ = keep accumulating), per-row and
     // per-column dequantisation vectors.  A VMEM load inside the main loop would make hipcc drain the DMA ring with
     // vmcnt(0), and dependent global loads in the epilogue cost ~1 us each on a lone wave — both avoided this way.
-    if (nk > 0) issue_tile(kt_begin, 0);
-    if (nk > 1) issue_tile(kt_begin + 1, 1);
+#pragma unroll
+    for (int i = 0; i < STAGES - 1; ++i)
+        if (i < nk) issue_tile(kt_begin + i, i);
     float* vtab = reinterpret_cast<float*>(smem + STAGES * STAGE_BYTES);   // [7][128]: R0 R1 R2 | alpha zw gamma vn
     float* ctab = vtab + 7 * 128;
     {
@@ -211,9 +211,10 @@ __global__ __launch_bounds__(256, 2) void gemm_wxa8_kernel(GemmParams p) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // DMA tiles 0,1 + the staging loads/stores
     __builtin_amdgcn_s_barrier();
 
+    // ring invariant at the top of iteration t: tiles t .. t+STAGES-2 are issued, tile t has landed.
+    int stage = 0, istage = STAGES - 1;
     for (int t = 0; t < nk; ++t) {
-        const int stage = t % STAGES;
-        if (t + 2 < nk) issue_tile(kt_begin + t + 2, (t + 2) % STAGES);
+        if (t + STAGES - 1 < nk) issue_tile(kt_begin + t + STAGES - 1, istage);
         const uint8_t* sa = smem + stage * STAGE_BYTES;
         const uint8_t* sw = sa + A_BYTES;
 #pragma unroll
@@ -252,10 +253,21 @@ __global__ __launch_bounds__(256, 2) void gemm_wxa8_kernel(GemmParams p) {
                 }
             }
         }
-        // tile t+1 must have landed (this wave's pieces) before anyone reads it; tile t+2 may stay in flight
-        if (t + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_TILE) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // tile t+1 must have landed (this wave's pieces) before anyone reads it; the STAGES-2 younger tiles may stay
+        // in flight (vmcnt counts the wave's DMA instructions in issue order)
+        {
+            const int younger = min(STAGES - 2, max(0, nk - 2 - t));
+            switch (younger) {
+                case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+                case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 * DMA_PER_TILE) : "memory"); break;
+                case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DMA_PER_TILE) : "memory"); break;
+                case 3: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * DMA_PER_TILE) : "memory"); break;
+                default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * DMA_PER_TILE) : "memory"); break;
+            }
+        }
         __builtin_amdgcn_s_barrier();
+        stage = (stage + 1 == STAGES) ? 0 : stage + 1;
+        istage = (istage + 1 == STAGES) ? 0 : istage + 1;
     }
 
     // epilogue.  The MFMA C/D layout (col = lane&15, row = (lane>>4)*4 + reg) would give 4-byte stores in 64-byte
@@ -360,19 +372,27 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(GemmParams p) {
     }
 }
 
-template <int WBITS, bool PER_M, typename TOut>
-static void launch_one(const GemmParams& p, hipStream_t st) {
+template <int WBITS, bool PER_M, typename TOut, int STAGES>
+static void launch_staged(const GemmParams& p, hipStream_t st) {
     constexpr int lds_stages = STAGES * (BM * BK + BN * ((WBITS == 4) ? BK / 2 : BK));
     constexpr int lds_max = lds_stages + 7 * 128 * 4 + 8192;    // + epilogue vectors + per-chunk scales (<= 2048 chunks)
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_wxa8_kernel<WBITS, PER_M, TOut>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_wxa8_kernel<WBITS, PER_M, TOut, STAGES>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
         attr_set = true;
     }
     const int lds = lds_stages + 7 * 128 * 4 + (PER_M ? 0 : ((2 * p.tiles_per_split * 4 + 15) & ~15));
     dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, p.splits), block(256);
-    hipLaunchKernelGGL((gemm_wxa8_kernel<WBITS, PER_M, TOut>), grid, block, lds, st, p);
+    hipLaunchKernelGGL((gemm_wxa8_kernel<WBITS, PER_M, TOut, STAGES>), grid, block, lds, st, p);
+}
+
+// STAGES is a template parameter, but only the 3-stage ring (2 blocks per CU) is launched: a 5-stage ring for grids
+// of <= 1 block per CU measured SLOWER (conv 64x64 320->320: 37 -> 52 us): a lone wave per SIMD is bound by its own
+// ds_read -> MFMA -> barrier chain (~0.6 us per K tile), not by DMA latency; co-resident blocks hide that chain.
+template <int WBITS, bool PER_M, typename TOut>
+static void launch_one(const GemmParams& p, hipStream_t st) {
+    launch_staged<WBITS, PER_M, TOut, 3>(p, st);
     if (p.splits > 1) {
         int64_t total = (int64_t)p.M * ((p.N + 3) / 4);
         int g = (int)((total + 255) / 256);

@@ -16,6 +16,9 @@ struct QuantActParams {
     float* rowsum;            // [ksplits][M] partial sums (the GEMM epilogue adds them in a fixed order)
     int M;
     int kp_per_split;         // multiple of 256
+    const float* pre_scale;   // optional [B][C]: v = x*scale + shift (fused GroupNorm), then pre_act
+    const float* pre_shift;
+    int pre_act;              // 0 none, 1 SiLU
 };
 
 template <typename TIn>
@@ -105,6 +108,15 @@ __global__ __launch_bounds__(256) void quant_act_kernel(QuantActParams p) {
             const bool inb = in_k && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
             if (inb) {
                 load4<TIn>(img + ((int64_t)hi * p.W + wi) * p.C + nc, v);
+                if (p.pre_scale) {
+                    const float4 sc = *reinterpret_cast<const float4*>(p.pre_scale + (int64_t)b * p.C + nc);
+                    const float4 sh = *reinterpret_cast<const float4*>(p.pre_shift + (int64_t)b * p.C + nc);
+                    v[0] = v[0] * sc.x + sh.x; v[1] = v[1] * sc.y + sh.y; v[2] = v[2] * sc.z + sh.z; v[3] = v[3] * sc.w + sh.w;
+                    if (p.pre_act == 1) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = v[j] / (1.0f + expf(-v[j]));
+                    }
+                }
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = 0.0f;
@@ -122,7 +134,12 @@ __global__ __launch_bounds__(256) void quant_act_kernel(QuantActParams p) {
                 valid[j] = e >= 0;
                 const int hi = hbase + ((e >> 24) & 0x7F), wi = wbase + ((e >> 16) & 0xFF), c = e & 0xFFFF;
                 const bool inb = valid[j] && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
-                v[j] = inb ? dgq_to_float(img[((int64_t)hi * p.W + wi) * p.C + c]) : 0.0f;
+                float val = inb ? dgq_to_float(img[((int64_t)hi * p.W + wi) * p.C + c]) : 0.0f;
+                if (p.pre_scale && inb) {
+                    val = val * p.pre_scale[(int64_t)b * p.C + c] + p.pre_shift[(int64_t)b * p.C + c];
+                    if (p.pre_act == 1) val = val / (1.0f + expf(-val));
+                }
+                v[j] = val;
             }
         }
         uint32_t w = 0;
@@ -165,7 +182,8 @@ extern "C" int dgq_quant_act(const void* x, int x_dtype, int B, int H, int W, in
                              int kh, int kw, int stride, int pad,
                              const int32_t* ksrc, int Kp,
                              int per_m, const float* delta, const float* zp, int L,
-                             int bits, int8_t* codes, float* rowsum, int ksplits, void* stream) {
+                             int bits, int8_t* codes, float* rowsum, int ksplits,
+                             const float* pre_scale, const float* pre_shift, int pre_act, void* stream) {
     DGQ_CHECK_ARG(x && delta && zp && codes && rowsum, "dgq_quant_act: null pointer");
     DGQ_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && kh > 0 && kw > 0 && stride > 0 && pad >= 0,
                   "dgq_quant_act: bad geometry");
@@ -174,6 +192,7 @@ extern "C" int dgq_quant_act(const void* x, int x_dtype, int B, int H, int W, in
     DGQ_CHECK_ARG(bits >= 2 && bits <= 8, "dgq_quant_act: bits=%d", bits);
     DGQ_CHECK_ARG(!per_m || L >= 1, "dgq_quant_act: per_m needs L >= 1");
     DGQ_CHECK_ARG(ksplits >= 1 && ksplits <= 64, "dgq_quant_act: ksplits=%d", ksplits);
+    DGQ_CHECK_ARG((pre_scale == nullptr) == (pre_shift == nullptr) && pre_act >= 0 && pre_act <= 1, "dgq_quant_act: bad prologue");
     int K = C * kh * kw;
     if (!ksrc) {
         DGQ_CHECK_ARG(C % 4 == 0, "dgq_quant_act: natural K order needs C %% 4 == 0 (C=%d)", C);
@@ -188,6 +207,7 @@ extern "C" int dgq_quant_act(const void* x, int x_dtype, int B, int H, int W, in
     p.offset = (float)(1 << (bits - 1));
     p.codes = codes; p.rowsum = rowsum; p.M = B * Ho * Wo;
     p.kp_per_split = (((Kp + ksplits - 1) / ksplits) + 255) / 256 * 256;
+    p.pre_scale = pre_scale; p.pre_shift = pre_shift; p.pre_act = pre_act;
     hipStream_t st = (hipStream_t)stream;
     switch (x_dtype) {
         case DGQ_F32: launch_quant_act<float>(p, ksrc != nullptr, per_m != 0, st); break;

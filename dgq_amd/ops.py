@@ -123,8 +123,22 @@ def act_ksplits(M, Kp):
     return _lib.load().dgq_quant_act_parts(Kp, ks)
 
 
-def quant_act(x_cl: torch.Tensor, B, H, W, C, kh, kw, stride, pad, ab: ActBinding):
-    """x_cl: contiguous channels-last storage [B][H][W][C] (any fp dtype). Returns (codes, rowsum[parts][M], M)."""
+def groupnorm_scale_shift(x_cl: torch.Tensor, B, HW, C, groups, eps, gamma, beta):
+    """GN(x) = x*scale + shift with scale/shift [B][C] (see dgq_groupnorm_scale_shift)."""
+    dev = x_cl.device
+    slices = max(1, min(32, (2048 + B * groups - 1) // (B * groups), HW // 64))
+    scale = torch.empty((B, C), dtype=torch.float32, device=dev)
+    shift = torch.empty((B, C), dtype=torch.float32, device=dev)
+    part = torch.empty((B * groups * slices * 3,), dtype=torch.float32, device=dev)
+    _lib_call("dgq_groupnorm_scale_shift", _lib.ptr(x_cl), _lib.DTYPE_CODE[x_cl.dtype], B, HW, C, groups,
+              _c.c_float(eps), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(part),
+              slices, _lib.stream())
+    return scale, shift
+
+
+def quant_act(x_cl: torch.Tensor, B, H, W, C, kh, kw, stride, pad, ab: ActBinding, pre=None):
+    """x_cl: contiguous channels-last storage [B][H][W][C] (any fp dtype). Returns (codes, rowsum[parts][M], M).
+    pre = (scale [B][C], shift [B][C], act) folds a GroupNorm (+SiLU when act == 1) into the load."""
     Ho = (H + 2 * pad - kh) // stride + 1
     Wo = (W + 2 * pad - kw) // stride + 1
     M = B * Ho * Wo
@@ -137,7 +151,8 @@ def quant_act(x_cl: torch.Tensor, B, H, W, C, kh, kw, stride, pad, ab: ActBindin
     L = 1 if ab.mode == "perK" else ab.L
     _lib_call("dgq_quant_act", _lib.ptr(x_cl), _lib.DTYPE_CODE[x_cl.dtype], B, H, W, C, kh, kw, stride, pad,
               _lib.ptr(ab.ksrc), ab.Kp, per_m, _lib.ptr(delta), _lib.ptr(zp), L, ab.abits,
-              _lib.ptr(codes), _lib.ptr(rowsum), parts, _lib.stream())
+              _lib.ptr(codes), _lib.ptr(rowsum), parts,
+              _lib.ptr(pre[0]) if pre else None, _lib.ptr(pre[1]) if pre else None, pre[2] if pre else 0, _lib.stream())
     return codes, rowsum, M
 
 
@@ -182,12 +197,18 @@ def quant_linear(x: torch.Tensor, ab: ActBinding):
     return y.view(*x.shape[:-1], ab.pw.N)
 
 
-def quant_conv2d(x: torch.Tensor, ab: ActBinding, kh, kw, stride, pad):
-    """x logical NCHW (any strides; made channels-last) -> logical NCHW output in channels-last storage."""
+def quant_conv2d(x: torch.Tensor, ab: ActBinding, kh, kw, stride, pad, norm=None):
+    """x logical NCHW (any strides; made channels-last) -> logical NCHW output in channels-last storage.
+    norm = (groups, eps, gamma, beta, act): GroupNorm (+SiLU) of x folded into the quantise-on-load pass."""
     B, C, H, W = x.shape
     xc = x.contiguous(memory_format=torch.channels_last)
     x_store = xc.permute(0, 2, 3, 1)                  # [B,H,W,C] view over the same storage, contiguous
-    codes, rowsum, M = quant_act(x_store, B, H, W, C, kh, kw, stride, pad, ab)
+    pre = None
+    if norm is not None:
+        groups, eps, gamma, beta, act = norm
+        sc, sh = groupnorm_scale_shift(x_store, B, H * W, C, groups, eps, gamma, beta)
+        pre = (sc, sh, act)
+    codes, rowsum, M = quant_act(x_store, B, H, W, C, kh, kw, stride, pad, ab, pre)
     y = gemm_wxa8(codes, rowsum, M, ab, x.dtype)
     Ho = (H + 2 * pad - kh) // stride + 1
     Wo = (W + 2 * pad - kw) // stride + 1

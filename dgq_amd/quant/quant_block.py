@@ -46,10 +46,19 @@ class QuantResnetBlock2D(BaseQuantBlock):
         self.nonlinearity = resnet.nonlinearity
         self.conv_shortcut = resnet.conv_shortcut
 
+    #: fold norm -> SiLU into the conv's quantise-on-load pass (dgq_groupnorm_scale_shift); switch off to obtain the
+    #: intermediate tensors (teacher-forced parity tests pin the unfused graph and compare both).
+    fuse_norm = True
+
+    def _norm_act_conv(self, norm, conv, x):
+        if self.fuse_norm and isinstance(conv, QuantLayer) and isinstance(norm, nn.GroupNorm) and conv.can_fuse_prenorm(x):
+            return conv.forward_prenorm(x, norm, silu=True)
+        return conv(F.silu(norm(x)))
+
     def forward(self, input_tensor, temb):
-        h = self.conv1(F.silu(self.norm1(input_tensor)))
+        h = self._norm_act_conv(self.norm1, self.conv1, input_tensor)
         h = h + self.time_emb_proj(F.silu(temb))[:, :, None, None]
-        h = self.conv2(F.silu(self.norm2(h)))
+        h = self._norm_act_conv(self.norm2, self.conv2, h)
         if self.conv_shortcut is not None:
             input_tensor = self.conv_shortcut(input_tensor)
         return input_tensor + h

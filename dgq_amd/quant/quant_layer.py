@@ -339,6 +339,20 @@ class QuantLayer(nn.Module):
             return ops.quant_conv2d(x, ab, kh, kw, self.fwd_kwargs["stride"][0], self.fwd_kwargs["padding"][0])
         return ops.quant_linear(x, ab)
 
+    def can_fuse_prenorm(self, x: torch.Tensor) -> bool:
+        """True when this layer runs on the integer path, so a preceding GroupNorm(+SiLU) can be folded into its
+        quantise-on-load pass (dgq_groupnorm_scale_shift + dgq_quant_act prologue)."""
+        return (self.is_conv and self.use_wq and self.use_aq and not self.disable_aq and x.is_cuda
+                and x.dtype == torch.float32
+                and (self.aqtizer.init or (self._slot_ref is not None and self._slot_ref.slot in self._act_tables)))
+
+    def forward_prenorm(self, x: torch.Tensor, norm: nn.GroupNorm, silu: bool = True) -> torch.Tensor:
+        """conv(act(GroupNorm(x))) without materialising the normalised tensor."""
+        ab = self._binding()
+        kh, kw = self.w.shape[2], self.w.shape[3]
+        return ops.quant_conv2d(x, ab, kh, kw, self.fwd_kwargs["stride"][0], self.fwd_kwargs["padding"][0],
+                                norm=(norm.num_groups, norm.eps, norm.weight.data, norm.bias.data, 1 if silu else 0))
+
     # -- state switches (quant_layer.py:663-686) -----------------------------------------------------------
     def set_quant_state(self, use_wq: bool = False, use_aq: bool = False) -> None:
         self.use_wq = use_wq if not self.ignore_recon else False

@@ -71,14 +71,24 @@ int dgq_pack_w8(const uint8_t* codes, int N, int K, const int32_t* kperm, int Kp
  *                rowsum[m] = Σ_kp s[m,kp]  (exact integer in f32)
  * bits: activation bits b; code offset = 2^(b-1) (s = q − 2^(b−1) is a centred int8).  Out-of-image taps read 0.0 and are
  * quantised like any value (F.unfold pads before the quantizer).
+ * pre_scale/pre_shift [B][C] (or NULL): the element is first mapped to x·scale + shift (a GroupNorm folded into
+ * the load, see dgq_groupnorm_scale_shift) and, with pre_act == 1, through SiLU; out-of-image taps stay 0.
  * ksplits >= 1 splits every row's K range over that many waves (low-M layers); rowsum then has
  * dgq_quant_act_parts(Kp, ksplits) x M entries ([part][m]) which dgq_gemm_wxa8 adds in a fixed order. */
 int dgq_quant_act(const void* x, int x_dtype, int B, int H, int W, int C,
                   int kh, int kw, int stride, int pad,
                   const int32_t* ksrc, int Kp,
                   int per_m, const float* delta, const float* zp, int L,
-                  int bits, int8_t* codes, float* rowsum, int ksplits, void* stream);
+                  int bits, int8_t* codes, float* rowsum, int ksplits,
+                  const float* pre_scale, const float* pre_shift, int pre_act, void* stream);
 int dgq_quant_act_parts(int Kp, int ksplits);
+
+/* GroupNorm of a channels-last tensor x [B][HW][C] as per-(b,c) scale/shift (biased variance, eps as F.group_norm):
+ * GN(x) = x·scale + shift.  Replaces norm1/norm2 of QuantResnetBlock2D.forward (quant_block.py:98-119) together with
+ * the SiLU that follows, which dgq_quant_act applies while loading.  partial_ws: B·G·slices·3 floats. */
+int dgq_groupnorm_scale_shift(const void* x, int x_dtype, int B, int HW, int C, int G, float eps,
+                              const float* gamma, const float* beta, float* scale, float* shift,
+                              float* partial_ws, int slices, void* stream);
 
 /* ---- the hot kernel: W4A8 / W8A8 MFMA GEMM with fused dequantisation ------------------------------
  * Replaces F.linear / `w.view(N,-1) @ unfolded` / F.conv2d on fake-quantised operands

@@ -268,3 +268,39 @@ def test_fused_attention_vs_reference_formulas(D, T, S, H, mode, skip, dev):
     torch.cuda.synchronize()
     err = rel_l2(o.cpu(), ref)
     assert err < (1e-5 if mode == 0 else 2e-3), err
+
+
+# ------------------------------------------------------------------------------------------ fused GroupNorm + SiLU
+@pytest.mark.parametrize("C,H,k", [(64, 12, 3), (320, 16, 3), (96, 9, 1)])
+def test_fused_groupnorm_silu_quant_codes(C, H, k, dev):
+    """norm -> SiLU -> conv with the GroupNorm folded into dgq_quant_act (dgq_groupnorm_scale_shift) against
+    F.group_norm + F.silu + unfused quantisation: codes may differ only where the (differently rounded) normalised
+    value sits on a rounding boundary (< 1e-3 of the elements, never by more than one step)."""
+    import torch.nn.functional as F
+    from dgq_amd import ops
+    from dgq_amd.plan import plan_act
+    g = torch.Generator().manual_seed(C + H)
+    B, N, taps = 2, 32, k * k
+    x = (torch.randn(B, C, H, H, generator=g) * 1.3 + 0.2)
+    gamma, beta = 1 + 0.1 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    w = torch.randn(N, C, k, k, generator=g) * 0.05
+    from dgq_amd.synth import channel_minmax, _group_params
+    wd, wz = channel_minmax(w, 4)
+    pw = ops.PackedWeight(w.to(dev), wd.to(dev), wz.to(dev), None, None, 4, C, taps)
+    d, z = _group_params(C * taps, 8, 8, "gnf", 0)
+    ab = ops.ActBinding(plan_act(d.view(1, -1, 1), z.view(1, -1, 1), "conv", C, taps, 8), pw, 8)
+    xg = x.to(dev).contiguous(memory_format=torch.channels_last)
+    y_ref_in = F.silu(F.group_norm(xg, 32, gamma.to(dev), beta.to(dev), 1e-5)).contiguous(memory_format=torch.channels_last)
+    pad = k // 2
+    c_ref, rs_ref, M = ops.quant_act(y_ref_in.permute(0, 2, 3, 1), B, H, H, C, k, k, 1, pad, ab)
+    sc, sh = ops.groupnorm_scale_shift(xg.permute(0, 2, 3, 1), B, H * H, C, 32, 1e-5, gamma.to(dev), beta.to(dev))
+    c_fus, rs_fus, _ = ops.quant_act(xg.permute(0, 2, 3, 1), B, H, H, C, k, k, 1, pad, ab, (sc, sh, 1))
+    torch.cuda.synchronize()
+    diff = (c_ref.int() - c_fus.int()).abs()
+    assert int(diff.max()) <= 1 and float((diff > 0).float().mean()) < 1e-3
+    # and the statistics themselves
+    mean = x.view(B, 32, -1).mean(-1)
+    var = x.view(B, 32, -1).var(-1, unbiased=False)
+    rstd = (var + 1e-5).rsqrt()
+    exp_scale = (rstd.repeat_interleave(C // 32, 1) * gamma[None])
+    assert rel_l2(sc.cpu(), exp_scale) < 1e-6
