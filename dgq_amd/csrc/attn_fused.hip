@@ -22,6 +22,7 @@
 //   the two key halves of the same query), and the S^T accumulator is directly the B operand of O^T = V^T · P^T
 //   (cdna guide §3 "accumulator tile as the next MFMA's operand"): register r holds key (r&3)+8(r>>2) in lanes 0-31
 //   and that key + 4 in lanes 32-63 — exactly the k = 0/1 pair of the 32x32x2 instruction.
+#include <cstdlib>
 #include "dgq_common.h"
 
 typedef float v16f __attribute__((ext_vector_type(16)));
@@ -213,6 +214,9 @@ static int launch_attn(const AttnParams& p, hipStream_t st) {
     return dgq_launch_status("dgq_attention_f32");
 }
 
+int dgq_attention_bf16x3(const float* q, const float* k, const float* v, float* o, int B, int H, int T, int S, int D,
+                         float scale, int mode, int skip, float qmax, float* stats_ws, float* delta_ws, hipStream_t st);
+
 extern "C" int dgq_attention_f32(const float* q, const float* k, const float* v, float* o, int B, int H, int T, int S,
                                  int D, float scale, int mode, int skip, const float* delta_in, int bits,
                                  float* stats_ws, float* delta_ws, void* stream) {
@@ -230,6 +234,13 @@ extern "C" int dgq_attention_f32(const float* q, const float* k, const float* v,
         if (hipMemcpyAsync(delta_ws, delta_in, sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) {
             dgq_set_error("dgq_attention_f32: memcpy"); return DGQ_ELAUNCH;
         }
+    }
+    // quantised modes: bf16x3 MFMA path (fp32-equivalent accuracy, 16x the matrix rate); DGQ_ATTN_FP32=1 forces the
+    // exact-fp32 MFMA kernels below, which also serve mode 0 and head dims the bf16x3 file does not instantiate
+    static const bool force_fp32 = getenv("DGQ_ATTN_FP32") != nullptr;
+    if (mode >= 1 && !force_fp32) {
+        const int rc = dgq_attention_bf16x3(q, k, v, o, B, H, T, S, D, scale, mode, skip, p.qmax, stats_ws, delta_ws, st);
+        if (rc != 1) return rc;
     }
     switch (D) {
         case 8: return launch_attn<8>(p, st);
