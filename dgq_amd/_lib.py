@@ -27,7 +27,8 @@ SIGNATURES = {
     "dgq_fakequant_rows": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp],
     "dgq_max_f32": [_vp, _i64, _i, _i, _vp, _vp],
     "dgq_logquant_f32": [_vp, _vp, _i64, _i, _i, _vp, _i, _vp],
-    "dgq_attention_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _vp, _i, _vp, _vp, _vp],
+    "dgq_attention_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _vp, _i, _vp, ctypes.c_size_t, _vp],
+    "dgq_attention_workspace_bytes": [_i, _i, _i, _i, _i],
 }
 
 _lib = None
@@ -45,7 +46,7 @@ def load():
         for name, args in SIGNATURES.items():
             fn = getattr(lib, name)
             fn.argtypes = args
-            fn.restype = ctypes.c_size_t if name == "dgq_gemm_workspace_bytes" else ctypes.c_int
+            fn.restype = ctypes.c_size_t if name.endswith("_workspace_bytes") else ctypes.c_int
         lib.dgq_last_error.argtypes = []
         lib.dgq_last_error.restype = ctypes.c_char_p
         _lib = lib

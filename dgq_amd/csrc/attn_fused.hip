@@ -215,12 +215,27 @@ static int launch_attn(const AttnParams& p, hipStream_t st) {
 }
 
 int dgq_attention_bf16x3(const float* q, const float* k, const float* v, float* o, int B, int H, int T, int S, int D,
-                         float scale, int mode, int skip, float qmax, float* stats_ws, float* delta_ws, hipStream_t st);
+                         float scale, int mode, int skip, float qmax, float* stats_ws, float* delta_ws, void* planes,
+                         hipStream_t st);
+size_t dgq_attention_bf16x3_bytes(int B, int H, int S, int D);
+
+// workspace layout: [0,256) δ scalar | stats B·H·T·2 floats (256-byte aligned) | bf16 split planes of K and V
+static size_t attn_stats_off() { return 256; }
+static size_t attn_planes_off(int B, int H, int T) { return 256 + (((size_t)B * H * T * 2 * sizeof(float) + 255) / 256) * 256; }
+
+extern "C" size_t dgq_attention_workspace_bytes(int B, int H, int T, int S, int D) {
+    return attn_planes_off(B, H, T) + dgq_attention_bf16x3_bytes(B, H, S, D);
+}
 
 extern "C" int dgq_attention_f32(const float* q, const float* k, const float* v, float* o, int B, int H, int T, int S,
                                  int D, float scale, int mode, int skip, const float* delta_in, int bits,
-                                 float* stats_ws, float* delta_ws, void* stream) {
-    DGQ_CHECK_ARG(q && k && v && o && stats_ws && delta_ws, "dgq_attention_f32: null pointer");
+                                 void* workspace, size_t workspace_bytes, void* stream) {
+    DGQ_CHECK_ARG(q && k && v && o && workspace, "dgq_attention_f32: null pointer");
+    DGQ_CHECK_ARG((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, "dgq_attention_f32: workspace must be 256-byte aligned");
+    DGQ_CHECK_ARG(workspace_bytes >= dgq_attention_workspace_bytes(B, H, T, S, D), "dgq_attention_f32: workspace too small");
+    float* delta_ws = reinterpret_cast<float*>(workspace);
+    float* stats_ws = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + attn_stats_off());
+    void* planes = reinterpret_cast<char*>(workspace) + attn_planes_off(B, H, T);
     DGQ_CHECK_ARG(B > 0 && H > 0 && T > 0 && S > 0, "dgq_attention_f32: bad shape");
     DGQ_CHECK_ARG(mode >= 0 && mode <= 3 && skip >= 0 && skip < S && bits >= 2 && bits <= 8, "dgq_attention_f32: bad mode");
     DGQ_CHECK_ARG(mode < 2 || delta_in, "dgq_attention_f32: static modes need delta");
@@ -239,7 +254,7 @@ extern "C" int dgq_attention_f32(const float* q, const float* k, const float* v,
     // exact-fp32 MFMA kernels below, which also serve mode 0 and head dims the bf16x3 file does not instantiate
     static const bool force_fp32 = getenv("DGQ_ATTN_FP32") != nullptr;
     if (mode >= 1 && !force_fp32) {
-        const int rc = dgq_attention_bf16x3(q, k, v, o, B, H, T, S, D, scale, mode, skip, p.qmax, stats_ws, delta_ws, st);
+        const int rc = dgq_attention_bf16x3(q, k, v, o, B, H, T, S, D, scale, mode, skip, p.qmax, stats_ws, delta_ws, planes, st);
         if (rc != 1) return rc;
     }
     switch (D) {

@@ -253,8 +253,8 @@ def attention_f32(q, k, v, H, D, scale, mode, skip, delta, bits):
     B, T, _ = q.shape
     S = k.shape[1]
     o = torch.empty_like(q)
-    stats = torch.empty((B * H * T * 2,), dtype=torch.float32, device=q.device)
-    dws = torch.empty((1,), dtype=torch.float32, device=q.device)
+    nbytes = _lib.load().dgq_attention_workspace_bytes(B, H, T, S, D)
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=q.device)      # caching allocator: 512-byte aligned
     _lib_call("dgq_attention_f32", _lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(o), B, H, T, S, D,
-              _c.c_float(scale), mode, skip, _lib.ptr(delta), bits, _lib.ptr(stats), _lib.ptr(dws), _lib.stream())
+              _c.c_float(scale), mode, skip, _lib.ptr(delta), bits, _lib.ptr(ws), nbytes, _lib.stream())
     return o

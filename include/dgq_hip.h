@@ -134,11 +134,14 @@ int dgq_logquant_f32(const float* p, float* y, int64_t rows, int S, int skip_col
  * mode 0: no quantiser; 1: T2ILogQuantizer real-time (δ = max probability over the whole [B,H,T,S≥skip] tensor,
  *         quant_layer_text.py:96-105, found by a first statistics pass); 2: T2ILogQuantizer with δ = delta_in[0];
  *         3: UniformAffineQuantizer always_zero with δ = delta_in[0] (quant_block.py:145-156).
- * skip = 1 bypasses key column 0 (start_peak, sd.py:191-195).  stats_ws: B·H·T·2 floats, delta_ws: 1 float
- * (caller-owned scratch).  head_dim D ∈ {8,16,40,64,80,160}. */
+ * skip = 1 bypasses key column 0 (start_peak, sd.py:191-195).  workspace: caller-owned, 256-byte aligned,
+ * >= dgq_attention_workspace_bytes(...) (δ scalar, per-row softmax statistics, bf16 split planes of K and V).
+ * head_dim D ∈ {8,16,40,64,80,160}.  Quantised modes with D <= 80 run on the bf16 MFMA with exact three-way bf16
+ * operand splits (fp32-equivalent accuracy); the rest on the exact fp32 MFMA. */
 int dgq_attention_f32(const float* q, const float* k, const float* v, float* o, int B, int H, int T, int S, int D,
                       float scale, int mode, int skip, const float* delta_in, int bits,
-                      float* stats_ws, float* delta_ws, void* stream);
+                      void* workspace, size_t workspace_bytes, void* stream);
+size_t dgq_attention_workspace_bytes(int B, int H, int T, int S, int D);
 
 #ifdef __cplusplus
 }
