@@ -70,6 +70,10 @@ __global__ __launch_bounds__(256) void quant_act_kernel(QuantActParams p) {
     const int ho = l / p.Wo, wo = l - ho * p.Wo;
     const int hbase = ho * p.stride - p.pad, wbase = wo * p.stride - p.pad;
     const TIn* img = x + (int64_t)b * p.H * p.W * p.C;
+    const int rowoff = (hbase * p.W + wbase) * p.C;
+    const bool interior = hbase >= 0 && wbase >= 0 && hbase + p.kh <= p.H && wbase + p.kw <= p.W;
+    const float* pre_sc = p.pre_scale ? p.pre_scale + (int64_t)b * p.C : nullptr;
+    const float* pre_sh = p.pre_shift ? p.pre_shift + (int64_t)b * p.C : nullptr;
     float md = 1.0f, mz = 0.0f, minv = 1.0f;
     if (PER_M) {
         const int li = row % p.L;
@@ -132,11 +136,17 @@ __global__ __launch_bounds__(256) void quant_act_kernel(QuantActParams p) {
             for (int j = 0; j < 4; ++j) {
                 const int e = idx[j];
                 valid[j] = e >= 0;
-                const int hi = hbase + ((e >> 24) & 0x7F), wi = wbase + ((e >> 16) & 0xFF), c = e & 0xFFFF;
-                const bool inb = valid[j] && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
-                float val = inb ? dgq_to_float(img[((int64_t)hi * p.W + wi) * p.C + c]) : 0.0f;
+                const int dh = (e >> 24) & 0x7F, dw = (e >> 16) & 0xFF, c = e & 0xFFFF;
+                bool inb = valid[j];
+                if (!interior) {                            // wave-uniform: only border rows pay for bounds checks
+                    const int hi = hbase + dh, wi = wbase + dw;
+                    inb = inb && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
+                }
+                // 32-bit element offset inside the image (an image has < 2^31 elements)
+                const int off = rowoff + (dh * p.W + dw) * p.C + c;
+                float val = inb ? dgq_to_float(img[off]) : 0.0f;
                 if (p.pre_scale && inb) {
-                    val = val * p.pre_scale[(int64_t)b * p.C + c] + p.pre_shift[(int64_t)b * p.C + c];
+                    val = val * pre_sc[c] + pre_sh[c];
                     if (p.pre_act == 1) val = val / (1.0f + expf(-val));
                 }
                 v[j] = val;
