@@ -14,6 +14,10 @@ from dgq_amd import synth
 
 pytestmark = pytest.mark.gpu
 
+# The SDXL / 32x32 / DDIM-50 cases build multi-GB synthetic checkpoints (the whole file takes ~18 min on an MI355X box);
+# they run with DGQ_SLOW_TESTS=1 and their last full output is kept in profiles/r01_parity_full_gpu_suite.txt.
+SLOW = pytest.mark.skipif(os.environ.get("DGQ_SLOW_TESTS") != "1", reason="set DGQ_SLOW_TESTS=1 (multi-GB checkpoints)")
+
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
@@ -101,8 +105,8 @@ def teacher_forced_check(qnn, io, run):
 N_QUANT_LAYERS = {"sd": 280, "sdxl": 792, "tiny": None}
 
 
-@pytest.mark.parametrize("arch,res,cname", [("tiny", 16, "C2"), ("sd", 16, "C2"), ("sd", 32, "C2"), ("tiny", 16, "C3"),
-                                            ("tiny", 16, "C5"), ("sdxl", 16, "C2")])
+@pytest.mark.parametrize("arch,res,cname", [("tiny", 16, "C2"), ("sd", 16, "C2"), pytest.param("sd", 32, "C2", marks=SLOW),
+                                            ("tiny", 16, "C3"), ("tiny", 16, "C5"), pytest.param("sdxl", 16, "C2", marks=SLOW)])
 def test_unet_teacher_forced_vs_oracle(arch, res, cname, tmp_path_factory):
     """Every operator of the HIP path against the CPU oracle (itself bit-identical to the reference,
     tests/test_oracle_golden.py) on identical inputs.  C2 = W4A8 g16 + log/real-time/start-peak + time-aware;
@@ -188,6 +192,7 @@ def test_full_unet_free_running_vs_reference_golden(name, c, tmp_path_factory):
             assert e < 1e-3, (name, t, e)
 
 
+@SLOW
 def test_sdxl_free_running_vs_reference_golden(tmp_path_factory):
     """C4: SDXL W4A8 g16 (log/real-time/start-peak, time-aware, 4 steps) at 128x128 latents, batch 1, against the REAL
     reference's output; bounded by the reference's own 1-thread/8-thread deviation like the SD configs."""
@@ -211,6 +216,7 @@ def test_sdxl_free_running_vs_reference_golden(tmp_path_factory):
         assert e < 2.5 * self_dev, (t, e, self_dev)
 
 
+@SLOW
 def test_ddim50_free_running_vs_reference_golden(tmp_path_factory):
     """C2 end to end: 50-step DDIM (CFG 7.5) with one hipGraph per timestep slot against the REAL reference's final
     latent.  Per DESIGN.md §5 the trajectory is chaotic (the reference deviates from itself by ~1e-1 per UNet call
