@@ -48,10 +48,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    torch.cuda.set_device(local_rank)
+    if "RANK" in os.environ:          # launched by torch.distributed.run: one rank per GPU over RCCL (timing only)
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
     from dgq_amd import ops, synth
@@ -68,7 +68,7 @@ def main():
     n_ts = min(K + W, 50)
     timesteps = [sch.timesteps[i % n_ts] for i in range(W + K)]
     slots = sorted({(1000 - t) // 20 for t in timesteps})
-    qnn, ckpt_path = build_synthetic_qnn("sd", CFG_C2, 64, 2, max(slots) + 1, rank=rank, barrier=barrier, device=dev)
+    qnn, ckpt_path = build_synthetic_qnn("sd", CFG_C2, 64, 2, max(slots) + 1, rank=local_rank, barrier=barrier, device=dev)
     if args.dtype == "fp16":
         qnn.half()
     elif args.dtype == "bf16":
