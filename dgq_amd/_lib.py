@@ -22,7 +22,7 @@ SIGNATURES = {
     "dgq_groupnorm_scale_shift": [_vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "dgq_quant_act_parts": [_i, _i],
     "dgq_gemm_wxa8": [_vp, _vp, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _vp, _i, _i,
-                      _vp, ctypes.c_size_t, _vp],
+                      _vp, ctypes.c_size_t, _vp, _vp],
     "dgq_gemm_workspace_bytes": [_i, _i, _i],
     "dgq_fakequant_rows": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp],
     "dgq_max_f32": [_vp, _i64, _i, _i, _vp, _vp],
@@ -30,6 +30,14 @@ SIGNATURES = {
     "dgq_attention_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _vp, _i, _vp, ctypes.c_size_t, _vp],
     "dgq_attention_workspace_bytes": [_i, _i, _i, _i, _i],
 }
+
+
+
+class GemmExtra(ctypes.Structure):
+    """dgq_gemm_extra_t of include/dgq_hip.h"""
+    _fields_ = [("residual", _vp), ("ldr", _i), ("fq_mode", _i), ("fq_delta", _vp), ("fq_zp", _vp),
+                ("fq_T", _i), ("fq_D", _i), ("fq_skip", _i), ("fq_qmax", _f)]
+
 
 _lib = None
 

@@ -48,6 +48,7 @@ struct GemmParams {
     float* slab;          // split-K partials [S][M][N] (nullptr when S == 1)
     int splits;
     int tiles_per_split;  // K tiles (of BK) per split
+    dgq_gemm_extra_t ex;  // optional epilogue extras (residual add, fused attention-side quantizer)
 };
 
 typedef __attribute__((address_space(1))) const void* gptr_t;
@@ -63,6 +64,20 @@ __device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_addr) {
                  : "=&s"(keep)
                  : "v"(gsrc), "s"(lds_addr)
                  : "memory");
+}
+
+// y -> [aqtizer_{q,k,v}(y)] -> [+ residual]; element (m, n) of the output
+__device__ __forceinline__ float dgq_extra(const dgq_gemm_extra_t& ex, float y, int m, int n) {
+    if (ex.fq_mode) {                                   // quant_layer.py:295-299 on the projection output (sd.py:174-182,199)
+        const int t = m % ex.fq_T;
+        if (t >= ex.fq_skip) {
+            const int idx = ex.fq_mode == 1 ? 0 : (ex.fq_mode == 2 ? t - ex.fq_skip : n % ex.fq_D);
+            const float d = ex.fq_delta[idx], z = ex.fq_zp[idx];
+            y = d * (dgq_affine_code(y, d, z, ex.fq_qmax) - z);
+        }
+    }
+    if (ex.residual) y += ex.residual[(int64_t)m * ex.ldr + n];
+    return y;
 }
 
 template <bool PER_M>
@@ -312,6 +327,7 @@ __global__ __launch_bounds__(256, (STAGES <= 3 ? 2 : 1)) void gemm_wxa8_kernel(G
     const float4 zw = *reinterpret_cast<const float4*>(vc + 128);
     const float4 ga = *reinterpret_cast<const float4*>(vc + 256);
     const float4 vn = *reinterpret_cast<const float4*>(vc + 384);
+    const bool has_extra = p.ex.fq_mode != 0 || p.ex.residual != nullptr;
     const bool st_vec = vec_ok && ((p.ldy * (int)sizeof(TOut)) % 16 == 0) &&
                         ((reinterpret_cast<uintptr_t>(p.y) & 15) == 0) && (sizeof(TOut) == 4 || (p.ldy & 3) == 0);
 #pragma unroll 4
@@ -328,6 +344,11 @@ __global__ __launch_bounds__(256, (STAGES <= 3 ? 2 : 1)) void gemm_wxa8_kernel(G
         o[1] = al.y * (r0 * v.y - zw.y * r1 + r2 * vn.y) + ga.y;
         o[2] = al.z * (r0 * v.z - zw.z * r1 + r2 * vn.z) + ga.z;
         o[3] = al.w * (r0 * v.w - zw.w * r1 + r2 * vn.w) + ga.w;
+        if (has_extra) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (nb + k < p.N) o[k] = dgq_extra(p.ex, o[k], m, nb + k);
+        }
         TOut* dst = y + (int64_t)m * p.ldy + nb;
         if (st_vec) {
             if (sizeof(TOut) == 4) {
@@ -366,7 +387,8 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(GemmParams p) {
         }
         for (int e = 0; e < 4 && nb + e < p.N; ++e) {
             const int n = nb + e;
-            const float out = dgq_epilogue<PER_M>(p, a[e], m, n, p.alpha[n], p.zw[n], p.gamma[n], PER_M ? p.vn[n] : 0.0f);
+            float out = dgq_epilogue<PER_M>(p, a[e], m, n, p.alpha[n], p.zw[n], p.gamma[n], PER_M ? p.vn[n] : 0.0f);
+            out = dgq_extra(p.ex, out, m, n);
             y[(int64_t)m * p.ldy + n] = dgq_from_float<TOut>(out);
         }
     }
@@ -445,7 +467,8 @@ extern "C" int dgq_gemm_wxa8(const int8_t* codes, const float* rowsum, int rowsu
                              int per_m, const float* cdelta, const uint8_t* cflush,
                              const float* mdelta, const float* mzp, int L, float offset,
                              const float* alpha, const float* zw, const float* gamma, const float* vn,
-                             void* y, int y_dtype, int ldy, void* workspace, size_t workspace_bytes, void* stream) {
+                             void* y, int y_dtype, int ldy, void* workspace, size_t workspace_bytes,
+                             const dgq_gemm_extra_t* extra, void* stream) {
     DGQ_CHECK_ARG(codes && rowsum && wpacked && alpha && zw && gamma && y, "dgq_gemm_wxa8: null pointer");
     DGQ_CHECK_ARG(M > 0 && N > 0 && Kp > 0 && Kp % DGQ_KTILE == 0, "dgq_gemm_wxa8: bad shape M=%d N=%d Kp=%d", M, N, Kp);
     DGQ_CHECK_ARG(w_bits == 4 || w_bits == 8, "dgq_gemm_wxa8: w_bits=%d unsupported", w_bits);
@@ -465,6 +488,15 @@ extern "C" int dgq_gemm_wxa8(const int8_t* codes, const float* rowsum, int rowsu
     p.wpacked = reinterpret_cast<const uint8_t*>(wpacked);
     p.cdelta = cdelta; p.cflush = cflush; p.mdelta = mdelta; p.mzp = mzp; p.L = per_m ? L : 1; p.offset = offset;
     p.alpha = alpha; p.zw = zw; p.gamma = gamma; p.vn = vn; p.y = y; p.ldy = ldy;
+    if (extra) {
+        p.ex = *extra;
+        DGQ_CHECK_ARG(p.ex.fq_mode >= 0 && p.ex.fq_mode <= 3, "dgq_gemm_wxa8: bad fq_mode");
+        DGQ_CHECK_ARG(p.ex.fq_mode == 0 || (p.ex.fq_delta && p.ex.fq_zp && p.ex.fq_T > 0 && p.ex.fq_D > 0), "dgq_gemm_wxa8: fused quantizer needs tables");
+        DGQ_CHECK_ARG(!p.ex.residual || p.ex.ldr >= N, "dgq_gemm_wxa8: ldr < N");
+    } else {
+        p.ex.residual = nullptr; p.ex.ldr = 0; p.ex.fq_mode = 0; p.ex.fq_delta = nullptr; p.ex.fq_zp = nullptr;
+        p.ex.fq_T = 1; p.ex.fq_D = 1; p.ex.fq_skip = 0; p.ex.fq_qmax = 255.0f;
+    }
     p.splits = workspace ? choose_splits(M, N, Kp, workspace_bytes) : 1;
     p.slab = p.splits > 1 ? reinterpret_cast<float*>(workspace) : nullptr;
     const int nk = Kp / BK;

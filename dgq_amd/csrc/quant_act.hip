@@ -18,7 +18,8 @@ struct QuantActParams {
     int kp_per_split;         // multiple of 256
     const float* pre_scale;   // optional [B][C]: v = x*scale + shift (fused GroupNorm), then pre_act
     const float* pre_shift;
-    int pre_act;              // 0 none, 1 SiLU
+    int pre_act;              // 0 none, 1 SiLU, 2 GEGLU: value = x[c]·gelu(x[C + c]) on rows of 2C elements
+    int ldc;                  // elements per input pixel/row (C, or 2C for GEGLU)
 };
 
 template <typename TIn>
@@ -69,8 +70,8 @@ __global__ __launch_bounds__(256) void quant_act_kernel(QuantActParams p) {
     const int l = row - b * L;
     const int ho = l / p.Wo, wo = l - ho * p.Wo;
     const int hbase = ho * p.stride - p.pad, wbase = wo * p.stride - p.pad;
-    const TIn* img = x + (int64_t)b * p.H * p.W * p.C;
-    const int rowoff = (hbase * p.W + wbase) * p.C;
+    const TIn* img = x + (int64_t)b * p.H * p.W * p.ldc;
+    const int rowoff = (hbase * p.W + wbase) * p.ldc;
     const bool interior = hbase >= 0 && wbase >= 0 && hbase + p.kh <= p.H && wbase + p.kw <= p.W;
     const float* pre_sc = p.pre_scale ? p.pre_scale + (int64_t)b * p.C : nullptr;
     const float* pre_sh = p.pre_shift ? p.pre_shift + (int64_t)b * p.C : nullptr;
@@ -111,15 +112,20 @@ __global__ __launch_bounds__(256) void quant_act_kernel(QuantActParams p) {
             const int hi = hbase + dh, wi = wbase + dw;
             const bool inb = in_k && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
             if (inb) {
-                load4<TIn>(img + ((int64_t)hi * p.W + wi) * p.C + nc, v);
+                load4<TIn>(img + ((int64_t)hi * p.W + wi) * p.ldc + nc, v);
                 if (p.pre_scale) {
                     const float4 sc = *reinterpret_cast<const float4*>(p.pre_scale + (int64_t)b * p.C + nc);
                     const float4 sh = *reinterpret_cast<const float4*>(p.pre_shift + (int64_t)b * p.C + nc);
                     v[0] = v[0] * sc.x + sh.x; v[1] = v[1] * sc.y + sh.y; v[2] = v[2] * sc.z + sh.z; v[3] = v[3] * sc.w + sh.w;
-                    if (p.pre_act == 1) {
+                }
+                if (p.pre_act == 1) {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] = v[j] / (1.0f + expf(-v[j]));
-                    }
+                    for (int j = 0; j < 4; ++j) v[j] = v[j] / (1.0f + expf(-v[j]));
+                } else if (p.pre_act == 2) {
+                    float g[4];
+                    load4<TIn>(img + ((int64_t)hi * p.W + wi) * p.ldc + p.C + nc, g);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = v[j] * (0.5f * g[j] * (1.0f + erff(g[j] * 0.70710678118654752f)));
                 }
             } else {
 #pragma unroll
@@ -143,11 +149,15 @@ __global__ __launch_bounds__(256) void quant_act_kernel(QuantActParams p) {
                     inb = inb && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
                 }
                 // 32-bit element offset inside the image (an image has < 2^31 elements)
-                const int off = rowoff + (dh * p.W + dw) * p.C + c;
+                const int off = rowoff + (dh * p.W + dw) * p.ldc + c;
                 float val = inb ? dgq_to_float(img[off]) : 0.0f;
-                if (p.pre_scale && inb) {
-                    val = val * pre_sc[c] + pre_sh[c];
+                if (inb) {
+                    if (p.pre_scale) val = val * pre_sc[c] + pre_sh[c];
                     if (p.pre_act == 1) val = val / (1.0f + expf(-val));
+                    else if (p.pre_act == 2) {
+                        const float g = dgq_to_float(img[off + p.C]);
+                        val = val * (0.5f * g * (1.0f + erff(g * 0.70710678118654752f)));
+                    }
                 }
                 v[j] = val;
             }
@@ -202,7 +212,8 @@ extern "C" int dgq_quant_act(const void* x, int x_dtype, int B, int H, int W, in
     DGQ_CHECK_ARG(bits >= 2 && bits <= 8, "dgq_quant_act: bits=%d", bits);
     DGQ_CHECK_ARG(!per_m || L >= 1, "dgq_quant_act: per_m needs L >= 1");
     DGQ_CHECK_ARG(ksplits >= 1 && ksplits <= 64, "dgq_quant_act: ksplits=%d", ksplits);
-    DGQ_CHECK_ARG((pre_scale == nullptr) == (pre_shift == nullptr) && pre_act >= 0 && pre_act <= 1, "dgq_quant_act: bad prologue");
+    DGQ_CHECK_ARG((pre_scale == nullptr) == (pre_shift == nullptr) && pre_act >= 0 && pre_act <= 2, "dgq_quant_act: bad prologue");
+    DGQ_CHECK_ARG(pre_act != 2 || (kh == 1 && kw == 1 && !pre_scale), "dgq_quant_act: GEGLU prologue is for Linear inputs");
     int K = C * kh * kw;
     if (!ksrc) {
         DGQ_CHECK_ARG(C % 4 == 0, "dgq_quant_act: natural K order needs C %% 4 == 0 (C=%d)", C);
@@ -218,6 +229,7 @@ extern "C" int dgq_quant_act(const void* x, int x_dtype, int B, int H, int W, in
     p.codes = codes; p.rowsum = rowsum; p.M = B * Ho * Wo;
     p.kp_per_split = (((Kp + ksplits - 1) / ksplits) + 255) / 256 * 256;
     p.pre_scale = pre_scale; p.pre_shift = pre_shift; p.pre_act = pre_act;
+    p.ldc = pre_act == 2 ? 2 * C : C;
     hipStream_t st = (hipStream_t)stream;
     switch (x_dtype) {
         case DGQ_F32: launch_quant_act<float>(p, ksrc != nullptr, per_m != 0, st); break;

@@ -152,23 +152,110 @@ def quant_act(x_cl: torch.Tensor, B, H, W, C, kh, kw, stride, pad, ab: ActBindin
     _lib_call("dgq_quant_act", _lib.ptr(x_cl), _lib.DTYPE_CODE[x_cl.dtype], B, H, W, C, kh, kw, stride, pad,
               _lib.ptr(ab.ksrc), ab.Kp, per_m, _lib.ptr(delta), _lib.ptr(zp), L, ab.abits,
               _lib.ptr(codes), _lib.ptr(rowsum), parts,
-              _lib.ptr(pre[0]) if pre else None, _lib.ptr(pre[1]) if pre else None, pre[2] if pre else 0, _lib.stream())
+              _lib.ptr(pre[0]) if pre and pre[0] is not None else None,
+              _lib.ptr(pre[1]) if pre and pre[1] is not None else None, pre[2] if pre else 0, _lib.stream())
     return codes, rowsum, M
 
 
 _WORKSPACE = {}
-WORKSPACE_BYTES = 256 << 20
+_SIDE_STREAMS = {}
+WORKSPACE_BYTES = 128 << 20
 
 
 def workspace(device):
-    """Persistent split-K scratch (caller-owned, per device): the library never allocates."""
-    key = str(device)
+    """Persistent split-K scratch (caller-owned; one per device AND stream, so that layers running concurrently on
+    forked streams never share it): the library never allocates."""
+    cur = torch.cuda.current_stream(device).cuda_stream
+    branch = "main"                      # every stream that is not one of the forked side streams (incl. capture streams)
+    for i, st in enumerate(_SIDE_STREAMS.get(str(device), [])):
+        if st.cuda_stream == cur:
+            branch = i
+    key = (str(device), branch)
     if key not in _WORKSPACE:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("dgq_amd: split-K workspace of a forked stream must exist before graph capture "
+                               "(ops.prepare_side_streams)")
         _WORKSPACE[key] = torch.empty(WORKSPACE_BYTES, dtype=torch.uint8, device=device)
     return _WORKSPACE[key]
 
 
-def gemm_wxa8(codes, rowsum, M, ab: ActBinding, out_dtype, out: Optional[torch.Tensor] = None):
+def prepare_side_streams(device, n=2):
+    """Create the forked streams used under graph capture and their split-K workspaces (outside any capture)."""
+    pool = _SIDE_STREAMS.setdefault(str(device), [])
+    while len(pool) < n:
+        pool.append(torch.cuda.Stream(device))
+    for st in pool[:n]:
+        with torch.cuda.stream(st):
+            workspace(device)
+    workspace(device)
+
+
+class Fork:
+    """Run independent branches of the layer graph on forked HIP streams (joined before use).  Only active while a
+    hipGraph is being captured: the concurrency is then baked into the graph (parallel branches of small kernels that
+    individually fill a fraction of the 256 CUs); eager execution stays on one stream."""
+
+    #: measured on MI355X / ROCm 7.2: forked branches inside a captured graph gave no speed-up on the SD1.4 step
+    #: (20.7 vs 20.3 ms) — kept for experiments, off by default.
+    ENABLED = False
+
+    def __init__(self, device, n_side):
+        self.active = Fork.ENABLED and torch.cuda.is_current_stream_capturing()
+        self.main = torch.cuda.current_stream(device)
+        self.side = []
+        self.used = []
+        if self.active:
+            pool = _SIDE_STREAMS.setdefault(str(device), [])
+            while len(pool) < n_side:
+                pool.append(torch.cuda.Stream(device))
+            self.side = pool[:n_side]
+
+    def run(self, i, fn, *inputs):
+        """Branch 0 runs on the main stream, branch i>0 on side stream i-1."""
+        if not self.active or i == 0:
+            return fn()
+        st = self.side[i - 1]
+        st.wait_stream(self.main)
+        for t in inputs:
+            t.record_stream(st)
+        with torch.cuda.stream(st):
+            out = fn()
+        self.used.append(st)
+        outs = out if isinstance(out, (tuple, list)) else (out,)
+        for t in outs:
+            if torch.is_tensor(t):
+                t.record_stream(self.main)
+        return out
+
+    def join(self):
+        for st in self.used:
+            self.main.wait_stream(st)
+        self.used = []
+
+
+def make_extra(residual=None, fq=None):
+    """dgq_gemm_extra_t: residual [M][N] fp32 (row stride = its stride(0)); fq = (mode, delta, zp, T, D, skip, bits)
+    with mode 1 scalar / 2 per token / 3 per head-dim.  Keeps the tensors alive on the returned object."""
+    if residual is None and fq is None:
+        return None
+    ex = _lib.GemmExtra()
+    keep = []
+    if residual is not None:
+        assert residual.dtype == torch.float32 and residual.stride(-1) == 1
+        ex.residual, ex.ldr = residual.data_ptr(), residual.stride(0)
+        keep.append(residual)
+    if fq is not None:
+        mode, delta, zp, T, D, skip, bits = fq
+        ex.fq_mode, ex.fq_delta, ex.fq_zp = mode, delta.data_ptr(), zp.data_ptr()
+        ex.fq_T, ex.fq_D, ex.fq_skip, ex.fq_qmax = T, D, skip, float(2 ** bits - 1)
+        keep += [delta, zp]
+    else:
+        ex.fq_T = ex.fq_D = 1
+    ex._keep = keep
+    return ex
+
+
+def gemm_wxa8(codes, rowsum, M, ab: ActBinding, out_dtype, out: Optional[torch.Tensor] = None, extra=None):
     pw = ab.pw
     ws = workspace(codes.device)
     if out is None:
@@ -181,25 +268,35 @@ def gemm_wxa8(codes, rowsum, M, ab: ActBinding, out_dtype, out: Optional[torch.T
               _lib.ptr(ab.mdelta) if per_m else None, _lib.ptr(ab.mzp) if per_m else None,
               ab.L if per_m else 1, _c.c_float(ab.offset),
               _lib.ptr(pw.alpha), _lib.ptr(pw.zw), _lib.ptr(ab.gamma), _lib.ptr(ab.vn) if per_m else None,
-              _lib.ptr(out), _lib.DTYPE_CODE[out.dtype], out.stride(0), _lib.ptr(ws), ws.numel(), _lib.stream())
+              _lib.ptr(out), _lib.DTYPE_CODE[out.dtype], out.stride(0), _lib.ptr(ws), ws.numel(),
+              _c.byref(extra) if extra is not None else None, _lib.stream())
     return out
 
 
-def quant_linear(x: torch.Tensor, ab: ActBinding):
-    """x [..., K] -> [..., N]."""
-    K = x.shape[-1]
-    x2 = x.reshape(-1, K)
+def quant_linear(x: torch.Tensor, ab: ActBinding, pre_act=0, residual=None, fq=None):
+    """x [..., K] -> [..., N].  pre_act: 0 none, 1 SiLU(x), 2 GEGLU (x is [..., 2K]: x[:K]·gelu(x[K:])) folded into the
+    quantise-on-load pass; residual [..., N] and fq (see make_extra) folded into the GEMM epilogue."""
+    Kin = x.shape[-1]
+    K = Kin // 2 if pre_act == 2 else Kin
+    x2 = x.reshape(-1, Kin)
     if not x2.is_contiguous():
         x2 = x2.contiguous()
     rows = x2.shape[0]
-    codes, rowsum, M = quant_act(x2, rows, 1, 1, K, 1, 1, 1, 0, ab)
-    y = gemm_wxa8(codes, rowsum, M, ab, x.dtype)
+    pre = (None, None, pre_act) if pre_act else None
+    codes, rowsum, M = quant_act(x2, rows, 1, 1, K, 1, 1, 1, 0, ab, pre)
+    res2 = None
+    if residual is not None:
+        res2 = residual.reshape(-1, ab.pw.N)
+        if not res2.is_contiguous():
+            res2 = res2.contiguous()
+    y = gemm_wxa8(codes, rowsum, M, ab, x.dtype, extra=make_extra(res2, fq))
     return y.view(*x.shape[:-1], ab.pw.N)
 
 
-def quant_conv2d(x: torch.Tensor, ab: ActBinding, kh, kw, stride, pad, norm=None):
+def quant_conv2d(x: torch.Tensor, ab: ActBinding, kh, kw, stride, pad, norm=None, residual=None):
     """x logical NCHW (any strides; made channels-last) -> logical NCHW output in channels-last storage.
-    norm = (groups, eps, gamma, beta, act): GroupNorm (+SiLU) of x folded into the quantise-on-load pass."""
+    norm = (groups, eps, gamma, beta, act): GroupNorm (+SiLU) of x folded into the quantise-on-load pass;
+    residual (logical NCHW, same shape as the output) is added in the GEMM epilogue."""
     B, C, H, W = x.shape
     xc = x.contiguous(memory_format=torch.channels_last)
     x_store = xc.permute(0, 2, 3, 1)                  # [B,H,W,C] view over the same storage, contiguous
@@ -209,7 +306,10 @@ def quant_conv2d(x: torch.Tensor, ab: ActBinding, kh, kw, stride, pad, norm=None
         sc, sh = groupnorm_scale_shift(x_store, B, H * W, C, groups, eps, gamma, beta)
         pre = (sc, sh, act)
     codes, rowsum, M = quant_act(x_store, B, H, W, C, kh, kw, stride, pad, ab, pre)
-    y = gemm_wxa8(codes, rowsum, M, ab, x.dtype)
+    res2 = None
+    if residual is not None:
+        res2 = residual.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1).reshape(M, ab.pw.N)
+    y = gemm_wxa8(codes, rowsum, M, ab, x.dtype, extra=make_extra(res2))
     Ho = (H + 2 * pad - kh) // stride + 1
     Wo = (W + 2 * pad - kw) // stride + 1
     return y.view(B, Ho, Wo, ab.pw.N).permute(0, 3, 1, 2)

@@ -339,6 +339,30 @@ class QuantLayer(nn.Module):
             return ops.quant_conv2d(x, ab, kh, kw, self.fwd_kwargs["stride"][0], self.fwd_kwargs["padding"][0])
         return ops.quant_linear(x, ab)
 
+    def on_integer_path(self, x: torch.Tensor) -> bool:
+        """True when forward(x) would run dgq_quant_act + dgq_gemm_wxa8 (weights and activations quantised, GPU)."""
+        return (self.use_wq and self.use_aq and not self.disable_aq and x.is_cuda
+                and (self.aqtizer.init or (self._slot_ref is not None and self._slot_ref.slot in self._act_tables)))
+
+    def forward_fused(self, x: torch.Tensor, pre_act: int = 0, residual=None, fq=None) -> torch.Tensor:
+        """``fq(self(act(x))) + residual`` with the elementwise pieces folded into the two kernels of the layer:
+        pre_act 1 = SiLU(x), 2 = GEGLU (x[..., :K]·gelu(x[..., K:])) inside the quantise-on-load pass; ``fq`` (an
+        attention-side quantizer, see ops.make_extra) and ``residual`` inside the GEMM epilogue.  Linear layers on the
+        integer path only; anything else falls back to the unfused sequence of the same kernels/ops."""
+        if self.is_conv or not self.on_integer_path(x) or x.dtype != torch.float32:
+            if pre_act == 1:
+                x = F.silu(x)
+            elif pre_act == 2:
+                a, g = x.chunk(2, dim=-1)
+                x = a * F.gelu(g)
+            y = self.forward(x)
+            if fq is not None:
+                mode, dd, zz, T, D, skip, bits = fq
+                y = y.contiguous()
+                ops.fakequant_rows(y.view(-1, y.shape[-1]), T, D, mode - 1, dd, zz, skip, bits)
+            return y if residual is None else y + residual
+        return ops.quant_linear(x, self._binding(), pre_act=pre_act, residual=residual, fq=fq)
+
     def can_fuse_prenorm(self, x: torch.Tensor) -> bool:
         """True when this layer runs on the integer path, so a preceding GroupNorm(+SiLU) can be folded into its
         quantise-on-load pass (dgq_groupnorm_scale_shift + dgq_quant_act prologue)."""
@@ -346,12 +370,21 @@ class QuantLayer(nn.Module):
                 and x.dtype == torch.float32
                 and (self.aqtizer.init or (self._slot_ref is not None and self._slot_ref.slot in self._act_tables)))
 
-    def forward_prenorm(self, x: torch.Tensor, norm: nn.GroupNorm, silu: bool = True) -> torch.Tensor:
-        """conv(act(GroupNorm(x))) without materialising the normalised tensor."""
+    def forward_prenorm(self, x: torch.Tensor, norm: nn.GroupNorm, silu: bool = True, residual=None) -> torch.Tensor:
+        """conv(act(GroupNorm(x))) [+ residual] without materialising the normalised tensor."""
         ab = self._binding()
         kh, kw = self.w.shape[2], self.w.shape[3]
         return ops.quant_conv2d(x, ab, kh, kw, self.fwd_kwargs["stride"][0], self.fwd_kwargs["padding"][0],
-                                norm=(norm.num_groups, norm.eps, norm.weight.data, norm.bias.data, 1 if silu else 0))
+                                norm=(norm.num_groups, norm.eps, norm.weight.data, norm.bias.data, 1 if silu else 0),
+                                residual=residual)
+
+    def forward_residual(self, x: torch.Tensor, residual) -> torch.Tensor:
+        """conv(x) + residual with the add in the GEMM epilogue (integer path), else unfused."""
+        if self.is_conv and self.on_integer_path(x) and x.dtype == torch.float32:
+            kh, kw = self.w.shape[2], self.w.shape[3]
+            return ops.quant_conv2d(x, self._binding(), kh, kw, self.fwd_kwargs["stride"][0],
+                                    self.fwd_kwargs["padding"][0], residual=residual)
+        return self.forward(x) + residual
 
     # -- state switches (quant_layer.py:663-686) -----------------------------------------------------------
     def set_quant_state(self, use_wq: bool = False, use_aq: bool = False) -> None:

@@ -72,7 +72,9 @@ int dgq_pack_w8(const uint8_t* codes, int N, int K, const int32_t* kperm, int Kp
  * bits: activation bits b; code offset = 2^(b-1) (s = q − 2^(b−1) is a centred int8).  Out-of-image taps read 0.0 and are
  * quantised like any value (F.unfold pads before the quantizer).
  * pre_scale/pre_shift [B][C] (or NULL): the element is first mapped to x·scale + shift (a GroupNorm folded into
- * the load, see dgq_groupnorm_scale_shift) and, with pre_act == 1, through SiLU; out-of-image taps stay 0.
+ * the load, see dgq_groupnorm_scale_shift); pre_act == 1 then applies SiLU (resnet norm→SiLU→conv, and SiLU(temb) →
+ * time_emb_proj); pre_act == 2 reads rows of 2C elements and forms x[c]·gelu(x[C+c]) (GEGLU in front of ff.net.2,
+ * sd.py:210-236); out-of-image taps stay 0.
  * ksplits >= 1 splits every row's K range over that many waves (low-M layers); rowsum then has
  * dgq_quant_act_parts(Kp, ksplits) x M entries ([part][m]) which dgq_gemm_wxa8 adds in a fixed order. */
 int dgq_quant_act(const void* x, int x_dtype, int B, int H, int W, int C,
@@ -99,12 +101,29 @@ int dgq_groupnorm_scale_shift(const void* x, int x_dtype, int B, int HW, int C, 
  * alpha = δw, zw = zero point in the stored code domain (zw − 8·0 for W4: unsigned nibbles; zw − 128 for W8);
  * gamma = bias (+ alpha·U for per_m==0, U[n] = Σ_k δx_k(offset − zx_k)(qw'[n,k] − zw[n]), precomputed per slot);
  * vn[n] = Σ_k qw'[n,k] − K·zw[n].  y [M][ldy] of y_dtype.  cflush[c] != 0 marks the last chunk of a group. */
+/* Optional epilogue extras (host struct, passed by pointer; NULL = none), applied in this order to the fp32 result:
+ *   fq_mode != 0 : the attention-side quantizer of the projection output, aqtizer_{q,k,v} (sd.py:174-182,199):
+ *                  y = δ·(clamp(rne(y/δ)+z, 0, fq_qmax) − z) with (δ,z) = table[0] (mode 1), table[(m % fq_T) − fq_skip]
+ *                  (mode 2, per token; tokens < fq_skip bypass: start_peak) or table[n % fq_D] (mode 3, per head-dim);
+ *   residual     : y += residual[m·ldr + n]  (x + attn(x), x + ff(x), shortcut + conv2(...) of the Quant blocks,
+ *                  quant_block.py:98-119,165-186) — fp32, may alias nothing written by this call. */
+typedef struct dgq_gemm_extra {
+    const float* residual;
+    int ldr;
+    int fq_mode;
+    const float* fq_delta;
+    const float* fq_zp;
+    int fq_T, fq_D, fq_skip;
+    float fq_qmax;
+} dgq_gemm_extra_t;
+
 int dgq_gemm_wxa8(const int8_t* codes, const float* rowsum, int rowsum_parts, int M, int Kp,
                   const void* wpacked, int w_bits, int N,
                   int per_m, const float* cdelta, const uint8_t* cflush,
                   const float* mdelta, const float* mzp, int L, float offset,
                   const float* alpha, const float* zw, const float* gamma, const float* vn,
-                  void* y, int y_dtype, int ldy, void* workspace, size_t workspace_bytes, void* stream);
+                  void* y, int y_dtype, int ldy, void* workspace, size_t workspace_bytes,
+                  const dgq_gemm_extra_t* extra, void* stream);
 /* Small tile grids are split along K (deterministic: fp32 partial slabs [S][M][N] in the caller's `workspace`,
  * summed in a fixed order by a second kernel). dgq_gemm_workspace_bytes returns what the preferred split of a
  * shape needs; with workspace == NULL (or too small) fewer / no splits are used — results do not depend on it

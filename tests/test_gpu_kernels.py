@@ -116,7 +116,7 @@ def test_gemm_exact_integer(dev):
         rc = lib.dgq_gemm_wxa8(_lib.ptr(codes), _lib.ptr(rs), 1, M, Kp, _lib.ptr(wp), wbits, N, 0,
                                _lib.ptr(cdg), _lib.ptr(flg), None, None, 1, ctypes.c_float(128.0),
                                _lib.ptr(al), _lib.ptr(zwg), _lib.ptr(ga), None,
-                               _lib.ptr(y), 0, N, _lib.ptr(ws), ws.numel(), _lib.stream())
+                               _lib.ptr(y), 0, N, _lib.ptr(ws), ws.numel(), None, _lib.stream())
         _lib.check(rc, "dgq_gemm_wxa8")
         torch.cuda.synchronize()
         assert torch.equal(y.cpu().double(), expect), (M, N, Kp, wbits, (y.cpu().double() - expect).abs().max())
@@ -134,7 +134,7 @@ def test_gemm_exact_integer(dev):
         rc = lib.dgq_gemm_wxa8(_lib.ptr(codes), _lib.ptr(rs), 1, M, Kp, _lib.ptr(wp), wbits, N, 1,
                                None, None, _lib.ptr(mdg), _lib.ptr(mzg), L, ctypes.c_float(128.0),
                                _lib.ptr(al), _lib.ptr(zwg), _lib.ptr(ga), _lib.ptr(vng),
-                               _lib.ptr(y), 0, N, _lib.ptr(ws), ws.numel(), _lib.stream())
+                               _lib.ptr(y), 0, N, _lib.ptr(ws), ws.numel(), None, _lib.stream())
         _lib.check(rc, "dgq_gemm_wxa8")
         torch.cuda.synchronize()
         got = y.cpu().double()

@@ -65,8 +65,8 @@ def teacher_forced_check(qnn, io, run):
         a log2 rounding tie flips a code (p changes 2x): ~1e-4 of a 1M-element tensor, 3e-3 with only 4 query
         tokens in the 16x16 mid block                                                 -> max tol 2e-2
     """
-    from dgq_amd.quant import QuantLayer, QuantResnetBlock2D
-    QuantResnetBlock2D.fuse_norm = False        # this test needs the intermediate tensors the fused path never forms
+    from dgq_amd.quant import QuantLayer, quant_block
+    quant_block.FUSION = False                  # this test needs the intermediate tensors the fused path never forms
     stats = {"out": [], "in": [], "attn": []}
     handles = []
 
@@ -96,7 +96,7 @@ def teacher_forced_check(qnn, io, run):
     try:
         run()
     finally:
-        QuantResnetBlock2D.fuse_norm = True
+        quant_block.FUSION = True
         for h in handles:
             h.remove()
     return stats
@@ -240,6 +240,31 @@ def test_ddim50_free_running_vs_reference_golden(tmp_path_factory):
     assert torch.isfinite(out).all()
     assert 0.5 < out.norm().item() / ref.norm().item() < 2.0
     assert e < 1.0, e
+
+
+def test_fused_equals_unfused(tmp_path_factory):
+    """Free-running tiny UNet with the kernel-level fusions on vs off.  SiLU / GEGLU / residual / aqtizer_{q,k,v}
+    fusions perform the same fp32 operations in the same order as the unfused kernels, so with the GroupNorm folding
+    off the outputs must agree to rounding (asserted < 1e-5).  The folded GroupNorm rounds differently
+    (x·(rstd·γ) + (β − mean·rstd·γ)), i.e. it is a ~1e-7 perturbation that the chaotic graph amplifies like any other
+    (DESIGN.md §5): asserted only to stay below the reference's own thread-count sensitivity."""
+    from dgq_amd.quant import quant_block
+    quant_block._F_RES = quant_block._F_FQ = quant_block._F_GEGLU = quant_block._F_SILU = True   # exercise every fusion
+    tmp = str(tmp_path_factory.mktemp("ck"))
+    qnn, _ = build_qnn("tiny", dict(C2, steps=2), 16, 2, 2, tmp)
+    inp = synth.synth_inputs("tiny", 2, 1, 16)
+    outs = {}
+    for name, fusion, fnorm in (("all", True, True), ("no_norm", True, False), ("none", False, False)):
+        quant_block.FUSION, quant_block.FUSE_NORM = fusion, fnorm
+        with torch.no_grad():
+            outs[name] = qnn(inp["sample"].cuda(), torch.tensor(999), inp["encoder_hidden_states"].cuda())[0].float().cpu()
+    quant_block.FUSION, quant_block.FUSE_NORM = True, True
+    quant_block._F_RES = quant_block._F_FQ = quant_block._F_GEGLU = False                         # shipped defaults
+    e1 = rel_l2(outs["no_norm"], outs["none"])
+    e2 = rel_l2(outs["all"], outs["none"])
+    print("fused (without GN folding) vs unfused: rel-L2 %.3g ; with GN folding: %.3g" % (e1, e2))
+    assert e1 < 1e-5, e1
+    assert e2 < 1e-1, e2
 
 
 def test_cli_tiny(tmp_path):
