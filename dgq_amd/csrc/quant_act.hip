@@ -7,6 +7,7 @@ struct QuantActParams {
     const void* x;
     int B, H, W, C, kh, kw, stride, pad, Ho, Wo;
     const int32_t* ksrc;      // [Kp] (dh<<24 | dw<<16 | c) or -1, or NULL (natural order kp = tap*C + c)
+    const int32_t* koff;      // optional [Kp]: (dh*W + dw)*ldc + c for THIS geometry, -1 for padding (interior rows)
     int Kp, K;
     const float* delta;       // per_m: [L]; else [Kp/64]
     const float* zp;
@@ -53,7 +54,20 @@ __device__ __forceinline__ float dgq_affine_code_fast(float x, float delta, floa
     float r = rintf(t);
     const float dist = fabsf(fabsf(t - r) - 0.5f);
     if (dist <= fabsf(t) * 2.4e-7f + 1e-30f || !(fabsf(t) < 3.0e6f)) r = rintf(__fdiv_rn(x, delta));
-    return fminf(fmaxf(r + zp, 0.0f), qmax);
+    return __builtin_amdgcn_fmed3f(r + zp, 0.0f, qmax);
+}
+
+// Four codes q_j ∈ [0, 2^b−1] (floats) -> one dword of centred int8 codes s_j = q_j − off, 0 for padding:
+// v_cvt_pk_u8_f32 inserts u8(q − off + 128) per byte, and u8(x + 128) ^ 0x80 is the two's-complement byte of x.
+// `biased[j]` = valid ? q_j − off + 128 : 128 ; returns the dword, adds Σ biased to `fsum` (exact small integers).
+__device__ __forceinline__ uint32_t dgq_pack4(const float (&biased)[4], float& fsum) {
+    uint32_t w = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        w = __builtin_amdgcn_cvt_pk_u8_f32(biased[j], j, w);
+        fsum += biased[j];
+    }
+    return w ^ 0x80808080u;
 }
 
 // One wave per output row; each lane owns 4 consecutive kp per 256-wide step (one packed dword), so that the
@@ -82,7 +96,6 @@ __global__ __launch_bounds__(256) void quant_act_kernel(QuantActParams p) {
         mz = p.zp[li];
         minv = 1.0f / md;
     }
-    const int ioff = (int)p.offset;
     float partial = 0.0f;
     uint32_t* out = reinterpret_cast<uint32_t*>(p.codes + (int64_t)row * p.Kp);
     // K range of this wave (blockIdx.y): low-M layers would otherwise leave the chip empty (M=512: 2 waves per CU)
@@ -95,6 +108,88 @@ __global__ __launch_bounds__(256) void quant_act_kernel(QuantActParams p) {
         ntap = k0 / p.C;
         nc = k0 - ntap * p.C;
     }
+    const float bias = 128.0f - p.offset;                  // biased code = q − off + 128 ∈ [0,255]
+    if (HAS_TABLE) {
+        // gather path, 4 steps (1024 kp) per iteration: all table reads, then all 16 gathers, then quantise + store.
+        // Interior rows (no tap outside the image: the great majority) read precomputed element offsets (koff) and skip
+        // every bounds check; border rows decode (dh, dw, c) from ksrc.
+        const TIn* __restrict__ imgr = img;
+        const bool fast = interior && p.koff != nullptr;
+        const int32_t* __restrict__ tab = fast ? p.koff : p.ksrc;
+        for (int kb = k_begin + lane * 4; kb < k_end; kb += 1024) {
+            int idx[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int kp0 = kb + 256 * u;
+                int4 t = make_int4(-1, -1, -1, -1);
+                if (kp0 < k_end) t = *reinterpret_cast<const int4*>(tab + kp0);
+                idx[u][0] = t.x; idx[u][1] = t.y; idx[u][2] = t.z; idx[u][3] = t.w;
+            }
+            float v[4][4];
+            if (fast) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int e = idx[u][j];
+                        v[u][j] = dgq_to_float(imgr[rowoff + max(e, 0)]);        // padding reads element 0: value unused
+                    }
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int e = idx[u][j];
+                        const int dh = (e >> 24) & 0x7F, dw = (e >> 16) & 0xFF, c = e & 0xFFFF;
+                        const int hi = hbase + dh, wi = wbase + dw;
+                        const bool inb = e >= 0 && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
+                        const int off = rowoff + (dh * p.W + dw) * p.ldc + c;      // < 2^31 elements per image
+                        v[u][j] = inb ? dgq_to_float(imgr[off]) : 0.0f;
+                        idx[u][j] = e >= 0 ? (inb ? off - rowoff : -2) : -1;       // -2: out-of-image tap (value 0, no prologue)
+                    }
+            }
+            if (p.pre_scale || p.pre_act) {                 // folded GroupNorm / SiLU / GEGLU (wave-uniform branch)
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int e = idx[u][j];
+                        if (e >= 0) {
+                            const int c = e % p.ldc;                          // e = (dh·W + dw)·ldc + c
+                            float val = v[u][j];
+                            if (p.pre_scale) val = val * pre_sc[c] + pre_sh[c];
+                            if (p.pre_act == 1) val = val / (1.0f + expf(-val));
+                            else if (p.pre_act == 2) {
+                                const float g = dgq_to_float(imgr[rowoff + e + p.C]);
+                                val = val * (0.5f * g * (1.0f + erff(g * 0.70710678118654752f)));
+                            }
+                            v[u][j] = val;
+                        }
+                    }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int kp0 = kb + 256 * u;
+                if (kp0 < k_end) {
+                    float d = md, z = mz, inv = minv;
+                    if (!PER_M) {
+                        d = p.delta[kp0 >> 6];
+                        z = p.zp[kp0 >> 6];
+                        inv = 1.0f / d;
+                    }
+                    float biased[4], fsum = 0.0f;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float q = dgq_affine_code_fast(v[u][j], d, inv, z, p.qmax);
+                        biased[j] = idx[u][j] != -1 ? q + bias : 128.0f;
+                    }
+                    out[kp0 >> 2] = dgq_pack4(biased, fsum);
+                    fsum -= 512.0f;                                              // Σ (biased − 128) = Σ s
+                    partial += PER_M ? fsum : d * fsum;
+                }
+            }
+        }
+    } else {
 #pragma unroll 2
     for (int kp0 = k_begin + lane * 4; kp0 < k_end; kp0 += 256) {
         float d = md, z = mz, inv = minv;
@@ -104,75 +199,43 @@ __global__ __launch_bounds__(256) void quant_act_kernel(QuantActParams p) {
             inv = 1.0f / d;
         }
         float v[4];
-        bool valid[4];
-        if (!HAS_TABLE) {
-            // natural order kp = tap*C + c ; 4 | C, so the lane's 4 elements are contiguous channels of one tap
-            const bool in_k = kp0 < p.K;
-            const int dh = ntap / p.kw, dw = ntap - dh * p.kw;
-            const int hi = hbase + dh, wi = wbase + dw;
-            const bool inb = in_k && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
-            if (inb) {
-                load4<TIn>(img + ((int64_t)hi * p.W + wi) * p.ldc + nc, v);
-                if (p.pre_scale) {
-                    const float4 sc = *reinterpret_cast<const float4*>(p.pre_scale + (int64_t)b * p.C + nc);
-                    const float4 sh = *reinterpret_cast<const float4*>(p.pre_shift + (int64_t)b * p.C + nc);
-                    v[0] = v[0] * sc.x + sh.x; v[1] = v[1] * sc.y + sh.y; v[2] = v[2] * sc.z + sh.z; v[3] = v[3] * sc.w + sh.w;
-                }
-                if (p.pre_act == 1) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = v[j] / (1.0f + expf(-v[j]));
-                } else if (p.pre_act == 2) {
-                    float g[4];
-                    load4<TIn>(img + ((int64_t)hi * p.W + wi) * p.ldc + p.C + nc, g);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = v[j] * (0.5f * g[j] * (1.0f + erff(g[j] * 0.70710678118654752f)));
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = 0.0f;
+        // natural order kp = tap*C + c ; 4 | C, so the lane's 4 elements are contiguous channels of one tap
+        const bool in_k = kp0 < p.K;
+        const int dh = ntap / p.kw, dw = ntap - dh * p.kw;
+        const int hi = hbase + dh, wi = wbase + dw;
+        const bool inb = in_k && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
+        if (inb) {
+            load4<TIn>(img + ((int64_t)hi * p.W + wi) * p.ldc + nc, v);
+            if (p.pre_scale) {
+                const float4 sc = *reinterpret_cast<const float4*>(p.pre_scale + (int64_t)b * p.C + nc);
+                const float4 sh = *reinterpret_cast<const float4*>(p.pre_shift + (int64_t)b * p.C + nc);
+                v[0] = v[0] * sc.x + sh.x; v[1] = v[1] * sc.y + sh.y; v[2] = v[2] * sc.z + sh.z; v[3] = v[3] * sc.w + sh.w;
             }
+            if (p.pre_act == 1) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) valid[j] = in_k;
-            nc += 256;
-            while (nc >= p.C) { nc -= p.C; ++ntap; }
+                for (int j = 0; j < 4; ++j) v[j] = v[j] / (1.0f + expf(-v[j]));
+            } else if (p.pre_act == 2) {
+                float g[4];
+                load4<TIn>(img + ((int64_t)hi * p.W + wi) * p.ldc + p.C + nc, g);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = v[j] * (0.5f * g[j] * (1.0f + erff(g[j] * 0.70710678118654752f)));
+            }
         } else {
-            const int4 t = *reinterpret_cast<const int4*>(p.ksrc + kp0);
-            const int idx[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int e = idx[j];
-                valid[j] = e >= 0;
-                const int dh = (e >> 24) & 0x7F, dw = (e >> 16) & 0xFF, c = e & 0xFFFF;
-                bool inb = valid[j];
-                if (!interior) {                            // wave-uniform: only border rows pay for bounds checks
-                    const int hi = hbase + dh, wi = wbase + dw;
-                    inb = inb && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
-                }
-                // 32-bit element offset inside the image (an image has < 2^31 elements)
-                const int off = rowoff + (dh * p.W + dw) * p.ldc + c;
-                float val = inb ? dgq_to_float(img[off]) : 0.0f;
-                if (inb) {
-                    if (p.pre_scale) val = val * pre_sc[c] + pre_sh[c];
-                    if (p.pre_act == 1) val = val / (1.0f + expf(-val));
-                    else if (p.pre_act == 2) {
-                        const float g = dgq_to_float(img[off + p.C]);
-                        val = val * (0.5f * g * (1.0f + erff(g * 0.70710678118654752f)));
-                    }
-                }
-                v[j] = val;
-            }
+            for (int j = 0; j < 4; ++j) v[j] = 0.0f;
         }
-        uint32_t w = 0;
-        int ssum = 0;
+        nc += 256;
+        while (nc >= p.C) { nc -= p.C; ++ntap; }
+        float biased[4], fsum = 0.0f;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float q = dgq_affine_code_fast(v[j], d, inv, z, p.qmax);
-            const int s = valid[j] ? ((int)q - ioff) : 0;
-            ssum += s;
-            w |= ((uint32_t)(s & 0xFF)) << (8 * j);
+            biased[j] = in_k ? q + bias : 128.0f;
         }
-        partial += PER_M ? (float)ssum : d * (float)ssum;
-        out[kp0 >> 2] = w;
+        out[kp0 >> 2] = dgq_pack4(biased, fsum);
+        fsum -= 512.0f;
+        partial += PER_M ? fsum : d * fsum;
+    }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) partial += __shfl_down(partial, o, 64);
@@ -200,7 +263,7 @@ extern "C" int dgq_quant_act_parts(int Kp, int ksplits) {
 
 extern "C" int dgq_quant_act(const void* x, int x_dtype, int B, int H, int W, int C,
                              int kh, int kw, int stride, int pad,
-                             const int32_t* ksrc, int Kp,
+                             const int32_t* ksrc, const int32_t* koff, int Kp,
                              int per_m, const float* delta, const float* zp, int L,
                              int bits, int8_t* codes, float* rowsum, int ksplits,
                              const float* pre_scale, const float* pre_shift, int pre_act, void* stream) {
@@ -223,7 +286,7 @@ extern "C" int dgq_quant_act(const void* x, int x_dtype, int B, int H, int W, in
     DGQ_CHECK_ARG(Ho > 0 && Wo > 0, "dgq_quant_act: empty output");
     QuantActParams p;
     p.x = x; p.B = B; p.H = H; p.W = W; p.C = C; p.kh = kh; p.kw = kw; p.stride = stride; p.pad = pad;
-    p.Ho = Ho; p.Wo = Wo; p.ksrc = ksrc; p.Kp = Kp; p.K = K; p.delta = delta; p.zp = zp; p.L = per_m ? L : 1;
+    p.Ho = Ho; p.Wo = Wo; p.ksrc = ksrc; p.koff = ksrc ? koff : nullptr; p.Kp = Kp; p.K = K; p.delta = delta; p.zp = zp; p.L = per_m ? L : 1;
     p.qmax = (float)((1 << bits) - 1);
     p.offset = (float)(1 << (bits - 1));
     p.codes = codes; p.rowsum = rowsum; p.M = B * Ho * Wo;

@@ -92,6 +92,17 @@ class PackedWeight:
 class ActBinding:
     """Device-resident tables of one (layer, timestep-slot) activation quantizer."""
 
+    def koff(self, W, ldc):
+        """ksrc resolved to element offsets (dh*W + dw)*ldc + c for one input geometry (cached)."""
+        if self.ksrc is None:
+            return None
+        key = (W, ldc)
+        if key not in self._koff:
+            e = self.ksrc
+            off = (((e >> 24) & 0x7F) * W + ((e >> 16) & 0xFF)) * ldc + (e & 0xFFFF)
+            self._koff[key] = torch.where(e >= 0, off, torch.full_like(off, -1)).to(torch.int32).contiguous()
+        return self._koff[key]
+
     def __init__(self, layout: ActLayout, pw: PackedWeight, abits: int):
         dev = pw.codes.device
         self.mode, self.abits, self.offset = layout.mode, abits, act_offset(abits)
@@ -99,6 +110,7 @@ class ActBinding:
         if layout.mode == "perK":
             self.Kp = layout.Kp
             self.ksrc = layout.ksrc.to(dev)
+            self._koff = {}
             self.cdelta = layout.cdelta.to(dev)
             self.czp = layout.czp.to(dev)
             self.cflush = layout.cflush.to(dev)
@@ -149,8 +161,9 @@ def quant_act(x_cl: torch.Tensor, B, H, W, C, kh, kw, stride, pad, ab: ActBindin
     delta = ab.cdelta if ab.mode == "perK" else ab.mdelta
     zp = ab.czp if ab.mode == "perK" else ab.mzp
     L = 1 if ab.mode == "perK" else ab.L
+    ldc = 2 * C if (pre and pre[2] == 2) else C
     _lib_call("dgq_quant_act", _lib.ptr(x_cl), _lib.DTYPE_CODE[x_cl.dtype], B, H, W, C, kh, kw, stride, pad,
-              _lib.ptr(ab.ksrc), ab.Kp, per_m, _lib.ptr(delta), _lib.ptr(zp), L, ab.abits,
+              _lib.ptr(ab.ksrc), _lib.ptr(ab.koff(W, ldc)), ab.Kp, per_m, _lib.ptr(delta), _lib.ptr(zp), L, ab.abits,
               _lib.ptr(codes), _lib.ptr(rowsum), parts,
               _lib.ptr(pre[0]) if pre and pre[0] is not None else None,
               _lib.ptr(pre[1]) if pre and pre[1] is not None else None, pre[2] if pre else 0, _lib.stream())
