@@ -389,6 +389,14 @@ static int launch_attn3(AttnParams p, unsigned short* kb, unsigned short* vt, hi
     hipLaunchKernelGGL((attn3_prep_kernel<D>), dim3(p.Spad / KT, p.B * p.H), dim3(256), 0, st, p.k, p.v, kb, vt, p.B, p.H,
                        p.S, p.Spad);
     dim3 grid((p.T + QROWS - 1) / QROWS, p.B * p.H), block(256);
+    static const bool lds_ok = [] {                            // up to 141 KB of dynamic LDS (D = 160): opt in once
+        const int bytes = 2 * (G::K_ELEMS + G::V_ELEMS) * 2;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn3_stats_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn3_pv_kernel<D, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn3_pv_kernel<D, false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        return true;
+    }();
+    (void)lds_ok;
     hipLaunchKernelGGL((attn3_stats_kernel<D>), grid, block, 2 * G::K_ELEMS * 2, st, p);
     if (p.mode == 3) hipLaunchKernelGGL((attn3_pv_kernel<D, true>), grid, block, 2 * (G::K_ELEMS + G::V_ELEMS) * 2, st, p);
     else hipLaunchKernelGGL((attn3_pv_kernel<D, false>), grid, block, 2 * (G::K_ELEMS + G::V_ELEMS) * 2, st, p);
@@ -406,6 +414,7 @@ size_t dgq_attention_bf16x3_bytes(int B, int H, int S, int D) {
         case 40: dp = Geo<40>::DP; dv = Geo<40>::NDT * 32; break;
         case 64: dp = Geo<64>::DP; dv = Geo<64>::NDT * 32; break;
         case 80: dp = Geo<80>::DP; dv = Geo<80>::NDT * 32; break;
+        case 160: dp = Geo<160>::DP; dv = Geo<160>::NDT * 32; break;
         default: return 0;
     }
     return (size_t)B * H * 3 * Spad * (dp + dv) * sizeof(unsigned short);
@@ -426,6 +435,7 @@ int dgq_attention_bf16x3(const float* q, const float* k, const float* v, float* 
         case 40: return launch_attn3<40>(p, kb, kb + (size_t)B * H * 3 * p.Spad * Geo<40>::DP, st);
         case 64: return launch_attn3<64>(p, kb, kb + (size_t)B * H * 3 * p.Spad * Geo<64>::DP, st);
         case 80: return launch_attn3<80>(p, kb, kb + (size_t)B * H * 3 * p.Spad * Geo<80>::DP, st);
+        case 160: return launch_attn3<160>(p, kb, kb + (size_t)B * H * 3 * p.Spad * Geo<160>::DP, st);
         default: return 1;
     }
 }

@@ -235,7 +235,7 @@ def test_fakequant_rows_and_logquant(dev):
 
 # ------------------------------------------------------------------------------------------ fused attention
 @pytest.mark.parametrize("D,T,S,H", [(40, 200, 200, 2), (8, 70, 77, 8), (16, 130, 40, 3), (64, 96, 77, 2),
-                                     (80, 257, 257, 2), (160, 64, 77, 2)])
+                                     (80, 257, 257, 2), (160, 64, 77, 2), (160, 256, 256, 8)])
 @pytest.mark.parametrize("mode,skip", [(0, 0), (1, 0), (1, 1), (2, 0), (3, 1)])
 def test_fused_attention_vs_reference_formulas(D, T, S, H, mode, skip, dev):
     """dgq_attention_f32 against the materialised reference sequence of sd.py:183-201 evaluated with torch on the
