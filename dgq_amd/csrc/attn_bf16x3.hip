@@ -22,7 +22,26 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define KT 32
 #define LOG2E 1.4426950408889634f
 
+// optional UniformAffineQuantizer applied to q / k / v as they are loaded (aqtizer_q/k/v, sd.py:165-181): same
+// addressing as dgq_fakequant_rows — mode 0 scalar, 1 per token (entry t − skip), 2 per head-dim element; tokens
+// < skip pass through (start_peak).  mode < 0: none.
+struct FqDesc {
+    int mode;
+    int skip;
+    float qmax;
+    const float* delta;
+    const float* zp;
+};
+
+__device__ __forceinline__ float fq_apply(const FqDesc& f, float x, int t, int d) {
+    if (f.mode < 0 || t < f.skip) return x;
+    const int idx = f.mode == 0 ? 0 : (f.mode == 1 ? t - f.skip : d);
+    const float dl = f.delta[idx], z = f.zp[idx];
+    return dl * (dgq_affine_code(x, dl, z, f.qmax) - z);
+}
+
 struct AttnParams {
+    FqDesc fq[3];          // q, k, v
     const float* q;
     const float* k;
     const float* v;
@@ -70,11 +89,13 @@ template <int D> struct Geo {
 template <int D>
 __global__ __launch_bounds__(256) void attn3_prep_kernel(const float* __restrict__ k, const float* __restrict__ v,
                                                          unsigned short* __restrict__ kb, unsigned short* __restrict__ vt,
-                                                         int B, int H, int S, int Spad) {
+                                                         int B, int H, int S, int Spad, FqDesc fk, FqDesc fv,
+                                                         float* __restrict__ delta_reset) {
     using G = Geo<D>;
     constexpr int DV = G::NDT * 32;
     const int bh = blockIdx.y, b = bh / H, hd = bh - b * H;
     const int s0 = blockIdx.x * KT;
+    if (delta_reset && blockIdx.x == 0 && bh == 0 && threadIdx.x == 0) *delta_reset = 0.0f;   // real-time δ: max starts at 0
     const float* kbase = k + ((int64_t)(b * S) * H + hd) * D;
     const float* vbase = v + ((int64_t)(b * S) * H + hd) * D;
     const int64_t HD = (int64_t)H * D;
@@ -83,7 +104,7 @@ __global__ __launch_bounds__(256) void attn3_prep_kernel(const float* __restrict
     for (int i = threadIdx.x; i < KT * G::DP; i += 256) {
         const int r = i / G::DP, c = i - r * G::DP;
         const int sidx = s0 + r;
-        const float x = (sidx < S && c < D) ? kbase[sidx * HD + c] : 0.0f;
+        const float x = (sidx < S && c < D) ? fq_apply(fk, kbase[sidx * HD + c], sidx, c) : 0.0f;
         unsigned short h, m, l;
         split3(x, h, m, l);
         const int64_t o = (int64_t)sidx * G::DP + c;
@@ -94,7 +115,7 @@ __global__ __launch_bounds__(256) void attn3_prep_kernel(const float* __restrict
     for (int i = threadIdx.x; i < KT * DV; i += 256) {
         const int key = i / DV, d = i - key * DV;
         const int sidx = s0 + key;
-        const float x = (sidx < S && d < D) ? vbase[sidx * HD + d] : 0.0f;
+        const float x = (sidx < S && d < D) ? fq_apply(fv, vbase[sidx * HD + d], sidx, d) : 0.0f;
         unsigned short h, m, l;
         split3(x, h, m, l);
         const int sg = key >> 4, a = (key >> 3) & 1, hh = (key >> 2) & 1, bb = key & 3;
@@ -147,7 +168,7 @@ template <int D> struct StageGeo {
 
 // Q rows of this lane as B-operand fragments: qf[split][kk] holds Q[t][16kk + 8h + j], j = 0..7
 template <int D>
-__device__ __forceinline__ void load_q(bf16x8 (&qf)[3][Geo<D>::NKK], const float* qrow, int h32) {
+__device__ __forceinline__ void load_q(bf16x8 (&qf)[3][Geo<D>::NKK], const float* qrow, int h32, const FqDesc& fq, int t) {
     using G = Geo<D>;
 #pragma unroll
     for (int kk = 0; kk < G::NKK; ++kk) {
@@ -155,8 +176,8 @@ __device__ __forceinline__ void load_q(bf16x8 (&qf)[3][Geo<D>::NKK], const float
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int d = 16 * kk + 8 * h32 + 2 * j;
-            const float x0 = (d < D) ? qrow[d] : 0.0f;
-            const float x1 = (d + 1 < D) ? qrow[d + 1] : 0.0f;
+            const float x0 = (d < D) ? fq_apply(fq, qrow[d], t, d) : 0.0f;
+            const float x1 = (d + 1 < D) ? fq_apply(fq, qrow[d + 1], t, d + 1) : 0.0f;
             unsigned short h0, m0, l0, h1, m1, l1;
             split3(x0, h0, m0, l0);
             split3(x1, h1, m1, l1);
@@ -207,7 +228,7 @@ __global__ __launch_bounds__(256) void attn3_stats_kernel(AttnParams p) {
     const int t = blockIdx.x * QROWS + wid * 32 + (lane & 31);
     const int tq = min(t, p.T - 1);
     bf16x8 qf[3][G::NKK];
-    load_q<D>(qf, p.q + ((int64_t)(b * p.T + tq) * p.H + hd) * D, h32);
+    load_q<D>(qf, p.q + ((int64_t)(b * p.T + tq) * p.H + hd) * D, h32, p.fq[0], tq);
     const float sl2 = p.scale * LOG2E;                   // scores in log2 units: p = 2^(s2 − m)/l
     float m = -INFINITY, l = 0.0f, m2 = -INFINITY;
     const unsigned short* kb_bh = p.kb + (int64_t)bh * 3 * p.Spad * G::DP;
@@ -271,7 +292,7 @@ __global__ __launch_bounds__(256) void attn3_pv_kernel(AttnParams p) {
     const int t = blockIdx.x * QROWS + wid * 32 + (lane & 31);
     const int tq = min(t, p.T - 1);
     bf16x8 qf[3][G::NKK];
-    load_q<D>(qf, p.q + ((int64_t)(b * p.T + tq) * p.H + hd) * D, h32);
+    load_q<D>(qf, p.q + ((int64_t)(b * p.T + tq) * p.H + hd) * D, h32, p.fq[0], tq);
     const float m = p.stats[((int64_t)bh * p.T + tq) * 2], l = p.stats[((int64_t)bh * p.T + tq) * 2 + 1];
     const float delta = p.delta[0];
     const float nsl2 = -(p.scale * LOG2E);
@@ -374,7 +395,7 @@ __global__ __launch_bounds__(256) void attn3_pv_kernel(AttnParams p) {
                 const int d = j * 32 + key_of(r, h32);
                 if (d < D) {
                     float o = delta * oacc[j][r];
-                    if (p.skip > 0) o += p_bypass * v0[d];
+                    if (p.skip > 0) o += p_bypass * fq_apply(p.fq[2], v0[d], 0, d);
                     op[d] = o;
                 }
             }
@@ -387,7 +408,7 @@ static int launch_attn3(AttnParams p, unsigned short* kb, unsigned short* vt, hi
     p.kb = kb;
     p.vt = vt;
     hipLaunchKernelGGL((attn3_prep_kernel<D>), dim3(p.Spad / KT, p.B * p.H), dim3(256), 0, st, p.k, p.v, kb, vt, p.B, p.H,
-                       p.S, p.Spad);
+                       p.S, p.Spad, p.fq[1], p.fq[2], p.mode == 1 ? p.delta : nullptr);
     dim3 grid((p.T + QROWS - 1) / QROWS, p.B * p.H), block(256);
     static const bool lds_ok = [] {                            // up to 141 KB of dynamic LDS (D = 160): opt in once
         const int bytes = 2 * (G::K_ELEMS + G::V_ELEMS) * 2;
@@ -403,7 +424,6 @@ static int launch_attn3(AttnParams p, unsigned short* kb, unsigned short* vt, hi
     return dgq_launch_status("dgq_attention_f32(bf16x3)");
 }
 
-// called from dgq_attention_f32 (attn_fused.hip) for the quantised modes; returns 1 when D is not instantiated here
 // bytes of K/V split planes for one call (0 when D is not instantiated here)
 size_t dgq_attention_bf16x3_bytes(int B, int H, int S, int D) {
     const size_t Spad = (size_t)(S + KT - 1) / KT * KT;
@@ -423,8 +443,15 @@ size_t dgq_attention_bf16x3_bytes(int B, int H, int S, int D) {
 // called from dgq_attention_f32 (attn_fused.hip) for the quantised modes; returns 1 when D is not instantiated here
 int dgq_attention_bf16x3(const float* q, const float* k, const float* v, float* o, int B, int H, int T, int S, int D,
                          float scale, int mode, int skip, float qmax, float* stats_ws, float* delta_ws, void* planes,
-                         hipStream_t st) {
+                         const dgq_attn_fq_t* fq, hipStream_t st) {
     AttnParams p;
+    for (int i = 0; i < 3; ++i) {
+        p.fq[i].mode = -1; p.fq[i].skip = 0; p.fq[i].qmax = 0.0f; p.fq[i].delta = nullptr; p.fq[i].zp = nullptr;
+        if (fq && fq[i].mode >= 0) {
+            p.fq[i].mode = fq[i].mode; p.fq[i].skip = fq[i].skip; p.fq[i].qmax = (float)((1 << fq[i].bits) - 1);
+            p.fq[i].delta = fq[i].delta; p.fq[i].zp = fq[i].zero_point;
+        }
+    }
     p.q = q; p.k = k; p.v = v; p.o = o; p.B = B; p.H = H; p.T = T; p.S = S; p.scale = scale; p.mode = mode; p.skip = skip;
     p.qmax = qmax; p.stats = stats_ws; p.delta = delta_ws;
     p.Spad = (S + KT - 1) / KT * KT;

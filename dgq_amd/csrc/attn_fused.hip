@@ -216,7 +216,7 @@ static int launch_attn(const AttnParams& p, hipStream_t st) {
 
 int dgq_attention_bf16x3(const float* q, const float* k, const float* v, float* o, int B, int H, int T, int S, int D,
                          float scale, int mode, int skip, float qmax, float* stats_ws, float* delta_ws, void* planes,
-                         hipStream_t st);
+                         const dgq_attn_fq_t* fq, hipStream_t st);
 size_t dgq_attention_bf16x3_bytes(int B, int H, int S, int D);
 
 // workspace layout: [0,256) δ scalar | stats B·H·T·2 floats (256-byte aligned) | bf16 split planes of K and V
@@ -227,9 +227,14 @@ extern "C" size_t dgq_attention_workspace_bytes(int B, int H, int T, int S, int 
     return attn_planes_off(B, H, T) + dgq_attention_bf16x3_bytes(B, H, S, D);
 }
 
+extern "C" int dgq_attention_fuses_fakequant(int D, int mode) {
+    static const bool force_fp32 = getenv("DGQ_ATTN_FP32") != nullptr;
+    return (mode >= 1 && mode <= 3 && !force_fp32 && dgq_attention_bf16x3_bytes(1, 1, 32, D) > 0) ? 1 : 0;
+}
+
 extern "C" int dgq_attention_f32(const float* q, const float* k, const float* v, float* o, int B, int H, int T, int S,
                                  int D, float scale, int mode, int skip, const float* delta_in, int bits,
-                                 void* workspace, size_t workspace_bytes, void* stream) {
+                                 const dgq_attn_fq_t* fq, void* workspace, size_t workspace_bytes, void* stream) {
     DGQ_CHECK_ARG(q && k && v && o && workspace, "dgq_attention_f32: null pointer");
     DGQ_CHECK_ARG((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, "dgq_attention_f32: workspace must be 256-byte aligned");
     DGQ_CHECK_ARG(workspace_bytes >= dgq_attention_workspace_bytes(B, H, T, S, D), "dgq_attention_f32: workspace too small");
@@ -243,20 +248,29 @@ extern "C" int dgq_attention_f32(const float* q, const float* k, const float* v,
     AttnParams p;
     p.q = q; p.k = k; p.v = v; p.o = o; p.B = B; p.H = H; p.T = T; p.S = S; p.scale = scale; p.mode = mode; p.skip = skip;
     p.qmax = (float)((1 << bits) - 1); p.stats = stats_ws; p.delta = delta_ws;
-    if (mode == 1) {
+    // quantised modes: bf16x3 MFMA path (fp32-equivalent accuracy, 16x the matrix rate); DGQ_ATTN_FP32=1 forces the
+    // exact-fp32 MFMA kernels below, which also serve mode 0 and head dims the bf16x3 file does not instantiate
+    const bool use3 = dgq_attention_fuses_fakequant(D, mode) != 0;
+    bool any_fq = false;
+    if (fq) for (int i = 0; i < 3; ++i) {
+        if (fq[i].mode < 0) continue;
+        any_fq = true;
+        DGQ_CHECK_ARG(fq[i].mode <= 2 && fq[i].delta && fq[i].zero_point && fq[i].skip >= 0 && fq[i].bits >= 2 && fq[i].bits <= 8,
+                      "dgq_attention_f32: bad q/k/v quantizer descriptor");
+    }
+    if (any_fq && !use3) {
+        dgq_set_error("dgq_attention_f32: q/k/v quantizers are fused only where dgq_attention_fuses_fakequant(D, mode) "
+                      "is 1; run dgq_fakequant_rows first");
+        return DGQ_EUNSUPPORTED;
+    }
+    if (mode == 1 && !use3) {                                  // (the bf16x3 pre-pass resets δ itself)
         if (hipMemsetAsync(delta_ws, 0, sizeof(float), st) != hipSuccess) { dgq_set_error("dgq_attention_f32: memset"); return DGQ_ELAUNCH; }
     } else if (mode >= 2) {
         if (hipMemcpyAsync(delta_ws, delta_in, sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) {
             dgq_set_error("dgq_attention_f32: memcpy"); return DGQ_ELAUNCH;
         }
     }
-    // quantised modes: bf16x3 MFMA path (fp32-equivalent accuracy, 16x the matrix rate); DGQ_ATTN_FP32=1 forces the
-    // exact-fp32 MFMA kernels below, which also serve mode 0 and head dims the bf16x3 file does not instantiate
-    static const bool force_fp32 = getenv("DGQ_ATTN_FP32") != nullptr;
-    if (mode >= 1 && !force_fp32) {
-        const int rc = dgq_attention_bf16x3(q, k, v, o, B, H, T, S, D, scale, mode, skip, p.qmax, stats_ws, delta_ws, planes, st);
-        if (rc != 1) return rc;
-    }
+    if (use3) return dgq_attention_bf16x3(q, k, v, o, B, H, T, S, D, scale, mode, skip, p.qmax, stats_ws, delta_ws, planes, fq, st);
     switch (D) {
         case 8: return launch_attn<8>(p, st);
         case 16: return launch_attn<16>(p, st);

@@ -360,14 +360,36 @@ def logquant_f32(p: torch.Tensor, delta: torch.Tensor, bits, skip_cols=0, out=No
 ATTN_HEAD_DIMS = (8, 16, 40, 64, 80, 160)
 
 
-def attention_f32(q, k, v, H, D, scale, mode, skip, delta, bits):
-    """q [B,T,H*D], k/v [B,S,H*D] fp32 contiguous -> o [B,T,H*D]; see dgq_attention_f32."""
+def attention_fuses_fakequant(D, mode):
+    """True where dgq_attention_f32 applies the q/k/v fake-quantizers itself (``fq=``)."""
+    return bool(_lib.load().dgq_attention_fuses_fakequant(D, mode))
+
+
+def attention_f32(q, k, v, H, D, scale, mode, skip, delta, bits, fq=None):
+    """q [B,T,H*D], k/v [B,S,H*D] fp32 contiguous -> o [B,T,H*D]; see dgq_attention_f32.
+    fq: optional 3-tuple for q, k, v of None | (mode, delta, zp, skip, bits) — the aqtizer_q/k/v quantizers applied on
+    load (only where ``attention_fuses_fakequant(D, mode)``)."""
     assert q.dtype == torch.float32 and q.is_contiguous() and k.is_contiguous() and v.is_contiguous()
     B, T, _ = q.shape
     S = k.shape[1]
     o = torch.empty_like(q)
     nbytes = _lib.load().dgq_attention_workspace_bytes(B, H, T, S, D)
     ws = torch.empty((nbytes,), dtype=torch.uint8, device=q.device)      # caching allocator: 512-byte aligned
+    desc = None
+    if fq is not None and any(f is not None for f in fq):
+        desc = (_lib.AttnFq * 3)()
+        for i, f in enumerate(fq):
+            if f is None:
+                desc[i].mode = -1
+                continue
+            fmode, fd, fz, fskip, fbits = f
+            ntok = (T if i == 0 else S) - fskip
+            need = 1 if fmode == 0 else (ntok if fmode == 1 else D)
+            assert fd.numel() == need and fz.numel() == need and fd.dtype == torch.float32 and fd.is_contiguous(), \
+                "q/k/v quantizer table has %d entries, kernel addresses %d" % (fd.numel(), need)
+            desc[i].mode, desc[i].skip, desc[i].bits = fmode, fskip, fbits
+            desc[i].delta, desc[i].zero_point = _lib.ptr(fd), _lib.ptr(fz)
     _lib_call("dgq_attention_f32", _lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(o), B, H, T, S, D,
-              _c.c_float(scale), mode, skip, _lib.ptr(delta), bits, _lib.ptr(ws), nbytes, _lib.stream())
+              _c.c_float(scale), mode, skip, _lib.ptr(delta), bits,
+              _c.cast(desc, _c.c_void_p) if desc is not None else None, _lib.ptr(ws), nbytes, _lib.stream())
     return o

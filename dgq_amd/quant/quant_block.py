@@ -33,6 +33,9 @@ _F_RES = _os.environ.get("DGQ_FUSE_RESIDUAL", "0") == "1"
 _F_FQ = _os.environ.get("DGQ_FUSE_FQ", "0") == "1"
 _F_GEGLU = _os.environ.get("DGQ_FUSE_GEGLU", "0") == "1"
 _F_SILU = _os.environ.get("DGQ_FUSE_SILU", "1") == "1"
+# aqtizer_{q,k,v} applied inside the attention kernels' operand loads (K/V split pre-pass, Q fragment load): three
+# launches per attention saved, nothing added to a GEMM grid
+_F_ATTN_FQ = _os.environ.get("DGQ_FUSE_ATTN_FQ", "0") == "1"   # measured +0.3 ms as written (exact divisions ahead of every Q block): off
 
 
 class BaseQuantBlock(nn.Module):
@@ -170,10 +173,25 @@ def quant_attention_forward(attn, hidden_states, encoder_hidden_states=None, res
     H, D = attn.num_heads, attn.head_dim
     use_aq = bool(getattr(attn, "use_aq", False))
 
+    # softmax-quantiser mode of dgq_attention_f32; where that kernel applies aqtizer_q/k/v itself on load, the three
+    # separate fake-quant passes are skipped (pending[...] carries their tables instead)
+    mode_w = 0
+    if use_aq:
+        wq_ = attn.aqtizer_w
+        mode_w = (1 if wq_.real_time else 2) if isinstance(wq_, T2ILogQuantizer) else 3
+    defer = (FUSION and _F_ATTN_FQ and use_aq and hidden_states.is_cuda and hidden_states.dtype == torch.float32
+             and D in ops.ATTN_HEAD_DIMS and (mode_w == 1 or attn.aqtizer_w.init)
+             and ops.attention_fuses_fakequant(D, mode_w))
+    pending = {}
+
     def project(layer, name, inp, skip):
-        """projection + its attention-side quantizer (fused into the GEMM epilogue when possible)"""
+        """projection + its attention-side quantizer (fused into the attention kernel's loads when possible)"""
         qz = getattr(attn, name) if use_aq else None
         ntok = inp.shape[1]
+        if defer and qz.init:
+            mode, dd, zz = _qparams(qz, inp.device)
+            pending[name] = (mode, dd, zz, skip, qz.bits)
+            return layer(inp)
         if (FUSION and _F_FQ and qz is not None and qz.init and isinstance(layer, QuantLayer) and layer.on_integer_path(inp)
                 and inp.dtype == torch.float32):
             mode, dd, zz = _qparams(qz, inp.device)
@@ -220,8 +238,9 @@ def quant_attention_forward(attn, hidden_states, encoder_hidden_states=None, res
                 if not wq.init:
                     _init_static_softmax_delta(attn, wq, q, k, b, t, s, H, D, skip)
                 mode, delta = 3, wq.delta.detach().reshape(1).float().to(q.device)
+        fq = tuple(pending.get(n) for n in ("aqtizer_q", "aqtizer_k", "aqtizer_v")) if pending else None
         o = ops.attention_f32(q.contiguous(), k.contiguous(), v.contiguous(), H, D, float(attn.scale), mode, skip,
-                              delta, bits)
+                              delta, bits, fq)
         return _attn_out(attn, o, residual)
     qh = q.view(b, t, H, D).transpose(1, 2)
     kh = k.view(b, s, H, D).transpose(1, 2)

@@ -157,11 +157,23 @@ int dgq_logquant_f32(const float* p, float* y, int64_t rows, int S, int skip_col
  *         3: UniformAffineQuantizer always_zero with δ = delta_in[0] (quant_block.py:145-156).
  * skip = 1 bypasses key column 0 (start_peak, sd.py:191-195).  workspace: caller-owned, 256-byte aligned,
  * >= dgq_attention_workspace_bytes(...) (δ scalar, per-row softmax statistics, bf16 split planes of K and V).
- * head_dim D ∈ {8,16,40,64,80,160}.  Quantised modes with D <= 80 run on the bf16 MFMA with exact three-way bf16
- * operand splits (fp32-equivalent accuracy); the rest on the exact fp32 MFMA. */
+ * head_dim D ∈ {8,16,40,64,80,160}.  Quantised modes run on the bf16 MFMA with exact three-way bf16 operand splits
+ * (fp32-equivalent accuracy); mode 0 on the exact fp32 MFMA.
+ * fq (optional, NULL = none): the aqtizer_q / aqtizer_k / aqtizer_v fake-quantizers (sd.py:165-181) applied to the
+ * operands as they are loaded, fq[0..2] = q, k, v, each addressed exactly like dgq_fakequant_rows (mode 0 scalar,
+ * 1 per token with entry t − skip, 2 per head-dim element; mode < 0 = none for that operand; tokens < skip pass
+ * through).  Only where dgq_attention_fuses_fakequant(D, mode) returns 1; DGQ_EUNSUPPORTED otherwise. */
+typedef struct dgq_attn_fq {
+    int mode;                  /* -1 none, 0 scalar, 1 per token, 2 per head-dim element */
+    int skip;                  /* leading tokens left unquantised (start_peak key 0) */
+    int bits;
+    const float* delta;        /* device */
+    const float* zero_point;   /* device */
+} dgq_attn_fq_t;
 int dgq_attention_f32(const float* q, const float* k, const float* v, float* o, int B, int H, int T, int S, int D,
-                      float scale, int mode, int skip, const float* delta_in, int bits,
+                      float scale, int mode, int skip, const float* delta_in, int bits, const dgq_attn_fq_t* fq,
                       void* workspace, size_t workspace_bytes, void* stream);
+int dgq_attention_fuses_fakequant(int D, int mode);
 size_t dgq_attention_workspace_bytes(int B, int H, int T, int S, int D);
 
 #ifdef __cplusplus

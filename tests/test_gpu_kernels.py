@@ -270,6 +270,37 @@ def test_fused_attention_vs_reference_formulas(D, T, S, H, mode, skip, dev):
     assert err < (1e-5 if mode == 0 else 2e-3), err
 
 
+@pytest.mark.parametrize("D,T,S,H", [(40, 200, 200, 2), (80, 96, 77, 3), (160, 64, 77, 2)])
+@pytest.mark.parametrize("mode", [1, 3])
+def test_attention_fused_qkv_quantizers_bit_identical(D, T, S, H, mode, dev):
+    """aqtizer_q/k/v applied inside dgq_attention_f32's operand loads == dgq_fakequant_rows followed by the same
+    attention, bit for bit (scalar, per-token with the start-peak key bypass, per-head-dim tables)."""
+    from dgq_amd import ops
+    assert ops.attention_fuses_fakequant(D, mode)
+    g = torch.Generator().manual_seed(D + T + mode)
+    B, bits, skip = 2, 8, 1
+    q, k, v = (torch.randn(B, n, H * D, generator=g).to(dev) for n in (T, S, S))
+
+    def table(n, lo):
+        d = (torch.rand(n, generator=g) * 0.02 + lo).to(dev)
+        z = torch.randint(100, 156, (n,), generator=g).float().to(dev)
+        return d, z
+    fq_q = (1,) + table(T, 0.02) + (0, bits)                 # per query token
+    fq_k = (1,) + table(S - skip, 0.02) + (skip, bits)       # per key token, key 0 bypassed
+    fq_v = (2,) + table(D, 0.02) + (0, bits)                 # per head-dim element
+    delta = torch.tensor([0.004], device=dev) if mode == 3 else None
+    scale = D ** -0.5
+    for fqs in ((fq_q, fq_k, fq_v), ((0,) + table(1, 0.03) + (0, bits), None, fq_v)):
+        qq, kk, vv = q.clone(), k.clone(), v.clone()
+        for ten, f, n in ((qq, fqs[0], T), (kk, fqs[1], S), (vv, fqs[2], S)):
+            if f is not None:
+                ops.fakequant_rows(ten.view(B * n, H * D), n, D, f[0], f[1], f[2], f[3], f[4])
+        ref = ops.attention_f32(qq, kk, vv, H, D, scale, mode, skip, delta, bits)
+        out = ops.attention_f32(q, k, v, H, D, scale, mode, skip, delta, bits, fq=fqs)
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref)
+
+
 # ------------------------------------------------------------------------------------------ fused GroupNorm + SiLU
 @pytest.mark.parametrize("C,H,k", [(64, 12, 3), (320, 16, 3), (96, 9, 1)])
 def test_fused_groupnorm_silu_quant_codes(C, H, k, dev):
