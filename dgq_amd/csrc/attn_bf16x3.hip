@@ -53,9 +53,8 @@ struct AttnParams {
     float qmax;
     float* stats;          // [B*H][T][2] : m (log2 units), l
     float* delta;
-    const unsigned short* kb;   // [B*H][3][Spad][DP] bf16 split planes of K
-    const unsigned short* vt;   // [B*H][3][DV][Spad] bf16 split planes of V^T, keys permuted within each 32-key tile
-    int Spad;
+    const unsigned char* planes;   // [B*H][NT] tile images of the bf16 split planes (Geo<D>::IMG_BYTES each)
+    int NT;                        // 32-key tiles per (batch, head)
 };
 
 __device__ __forceinline__ unsigned short bf16_bits(float x) {
@@ -76,95 +75,124 @@ template <int D> struct Geo {
     static constexpr int DP = (D + 15) / 16 * 16;      // K depth of the score product
     static constexpr int NKK = DP / 16;
     static constexpr int NDT = (D + 31) / 32;          // 32-wide d tiles of O^T
+    static constexpr int DV = NDT * 32;
     static constexpr int KLD = DP + 8;                 // bf16 elements per K row (16-byte aligned, de-conflicted)
     static constexpr int VLD = KT + 8;                 // bf16 elements per V^T row
     static constexpr int K_ELEMS = 3 * KT * KLD;
-    static constexpr int V_ELEMS = 3 * NDT * 32 * VLD;
+    static constexpr int V_ELEMS = 3 * DV * VLD;
+    // One 32-key tile of a (batch, head) is ONE contiguous image in global memory, laid out exactly as it sits in LDS
+    // (K planes [3][KT][KLD] then V^T planes [3][DV][VLD], padding included), so staging is a flat LDS-DMA copy in
+    // 1-KB pieces (64 lanes x 16 B) with no registers in between.
+    static constexpr int K_PIECES = (2 * K_ELEMS + 1023) / 1024;              // statistics pass: K part only
+    static constexpr int IMG_PIECES = (2 * (K_ELEMS + V_ELEMS) + 1023) / 1024;
+    static constexpr int IMG_BYTES = IMG_PIECES * 1024;
+    // ring depths: prefetch distance STAGES-1 tiles; sized so that two blocks share a CU's 160 KB where the grid is
+    // large (D = 40: 3 x 26 KB) and by what fits otherwise
+    static constexpr int STATS_STAGES = D <= 80 ? 4 : 3;
+    static constexpr int PV_STAGES = (D <= 40 || D == 80) ? 3 : 2;
 };
 
-// One pre-pass per attention call: split K and V exactly into three bf16 planes, laid out so that a 32-key tile is a
-// set of whole 16-byte chunks for the main kernels (K: rows of DP elements; V: transposed, key order inside a tile =
-// the k order of an accumulator tile used as the next MFMA's B operand: key 16s + 8a + 4h + b -> slot 16s + 8h + 4a + b).
-// Every Q block of a (batch, head) re-reads these planes; splitting them inside the main loop cost more than the MFMAs.
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// LDS-DMA of 16 B per lane: LDS[lds_addr + lane*16] <- *gsrc (inline asm: see gemm_wxa8.hip — the builtin form makes
+// hipcc drain every DMA with vmcnt(0) before the next ds_read; the ring below is ordered by counted vmcnt + barrier).
+__device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_addr) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_addr)
+                 : "memory");
+}
+
+// this wave's share of one tile image: pieces wid, wid+4, ... < NP
+template <int NP>
+__device__ __forceinline__ void issue_image(const unsigned char* img_lane, uint32_t lds_stage, int wid) {
+#pragma unroll
+    for (int i = 0; i < (NP + 3) / 4; ++i) {
+        const int j = wid + 4 * i;
+        if (j < NP) glds16(img_lane + 1024 * j, __builtin_amdgcn_readfirstlane(lds_stage + 1024 * j));
+    }
+}
+
+// wait until all but the youngest YOUNGER tiles of this wave's DMA pieces have landed (vmcnt counts in issue order;
+// a wave issues ceil or floor of NP/4 pieces per tile depending on its index)
+template <int NP, int YOUNGER>
+__device__ __forceinline__ void wait_image(int wid) {
+    constexpr int HI = (NP + 3) / 4, LO = NP / 4;
+    if (HI == LO || wid < NP % 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(HI * YOUNGER) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LO * YOUNGER) : "memory");
+}
+
+// One pre-pass per attention call: fake-quantise (optional) and split K and V exactly into three bf16 planes, written
+// as the per-tile LDS images described above.  V is stored transposed with the keys of a tile permuted into the k
+// order of an accumulator tile used as the next MFMA's B operand: key 16s + 8a + 4h + b -> slot 16s + 8h + 4a + b.
+// Every Q block of a (batch, head) re-reads these images; splitting inside the main loop cost more than the MFMAs.
 template <int D>
 __global__ __launch_bounds__(256) void attn3_prep_kernel(const float* __restrict__ k, const float* __restrict__ v,
-                                                         unsigned short* __restrict__ kb, unsigned short* __restrict__ vt,
-                                                         int B, int H, int S, int Spad, FqDesc fk, FqDesc fv,
-                                                         float* __restrict__ delta_reset) {
+                                                         unsigned char* __restrict__ planes, int B, int H, int S, int NT,
+                                                         FqDesc fk, FqDesc fv, float* __restrict__ delta_reset) {
     using G = Geo<D>;
-    constexpr int DV = G::NDT * 32;
+    static_assert(D % 8 == 0, "head_dim must be a multiple of 8");
     const int bh = blockIdx.y, b = bh / H, hd = bh - b * H;
     const int s0 = blockIdx.x * KT;
     if (delta_reset && blockIdx.x == 0 && bh == 0 && threadIdx.x == 0) *delta_reset = 0.0f;   // real-time δ: max starts at 0
     const float* kbase = k + ((int64_t)(b * S) * H + hd) * D;
     const float* vbase = v + ((int64_t)(b * S) * H + hd) * D;
     const int64_t HD = (int64_t)H * D;
-    unsigned short* kdst = kb + (int64_t)bh * 3 * Spad * G::DP;
-    unsigned short* vdst = vt + (int64_t)bh * 3 * DV * Spad;
-    for (int i = threadIdx.x; i < KT * G::DP; i += 256) {
-        const int r = i / G::DP, c = i - r * G::DP;
+    unsigned short* kimg = reinterpret_cast<unsigned short*>(planes + ((int64_t)bh * NT + blockIdx.x) * G::IMG_BYTES);
+    unsigned short* vimg = kimg + G::K_ELEMS;
+    constexpr int KC = G::KLD / 8;                       // 16-byte chunks per K row (padding chunks are zero)
+    for (int i = threadIdx.x; i < KT * KC; i += 256) {
+        const int r = i / KC, c8 = i - r * KC;
         const int sidx = s0 + r;
-        const float x = (sidx < S && c < D) ? fq_apply(fk, kbase[sidx * HD + c], sidx, c) : 0.0f;
-        unsigned short h, m, l;
-        split3(x, h, m, l);
-        const int64_t o = (int64_t)sidx * G::DP + c;
-        kdst[o] = h;
-        kdst[(int64_t)Spad * G::DP + o] = m;
-        kdst[2 * (int64_t)Spad * G::DP + o] = l;
+        unsigned wh[4], wm[4], wl[4];
+        const bool live = sidx < S && 8 * c8 < D;
+        float x[8];
+        if (live) {
+            const float4 a = *reinterpret_cast<const float4*>(kbase + sidx * HD + 8 * c8);
+            const float4 c = *reinterpret_cast<const float4*>(kbase + sidx * HD + 8 * c8 + 4);
+            x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = c.x; x[5] = c.y; x[6] = c.z; x[7] = c.w;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            unsigned short h0 = 0, m0 = 0, l0 = 0, h1 = 0, m1 = 0, l1 = 0;
+            if (live) {
+                split3(fq_apply(fk, x[2 * j], sidx, 8 * c8 + 2 * j), h0, m0, l0);
+                split3(fq_apply(fk, x[2 * j + 1], sidx, 8 * c8 + 2 * j + 1), h1, m1, l1);
+            }
+            wh[j] = (unsigned)h0 | ((unsigned)h1 << 16);
+            wm[j] = (unsigned)m0 | ((unsigned)m1 << 16);
+            wl[j] = (unsigned)l0 | ((unsigned)l1 << 16);
+        }
+        unsigned short* dst = kimg + r * G::KLD + 8 * c8;
+        *reinterpret_cast<uint4*>(dst) = make_uint4(wh[0], wh[1], wh[2], wh[3]);
+        *reinterpret_cast<uint4*>(dst + KT * G::KLD) = make_uint4(wm[0], wm[1], wm[2], wm[3]);
+        *reinterpret_cast<uint4*>(dst + 2 * KT * G::KLD) = make_uint4(wl[0], wl[1], wl[2], wl[3]);
     }
-    for (int i = threadIdx.x; i < KT * DV; i += 256) {
-        const int key = i / DV, d = i - key * DV;
-        const int sidx = s0 + key;
-        const float x = (sidx < S && d < D) ? fq_apply(fv, vbase[sidx * HD + d], sidx, d) : 0.0f;
-        unsigned short h, m, l;
-        split3(x, h, m, l);
-        const int sg = key >> 4, a = (key >> 3) & 1, hh = (key >> 2) & 1, bb = key & 3;
-        const int slot = 16 * sg + 8 * hh + 4 * a + bb;
-        const int64_t o = (int64_t)d * Spad + s0 + slot;
-        vdst[o] = h;
-        vdst[(int64_t)DV * Spad + o] = m;
-        vdst[2 * (int64_t)DV * Spad + o] = l;
+    constexpr int VC = G::VLD / 8;                       // 4 chunks of 8 key slots + 1 padding chunk per V^T row
+    for (int i = threadIdx.x; i < G::DV * VC; i += 256) {
+        const int c8 = i / G::DV, d = i - c8 * G::DV;    // lanes run over d: coalesced reads of every key row
+        unsigned wh[4], wm[4], wl[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            unsigned short hh[2] = {0, 0}, mm[2] = {0, 0}, ll[2] = {0, 0};
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int slot8 = 2 * j + e;                               // slot within the chunk = 4a + b
+                const int key = 16 * (c8 >> 1) + 8 * (slot8 >> 2) + 4 * (c8 & 1) + (slot8 & 3);
+                const int sidx = s0 + key;
+                if (c8 < 4 && sidx < S && d < D) split3(fq_apply(fv, vbase[sidx * HD + d], sidx, d), hh[e], mm[e], ll[e]);
+            }
+            wh[j] = (unsigned)hh[0] | ((unsigned)hh[1] << 16);
+            wm[j] = (unsigned)mm[0] | ((unsigned)mm[1] << 16);
+            wl[j] = (unsigned)ll[0] | ((unsigned)ll[1] << 16);
+        }
+        unsigned short* dst = vimg + d * G::VLD + 8 * c8;
+        *reinterpret_cast<uint4*>(dst) = make_uint4(wh[0], wh[1], wh[2], wh[3]);
+        *reinterpret_cast<uint4*>(dst + G::DV * G::VLD) = make_uint4(wm[0], wm[1], wm[2], wm[3]);
+        *reinterpret_cast<uint4*>(dst + 2 * G::DV * G::VLD) = make_uint4(wl[0], wl[1], wl[2], wl[3]);
     }
 }
-
-// 16-byte chunk copies of one tile: global planes -> registers -> LDS (padded rows).  Written as macros over local
-// arrays with compile-time trip counts: as struct members the register arrays were demoted to scratch.
-template <int D> struct StageGeo {
-    using G = Geo<D>;
-    static constexpr int CPR = G::DP / 8;                       // 16-byte chunks per K row
-    static constexpr int KCHUNKS = 3 * KT * CPR;
-    static constexpr int KPER = (KCHUNKS + 255) / 256;
-    static constexpr int DV = G::NDT * 32;
-    static constexpr int VCHUNKS = 3 * DV * 4;                  // 4 chunks (32 keys) per V^T row
-    static constexpr int VPER = (VCHUNKS + 255) / 256;
-};
-
-#define K_LOAD(kr, kb_bh, s0_)                                                                                        \
-    _Pragma("unroll") for (int i_ = 0; i_ < SG::KPER; ++i_) {                                                          \
-        const int id_ = min(tid + 256 * i_, SG::KCHUNKS - 1);      /* clamped: every register is always written */ \
-        const int pl_ = id_ / (KT * SG::CPR), rem_ = id_ - pl_ * (KT * SG::CPR), row_ = rem_ / SG::CPR,                \
-                  c_ = rem_ - row_ * SG::CPR;                                                                          \
-        kr[i_] = *reinterpret_cast<const uint4*>((kb_bh) + ((int64_t)pl_ * p.Spad + (s0_) + row_) * G::DP + 8 * c_);   \
-    }
-#define K_STORE(kr, lds_)                                                                                             \
-    _Pragma("unroll") for (int i_ = 0; i_ < SG::KPER; ++i_) {                                                          \
-        const int id_ = tid + 256 * i_;                                                                                \
-        if (id_ < SG::KCHUNKS) {                                                                                       \
-            const int pl_ = id_ / (KT * SG::CPR), rem_ = id_ - pl_ * (KT * SG::CPR), row_ = rem_ / SG::CPR,            \
-                      c_ = rem_ - row_ * SG::CPR;                                                                      \
-            *reinterpret_cast<uint4*>((lds_) + (pl_ * KT + row_) * G::KLD + 8 * c_) = kr[i_];                          \
-        }                                                                                                              \
-    }
-#define V_LOAD(vr, vt_bh, s0_)                                                                                        \
-    _Pragma("unroll") for (int i_ = 0; i_ < SG::VPER; ++i_) {                                                          \
-        const int id_ = min(tid + 256 * i_, SG::VCHUNKS - 1);                                                          \
-        vr[i_] = *reinterpret_cast<const uint4*>((vt_bh) + (int64_t)(id_ >> 2) * p.Spad + (s0_) + 8 * (id_ & 3));      \
-    }
-#define V_STORE(vr, lds_)                                                                                             \
-    _Pragma("unroll") for (int i_ = 0; i_ < SG::VPER; ++i_) {                                                          \
-        const int id_ = tid + 256 * i_;                                                                                \
-        if (id_ < SG::VCHUNKS) *reinterpret_cast<uint4*>((lds_) + (id_ >> 2) * G::VLD + 8 * (id_ & 3)) = vr[i_];       \
-    }
 
 // Q rows of this lane as B-operand fragments: qf[split][kk] holds Q[t][16kk + 8h + j], j = 0..7
 template <int D>
@@ -220,60 +248,70 @@ __device__ __forceinline__ int key_of(int r, int h) { return (r & 3) + 8 * (r >>
 template <int D>
 __global__ __launch_bounds__(256) void attn3_stats_kernel(AttnParams p) {
     using G = Geo<D>;
-    extern __shared__ __attribute__((aligned(16))) unsigned short lds16[];
-    unsigned short* kb = lds16;
+    constexpr int ST = G::STATS_STAGES, NP = G::K_PIECES, SB = NP * 1024;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds8[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, h32 = lane >> 5;
     const int bh = blockIdx.y, b = bh / p.H, hd = bh - b * p.H;
-    const int HD = p.H * D;
     const int t = blockIdx.x * QROWS + wid * 32 + (lane & 31);
     const int tq = min(t, p.T - 1);
+    const unsigned char* img_lane = p.planes + (int64_t)bh * p.NT * G::IMG_BYTES + lane * 16;
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(lptr_t)lds8;
+    // ring invariant at the top of iteration i: tiles i .. i+ST-2 are issued (indices clamped to the last tile, so
+    // the in-flight count is the same in every iteration), tile i has landed
+#pragma unroll
+    for (int i = 0; i < ST - 1; ++i)
+        issue_image<NP>(img_lane + (int64_t)min(i, p.NT - 1) * G::IMG_BYTES, lds_base + i * SB, wid);
     bf16x8 qf[3][G::NKK];
     load_q<D>(qf, p.q + ((int64_t)(b * p.T + tq) * p.H + hd) * D, h32, p.fq[0], tq);
     const float sl2 = p.scale * LOG2E;                   // scores in log2 units: p = 2^(s2 − m)/l
-    float m = -INFINITY, l = 0.0f, m2 = -INFINITY;
-    const unsigned short* kb_bh = p.kb + (int64_t)bh * 3 * p.Spad * G::DP;
-    using SG = StageGeo<D>;
-    uint4 kr[SG::KPER];
-    K_LOAD(kr, kb_bh, 0)
-    K_STORE(kr, kb)
-    __syncthreads();
-    int cur = 0;
-    for (int s0 = 0; s0 < p.S; s0 += KT) {
-        const bool more = s0 + KT < p.S;
-        const int s_next = more ? s0 + KT : s0;                   // unconditional (a conditional load demotes kr to scratch)
-        K_LOAD(kr, kb_bh, s_next)                                  // in flight during the MFMAs of this tile
-        const unsigned short* kbc = kb + cur * G::K_ELEMS;
-        v16f acc = score_tile<D>(kbc, qf, lane);
+    float mraw = -INFINITY, l = 0.0f, m2raw = -INFINITY; // running maxima of the UNSCALED scores (scale > 0)
+    wait_image<NP, ST - 2>(wid);
+    __builtin_amdgcn_s_barrier();
+    int stage = 0, istage = ST - 1;
+    for (int i = 0; i < p.NT; ++i) {
+        issue_image<NP>(img_lane + (int64_t)min(i + ST - 1, p.NT - 1) * G::IMG_BYTES, lds_base + istage * SB, wid);
+        const int s0 = i * KT;
+        v16f acc = score_tile<D>(reinterpret_cast<const unsigned short*>(lds8 + stage * SB), qf, lane);
+        const bool edge = (s0 + KT > p.S) || (s0 < p.skip);      // block-uniform: only the first / a partial last tile
         float tmax = -INFINITY, tmax2 = -INFINITY;
+        if (edge) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int s = s0 + key_of(r, h32);
-            const float sc = (s < p.S) ? acc[r] * sl2 : -INFINITY;
-            acc[r] = sc;
-            tmax = fmaxf(tmax, sc);
-            if (s >= p.skip) tmax2 = fmaxf(tmax2, sc);
+            for (int r = 0; r < 16; ++r) {
+                const int s = s0 + key_of(r, h32);
+                if (s >= p.S) acc[r] = -INFINITY;
+                tmax = fmaxf(tmax, acc[r]);
+                if (s >= p.skip) tmax2 = fmaxf(tmax2, acc[r]);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, acc[r]);
+            tmax2 = tmax;
         }
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
         tmax2 = fmaxf(tmax2, __shfl_xor(tmax2, 32, 64));
-        const float mn = fmaxf(m, tmax);
+        const float mn = fmaxf(mraw, tmax);
+        const float nb = -(mn * sl2);
         float part = 0.0f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) part += exp2f(acc[r] - mn);
+        for (int r = 0; r < 16; ++r) part += __builtin_amdgcn_exp2f(fmaf(acc[r], sl2, nb));   // args <= 0: no range fix-up needed
         part += __shfl_xor(part, 32, 64);
-        l = l * exp2f(m - mn) + part;
-        m = mn;
-        m2 = fmaxf(m2, tmax2);
-        if (more) { K_STORE(kr, kb + (cur ^ 1) * G::K_ELEMS) }    // the other buffer was last read one barrier ago
-        __syncthreads();
-        cur ^= 1;
+        l = l * __builtin_amdgcn_exp2f(fmaf(mraw, sl2, nb)) + part;
+        mraw = mn;
+        m2raw = fmaxf(m2raw, tmax2);
+        wait_image<NP, ST - 2>(wid);                      // tile i+1 (this wave's pieces) has landed
+        __builtin_amdgcn_s_barrier();                     // ... everyone's; and everyone is done reading `stage`
+        stage = (stage + 1 == ST) ? 0 : stage + 1;
+        istage = (istage + 1 == ST) ? 0 : istage + 1;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // no DMA may outlive the block's LDS allocation
+    const float m = mraw * sl2;
     if (t < p.T && h32 == 0) {
         float* st = p.stats + ((int64_t)bh * p.T + t) * 2;
         st[0] = m;
         st[1] = l;
     }
     if (p.mode == 1) {
-        float pm = (t < p.T) ? exp2f(m2 - m) / l : 0.0f;
+        float pm = (t < p.T) ? exp2f(m2raw * sl2 - m) / l : 0.0f;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) pm = fmaxf(pm, __shfl_xor(pm, o, 64));
         if (lane == 0) atomicMax(reinterpret_cast<int*>(p.delta), __float_as_int(pm));
@@ -283,48 +321,45 @@ __global__ __launch_bounds__(256) void attn3_stats_kernel(AttnParams p) {
 template <int D, bool UNIFORM>
 __global__ __launch_bounds__(256) void attn3_pv_kernel(AttnParams p) {
     using G = Geo<D>;
-    extern __shared__ __attribute__((aligned(16))) unsigned short lds16[];
-    unsigned short* kb = lds16;
-    unsigned short* vt = lds16 + G::K_ELEMS;
+    constexpr int ST = G::PV_STAGES, NP = G::IMG_PIECES, SB = G::IMG_BYTES;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds8[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, h32 = lane >> 5;
     const int bh = blockIdx.y, b = bh / p.H, hd = bh - b * p.H;
-    const int HD = p.H * D;
     const int t = blockIdx.x * QROWS + wid * 32 + (lane & 31);
     const int tq = min(t, p.T - 1);
+    const unsigned char* img_lane = p.planes + (int64_t)bh * p.NT * G::IMG_BYTES + lane * 16;
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(lptr_t)lds8;
+#pragma unroll
+    for (int i = 0; i < ST - 1; ++i)
+        issue_image<NP>(img_lane + (int64_t)min(i, p.NT - 1) * G::IMG_BYTES, lds_base + i * SB, wid);
     bf16x8 qf[3][G::NKK];
     load_q<D>(qf, p.q + ((int64_t)(b * p.T + tq) * p.H + hd) * D, h32, p.fq[0], tq);
     const float m = p.stats[((int64_t)bh * p.T + tq) * 2], l = p.stats[((int64_t)bh * p.T + tq) * 2 + 1];
     const float delta = p.delta[0];
-    const float nsl2 = -(p.scale * LOG2E);
+    const float sl2 = p.scale * LOG2E;
+    const float nsl2 = -sl2;
     const float a0 = m + log2f(l) + log2f(delta);       // −log2(p/δ) = a0 − s2
     const float inv_l = 1.0f / l;
+    // log2 codes by the magic-number route: rne(x) = bits(x + 1.5·2^23) − bits(1.5·2^23); clamp as integers to
+    // [0, min(2^b−1, 127)] (2^-127 and below is 0 to the fp32 sum), then 2^-code = bits(1.0) − (code << 23)
+    constexpr float MAGIC = 12582912.0f;
+    constexpr int MAGIC_I = 0x4B400000;
+    const int cmax_i = MAGIC_I + min((int)p.qmax, 127);
     float p_bypass = 0.0f;                               // unquantised probability of key 0 (start-peak)
     v16f oacc[G::NDT];
 #pragma unroll
     for (int j = 0; j < G::NDT; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[j][r] = 0.0f;
-    constexpr int VPL = G::NDT * 32 * G::VLD;
-
-    const unsigned short* kb_bh = p.kb + (int64_t)bh * 3 * p.Spad * G::DP;
-    const unsigned short* vt_bh = p.vt + (int64_t)bh * 3 * (G::NDT * 32) * p.Spad;
-    using SG = StageGeo<D>;
-    uint4 kr[SG::KPER];
-    uint4 vr[SG::VPER];
-    K_LOAD(kr, kb_bh, 0)
-    V_LOAD(vr, vt_bh, 0)
-    K_STORE(kr, kb)
-    V_STORE(vr, vt)
-    __syncthreads();
-    int cur = 0;
-    constexpr int BUF = G::K_ELEMS + G::V_ELEMS;
-    for (int s0 = 0; s0 < p.S; s0 += KT) {
-        const bool more = s0 + KT < p.S;
-        const int s_next = more ? s0 + KT : s0;                   // unconditional (a conditional load demotes kr/vr to scratch)
-        K_LOAD(kr, kb_bh, s_next)
-        V_LOAD(vr, vt_bh, s_next)
-        const unsigned short* kbc = kb + cur * BUF;
-        const unsigned short* vtc = vt + cur * BUF;
+    constexpr int VPL = G::DV * G::VLD;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the stats / δ loads above share the counter: drain once)
+    __builtin_amdgcn_s_barrier();
+    int stage = 0, istage = ST - 1;
+    for (int i = 0; i < p.NT; ++i) {
+        issue_image<NP>(img_lane + (int64_t)min(i + ST - 1, p.NT - 1) * G::IMG_BYTES, lds_base + istage * SB, wid);
+        const int s0 = i * KT;
+        const unsigned short* kbc = reinterpret_cast<const unsigned short*>(lds8 + stage * SB);
+        const unsigned short* vtc = kbc + G::K_ELEMS;
         v16f acc = score_tile<D>(kbc, qf, lane);
         // interior tiles carry no per-key conditions; only the first tile (bypassed column) and a partial last tile do
         const bool edge = (s0 + KT > p.S) || (s0 < p.skip);      // block-uniform
@@ -334,20 +369,19 @@ __global__ __launch_bounds__(256) void attn3_pv_kernel(AttnParams p) {
             for (int r = 0; r < 16; ++r) {
                 float ph;
                 if (UNIFORM) {
-                    const float pr = exp2f(fmaf(acc[r], -nsl2, -m)) * inv_l;     // always_zero: code = clamp(rne(p/δ), 0, 2^b−1)
+                    const float pr = exp2f(fmaf(acc[r], sl2, -m)) * inv_l;     // always_zero: code = clamp(rne(p/δ), 0, 2^b−1)
                     ph = fminf(fmaxf(rintf(__fdiv_rn(pr, delta)), 0.0f), p.qmax);
                 } else {
-                    float code = rintf(fmaf(acc[r], nsl2, a0));
-                    code = fminf(fmaxf(code, 0.0f), p.qmax);
-                    // 2^-code as fp32 bits; codes > 126 (p̂ < 2^-126·δ) are below anything the fp32 sum can resolve
-                    const int e = 127 - (int)code;
-                    ph = e > 0 ? __int_as_float(e << 23) : 0.0f;
+                    const float x = fmaf(acc[r], nsl2, a0);
+                    int ci = __float_as_int(x + MAGIC);    // out-of-range x lands outside [MAGIC_I, cmax_i]: clamped below
+                    ci = min(max(ci, MAGIC_I), cmax_i);
+                    ph = __int_as_float(0x3F800000 - (ci << 23));              // (MAGIC_I << 23) wraps to 0
                 }
                 if (EDGE) {
                     const int s = s0 + key_of(r, h32);
                     if (s >= p.S) ph = 0.0f;
                     else if (s < p.skip) {
-                        p_bypass = exp2f(fmaf(acc[r], -nsl2, -m)) * inv_l;
+                        p_bypass = exp2f(fmaf(acc[r], sl2, -m)) * inv_l;
                         ph = 0.0f;
                     }
                 }
@@ -377,13 +411,12 @@ __global__ __launch_bounds__(256) void attn3_pv_kernel(AttnParams p) {
                 oacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pf[ks], oacc[j], 0, 0, 0);
             }
         }
-        if (more) {
-            K_STORE(kr, kb + (cur ^ 1) * BUF)
-            V_STORE(vr, vt + (cur ^ 1) * BUF)
-        }
-        __syncthreads();
-        cur ^= 1;
+        wait_image<NP, ST - 2>(wid);
+        __builtin_amdgcn_s_barrier();
+        stage = (stage + 1 == ST) ? 0 : stage + 1;
+        istage = (istage + 1 == ST) ? 0 : istage + 1;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // no DMA may outlive the block's LDS allocation
     if (p.skip > 0) p_bypass = __shfl(p_bypass, lane & 31, 64);   // key 0 lives in the lower half-wave
     if (t < p.T) {
         float* op = p.o + ((int64_t)(b * p.T + t) * p.H + hd) * D;
@@ -403,41 +436,42 @@ __global__ __launch_bounds__(256) void attn3_pv_kernel(AttnParams p) {
 }
 
 template <int D>
-static int launch_attn3(AttnParams p, unsigned short* kb, unsigned short* vt, hipStream_t st) {
+static int launch_attn3(AttnParams p, unsigned char* planes, hipStream_t st) {
     using G = Geo<D>;
-    p.kb = kb;
-    p.vt = vt;
-    hipLaunchKernelGGL((attn3_prep_kernel<D>), dim3(p.Spad / KT, p.B * p.H), dim3(256), 0, st, p.k, p.v, kb, vt, p.B, p.H,
-                       p.S, p.Spad, p.fq[1], p.fq[2], p.mode == 1 ? p.delta : nullptr);
-    dim3 grid((p.T + QROWS - 1) / QROWS, p.B * p.H), block(256);
-    static const bool lds_ok = [] {                            // up to 141 KB of dynamic LDS (D = 160): opt in once
-        const int bytes = 2 * (G::K_ELEMS + G::V_ELEMS) * 2;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn3_stats_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn3_pv_kernel<D, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn3_pv_kernel<D, false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    p.planes = planes;
+    constexpr int stats_lds = G::STATS_STAGES * G::K_PIECES * 1024;
+    constexpr int pv_lds = G::PV_STAGES * G::IMG_BYTES;
+    static_assert(stats_lds <= 160 * 1024 && pv_lds <= 160 * 1024, "LDS ring too large");
+    static const bool lds_ok = [] {                            // up to 138 KB of dynamic LDS (D = 160): opt in once
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn3_stats_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, stats_lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn3_pv_kernel<D, true>), hipFuncAttributeMaxDynamicSharedMemorySize, pv_lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn3_pv_kernel<D, false>), hipFuncAttributeMaxDynamicSharedMemorySize, pv_lds);
         return true;
     }();
     (void)lds_ok;
-    hipLaunchKernelGGL((attn3_stats_kernel<D>), grid, block, 2 * G::K_ELEMS * 2, st, p);
-    if (p.mode == 3) hipLaunchKernelGGL((attn3_pv_kernel<D, true>), grid, block, 2 * (G::K_ELEMS + G::V_ELEMS) * 2, st, p);
-    else hipLaunchKernelGGL((attn3_pv_kernel<D, false>), grid, block, 2 * (G::K_ELEMS + G::V_ELEMS) * 2, st, p);
+    hipLaunchKernelGGL((attn3_prep_kernel<D>), dim3(p.NT, p.B * p.H), dim3(256), 0, st, p.k, p.v, planes, p.B, p.H, p.S,
+                       p.NT, p.fq[1], p.fq[2], p.mode == 1 ? p.delta : nullptr);
+    dim3 grid((p.T + QROWS - 1) / QROWS, p.B * p.H), block(256);
+    hipLaunchKernelGGL((attn3_stats_kernel<D>), grid, block, stats_lds, st, p);
+    if (p.mode == 3) hipLaunchKernelGGL((attn3_pv_kernel<D, true>), grid, block, pv_lds, st, p);
+    else hipLaunchKernelGGL((attn3_pv_kernel<D, false>), grid, block, pv_lds, st, p);
     return dgq_launch_status("dgq_attention_f32(bf16x3)");
 }
 
-// bytes of K/V split planes for one call (0 when D is not instantiated here)
+// bytes of the K/V tile images for one call (0 when D is not instantiated here)
 size_t dgq_attention_bf16x3_bytes(int B, int H, int S, int D) {
-    const size_t Spad = (size_t)(S + KT - 1) / KT * KT;
-    size_t dp, dv;
+    const size_t NT = (size_t)(S + KT - 1) / KT;
+    size_t img;
     switch (D) {
-        case 8: dp = Geo<8>::DP; dv = Geo<8>::NDT * 32; break;
-        case 16: dp = Geo<16>::DP; dv = Geo<16>::NDT * 32; break;
-        case 40: dp = Geo<40>::DP; dv = Geo<40>::NDT * 32; break;
-        case 64: dp = Geo<64>::DP; dv = Geo<64>::NDT * 32; break;
-        case 80: dp = Geo<80>::DP; dv = Geo<80>::NDT * 32; break;
-        case 160: dp = Geo<160>::DP; dv = Geo<160>::NDT * 32; break;
+        case 8: img = Geo<8>::IMG_BYTES; break;
+        case 16: img = Geo<16>::IMG_BYTES; break;
+        case 40: img = Geo<40>::IMG_BYTES; break;
+        case 64: img = Geo<64>::IMG_BYTES; break;
+        case 80: img = Geo<80>::IMG_BYTES; break;
+        case 160: img = Geo<160>::IMG_BYTES; break;
         default: return 0;
     }
-    return (size_t)B * H * 3 * Spad * (dp + dv) * sizeof(unsigned short);
+    return (size_t)B * H * NT * img;
 }
 
 // called from dgq_attention_f32 (attn_fused.hip) for the quantised modes; returns 1 when D is not instantiated here
@@ -454,15 +488,15 @@ int dgq_attention_bf16x3(const float* q, const float* k, const float* v, float* 
     }
     p.q = q; p.k = k; p.v = v; p.o = o; p.B = B; p.H = H; p.T = T; p.S = S; p.scale = scale; p.mode = mode; p.skip = skip;
     p.qmax = qmax; p.stats = stats_ws; p.delta = delta_ws;
-    p.Spad = (S + KT - 1) / KT * KT;
-    unsigned short* kb = reinterpret_cast<unsigned short*>(planes);
+    p.NT = (S + KT - 1) / KT;
+    unsigned char* img = reinterpret_cast<unsigned char*>(planes);
     switch (D) {
-        case 8: return launch_attn3<8>(p, kb, kb + (size_t)B * H * 3 * p.Spad * Geo<8>::DP, st);
-        case 16: return launch_attn3<16>(p, kb, kb + (size_t)B * H * 3 * p.Spad * Geo<16>::DP, st);
-        case 40: return launch_attn3<40>(p, kb, kb + (size_t)B * H * 3 * p.Spad * Geo<40>::DP, st);
-        case 64: return launch_attn3<64>(p, kb, kb + (size_t)B * H * 3 * p.Spad * Geo<64>::DP, st);
-        case 80: return launch_attn3<80>(p, kb, kb + (size_t)B * H * 3 * p.Spad * Geo<80>::DP, st);
-        case 160: return launch_attn3<160>(p, kb, kb + (size_t)B * H * 3 * p.Spad * Geo<160>::DP, st);
+        case 8: return launch_attn3<8>(p, img, st);
+        case 16: return launch_attn3<16>(p, img, st);
+        case 40: return launch_attn3<40>(p, img, st);
+        case 64: return launch_attn3<64>(p, img, st);
+        case 80: return launch_attn3<80>(p, img, st);
+        case 160: return launch_attn3<160>(p, img, st);
         default: return 1;
     }
 }

@@ -267,7 +267,12 @@ def test_fused_attention_vs_reference_formulas(D, T, S, H, mode, skip, dev):
                           delta.to(dev) if delta is not None else None, bits)
     torch.cuda.synchronize()
     err = rel_l2(o.cpu(), ref)
-    assert err < (1e-5 if mode == 0 else 2e-3), err
+    # a probability whose −log2(p/δ) (or p/δ) lies within fp32 rounding of a tie gets the neighbouring code (measured:
+    # ~3e-6 of the entries, the rate fp32 evaluation-order differences imply); every other row agrees to fp32 accuracy
+    assert err < (1e-5 if mode == 0 else 4e-3), err
+    row_err = (o.cpu() - ref).view(B * T, -1).norm(dim=1) / ref.view(B * T, -1).norm(dim=1)
+    assert row_err.median().item() < 1e-5
+    assert (row_err > 1e-4).float().mean().item() < 0.02
 
 
 @pytest.mark.parametrize("D,T,S,H", [(40, 200, 200, 2), (80, 96, 77, 3), (160, 64, 77, 2)])
