@@ -168,6 +168,11 @@ class BasicTransformerBlock(nn.Module):
         return x + self.ff(self.norm3(x))
 
 
+def _fusion_on():
+    from ..quant import quant_block
+    return quant_block.FUSION and quant_block.FUSE_NORM
+
+
 class Transformer2DModel(nn.Module):
     def __init__(self, channels, n_layers, ctx_dim, heads, head_dim, proj):
         super().__init__()
@@ -182,9 +187,13 @@ class Transformer2DModel(nn.Module):
     def forward(self, x, encoder_hidden_states=None):
         b, c, hh, ww = x.shape
         res = x
-        h = self.norm(x)
-        if self.proj_kind == "conv":
-            h = self.proj_in(h)
+        fuse = getattr(self.proj_in, "can_fuse_prenorm", None)
+        if self.proj_kind == "conv" and fuse is not None and _fusion_on() and fuse(x):
+            h = self.proj_in.forward_prenorm(x, self.norm, silu=False)     # GroupNorm folded into the quantise-on-load pass
+        else:
+            h = self.norm(x)
+            if self.proj_kind == "conv":
+                h = self.proj_in(h)
         h = _cl(h).permute(0, 2, 3, 1).reshape(b, hh * ww, c)
         if self.proj_kind != "conv":
             h = self.proj_in(h)
@@ -335,4 +344,7 @@ class UNet2DConditionModel(nn.Module):
         h = self.mid_block.run_mid(h, emb, ctx)
         for blk in self.up_blocks:
             h = blk.run_up(h, emb, ctx, skips)
+        fuse = getattr(self.conv_out, "can_fuse_prenorm", None)
+        if fuse is not None and _fusion_on() and isinstance(self.conv_act, nn.SiLU) and fuse(h):
+            return [self.conv_out.forward_prenorm(h, self.conv_norm_out, silu=True)]
         return [self.conv_out(self.conv_act(self.conv_norm_out(h)))]
