@@ -17,7 +17,7 @@ SIGNATURES = {
     "dgq_pack_w4": [_vp, _i, _i, _vp, _i, _vp, _vp],
     "dgq_unpack_w4": [_vp, _i, _i, _vp, _vp],
     "dgq_pack_w8": [_vp, _i, _i, _vp, _i, _vp, _vp],
-    "dgq_quant_act": [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _i,
+    "dgq_quant_act": [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _i,
                       _vp, _vp, _i, _vp],
     "dgq_groupnorm_scale_shift": [_vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "dgq_quant_act_parts": [_i, _i],

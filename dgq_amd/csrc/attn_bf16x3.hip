@@ -37,7 +37,7 @@ __device__ __forceinline__ float fq_apply(const FqDesc& f, float x, int t, int d
     if (f.mode < 0 || t < f.skip) return x;
     const int idx = f.mode == 0 ? 0 : (f.mode == 1 ? t - f.skip : d);
     const float dl = f.delta[idx], z = f.zp[idx];
-    return dl * (dgq_affine_code(x, dl, z, f.qmax) - z);
+    return dl * (dgq_affine_code_fast(x, dl, dgq_rcp(dl), z, f.qmax) - z);
 }
 
 struct AttnParams {

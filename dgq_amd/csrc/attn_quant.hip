@@ -16,7 +16,7 @@ __global__ __launch_bounds__(256) void fakequant_rows_kernel(const T* __restrict
         if (t >= skip) {
             int idx = mode == 0 ? 0 : (mode == 1 ? t - skip : col % D);
             float d = delta[idx], z = zp[idx];
-            float q = dgq_affine_code(v, d, z, qmax);
+            float q = dgq_affine_code_fast(v, d, dgq_rcp(d), z, qmax);
             v = d * (q - z);
         }
         y[i] = dgq_from_float<T>(v);

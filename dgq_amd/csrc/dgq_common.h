@@ -45,3 +45,16 @@ __device__ __forceinline__ float dgq_affine_code(float x, float delta, float zp,
     float u = r + zp;
     return fminf(fmaxf(u, 0.0f), qmax);
 }
+
+// The same code, bit for bit, at the cost of a multiply: with inv = v_rcp_f32(δ) (1 ulp), t = fl(x·inv) differs from the
+// real quotient q by < |q|·1.8e-7, and the correctly rounded fl(q) by < |q|·0.6e-7; so whenever t is farther than
+// |t|·4e-7 from every half-integer, rint(t) == rint(fl(x/δ)).  Only values inside that band (probability ~1e-4 per
+// element), or too large for the argument, take the IEEE division.
+__device__ __forceinline__ float dgq_rcp(float d) { return __builtin_amdgcn_rcpf(d); }
+__device__ __forceinline__ float dgq_affine_code_fast(float x, float delta, float inv_delta, float zp, float qmax) {
+    const float t = x * inv_delta;
+    float r = rintf(t);
+    const float dist = fabsf(fabsf(t - r) - 0.5f);
+    if (dist <= fabsf(t) * 4.0e-7f + 1e-30f || !(fabsf(t) < 3.0e6f)) r = rintf(__fdiv_rn(x, delta));
+    return __builtin_amdgcn_fmed3f(r + zp, 0.0f, qmax);
+}

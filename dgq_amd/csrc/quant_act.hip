@@ -1,6 +1,7 @@
 // Activation quantise-on-load pre-pass: channels-last fp tensor -> int8 codes of the (implicit) unfolded
 // operand in the packed weight's K order, + one float per row.  HBM-bound; one wave per output row, 4 consecutive
 // kp (one packed dword) per lane per 256-wide step; rounding bit-identical to fp32 true division (see below).
+#include <algorithm>
 #include "dgq_common.h"
 
 struct QuantActParams {
@@ -8,6 +9,7 @@ struct QuantActParams {
     int B, H, W, C, kh, kw, stride, pad, Ho, Wo;
     const int32_t* ksrc;      // [Kp] (dh<<24 | dw<<16 | c) or -1, or NULL (natural order kp = tap*C + c)
     const int32_t* koff;      // optional [Kp]: (dh*W + dw)*ldc + c for THIS geometry, -1 for padding (interior rows)
+    const int32_t* klds;      // optional [Kp]: (dh*kw + dw)*C + c, -1 for padding (LDS-staged conv path)
     int Kp, K;
     const float* delta;       // per_m: [L]; else [Kp/64]
     const float* zp;
@@ -43,18 +45,6 @@ __device__ __forceinline__ void load4<__hip_bfloat16>(const __hip_bfloat16* p, f
     const uint16_t* h = reinterpret_cast<const uint16_t*>(&t);
 #pragma unroll
     for (int j = 0; j < 4; ++j) v[j] = __uint_as_float(((uint32_t)h[j]) << 16);
-}
-
-// clamp(rne(x/δ)+z, 0, qmax) with the reference's exact semantics (true division, quant_layer.py:297) at the cost
-// of a multiply: t = x·fl(1/δ) differs from the real quotient q by < |q|·1.2e-7, and so does the correctly rounded
-// fl(q); whenever t is farther than |t|·2.4e-7 from every half-integer, rint(t) == rint(fl(x/δ)).  Only lanes
-// inside that band (probability ~5e-5 per element) take the IEEE division.
-__device__ __forceinline__ float dgq_affine_code_fast(float x, float delta, float inv_delta, float zp, float qmax) {
-    const float t = x * inv_delta;
-    float r = rintf(t);
-    const float dist = fabsf(fabsf(t - r) - 0.5f);
-    if (dist <= fabsf(t) * 2.4e-7f + 1e-30f || !(fabsf(t) < 3.0e6f)) r = rintf(__fdiv_rn(x, delta));
-    return __builtin_amdgcn_fmed3f(r + zp, 0.0f, qmax);
 }
 
 // Four codes q_j ∈ [0, 2^b−1] (floats) -> one dword of centred int8 codes s_j = q_j − off, 0 for padding:
@@ -94,7 +84,7 @@ __global__ __launch_bounds__(256) void quant_act_kernel(QuantActParams p) {
         const int li = row % p.L;
         md = p.delta[li];
         mz = p.zp[li];
-        minv = 1.0f / md;
+        minv = dgq_rcp(md);
     }
     float partial = 0.0f;
     uint32_t* out = reinterpret_cast<uint32_t*>(p.codes + (int64_t)row * p.Kp);
@@ -175,7 +165,7 @@ __global__ __launch_bounds__(256) void quant_act_kernel(QuantActParams p) {
                     if (!PER_M) {
                         d = p.delta[kp0 >> 6];
                         z = p.zp[kp0 >> 6];
-                        inv = 1.0f / d;
+                        inv = dgq_rcp(d);
                     }
                     float biased[4], fsum = 0.0f;
 #pragma unroll
@@ -196,7 +186,7 @@ __global__ __launch_bounds__(256) void quant_act_kernel(QuantActParams p) {
         if (!PER_M) {
             d = p.delta[kp0 >> 6];
             z = p.zp[kp0 >> 6];
-            inv = 1.0f / d;
+            inv = dgq_rcp(d);
         }
         float v[4];
         // natural order kp = tap*C + c ; 4 | C, so the lane's 4 elements are contiguous channels of one tap
@@ -242,9 +232,119 @@ __global__ __launch_bounds__(256) void quant_act_kernel(QuantActParams p) {
     if (lane == 0) p.rowsum[(int64_t)blockIdx.y * p.M + row] = partial;
 }
 
+// Per-K conv layers (the quantizer sees the unfolded operand, so each (c, tap) may carry its own group): the table
+// gathers 4-byte elements scattered over the kh·kw pixel rows of this output position.  Straight from global memory
+// that is one L1 access per element (measured: TCP_TOTAL_CACHE_ACCESSES = 32 per wave-instruction, the kernel runs at
+// the L1's access rate, ~50 us for 8192 x 2880); here each wave first copies its taps — C contiguous floats each, with
+// GroupNorm / SiLU applied and zeros for taps outside the image — into its own LDS strip with coalesced 16-byte loads
+// and gathers from LDS.  No block-level sync: a wave only reads what it wrote.
+template <typename TIn, bool PER_M>
+__global__ __launch_bounds__(256) void quant_act_staged_kernel(QuantActParams p) {
+    extern __shared__ __attribute__((aligned(16))) float strips[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int row = blockIdx.x * (blockDim.x >> 6) + wv;
+    if (row >= p.M) return;                                 // whole wave leaves; no barriers below
+    const TIn* x = reinterpret_cast<const TIn*>(p.x);
+    const int L = p.Ho * p.Wo;
+    const int b = row / L;
+    const int l = row - b * L;
+    const int ho = l / p.Wo, wo = l - ho * p.Wo;
+    const int hbase = ho * p.stride - p.pad, wbase = wo * p.stride - p.pad;
+    const TIn* img = x + (int64_t)b * p.H * p.W * p.C;
+    const int taps = p.kh * p.kw;
+    float* strip = strips + wv * taps * p.C;
+    const float* pre_sc = p.pre_scale ? p.pre_scale + (int64_t)b * p.C : nullptr;
+    const float* pre_sh = p.pre_shift ? p.pre_shift + (int64_t)b * p.C : nullptr;
+    for (int tap = 0; tap < taps; ++tap) {
+        const int dh = tap / p.kw, dw = tap - dh * p.kw;
+        const int hi = hbase + dh, wi = wbase + dw;
+        const bool inb = hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;     // wave-uniform
+        const TIn* src = img + ((int64_t)hi * p.W + wi) * p.C;
+        float* dst = strip + tap * p.C;
+        for (int c = lane * 4; c < p.C; c += 256) {
+            float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (inb) {
+                load4<TIn>(src + c, v);
+                if (pre_sc) {
+                    const float4 sc = *reinterpret_cast<const float4*>(pre_sc + c);
+                    const float4 sh = *reinterpret_cast<const float4*>(pre_sh + c);
+                    v[0] = v[0] * sc.x + sh.x; v[1] = v[1] * sc.y + sh.y; v[2] = v[2] * sc.z + sh.z; v[3] = v[3] * sc.w + sh.w;
+                }
+                if (p.pre_act == 1) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = v[j] / (1.0f + expf(-v[j]));
+                }
+            }
+            *reinterpret_cast<float4*>(dst + c) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+    float md = 1.0f, mz = 0.0f, minv = 1.0f;
+    if (PER_M) {
+        const int li = row % p.L;
+        md = p.delta[li];
+        mz = p.zp[li];
+        minv = dgq_rcp(md);
+    }
+    float partial = 0.0f;
+    uint32_t* out = reinterpret_cast<uint32_t*>(p.codes + (int64_t)row * p.Kp);
+    const int k_begin = blockIdx.y * p.kp_per_split;
+    const int k_end = min(p.Kp, k_begin + p.kp_per_split);
+    const float bias = 128.0f - p.offset;
+    const int32_t* __restrict__ tab = p.klds;
+    for (int kb = k_begin + lane * 4; kb < k_end; kb += 1024) {
+        int idx[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int kp0 = kb + 256 * u;
+            int4 t = make_int4(-1, -1, -1, -1);
+            if (kp0 < k_end) t = *reinterpret_cast<const int4*>(tab + kp0);
+            idx[u][0] = t.x; idx[u][1] = t.y; idx[u][2] = t.z; idx[u][3] = t.w;
+        }
+        float v[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[u][j] = strip[max(idx[u][j], 0)];       // padding reads element 0: value unused
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int kp0 = kb + 256 * u;
+            if (kp0 < k_end) {
+                float d = md, z = mz, inv = minv;
+                if (!PER_M) {
+                    d = p.delta[kp0 >> 6];
+                    z = p.zp[kp0 >> 6];
+                    inv = dgq_rcp(d);
+                }
+                float biased[4], fsum = 0.0f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float q = dgq_affine_code_fast(v[u][j], d, inv, z, p.qmax);
+                    biased[j] = idx[u][j] >= 0 ? q + bias : 128.0f;
+                }
+                out[kp0 >> 2] = dgq_pack4(biased, fsum);
+                fsum -= 512.0f;
+                partial += PER_M ? fsum : d * fsum;
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) partial += __shfl_down(partial, o, 64);
+    if (lane == 0) p.rowsum[(int64_t)blockIdx.y * p.M + row] = partial;
+}
+
 template <typename TIn>
 static void launch_quant_act(const QuantActParams& p, bool table, bool per_m, hipStream_t st) {
     const int ks = (p.Kp + p.kp_per_split - 1) / p.kp_per_split;
+    const size_t strip_bytes = (size_t)p.kh * p.kw * p.C * sizeof(float);
+    // measured (SD1.4 layers): staging wins at C = 320 (4 rows per block, 3 blocks per CU: 88 -> 64 us) and loses once the
+    // strips cut occupancy (C >= 640) or the K range is split over blocks that would each re-stage every tap
+    if (table && p.klds && p.kh * p.kw > 1 && p.C % 4 == 0 && p.pre_act != 2 && strip_bytes <= 16 * 1024 && ks == 1) {
+        const int nw = 4;                                                       // waves (= rows) per block, <= 64 KB of LDS
+        dim3 sgrid((p.M + nw - 1) / nw, ks), sblock(64 * nw);
+        if (per_m) hipLaunchKernelGGL((quant_act_staged_kernel<TIn, true>), sgrid, sblock, nw * strip_bytes, st, p);
+        else hipLaunchKernelGGL((quant_act_staged_kernel<TIn, false>), sgrid, sblock, nw * strip_bytes, st, p);
+        return;
+    }
     dim3 grid((p.M + 3) / 4, ks), block(256);
     if (table) {
         if (per_m) hipLaunchKernelGGL((quant_act_kernel<TIn, true, true>), grid, block, 0, st, p);
@@ -263,7 +363,7 @@ extern "C" int dgq_quant_act_parts(int Kp, int ksplits) {
 
 extern "C" int dgq_quant_act(const void* x, int x_dtype, int B, int H, int W, int C,
                              int kh, int kw, int stride, int pad,
-                             const int32_t* ksrc, const int32_t* koff, int Kp,
+                             const int32_t* ksrc, const int32_t* koff, const int32_t* klds, int Kp,
                              int per_m, const float* delta, const float* zp, int L,
                              int bits, int8_t* codes, float* rowsum, int ksplits,
                              const float* pre_scale, const float* pre_shift, int pre_act, void* stream) {
@@ -286,7 +386,7 @@ extern "C" int dgq_quant_act(const void* x, int x_dtype, int B, int H, int W, in
     DGQ_CHECK_ARG(Ho > 0 && Wo > 0, "dgq_quant_act: empty output");
     QuantActParams p;
     p.x = x; p.B = B; p.H = H; p.W = W; p.C = C; p.kh = kh; p.kw = kw; p.stride = stride; p.pad = pad;
-    p.Ho = Ho; p.Wo = Wo; p.ksrc = ksrc; p.koff = ksrc ? koff : nullptr; p.Kp = Kp; p.K = K; p.delta = delta; p.zp = zp; p.L = per_m ? L : 1;
+    p.Ho = Ho; p.Wo = Wo; p.ksrc = ksrc; p.koff = ksrc ? koff : nullptr; p.klds = ksrc ? klds : nullptr; p.Kp = Kp; p.K = K; p.delta = delta; p.zp = zp; p.L = per_m ? L : 1;
     p.qmax = (float)((1 << bits) - 1);
     p.offset = (float)(1 << (bits - 1));
     p.codes = codes; p.rowsum = rowsum; p.M = B * Ho * Wo;

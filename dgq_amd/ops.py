@@ -103,6 +103,17 @@ class ActBinding:
             self._koff[key] = torch.where(e >= 0, off, torch.full_like(off, -1)).to(torch.int32).contiguous()
         return self._koff[key]
 
+    def klds(self, kw, C):
+        """ksrc resolved to indices (dh*kw + dw)*C + c into a [tap][C] strip (cached; conv layers only)."""
+        if self.ksrc is None or self.pw.taps <= 1:
+            return None
+        key = ("lds", kw, C)
+        if key not in self._koff:
+            e = self.ksrc
+            idx = (((e >> 24) & 0x7F) * kw + ((e >> 16) & 0xFF)) * C + (e & 0xFFFF)
+            self._koff[key] = torch.where(e >= 0, idx, torch.full_like(idx, -1)).to(torch.int32).contiguous()
+        return self._koff[key]
+
     def __init__(self, layout: ActLayout, pw: PackedWeight, abits: int):
         dev = pw.codes.device
         self.mode, self.abits, self.offset = layout.mode, abits, act_offset(abits)
@@ -163,7 +174,7 @@ def quant_act(x_cl: torch.Tensor, B, H, W, C, kh, kw, stride, pad, ab: ActBindin
     L = 1 if ab.mode == "perK" else ab.L
     ldc = 2 * C if (pre and pre[2] == 2) else C
     _lib_call("dgq_quant_act", _lib.ptr(x_cl), _lib.DTYPE_CODE[x_cl.dtype], B, H, W, C, kh, kw, stride, pad,
-              _lib.ptr(ab.ksrc), _lib.ptr(ab.koff(W, ldc)), ab.Kp, per_m, _lib.ptr(delta), _lib.ptr(zp), L, ab.abits,
+              _lib.ptr(ab.ksrc), _lib.ptr(ab.koff(W, ldc)), _lib.ptr(ab.klds(kw, C)), ab.Kp, per_m, _lib.ptr(delta), _lib.ptr(zp), L, ab.abits,
               _lib.ptr(codes), _lib.ptr(rowsum), parts,
               _lib.ptr(pre[0]) if pre and pre[0] is not None else None,
               _lib.ptr(pre[1]) if pre and pre[1] is not None else None, pre[2] if pre else 0, _lib.stream())

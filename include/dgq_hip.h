@@ -65,7 +65,8 @@ int dgq_pack_w8(const uint8_t* codes, int N, int K, const int32_t* kperm, int Kp
  *   ksrc == NULL : natural order kp = tap·C + c   (tap = dh·kw + dw)
  *   ksrc != NULL : ksrc[kp] = (dh << 24) | (dw << 16) | c, or -1 for padding (zero code); koff (optional, NULL = derive
  *                  from ksrc) = the same table resolved for this geometry, (dh·W + dw)·ldc + c or -1, read by rows whose
- *                  taps all lie inside the image (no bounds checks).
+ *                  taps all lie inside the image (no bounds checks); klds (optional) = (dh·kw + dw)·C + c or -1: the
+ *                  index into the [tap][C] strip a wave stages in LDS (kh·kw > 1 and kh·kw·C·4 <= 64 KB).
  * Quantiser parameters:
  *   per_m == 0 : cdelta/czp [Kp/64] — one (δ,z) per 64-wide chunk (DGQ groups are chunk aligned);
  *                rowsum[m] = Σ_kp δ(kp)·s[m,kp]
@@ -81,7 +82,7 @@ int dgq_pack_w8(const uint8_t* codes, int N, int K, const int32_t* kperm, int Kp
  * dgq_quant_act_parts(Kp, ksplits) x M entries ([part][m]) which dgq_gemm_wxa8 adds in a fixed order. */
 int dgq_quant_act(const void* x, int x_dtype, int B, int H, int W, int C,
                   int kh, int kw, int stride, int pad,
-                  const int32_t* ksrc, const int32_t* koff, int Kp,
+                  const int32_t* ksrc, const int32_t* koff, const int32_t* klds, int Kp,
                   int per_m, const float* delta, const float* zp, int L,
                   int bits, int8_t* codes, float* rowsum, int ksplits,
                   const float* pre_scale, const float* pre_shift, int pre_act, void* stream);
