@@ -40,6 +40,25 @@ __device__ __forceinline__ float fq_apply(const FqDesc& f, float x, int t, int d
     return dl * (dgq_affine_code_fast(x, dl, dgq_rcp(dl), z, f.qmax) - z);
 }
 
+// eight consecutive head-dim elements d0 .. d0+7 of token t (d0 % 8 == 0): the table entries are fetched once per
+// token (modes 0/1) or as four 16-byte loads (mode 2) instead of two dependent loads per element
+__device__ __forceinline__ void fq_apply8(const FqDesc& f, float (&x)[8], int t, int d0) {
+    if (f.mode < 0 || t < f.skip) return;
+    if (f.mode == 2) {
+        const float4 da = *reinterpret_cast<const float4*>(f.delta + d0), db = *reinterpret_cast<const float4*>(f.delta + d0 + 4);
+        const float4 za = *reinterpret_cast<const float4*>(f.zp + d0), zb = *reinterpret_cast<const float4*>(f.zp + d0 + 4);
+        const float dl[8] = {da.x, da.y, da.z, da.w, db.x, db.y, db.z, db.w};
+        const float zz[8] = {za.x, za.y, za.z, za.w, zb.x, zb.y, zb.z, zb.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = dl[j] * (dgq_affine_code_fast(x[j], dl[j], dgq_rcp(dl[j]), zz[j], f.qmax) - zz[j]);
+    } else {
+        const int idx = f.mode == 0 ? 0 : t - f.skip;
+        const float dl = f.delta[idx], z = f.zp[idx], inv = dgq_rcp(dl);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = dl * (dgq_affine_code_fast(x[j], dl, inv, z, f.qmax) - z);
+    }
+}
+
 struct AttnParams {
     FqDesc fq[3];          // q, k, v
     const float* q;
@@ -130,10 +149,29 @@ __device__ __forceinline__ void wait_image(int wid) {
 template <int D>
 __global__ __launch_bounds__(256) void attn3_prep_kernel(const float* __restrict__ k, const float* __restrict__ v,
                                                          unsigned char* __restrict__ planes, int B, int H, int S, int NT,
-                                                         FqDesc fk, FqDesc fv, float* __restrict__ delta_reset) {
+                                                         FqDesc fk, FqDesc fv, float* __restrict__ delta_reset,
+                                                         const float* __restrict__ q, float* __restrict__ qfq, int T, FqDesc fqq) {
     using G = Geo<D>;
     static_assert(D % 8 == 0, "head_dim must be a multiple of 8");
     const int bh = blockIdx.y, b = bh / H, hd = bh - b * H;
+    if ((int)blockIdx.x >= NT) {
+        // extra blocks (only when aqtizer_q is fused): fake-quantised copy of 32 query rows of this (batch, head), so
+        // that the Q-fragment loads of the two main kernels stay plain loads
+        const int t0 = ((int)blockIdx.x - NT) * 32;
+        constexpr int QC = D / 8;
+        for (int i = threadIdx.x; i < 32 * QC; i += 256) {
+            const int r = i / QC, c8 = i - r * QC;
+            const int t = t0 + r;
+            if (t >= T) continue;
+            const int64_t o = ((int64_t)(b * T + t) * H + hd) * D + 8 * c8;
+            const float4 a = *reinterpret_cast<const float4*>(q + o), c = *reinterpret_cast<const float4*>(q + o + 4);
+            float x[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+            fq_apply8(fqq, x, t, 8 * c8);
+            *reinterpret_cast<float4*>(qfq + o) = make_float4(x[0], x[1], x[2], x[3]);
+            *reinterpret_cast<float4*>(qfq + o + 4) = make_float4(x[4], x[5], x[6], x[7]);
+        }
+        return;
+    }
     const int s0 = blockIdx.x * KT;
     if (delta_reset && blockIdx.x == 0 && bh == 0 && threadIdx.x == 0) *delta_reset = 0.0f;   // real-time δ: max starts at 0
     const float* kbase = k + ((int64_t)(b * S) * H + hd) * D;
@@ -152,13 +190,14 @@ __global__ __launch_bounds__(256) void attn3_prep_kernel(const float* __restrict
             const float4 a = *reinterpret_cast<const float4*>(kbase + sidx * HD + 8 * c8);
             const float4 c = *reinterpret_cast<const float4*>(kbase + sidx * HD + 8 * c8 + 4);
             x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = c.x; x[5] = c.y; x[6] = c.z; x[7] = c.w;
+            fq_apply8(fk, x, sidx, 8 * c8);
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             unsigned short h0 = 0, m0 = 0, l0 = 0, h1 = 0, m1 = 0, l1 = 0;
             if (live) {
-                split3(fq_apply(fk, x[2 * j], sidx, 8 * c8 + 2 * j), h0, m0, l0);
-                split3(fq_apply(fk, x[2 * j + 1], sidx, 8 * c8 + 2 * j + 1), h1, m1, l1);
+                split3(x[2 * j], h0, m0, l0);
+                split3(x[2 * j + 1], h1, m1, l1);
             }
             wh[j] = (unsigned)h0 | ((unsigned)h1 << 16);
             wm[j] = (unsigned)m0 | ((unsigned)m1 << 16);
@@ -200,15 +239,19 @@ __device__ __forceinline__ void load_q(bf16x8 (&qf)[3][Geo<D>::NKK], const float
     using G = Geo<D>;
 #pragma unroll
     for (int kk = 0; kk < G::NKK; ++kk) {
+        const int d0 = 16 * kk + 8 * h32;                   // D % 8 == 0: the 8 elements are all inside D or all padding
+        float x[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        if (d0 < D) {
+            const float4 a = *reinterpret_cast<const float4*>(qrow + d0), c = *reinterpret_cast<const float4*>(qrow + d0 + 4);
+            x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = c.x; x[5] = c.y; x[6] = c.z; x[7] = c.w;
+            fq_apply8(fq, x, t, d0);
+        }
         unsigned wh[4], wm[4], wl[4];                       // packed pairs (no sub-dword arrays: those go to scratch)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int d = 16 * kk + 8 * h32 + 2 * j;
-            const float x0 = (d < D) ? fq_apply(fq, qrow[d], t, d) : 0.0f;
-            const float x1 = (d + 1 < D) ? fq_apply(fq, qrow[d + 1], t, d + 1) : 0.0f;
             unsigned short h0, m0, l0, h1, m1, l1;
-            split3(x0, h0, m0, l0);
-            split3(x1, h1, m1, l1);
+            split3(x[2 * j], h0, m0, l0);
+            split3(x[2 * j + 1], h1, m1, l1);
             wh[j] = (unsigned)h0 | ((unsigned)h1 << 16);
             wm[j] = (unsigned)m0 | ((unsigned)m1 << 16);
             wl[j] = (unsigned)l0 | ((unsigned)l1 << 16);
@@ -436,7 +479,7 @@ __global__ __launch_bounds__(256) void attn3_pv_kernel(AttnParams p) {
 }
 
 template <int D>
-static int launch_attn3(AttnParams p, unsigned char* planes, hipStream_t st) {
+static int launch_attn3(AttnParams p, unsigned char* planes, float* qfq, hipStream_t st) {
     using G = Geo<D>;
     p.planes = planes;
     constexpr int stats_lds = G::STATS_STAGES * G::K_PIECES * 1024;
@@ -449,8 +492,14 @@ static int launch_attn3(AttnParams p, unsigned char* planes, hipStream_t st) {
         return true;
     }();
     (void)lds_ok;
-    hipLaunchKernelGGL((attn3_prep_kernel<D>), dim3(p.NT, p.B * p.H), dim3(256), 0, st, p.k, p.v, planes, p.B, p.H, p.S,
-                       p.NT, p.fq[1], p.fq[2], p.mode == 1 ? p.delta : nullptr);
+    const bool q_copy = p.fq[0].mode >= 0 && qfq != nullptr;
+    hipLaunchKernelGGL((attn3_prep_kernel<D>), dim3(p.NT + (q_copy ? (p.T + 31) / 32 : 0), p.B * p.H), dim3(256), 0, st, p.k,
+                       p.v, planes, p.B, p.H, p.S, p.NT, p.fq[1], p.fq[2], p.mode == 1 ? p.delta : nullptr, p.q, qfq, p.T,
+                       p.fq[0]);
+    if (q_copy) {
+        p.q = qfq;
+        p.fq[0].mode = -1;
+    }
     dim3 grid((p.T + QROWS - 1) / QROWS, p.B * p.H), block(256);
     hipLaunchKernelGGL((attn3_stats_kernel<D>), grid, block, stats_lds, st, p);
     if (p.mode == 3) hipLaunchKernelGGL((attn3_pv_kernel<D, true>), grid, block, pv_lds, st, p);
@@ -477,7 +526,7 @@ size_t dgq_attention_bf16x3_bytes(int B, int H, int S, int D) {
 // called from dgq_attention_f32 (attn_fused.hip) for the quantised modes; returns 1 when D is not instantiated here
 int dgq_attention_bf16x3(const float* q, const float* k, const float* v, float* o, int B, int H, int T, int S, int D,
                          float scale, int mode, int skip, float qmax, float* stats_ws, float* delta_ws, void* planes,
-                         const dgq_attn_fq_t* fq, hipStream_t st) {
+                         float* qfq, const dgq_attn_fq_t* fq, hipStream_t st) {
     AttnParams p;
     for (int i = 0; i < 3; ++i) {
         p.fq[i].mode = -1; p.fq[i].skip = 0; p.fq[i].qmax = 0.0f; p.fq[i].delta = nullptr; p.fq[i].zp = nullptr;
@@ -491,12 +540,12 @@ int dgq_attention_bf16x3(const float* q, const float* k, const float* v, float* 
     p.NT = (S + KT - 1) / KT;
     unsigned char* img = reinterpret_cast<unsigned char*>(planes);
     switch (D) {
-        case 8: return launch_attn3<8>(p, img, st);
-        case 16: return launch_attn3<16>(p, img, st);
-        case 40: return launch_attn3<40>(p, img, st);
-        case 64: return launch_attn3<64>(p, img, st);
-        case 80: return launch_attn3<80>(p, img, st);
-        case 160: return launch_attn3<160>(p, img, st);
+        case 8: return launch_attn3<8>(p, img, qfq, st);
+        case 16: return launch_attn3<16>(p, img, qfq, st);
+        case 40: return launch_attn3<40>(p, img, qfq, st);
+        case 64: return launch_attn3<64>(p, img, qfq, st);
+        case 80: return launch_attn3<80>(p, img, qfq, st);
+        case 160: return launch_attn3<160>(p, img, qfq, st);
         default: return 1;
     }
 }

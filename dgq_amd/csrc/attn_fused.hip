@@ -216,15 +216,16 @@ static int launch_attn(const AttnParams& p, hipStream_t st) {
 
 int dgq_attention_bf16x3(const float* q, const float* k, const float* v, float* o, int B, int H, int T, int S, int D,
                          float scale, int mode, int skip, float qmax, float* stats_ws, float* delta_ws, void* planes,
-                         const dgq_attn_fq_t* fq, hipStream_t st);
+                         float* qfq, const dgq_attn_fq_t* fq, hipStream_t st);
 size_t dgq_attention_bf16x3_bytes(int B, int H, int S, int D);
 
-// workspace layout: [0,256) δ scalar | stats B·H·T·2 floats (256-byte aligned) | bf16 split planes of K and V
+// workspace layout: [0,256) δ scalar | stats B·H·T·2 floats (256-byte aligned) | tile images of the bf16 split planes of
+// K and V | fake-quantised copy of q (used when aqtizer_q is fused)
 static size_t attn_stats_off() { return 256; }
 static size_t attn_planes_off(int B, int H, int T) { return 256 + (((size_t)B * H * T * 2 * sizeof(float) + 255) / 256) * 256; }
 
 extern "C" size_t dgq_attention_workspace_bytes(int B, int H, int T, int S, int D) {
-    return attn_planes_off(B, H, T) + dgq_attention_bf16x3_bytes(B, H, S, D);
+    return attn_planes_off(B, H, T) + dgq_attention_bf16x3_bytes(B, H, S, D) + (size_t)B * T * H * D * sizeof(float);
 }
 
 extern "C" int dgq_attention_fuses_fakequant(int D, int mode) {
@@ -270,7 +271,8 @@ extern "C" int dgq_attention_f32(const float* q, const float* k, const float* v,
             dgq_set_error("dgq_attention_f32: memcpy"); return DGQ_ELAUNCH;
         }
     }
-    if (use3) return dgq_attention_bf16x3(q, k, v, o, B, H, T, S, D, scale, mode, skip, p.qmax, stats_ws, delta_ws, planes, fq, st);
+    float* qfq = reinterpret_cast<float*>(reinterpret_cast<char*>(planes) + dgq_attention_bf16x3_bytes(B, H, S, D));
+    if (use3) return dgq_attention_bf16x3(q, k, v, o, B, H, T, S, D, scale, mode, skip, p.qmax, stats_ws, delta_ws, planes, qfq, fq, st);
     switch (D) {
         case 8: return launch_attn<8>(p, st);
         case 16: return launch_attn<16>(p, st);

@@ -33,9 +33,9 @@ _F_RES = _os.environ.get("DGQ_FUSE_RESIDUAL", "0") == "1"
 _F_FQ = _os.environ.get("DGQ_FUSE_FQ", "0") == "1"
 _F_GEGLU = _os.environ.get("DGQ_FUSE_GEGLU", "0") == "1"
 _F_SILU = _os.environ.get("DGQ_FUSE_SILU", "1") == "1"
-# aqtizer_{q,k,v} applied inside the attention kernels' operand loads (K/V split pre-pass, Q fragment load): three
-# launches per attention saved, nothing added to a GEMM grid
-_F_ATTN_FQ = _os.environ.get("DGQ_FUSE_ATTN_FQ", "0") == "1"   # measured +0.3 ms as written (exact divisions ahead of every Q block): off
+# aqtizer_{q,k,v} applied inside the attention pre-pass (K/V while they are split into bf16 planes, Q into a scratch
+# copy by extra blocks of the same launch): three launches per attention saved, nothing added to a GEMM grid (-0.16 ms)
+_F_ATTN_FQ = _os.environ.get("DGQ_FUSE_ATTN_FQ", "1") == "1"
 
 
 class BaseQuantBlock(nn.Module):
