@@ -116,36 +116,54 @@ def main():
         elapsed = float(tt.item())
 
     # ---- roofline of the dominant north-star kernel (W4A8 GEMM), measured live with HIP events ------------------
+    # One eager step with ops.gemm_wxa8 wrapped: every one of the 280 launches (its split-K reduction included) is
+    # replayed REP times back to back from a hipGraph on the current stream and bracketed by HIP events — eager
+    # per-launch events would time the host-side launch gaps, not the kernels.  Sum over the step = the kernel time
+    # rocprofv3 reports for gemm_wxa8_kernel + splitk_epilogue_kernel (profiles/).
     roofline = None
     if rank == 0:
-        events, algo_ops, algo_bytes = [], [], []
+        REP = 5
+        times_ms, algo_ops, algo_bytes = [], [], []
         orig = ops.gemm_wxa8
 
         def timed(codes, rowsum, M, ab, out_dtype, out=None, extra=None):
+            y = orig(codes, rowsum, M, ab, out_dtype, out, extra)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                for _ in range(REP):
+                    orig(codes, rowsum, M, ab, out_dtype, y, extra)
+            g.replay()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            y = orig(codes, rowsum, M, ab, out_dtype, out, extra)
+            g.replay()
             e1.record()
-            events.append((e0, e1))
+            e1.synchronize()
+            times_ms.append(e0.elapsed_time(e1) / REP)
             algo_ops.append(2.0 * M * ab.pw.N * ab.pw.K)
             # un-unfolded input counted once at 1 B/code, int4 weights, output at its dtype
             algo_bytes.append(M * ab.pw.K / max(1, ab.pw.taps) + ab.pw.N * ab.pw.K / 2 + M * ab.pw.N * y.element_size())
             return y
         ops.gemm_wxa8 = timed
         graphs_were = qnn._graphs
-        qnn._graphs = None                                  # eager: the events bracket each launch
+        qnn._graphs = None
         with torch.no_grad():
             one_step(lat, timesteps[W])
         torch.cuda.synchronize()
         qnn._graphs = graphs_were
         ops.gemm_wxa8 = orig
-        gemm_ms = sum(a.elapsed_time(b) for a, b in events)
+        gemm_ms = sum(times_ms)
         tops = sum(algo_ops) / (gemm_ms * 1e-3) / 1e12
-        roofline = {"kernel": "gemm_wxa8_kernel<4,*> (dgq_gemm_wxa8)", "bound": "mfma", "achieved": round(tops, 2),
-                    "peak": INT8_PEAK_TOPS, "unit": "TOP/s", "frac": round(tops / INT8_PEAK_TOPS, 4), "traffic": None,
-                    "launches_per_step": len(events), "kernel_ms_per_step": round(gemm_ms, 3),
-                    "algorithmic_Top_per_step": round(sum(algo_ops) / 1e12, 4),
-                    "algorithmic_GB_per_step": round(sum(algo_bytes) / 1e9, 4)}
+        traffic = None
+        tj = os.path.join(ROOT, "profiles", "r01_gemm_hbm_traffic.json")   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+        if os.path.exists(tj):
+            traffic = round(json.load(open(tj))["traffic_bytes_per_launch"] / 1e6, 3)
+        n = len(times_ms)
+        roofline = {"kernel": "gemm_wxa8_kernel<4,*> + splitk_epilogue_kernel (dgq_gemm_wxa8)", "bound": "mfma",
+                    "achieved": round(tops, 2), "peak": INT8_PEAK_TOPS, "unit": "TOP/s", "frac": round(tops / INT8_PEAK_TOPS, 4),
+                    "traffic": traffic, "traffic_unit": "MB of HBM-side reads+writes per launch (PMC, profiles/r01_gemm_hbm_traffic.json)",
+                    "launches_per_step": n, "avg_launch_us": round(1e3 * gemm_ms / n, 2), "kernel_ms_per_step": round(gemm_ms, 3),
+                    "algorithmic_Gop_per_launch": round(sum(algo_ops) / n / 1e9, 3),
+                    "algorithmic_MB_per_launch": round(sum(algo_bytes) / n / 1e6, 3)}
 
     # ---- CPU baseline: the reference's op sequence (oracle port) on this box's host cores, one step --------------
     cpu_baseline = None
