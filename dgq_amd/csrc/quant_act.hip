@@ -23,7 +23,12 @@ struct QuantActParams {
     const float* pre_shift;
     int pre_act;              // 0 none, 1 SiLU, 2 GEGLU: value = x[c]·gelu(x[C + c]) on rows of 2C elements
     int ldc;                  // elements per input pixel/row (C, or 2C for GEGLU)
+    const float* ln_gamma;    // optional [C]: LayerNorm over the C elements of the row, v = (x − μ)·rstd·γ + β (1x1 only)
+    const float* ln_beta;
+    float ln_eps;
 };
+
+
 
 template <typename TIn>
 __device__ __forceinline__ void load4(const TIn* p, float (&v)[4]);
@@ -45,6 +50,39 @@ __device__ __forceinline__ void load4<__hip_bfloat16>(const __hip_bfloat16* p, f
     const uint16_t* h = reinterpret_cast<const uint16_t*>(&t);
 #pragma unroll
     for (int j = 0; j < 4; ++j) v[j] = __uint_as_float(((uint32_t)h[j]) << 16);
+}
+
+// LayerNorm statistics of one row of C <= 2048 elements (C % 4 == 0), computed by the wave that quantises the row: the
+// row is read ONCE into registers (8 float4 per lane), mean first, then Σ(x − mean)² from the registers; biased
+// variance, rstd = 1/sqrt(var + eps) as nn.LayerNorm.
+#define DGQ_LN_MAX_C 2048
+template <typename TIn>
+__device__ __forceinline__ void row_layernorm_stats(const TIn* xr, int C, float eps, int lane, float& mu, float& rstd) {
+    float v[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = lane * 4 + 256 * i;
+        if (c < C) load4<TIn>(xr + c, v[i]);
+        else v[i][0] = v[i][1] = v[i][2] = v[i][3] = 0.0f;
+    }
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    mu = s / (float)C;
+    float q = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = lane * 4 + 256 * i;
+        if (c < C) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) q += (v[i][j] - mu) * (v[i][j] - mu);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+    rstd = 1.0f / sqrtf(q / (float)C + eps);
 }
 
 // Four codes q_j ∈ [0, 2^b−1] (floats) -> one dword of centred int8 codes s_j = q_j − off, 0 for padding:
@@ -87,6 +125,8 @@ __global__ __launch_bounds__(256) void quant_act_kernel(QuantActParams p) {
         minv = dgq_rcp(md);
     }
     float partial = 0.0f;
+    float ln_mu = 0.0f, ln_rstd = 1.0f;
+    if (p.ln_gamma) row_layernorm_stats<TIn>(img + rowoff, p.C, p.ln_eps, lane, ln_mu, ln_rstd);   // 1x1: the row itself
     uint32_t* out = reinterpret_cast<uint32_t*>(p.codes + (int64_t)row * p.Kp);
     // K range of this wave (blockIdx.y): low-M layers would otherwise leave the chip empty (M=512: 2 waves per CU)
     const int k_begin = blockIdx.y * p.kp_per_split;
@@ -138,7 +178,7 @@ __global__ __launch_bounds__(256) void quant_act_kernel(QuantActParams p) {
                         idx[u][j] = e >= 0 ? (inb ? off - rowoff : -2) : -1;       // -2: out-of-image tap (value 0, no prologue)
                     }
             }
-            if (p.pre_scale || p.pre_act) {                 // folded GroupNorm / SiLU / GEGLU (wave-uniform branch)
+            if (p.pre_scale || p.pre_act || p.ln_gamma) {   // folded GroupNorm / LayerNorm / SiLU / GEGLU (wave-uniform branch)
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -148,6 +188,7 @@ __global__ __launch_bounds__(256) void quant_act_kernel(QuantActParams p) {
                             const int c = e % p.ldc;                          // e = (dh·W + dw)·ldc + c
                             float val = v[u][j];
                             if (p.pre_scale) val = val * pre_sc[c] + pre_sh[c];
+                            if (p.ln_gamma) val = (val - ln_mu) * ln_rstd * p.ln_gamma[c] + p.ln_beta[c];
                             if (p.pre_act == 1) val = val / (1.0f + expf(-val));
                             else if (p.pre_act == 2) {
                                 const float g = dgq_to_float(imgr[rowoff + e + p.C]);
@@ -200,6 +241,12 @@ __global__ __launch_bounds__(256) void quant_act_kernel(QuantActParams p) {
                 const float4 sc = *reinterpret_cast<const float4*>(p.pre_scale + (int64_t)b * p.C + nc);
                 const float4 sh = *reinterpret_cast<const float4*>(p.pre_shift + (int64_t)b * p.C + nc);
                 v[0] = v[0] * sc.x + sh.x; v[1] = v[1] * sc.y + sh.y; v[2] = v[2] * sc.z + sh.z; v[3] = v[3] * sc.w + sh.w;
+            }
+            if (p.ln_gamma) {
+                const float4 ga = *reinterpret_cast<const float4*>(p.ln_gamma + nc);
+                const float4 be = *reinterpret_cast<const float4*>(p.ln_beta + nc);
+                v[0] = (v[0] - ln_mu) * ln_rstd * ga.x + be.x; v[1] = (v[1] - ln_mu) * ln_rstd * ga.y + be.y;
+                v[2] = (v[2] - ln_mu) * ln_rstd * ga.z + be.z; v[3] = (v[3] - ln_mu) * ln_rstd * ga.w + be.w;
             }
             if (p.pre_act == 1) {
 #pragma unroll
@@ -366,7 +413,8 @@ extern "C" int dgq_quant_act(const void* x, int x_dtype, int B, int H, int W, in
                              const int32_t* ksrc, const int32_t* koff, const int32_t* klds, int Kp,
                              int per_m, const float* delta, const float* zp, int L,
                              int bits, int8_t* codes, float* rowsum, int ksplits,
-                             const float* pre_scale, const float* pre_shift, int pre_act, void* stream) {
+                             const float* pre_scale, const float* pre_shift, int pre_act,
+                             const float* ln_gamma, const float* ln_beta, float ln_eps, void* stream) {
     DGQ_CHECK_ARG(x && delta && zp && codes && rowsum, "dgq_quant_act: null pointer");
     DGQ_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && kh > 0 && kw > 0 && stride > 0 && pad >= 0,
                   "dgq_quant_act: bad geometry");
@@ -377,6 +425,9 @@ extern "C" int dgq_quant_act(const void* x, int x_dtype, int B, int H, int W, in
     DGQ_CHECK_ARG(ksplits >= 1 && ksplits <= 64, "dgq_quant_act: ksplits=%d", ksplits);
     DGQ_CHECK_ARG((pre_scale == nullptr) == (pre_shift == nullptr) && pre_act >= 0 && pre_act <= 2, "dgq_quant_act: bad prologue");
     DGQ_CHECK_ARG(pre_act != 2 || (kh == 1 && kw == 1 && !pre_scale), "dgq_quant_act: GEGLU prologue is for Linear inputs");
+    DGQ_CHECK_ARG((ln_gamma == nullptr) == (ln_beta == nullptr), "dgq_quant_act: LayerNorm prologue needs gamma and beta");
+    DGQ_CHECK_ARG(!ln_gamma || (kh == 1 && kw == 1 && !pre_scale && pre_act == 0 && C % 4 == 0 && C <= DGQ_LN_MAX_C && ln_eps > 0.0f),
+                  "dgq_quant_act: LayerNorm prologue is for Linear inputs (1x1, C %% 4 == 0, C <= 2048, no other prologue)");
     int K = C * kh * kw;
     if (!ksrc) {
         DGQ_CHECK_ARG(C % 4 == 0, "dgq_quant_act: natural K order needs C %% 4 == 0 (C=%d)", C);
@@ -392,6 +443,7 @@ extern "C" int dgq_quant_act(const void* x, int x_dtype, int B, int H, int W, in
     p.codes = codes; p.rowsum = rowsum; p.M = B * Ho * Wo;
     p.kp_per_split = (((Kp + ksplits - 1) / ksplits) + 255) / 256 * 256;
     p.pre_scale = pre_scale; p.pre_shift = pre_shift; p.pre_act = pre_act;
+    p.ln_gamma = ln_gamma; p.ln_beta = ln_beta; p.ln_eps = ln_eps;
     p.ldc = pre_act == 2 ? 2 * C : C;
     hipStream_t st = (hipStream_t)stream;
     switch (x_dtype) {

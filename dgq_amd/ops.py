@@ -159,9 +159,10 @@ def groupnorm_scale_shift(x_cl: torch.Tensor, B, HW, C, groups, eps, gamma, beta
     return scale, shift
 
 
-def quant_act(x_cl: torch.Tensor, B, H, W, C, kh, kw, stride, pad, ab: ActBinding, pre=None):
+def quant_act(x_cl: torch.Tensor, B, H, W, C, kh, kw, stride, pad, ab: ActBinding, pre=None, ln=None):
     """x_cl: contiguous channels-last storage [B][H][W][C] (any fp dtype). Returns (codes, rowsum[parts][M], M).
-    pre = (scale [B][C], shift [B][C], act) folds a GroupNorm (+SiLU when act == 1) into the load."""
+    pre = (scale [B][C], shift [B][C], act) folds a GroupNorm (+SiLU when act == 1) into the load;
+    ln = (gamma [C], beta [C], eps) folds a LayerNorm over each row's C elements (Linear inputs)."""
     Ho = (H + 2 * pad - kh) // stride + 1
     Wo = (W + 2 * pad - kw) // stride + 1
     M = B * Ho * Wo
@@ -177,7 +178,9 @@ def quant_act(x_cl: torch.Tensor, B, H, W, C, kh, kw, stride, pad, ab: ActBindin
               _lib.ptr(ab.ksrc), _lib.ptr(ab.koff(W, ldc)), _lib.ptr(ab.klds(kw, C)), ab.Kp, per_m, _lib.ptr(delta), _lib.ptr(zp), L, ab.abits,
               _lib.ptr(codes), _lib.ptr(rowsum), parts,
               _lib.ptr(pre[0]) if pre and pre[0] is not None else None,
-              _lib.ptr(pre[1]) if pre and pre[1] is not None else None, pre[2] if pre else 0, _lib.stream())
+              _lib.ptr(pre[1]) if pre and pre[1] is not None else None, pre[2] if pre else 0,
+              _lib.ptr(ln[0]) if ln else None, _lib.ptr(ln[1]) if ln else None, _c.c_float(ln[2] if ln else 0.0),
+              _lib.stream())
     return codes, rowsum, M
 
 
@@ -297,7 +300,7 @@ def gemm_wxa8(codes, rowsum, M, ab: ActBinding, out_dtype, out: Optional[torch.T
     return out
 
 
-def quant_linear(x: torch.Tensor, ab: ActBinding, pre_act=0, residual=None, fq=None):
+def quant_linear(x: torch.Tensor, ab: ActBinding, pre_act=0, residual=None, fq=None, ln=None):
     """x [..., K] -> [..., N].  pre_act: 0 none, 1 SiLU(x), 2 GEGLU (x is [..., 2K]: x[:K]·gelu(x[K:])) folded into the
     quantise-on-load pass; residual [..., N] and fq (see make_extra) folded into the GEMM epilogue."""
     Kin = x.shape[-1]
@@ -307,7 +310,7 @@ def quant_linear(x: torch.Tensor, ab: ActBinding, pre_act=0, residual=None, fq=N
         x2 = x2.contiguous()
     rows = x2.shape[0]
     pre = (None, None, pre_act) if pre_act else None
-    codes, rowsum, M = quant_act(x2, rows, 1, 1, K, 1, 1, 1, 0, ab, pre)
+    codes, rowsum, M = quant_act(x2, rows, 1, 1, K, 1, 1, 1, 0, ab, pre, ln)
     res2 = None
     if residual is not None:
         res2 = residual.reshape(-1, ab.pw.N)

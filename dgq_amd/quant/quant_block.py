@@ -35,6 +35,8 @@ _F_GEGLU = _os.environ.get("DGQ_FUSE_GEGLU", "0") == "1"
 _F_SILU = _os.environ.get("DGQ_FUSE_SILU", "1") == "1"
 # aqtizer_{q,k,v} applied inside the attention pre-pass (K/V while they are split into bf16 planes, Q into a scratch
 # copy by extra blocks of the same launch): three launches per attention saved, nothing added to a GEMM grid (-0.16 ms)
+# norm1/2/3 of the transformer block folded into the quantise-on-load pass of the layers that consume them
+_F_LN = _os.environ.get("DGQ_FUSE_LN", "1") == "1"
 _F_ATTN_FQ = _os.environ.get("DGQ_FUSE_ATTN_FQ", "1") == "1"
 
 
@@ -113,6 +115,40 @@ def _qparams(q: UniformAffineQuantizer, dev):
     return mode, dd, zz
 
 
+class PreLN:
+    """A tensor with an nn.LayerNorm pending.  QuantLayers on the integer path fold the norm into their quantise-on-load
+    pass (``forward_fused(x, ln=norm)``); anything else gets the materialised LayerNorm output (computed once)."""
+
+    def __init__(self, x, norm):
+        self.x, self.norm, self._y = x, norm, None
+        self.shape, self.device, self.dtype, self.is_cuda = x.shape, x.device, x.dtype, x.is_cuda
+
+    def materialise(self):
+        if self._y is None:
+            self._y = self.norm(self.x)
+        return self._y
+
+
+def _fusable_ln(norm):
+    return (FUSION and FUSE_NORM and _F_LN and isinstance(norm, nn.LayerNorm) and norm.elementwise_affine
+            and norm.bias is not None and len(norm.normalized_shape) == 1)
+
+
+def _prenorm(x, norm):
+    return PreLN(x, norm) if (_fusable_ln(norm) and x.is_cuda and x.dtype == torch.float32) else norm(x)
+
+
+def _apply(layer, inp, **kw):
+    """layer(inp) where inp may carry a pending LayerNorm"""
+    if isinstance(inp, PreLN):
+        if isinstance(layer, QuantLayer) and not layer.is_conv:
+            return layer.forward_fused(inp.x, ln=inp.norm, **kw)
+        inp = inp.materialise()
+    if kw:
+        return layer.forward_fused(inp, **kw)
+    return layer(inp)
+
+
 class QuantBasicTransformerBlock(BaseQuantBlock):
     def __init__(self, tran: nn.Module, aq_params: dict = {}, softmax_aq_params: dict = {}) -> None:
         super().__init__(aq_params)
@@ -152,12 +188,15 @@ class QuantBasicTransformerBlock(BaseQuantBlock):
             x = x + self.attn1(self.norm1(x))
             x = x + self.attn2(self.norm2(x), encoder_hidden_states=encoder_hidden_states)
             return x + self.ff(self.norm3(x))
-        x = quant_attention_forward(self.attn1, self.norm1(x), None, residual=x)
-        x = quant_attention_forward(self.attn2, self.norm2(x), encoder_hidden_states, residual=x)
+        x = quant_attention_forward(self.attn1, _prenorm(x, self.norm1), None, residual=x)
+        x = quant_attention_forward(self.attn2, _prenorm(x, self.norm2), encoder_hidden_states, residual=x)
         net = self.ff.net
-        if _F_GEGLU and isinstance(net[2], QuantLayer) and hasattr(net[0], "proj"):
-            h = net[0].proj(self.norm3(x))                    # GEGLU projection; a·gelu(g) happens in ff.net.2's load
-            return net[2].forward_fused(h, pre_act=2, residual=x)
+        if len(net) == 3 and hasattr(net[0], "proj") and isinstance(net[1], nn.Dropout):
+            h = _apply(net[0].proj, _prenorm(x, self.norm3))  # GEGLU projection (sd.py:210-236)
+            if _F_GEGLU and isinstance(net[2], QuantLayer):
+                return net[2].forward_fused(h, pre_act=2, residual=x)   # a·gelu(g) happens in ff.net.2's load
+            a, g = h.chunk(2, dim=-1)
+            return x + net[2](net[1](a * F.gelu(g)))
         return x + self.ff(self.norm3(x))
 
 
@@ -191,12 +230,12 @@ def quant_attention_forward(attn, hidden_states, encoder_hidden_states=None, res
         if defer and qz.init:
             mode, dd, zz = _qparams(qz, inp.device)
             pending[name] = (mode, dd, zz, skip, qz.bits)
-            return layer(inp)
-        if (FUSION and _F_FQ and qz is not None and qz.init and isinstance(layer, QuantLayer) and layer.on_integer_path(inp)
-                and inp.dtype == torch.float32):
+            return _apply(layer, inp)
+        if (FUSION and _F_FQ and qz is not None and qz.init and isinstance(layer, QuantLayer)
+                and layer.on_integer_path(inp.x if isinstance(inp, PreLN) else inp) and inp.dtype == torch.float32):
             mode, dd, zz = _qparams(qz, inp.device)
-            return layer.forward_fused(inp, fq=(mode + 1, dd, zz, ntok, D, skip, qz.bits))
-        ten = layer(inp)
+            return _apply(layer, inp, fq=(mode + 1, dd, zz, ntok, D, skip, qz.bits))
+        ten = _apply(layer, inp)
         if use_aq:
             bb, ntok, cc = ten.shape
             if not qz.init:                                          # first-forward scalar self-init
@@ -211,8 +250,9 @@ def quant_attention_forward(attn, hidden_states, encoder_hidden_states=None, res
     fork = ops.Fork(hidden_states.device, 2) if hidden_states.is_cuda else None
     if fork is not None and fork.active:
         q = fork.run(0, lambda: project(attn.to_q, "aqtizer_q", hidden_states, 0))
-        k = fork.run(1, lambda: project(attn.to_k, "aqtizer_k", src, 1 if start_peak else 0), src)
-        v = fork.run(2, lambda: project(attn.to_v, "aqtizer_v", src, 0), src)
+        src_t = src.x if isinstance(src, PreLN) else src
+        k = fork.run(1, lambda: project(attn.to_k, "aqtizer_k", src, 1 if start_peak else 0), src_t)
+        v = fork.run(2, lambda: project(attn.to_v, "aqtizer_v", src, 0), src_t)
         fork.join()
     else:
         q = project(attn.to_q, "aqtizer_q", hidden_states, 0)

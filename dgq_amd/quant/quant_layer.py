@@ -344,11 +344,16 @@ class QuantLayer(nn.Module):
         return (self.use_wq and self.use_aq and not self.disable_aq and x.is_cuda
                 and (self.aqtizer.init or (self._slot_ref is not None and self._slot_ref.slot in self._act_tables)))
 
-    def forward_fused(self, x: torch.Tensor, pre_act: int = 0, residual=None, fq=None) -> torch.Tensor:
+    def forward_fused(self, x: torch.Tensor, pre_act: int = 0, residual=None, fq=None, ln=None) -> torch.Tensor:
         """``fq(self(act(x))) + residual`` with the elementwise pieces folded into the two kernels of the layer:
         pre_act 1 = SiLU(x), 2 = GEGLU (x[..., :K]·gelu(x[..., K:])) inside the quantise-on-load pass; ``fq`` (an
         attention-side quantizer, see ops.make_extra) and ``residual`` inside the GEMM epilogue.  Linear layers on the
-        integer path only; anything else falls back to the unfused sequence of the same kernels/ops."""
+        integer path only; anything else falls back to the unfused sequence of the same kernels/ops.  ``ln`` = an
+        nn.LayerNorm module applied to x first, folded into the same load pass (per-row statistics in the kernel)."""
+        if ln is not None and (self.is_conv or not self.on_integer_path(x) or x.dtype != torch.float32 or pre_act
+                               or x.shape[-1] % 4 or x.shape[-1] > 2048):
+            x = ln(x)                                           # nn.LayerNorm module: unfused
+            ln = None
         if self.is_conv or not self.on_integer_path(x) or x.dtype != torch.float32:
             if pre_act == 1:
                 x = F.silu(x)
@@ -361,7 +366,8 @@ class QuantLayer(nn.Module):
                 y = y.contiguous()
                 ops.fakequant_rows(y.view(-1, y.shape[-1]), T, D, mode - 1, dd, zz, skip, bits)
             return y if residual is None else y + residual
-        return ops.quant_linear(x, self._binding(), pre_act=pre_act, residual=residual, fq=fq)
+        lnp = (ln.weight.data, ln.bias.data, float(ln.eps)) if ln is not None else None
+        return ops.quant_linear(x, self._binding(), pre_act=pre_act, residual=residual, fq=fq, ln=lnp)
 
     def can_fuse_prenorm(self, x: torch.Tensor) -> bool:
         """True when this layer runs on the integer path, so a preceding GroupNorm(+SiLU) can be folded into its

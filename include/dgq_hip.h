@@ -78,6 +78,9 @@ int dgq_pack_w8(const uint8_t* codes, int N, int K, const int32_t* kperm, int Kp
  * the load, see dgq_groupnorm_scale_shift); pre_act == 1 then applies SiLU (resnet norm→SiLU→conv, and SiLU(temb) →
  * time_emb_proj); pre_act == 2 reads rows of 2C elements and forms x[c]·gelu(x[C+c]) (GEGLU in front of ff.net.2,
  * sd.py:210-236); out-of-image taps stay 0.
+ * ln_gamma/ln_beta [C] (or NULL) + ln_eps: nn.LayerNorm over the C elements of each row folded into the load
+ * (norm1/2/3 of BasicTransformerBlock in front of to_q/to_k/to_v/ff.net.0.proj, sd.py:245-268): the wave that
+ * quantises a row computes its mean / biased variance and maps x to (x − μ)·rstd·γ + β.  1x1 only, no other prologue.
  * ksplits >= 1 splits every row's K range over that many waves (low-M layers); rowsum then has
  * dgq_quant_act_parts(Kp, ksplits) x M entries ([part][m]) which dgq_gemm_wxa8 adds in a fixed order. */
 int dgq_quant_act(const void* x, int x_dtype, int B, int H, int W, int C,
@@ -85,7 +88,8 @@ int dgq_quant_act(const void* x, int x_dtype, int B, int H, int W, int C,
                   const int32_t* ksrc, const int32_t* koff, const int32_t* klds, int Kp,
                   int per_m, const float* delta, const float* zp, int L,
                   int bits, int8_t* codes, float* rowsum, int ksplits,
-                  const float* pre_scale, const float* pre_shift, int pre_act, void* stream);
+                  const float* pre_scale, const float* pre_shift, int pre_act,
+                  const float* ln_gamma, const float* ln_beta, float ln_eps, void* stream);
 int dgq_quant_act_parts(int Kp, int ksplits);
 
 /* GroupNorm of a channels-last tensor x [B][HW][C] as per-(b,c) scale/shift (biased variance, eps as F.group_norm):

@@ -340,3 +340,41 @@ def test_fused_groupnorm_silu_quant_codes(C, H, k, dev):
     rstd = (var + 1e-5).rsqrt()
     exp_scale = (rstd.repeat_interleave(C // 32, 1) * gamma[None])
     assert rel_l2(sc.cpu(), exp_scale) < 1e-6
+
+
+@pytest.mark.parametrize("C,T,layout", [(320, 70, "perK"), (64, 33, "perM"), (1280, 9, "perK"), (96, 40, "scalar")])
+def test_fused_layernorm_quant_codes(C, T, layout, dev):
+    """norm -> Linear with the LayerNorm folded into dgq_quant_act (per-row statistics inside the kernel) against
+    F.layer_norm + unfused quantisation: codes may differ only where the (differently rounded) normalised value sits on
+    a rounding boundary (< 1e-3 of the elements, never by more than one step)."""
+    import torch.nn.functional as F
+    from dgq_amd import ops
+    from dgq_amd.plan import plan_act
+    from dgq_amd.synth import channel_minmax, _group_params
+    g = torch.Generator().manual_seed(C + T)
+    B, N = 2, 48
+    x = (torch.randn(B, T, C, generator=g) * 1.7 - 0.4)
+    gamma, beta = 1 + 0.1 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    w = torch.randn(N, C, generator=g) * 0.05
+    wd, wz = channel_minmax(w, 4)
+    pw = ops.PackedWeight(w.to(dev), wd.to(dev), wz.to(dev), None, torch.zeros(N, device=dev), 4, C, 1)
+    if layout == "perK":
+        d, z = _group_params(C, 8, 8, "lnf", 0)
+        lay = plan_act(d.view(1, 1, -1), z.view(1, 1, -1), "linear", C, 1, 8)
+    elif layout == "perM":
+        d, z = _group_params(T, 4, 8, "lnf", 0)
+        lay = plan_act(d.view(1, -1, 1), z.view(1, -1, 1), "linear", C, 1, 8)
+    else:
+        lay = plan_act(torch.tensor(0.031), torch.tensor(131.0), "linear", C, 1, 8)
+    ab = ops.ActBinding(lay, pw, 8)
+    xg = x.to(dev)
+    ref_in = F.layer_norm(xg, (C,), gamma.to(dev), beta.to(dev), 1e-5)
+    c_ref, rs_ref, M = ops.quant_act(ref_in.view(B * T, C), B * T, 1, 1, C, 1, 1, 1, 0, ab)
+    c_fus, rs_fus, _ = ops.quant_act(xg.view(B * T, C), B * T, 1, 1, C, 1, 1, 1, 0, ab, None, (gamma.to(dev), beta.to(dev), 1e-5))
+    torch.cuda.synchronize()
+    diff = (c_ref.int() - c_fus.int()).abs()
+    assert int(diff.max()) <= 1 and float((diff > 0).float().mean()) < 1e-3
+    y_ref = ops.quant_linear(ref_in, ab)
+    y_fus = ops.quant_linear(xg, ab, ln=(gamma.to(dev), beta.to(dev), 1e-5))
+    torch.cuda.synchronize()
+    assert rel_l2(y_fus.cpu(), y_ref.cpu()) < 2e-3
