@@ -266,9 +266,13 @@ __device__ __forceinline__ void load_q(bf16x8 (&qf)[3][Geo<D>::NKK], const float
 template <int D>
 __device__ __forceinline__ v16f score_tile(const unsigned short* kb, const bf16x8 (&qf)[3][Geo<D>::NKK], int lane) {
     using G = Geo<D>;
-    v16f acc;
+    // D >= 64 (one block per CU, a lone wave per SIMD): two independent accumulator chains — a dependent MFMA cannot
+    // issue until its predecessor has left the pipe and nothing else fills that gap (measured: D=160 86 -> 74 us, D=80
+    // 121 -> 117).  D <= 40 runs two waves per SIMD that fill each other's gaps; there the 16 extra adds cost 5 %.
+    constexpr bool DUAL = D >= 64;
+    v16f acc, acc2;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    for (int r = 0; r < 16; ++r) acc[r] = acc2[r] = 0.0f;
     const unsigned short* kp = kb + (lane & 31) * G::KLD + 8 * (lane >> 5);
     constexpr int PL = KT * G::KLD;
 #pragma unroll
@@ -276,12 +280,25 @@ __device__ __forceinline__ v16f score_tile(const unsigned short* kb, const bf16x
         const bf16x8 kh = *reinterpret_cast<const bf16x8*>(kp + 16 * kk);
         const bf16x8 km = *reinterpret_cast<const bf16x8*>(kp + PL + 16 * kk);
         const bf16x8 kl = *reinterpret_cast<const bf16x8*>(kp + 2 * PL + 16 * kk);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qf[0][kk], acc, 0, 0, 0);    // smallest terms first
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qf[2][kk], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(km, qf[1][kk], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(km, qf[0][kk], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qf[1][kk], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qf[0][kk], acc, 0, 0, 0);
+        if (DUAL) {
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qf[0][kk], acc2, 0, 0, 0);   // smallest terms first
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(km, qf[0][kk], acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qf[2][kk], acc2, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qf[1][kk], acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(km, qf[1][kk], acc2, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qf[0][kk], acc, 0, 0, 0);
+        } else {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qf[0][kk], acc, 0, 0, 0);     // smallest terms first
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qf[2][kk], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(km, qf[1][kk], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(km, qf[0][kk], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qf[1][kk], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qf[0][kk], acc, 0, 0, 0);
+        }
+    }
+    if (DUAL) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] += acc2[r];
     }
     return acc;
 }

@@ -3,7 +3,8 @@
 // GN(x) and SiLU(GN(x)) (QuantResnetBlock2D.forward: norm1 -> SiLU -> conv1, norm2 -> SiLU -> conv2,
 // quant/quant_block.py:98-119):   GN(x)[b,c] = x·scale[b,c] + shift[b,c],
 //   scale = rstd[b,g]·γ[c],  shift = β[c] − mean[b,g]·rstd[b,g]·γ[c].
-// Two launches: partial Welford moments per (b, group, spatial slice), then a merge (Chan) + scale/shift kernel.
+// One launch when a (batch, group) fits one block (slices == 1), else partial moments per (b, group, spatial slice)
+// followed by a merge (Chan) + scale/shift kernel.
 #include "dgq_common.h"
 
 struct Moments { float n, mean, m2; };
@@ -19,23 +20,37 @@ __device__ __forceinline__ Moments merge(Moments a, Moments b) {
     return r;
 }
 
-// grid (B*G, S): block handles spatial rows [s*rows_per, ...) of group g of image b
-template <typename T>
+// grid (B*G, S): block handles spatial rows [s*rows_per, ...) of group g of image b.  Per thread: shifted sums
+// Σ(x − K), Σ(x − K)² with K = the first element of the block's range (3 VALU per element, no cancellation worth
+// mentioning because K sits inside the data), converted to (n, mean, M2) and merged pairwise (Chan) in a fixed order.
+// S == 1 (FINAL): the block also writes the group's scale/shift, so the whole GroupNorm statistic is one launch.
+template <typename T, bool FINAL>
 __global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x, int HW, int C, int G, int rows_per,
-                                                         float* __restrict__ part) {
+                                                         float* __restrict__ part, float eps,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         float* __restrict__ scale, float* __restrict__ shift) {
     const int bg = blockIdx.x, b = bg / G, g = bg - b * G;
     const int Cg = C / G;
     const int r0 = blockIdx.y * rows_per, r1 = min(HW, r0 + rows_per);
     const T* base = x + ((int64_t)b * HW) * C + g * Cg;
-    Moments m = {0.0f, 0.0f, 0.0f};
+    const float K = dgq_to_float(base[(int64_t)r0 * C]);
     const int total = (r1 - r0) * Cg;
+    float s1 = 0.0f, s2 = 0.0f, cnt = 0.0f;
+    int r = threadIdx.x / Cg, c = threadIdx.x - r * Cg;     // element i = r*Cg + c, advanced by 256 without divisions
+    const int dr = 256 / Cg, dc = 256 - dr * Cg;
     for (int i = threadIdx.x; i < total; i += 256) {
-        const int r = i / Cg, c = i - r * Cg;
-        const float v = dgq_to_float(base[(int64_t)(r0 + r) * C + c]);
-        m.n += 1.0f;
-        const float d = v - m.mean;
-        m.mean += d / m.n;
-        m.m2 += d * (v - m.mean);
+        const float d = dgq_to_float(base[(int64_t)(r0 + r) * C + c]) - K;
+        s1 += d;
+        s2 += d * d;
+        cnt += 1.0f;
+        r += dr; c += dc;
+        if (c >= Cg) { c -= Cg; ++r; }
+    }
+    Moments m = {cnt, 0.0f, 0.0f};
+    if (cnt > 0.0f) {
+        const float md = s1 / cnt;
+        m.mean = K + md;
+        m.m2 = fmaxf(s2 - s1 * md, 0.0f);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -46,12 +61,28 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x
         m = merge(m, other);
     }
     __shared__ Moments sm[4];
+    __shared__ float fin[2];
     if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
     __syncthreads();
     if (threadIdx.x == 0) {
         m = merge(merge(sm[0], sm[1]), merge(sm[2], sm[3]));
-        float* p = part + ((int64_t)bg * gridDim.y + blockIdx.y) * 3;
-        p[0] = m.n; p[1] = m.mean; p[2] = m.m2;
+        if (FINAL) {
+            fin[0] = m.mean;
+            fin[1] = rsqrtf(m.m2 / m.n + eps);            // biased variance, as F.group_norm
+        } else {
+            float* p = part + ((int64_t)bg * gridDim.y + blockIdx.y) * 3;
+            p[0] = m.n; p[1] = m.mean; p[2] = m.m2;
+        }
+    }
+    if (FINAL) {
+        __syncthreads();
+        const float mean = fin[0], rstd = fin[1];
+        for (int cc = threadIdx.x; cc < Cg; cc += 256) {
+            const int ch = g * Cg + cc;
+            const float sc = rstd * gamma[ch];
+            scale[(int64_t)b * C + ch] = sc;
+            shift[(int64_t)b * C + ch] = beta[ch] - mean * sc;
+        }
     }
 }
 
@@ -87,12 +118,16 @@ extern "C" int dgq_groupnorm_scale_shift(const void* x, int x_dtype, int B, int 
     const int rows_per = (HW + slices - 1) / slices;
     const int S = (HW + rows_per - 1) / rows_per;
     dim3 grid(B * G, S), block(256);
+#define DGQ_GN_LAUNCH(TT, FIN) hipLaunchKernelGGL((gn_partial_kernel<TT, FIN>), grid, block, 0, st, (const TT*)x, HW, C, G, \
+                                                  rows_per, partial_ws, eps, gamma, beta, scale, shift)
     switch (x_dtype) {
-        case DGQ_F32: hipLaunchKernelGGL(gn_partial_kernel<float>, grid, block, 0, st, (const float*)x, HW, C, G, rows_per, partial_ws); break;
-        case DGQ_F16: hipLaunchKernelGGL(gn_partial_kernel<__half>, grid, block, 0, st, (const __half*)x, HW, C, G, rows_per, partial_ws); break;
-        case DGQ_BF16: hipLaunchKernelGGL(gn_partial_kernel<__hip_bfloat16>, grid, block, 0, st, (const __hip_bfloat16*)x, HW, C, G, rows_per, partial_ws); break;
+        case DGQ_F32: if (S == 1) DGQ_GN_LAUNCH(float, true); else DGQ_GN_LAUNCH(float, false); break;
+        case DGQ_F16: if (S == 1) DGQ_GN_LAUNCH(__half, true); else DGQ_GN_LAUNCH(__half, false); break;
+        case DGQ_BF16: if (S == 1) DGQ_GN_LAUNCH(__hip_bfloat16, true); else DGQ_GN_LAUNCH(__hip_bfloat16, false); break;
         default: dgq_set_error("dgq_groupnorm_scale_shift: unknown dtype %d", x_dtype); return DGQ_EINVAL;
     }
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * G), dim3(64), 0, st, partial_ws, S, C, G, eps, gamma, beta, scale, shift);
+#undef DGQ_GN_LAUNCH
+    if (S > 1)
+        hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * G), dim3(64), 0, st, partial_ws, S, C, G, eps, gamma, beta, scale, shift);
     return dgq_launch_status("dgq_groupnorm_scale_shift");
 }
