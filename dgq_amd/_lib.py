@@ -6,7 +6,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libdgq_hip.so")
+LIB_PATH = os.environ.get("DGQ_HIP_LIB") or os.path.join(_HERE, "csrc", "libdgq_hip.so")   # override: A/B builds of the kernels
 
 _vp, _i, _f, _i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64
 

@@ -21,6 +21,7 @@
 // Small grids (most SD1.4 layers give 10..192 tiles on 256 CUs) use deterministic split-K: grid.z slices of the
 // K-tile range write fp32 partial slabs [S][M][N] to a caller-provided workspace; splitk_epilogue_kernel sums
 // them in a fixed order and applies the dequantisation epilogue (no float atomics: results are bit-reproducible).
+#include <type_traits>
 #include "dgq_common.h"
 
 #define BM 128
@@ -57,13 +58,15 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // LDS-DMA of 16 B per lane: LDS[lds_addr + lane*16] <- *gsrc.  Issued from inline asm on purpose: with the builtin
 // hipcc treats the DMA as an LDS store that every later ds_read may alias and drains it with s_waitcnt vmcnt(0)
 // before the first ds_read of each K step; here the ring is ordered by hand (counted vmcnt + barrier below).
-// M0 carries the wave-uniform LDS base and is written in the same statement that uses it (cdna guide §5.7).
+// M0 carries the wave-uniform LDS base, is written in the same statement that uses it (cdna guide §5.7) and is declared
+// clobbered rather than saved/restored.  Measured on 8192^3: each DMA piece costs ~4.5 % of the loop (skipping the two
+// weight pieces of the six per wave per K tile: 521 -> 474 us) — the largest non-MFMA cost, ~100 cycles per piece
+// against 512 cycles of MFMA per wave per K tile.
 __device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_addr) {
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                 :
                  : "v"(gsrc), "s"(lds_addr)
-                 : "memory");
+                 : "memory", "m0");
 }
 
 // y -> [aqtizer_{q,k,v}(y)] -> [+ residual]; element (m, n) of the output
@@ -227,62 +230,82 @@ __global__ __launch_bounds__(256, (STAGES <= 3 ? 2 : 1)) void gemm_wxa8_kernel(G
     __builtin_amdgcn_s_barrier();
 
     // ring invariant at the top of iteration t: tiles t .. t+STAGES-2 are issued, tile t has landed.
+    // The fragment loads are software-pipelined one K-half ahead of the MFMAs that consume them: while the 16 MFMAs of
+    // half h run, the ds_reads of the next half (or of the next tile's first half, after the barrier) are in flight.
+    // A/B on one box (8192^3): per-K g16 34.3 -> 35.3 % of peak, per-M 41.7 -> 41.9 %.  int4 stays packed in the fragment
+    // registers and is widened right before its MFMAs, so the load itself has no consumer until then.  (Tried and
+    // dropped: MFMAs with a constant-0 C operand after a flush instead of clearing the tile — a second copy of the
+    // 16 MFMAs behind a wave-uniform branch; no gain.)
+    typedef typename std::conditional<WBITS == 4, uint2, v4i>::type wfrag_t;
+    auto load_frags = [&](const uint8_t* sa, const uint8_t* sw, int h, v4i (&af)[4], wfrag_t (&wf)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const v4i*>(sa + a_off[i][h]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const wfrag_t*>(sw + w_off[j][h]);
+    };
+    auto mma_half = [&](const v4i (&af)[4], const wfrag_t (&wf)[4], int chunk) {
+        v4i bf[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if constexpr (WBITS == 4) {
+                const uint2 v = wf[j];
+                bf[j] = (v4i){(int)(v.x & 0x0F0F0F0Fu), (int)((v.x >> 4) & 0x0F0F0F0Fu),
+                              (int)(v.y & 0x0F0F0F0Fu), (int)((v.y >> 4) & 0x0F0F0F0Fu)};
+            } else {
+                bf[j] = wf[j];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[i], bf[j], acc[i][j], 0, 0, 0);
+        if (!PER_M) {
+            // wave-uniform: > 0 on the last chunk of a DGQ group or of this K split
+            const float sc = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(
+                __builtin_bit_cast(int, ctab[chunk])));
+            if (sc > 0.0f) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) accf[i][j][r] += sc * (float)acc[i][j][r];
+                        acc[i][j] = (v4i){0, 0, 0, 0};
+                    }
+            }
+        }
+    };
+    v4i af0[4], af1[4];
+    wfrag_t wf0[4], wf1[4];
     int stage = 0, istage = STAGES - 1;
+    load_frags(smem, smem + A_BYTES, 0, af0, wf0);
     for (int t = 0; t < nk; ++t) {
         if (t + STAGES - 1 < nk) issue_tile(kt_begin + t + STAGES - 1, istage);
         const uint8_t* sa = smem + stage * STAGE_BYTES;
-        const uint8_t* sw = sa + A_BYTES;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            v4i af[4], bf[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const v4i*>(sa + a_off[i][h]);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (WBITS == 4) {
-                    const uint2 v = *reinterpret_cast<const uint2*>(sw + w_off[j][h]);
-                    bf[j] = (v4i){(int)(v.x & 0x0F0F0F0Fu), (int)((v.x >> 4) & 0x0F0F0F0Fu),
-                                  (int)(v.y & 0x0F0F0F0Fu), (int)((v.y >> 4) & 0x0F0F0F0Fu)};
-                } else {
-                    bf[j] = *reinterpret_cast<const v4i*>(sw + w_off[j][h]);
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[i], bf[j], acc[i][j], 0, 0, 0);
-            if (!PER_M) {
-                // wave-uniform: > 0 on the last chunk of a DGQ group or of this K split
-                const float sc = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(
-                    __builtin_bit_cast(int, ctab[2 * t + h])));
-                if (sc > 0.0f) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) accf[i][j][r] += sc * (float)acc[i][j][r];
-                            acc[i][j] = (v4i){0, 0, 0, 0};
-                        }
-                }
-            }
-        }
+        load_frags(sa, sa + A_BYTES, 1, af1, wf1);
+        mma_half(af0, wf0, 2 * t);
         // tile t+1 must have landed (this wave's pieces) before anyone reads it; the STAGES-2 younger tiles may stay
-        // in flight (vmcnt counts the wave's DMA instructions in issue order)
+        // in flight (vmcnt counts the wave's DMA instructions in issue order).  lgkmcnt(0): this wave's reads of tile t
+        // are complete, so after the barrier its stage may be overwritten.
         {
             const int younger = min(STAGES - 2, max(0, nk - 2 - t));
             switch (younger) {
-                case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-                case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 * DMA_PER_TILE) : "memory"); break;
-                case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DMA_PER_TILE) : "memory"); break;
-                case 3: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * DMA_PER_TILE) : "memory"); break;
-                default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * DMA_PER_TILE) : "memory"); break;
+                case 0: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); break;
+                case 1: asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(1 * DMA_PER_TILE) : "memory"); break;
+                case 2: asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * DMA_PER_TILE) : "memory"); break;
+                case 3: asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(3 * DMA_PER_TILE) : "memory"); break;
+                default: asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(4 * DMA_PER_TILE) : "memory"); break;
             }
         }
         __builtin_amdgcn_s_barrier();
         stage = (stage + 1 == STAGES) ? 0 : stage + 1;
         istage = (istage + 1 == STAGES) ? 0 : istage + 1;
+        if (t + 1 < nk) {
+            const uint8_t* sn = smem + stage * STAGE_BYTES;
+            load_frags(sn, sn + A_BYTES, 0, af0, wf0);
+        }
+        mma_half(af1, wf1, 2 * t + 1);
     }
 
     // epilogue.  The MFMA C/D layout (col = lane&15, row = (lane>>4)*4 + reg) would give 4-byte stores in 64-byte

@@ -11,7 +11,7 @@ dev = torch.device("cuda:0")
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 PEAK = 5000.0
 # (name, M, N, C, taps, mode)
-SHAPES = [
+SHAPES_ALL = [
     ("sd conv3x3 64x64 320->320", 8192, 320, 320, 9, "perK"),
     ("sd conv3x3 32x32 640->640", 2048, 640, 640, 9, "perK"),
     ("sd conv3x3 16x16 1280->1280", 512, 1280, 1280, 9, "perK"),
@@ -31,6 +31,7 @@ SHAPES = [
     ("big 8192x8192x8192 perM", 8192, 8192, 8192, 1, "perM"),
     ("big 8192x8192x8192 perK g16", 8192, 8192, 8192, 1, "perK"),
 ]
+SHAPES = SHAPES_ALL[-2:] if os.environ.get("BIG_ONLY") else SHAPES_ALL
 print("%-40s %6s %6s %6s  %9s %9s %7s" % ("shape", "M", "N", "K", "us", "TOP/s", "frac"))
 for name, M, N, C, taps, mode in SHAPES:
     K = C * taps
