@@ -46,6 +46,23 @@ __device__ __forceinline__ float dgq_affine_code(float x, float delta, float zp,
     return fminf(fmaxf(u, 0.0f), qmax);
 }
 
+// SiLU x/(1 + e^-x) to ~1 ulp in 13 VALU operations (libm expf + IEEE division: ~30): e^-x = 2^t with t = −x·log2e carried
+// as a rounded product plus its exact residual (fma) and the low part of log2e, v_exp_f32 on the rounded part, first-
+// order correction for the rest; 1/(1 + e) by v_rcp_f32 + one Newton step.  t is capped at 126 so that 1 + e stays
+// finite (x < −87: the result is −0 … −1e-36 either way).
+__device__ __forceinline__ float dgq_silu(float x) {
+    const float L_HI = -1.44269502162933349609375f, L_LO = -1.925963033500011e-8f;   // −log2(e) = L_HI + L_LO
+    float t = x * L_HI;
+    float r = fmaf(x, L_HI, -t) + x * L_LO;
+    t = fminf(t, 126.0f);
+    float e = __builtin_amdgcn_exp2f(t);
+    e = fmaf(e, r * 0.693147180559945f, e);
+    const float den = 1.0f + e;
+    float q = __builtin_amdgcn_rcpf(den);
+    q = fmaf(fmaf(-den, q, 1.0f), q, q);
+    return x * q;
+}
+
 // The same code, bit for bit, at the cost of a multiply: with inv = v_rcp_f32(δ) (1 ulp), t = fl(x·inv) differs from the
 // real quotient q by < |q|·1.8e-7, and the correctly rounded fl(q) by < |q|·0.6e-7; so whenever t is farther than
 // |t|·4e-7 from every half-integer, rint(t) == rint(fl(x/δ)).  Only values inside that band (probability ~1e-4 per

@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void quant_act_kernel(QuantActParams p) {
                             float val = v[u][j];
                             if (p.pre_scale) val = val * pre_sc[c] + pre_sh[c];
                             if (p.ln_gamma) val = (val - ln_mu) * ln_rstd * p.ln_gamma[c] + p.ln_beta[c];
-                            if (p.pre_act == 1) val = val / (1.0f + expf(-val));
+                            if (p.pre_act == 1) val = dgq_silu(val);
                             else if (p.pre_act == 2) {
                                 const float g = dgq_to_float(imgr[rowoff + e + p.C]);
                                 val = val * (0.5f * g * (1.0f + erff(g * 0.70710678118654752f)));
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256) void quant_act_kernel(QuantActParams p) {
             }
             if (p.pre_act == 1) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = v[j] / (1.0f + expf(-v[j]));
+                for (int j = 0; j < 4; ++j) v[j] = dgq_silu(v[j]);
             } else if (p.pre_act == 2) {
                 float g[4];
                 load4<TIn>(img + ((int64_t)hi * p.W + wi) * p.ldc + p.C + nc, g);
@@ -319,7 +319,7 @@ __global__ __launch_bounds__(256) void quant_act_staged_kernel(QuantActParams p)
                 }
                 if (p.pre_act == 1) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = v[j] / (1.0f + expf(-v[j]));
+                    for (int j = 0; j < 4; ++j) v[j] = dgq_silu(v[j]);
                 }
             }
             *reinterpret_cast<float4*>(dst + c) = make_float4(v[0], v[1], v[2], v[3]);
