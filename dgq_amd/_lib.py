@@ -36,7 +36,7 @@ SIGNATURES = {
 
 class GemmExtra(ctypes.Structure):
     """dgq_gemm_extra_t of include/dgq_hip.h"""
-    _fields_ = [("residual", _vp), ("ldr", _i), ("fq_mode", _i), ("fq_delta", _vp), ("fq_zp", _vp),
+    _fields_ = [("residual", _vp), ("ldr", _i), ("res_div", _i), ("fq_mode", _i), ("fq_delta", _vp), ("fq_zp", _vp),
                 ("fq_T", _i), ("fq_D", _i), ("fq_skip", _i), ("fq_qmax", _f)]
 
 

@@ -79,7 +79,7 @@ __device__ __forceinline__ float dgq_extra(const dgq_gemm_extra_t& ex, float y, 
             y = d * (dgq_affine_code(y, d, z, ex.fq_qmax) - z);
         }
     }
-    if (ex.residual) y += ex.residual[(int64_t)m * ex.ldr + n];
+    if (ex.residual) y += ex.residual[(int64_t)(m / ex.res_div) * ex.ldr + n];
     return y;
 }
 
@@ -350,10 +350,24 @@ __global__ __launch_bounds__(256, (STAGES <= 3 ? 2 : 1)) void gemm_wxa8_kernel(G
     const float4 zw = *reinterpret_cast<const float4*>(vc + 128);
     const float4 ga = *reinterpret_cast<const float4*>(vc + 256);
     const float4 vn = *reinterpret_cast<const float4*>(vc + 384);
-    const bool has_extra = p.ex.fq_mode != 0 || p.ex.residual != nullptr;
     const bool st_vec = vec_ok && ((p.ldy * (int)sizeof(TOut)) % 16 == 0) &&
                         ((reinterpret_cast<uintptr_t>(p.y) & 15) == 0) && (sizeof(TOut) == 4 || (p.ldy & 3) == 0);
-#pragma unroll 4
+    // residual tile: all 16 rows of this lane fetched up front as 16-byte loads, so the epilogue pays one memory latency
+    // (fetched row by row inside the store loop, the dependent loads made the fused add slower than a separate kernel)
+    const bool res_vec = p.ex.residual != nullptr && vec_ok && (p.ex.ldr & 3) == 0 &&
+                         (reinterpret_cast<uintptr_t>(p.ex.residual) & 15) == 0;
+    float4 res[16];
+    if (res_vec) {
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+            const int m = min(m0 + wave_m * 64 + rr * 4 + (lane >> 4), p.M - 1);
+            res[rr] = *reinterpret_cast<const float4*>(p.ex.residual + (int64_t)(m / p.ex.res_div) * p.ex.ldr + nb);
+        }
+    }
+    dgq_gemm_extra_t exl = p.ex;
+    if (res_vec) exl.residual = nullptr;                 // added below from the prefetched tile
+    const bool has_extra = exl.fq_mode != 0 || exl.residual != nullptr;
+#pragma unroll
     for (int rr = 0; rr < 16; ++rr) {
         const int row = rr * 4 + (lane >> 4);
         const int m = m0 + wave_m * 64 + row;
@@ -370,7 +384,10 @@ __global__ __launch_bounds__(256, (STAGES <= 3 ? 2 : 1)) void gemm_wxa8_kernel(G
         if (has_extra) {
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-                if (nb + k < p.N) o[k] = dgq_extra(p.ex, o[k], m, nb + k);
+                if (nb + k < p.N) o[k] = dgq_extra(exl, o[k], m, nb + k);
+        }
+        if (res_vec) {
+            o[0] += res[rr].x; o[1] += res[rr].y; o[2] += res[rr].z; o[3] += res[rr].w;
         }
         TOut* dst = y + (int64_t)m * p.ldy + nb;
         if (st_vec) {
@@ -515,9 +532,9 @@ extern "C" int dgq_gemm_wxa8(const int8_t* codes, const float* rowsum, int rowsu
         p.ex = *extra;
         DGQ_CHECK_ARG(p.ex.fq_mode >= 0 && p.ex.fq_mode <= 3, "dgq_gemm_wxa8: bad fq_mode");
         DGQ_CHECK_ARG(p.ex.fq_mode == 0 || (p.ex.fq_delta && p.ex.fq_zp && p.ex.fq_T > 0 && p.ex.fq_D > 0), "dgq_gemm_wxa8: fused quantizer needs tables");
-        DGQ_CHECK_ARG(!p.ex.residual || p.ex.ldr >= N, "dgq_gemm_wxa8: ldr < N");
+        DGQ_CHECK_ARG(!p.ex.residual || (p.ex.ldr >= N && p.ex.res_div >= 1), "dgq_gemm_wxa8: ldr < N or res_div < 1");
     } else {
-        p.ex.residual = nullptr; p.ex.ldr = 0; p.ex.fq_mode = 0; p.ex.fq_delta = nullptr; p.ex.fq_zp = nullptr;
+        p.ex.residual = nullptr; p.ex.ldr = 0; p.ex.res_div = 1; p.ex.fq_mode = 0; p.ex.fq_delta = nullptr; p.ex.fq_zp = nullptr;
         p.ex.fq_T = 1; p.ex.fq_D = 1; p.ex.fq_skip = 0; p.ex.fq_qmax = 255.0f;
     }
     p.splits = workspace ? choose_splits(M, N, Kp, workspace_bytes) : 1;

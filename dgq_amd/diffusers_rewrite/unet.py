@@ -168,6 +168,11 @@ class BasicTransformerBlock(nn.Module):
         return x + self.ff(self.norm3(x))
 
 
+def _residual_fusion_on():
+    from ..quant import quant_block
+    return quant_block.FUSION and quant_block._F_RES
+
+
 def _fusion_on():
     from ..quant import quant_block
     return quant_block.FUSION and quant_block.FUSE_NORM
@@ -203,6 +208,9 @@ class Transformer2DModel(nn.Module):
             h = self.proj_out(h)
         h = h.reshape(b, hh, ww, c).permute(0, 3, 1, 2)      # NHWC storage viewed as NCHW
         if self.proj_kind == "conv":
+            fr = getattr(self.proj_out, "forward_residual", None)
+            if fr is not None and _residual_fusion_on():
+                return fr(h, res)                                  # h + res in proj_out's GEMM epilogue
             h = self.proj_out(h)
         return h + res
 

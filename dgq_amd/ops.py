@@ -262,16 +262,18 @@ class Fork:
         self.used = []
 
 
-def make_extra(residual=None, fq=None):
-    """dgq_gemm_extra_t: residual [M][N] fp32 (row stride = its stride(0)); fq = (mode, delta, zp, T, D, skip, bits)
-    with mode 1 scalar / 2 per token / 3 per head-dim.  Keeps the tensors alive on the returned object."""
+def make_extra(residual=None, fq=None, res_div=1):
+    """dgq_gemm_extra_t: residual [M / res_div][N] fp32 (row stride = its stride(0); res_div > 1 broadcasts each row
+    over res_div consecutive output rows); fq = (mode, delta, zp, T, D, skip, bits) with mode 1 scalar / 2 per token /
+    3 per head-dim.  Keeps the tensors alive on the returned object."""
     if residual is None and fq is None:
         return None
     ex = _lib.GemmExtra()
+    ex.res_div = 1
     keep = []
     if residual is not None:
         assert residual.dtype == torch.float32 and residual.stride(-1) == 1
-        ex.residual, ex.ldr = residual.data_ptr(), residual.stride(0)
+        ex.residual, ex.ldr, ex.res_div = residual.data_ptr(), residual.stride(0), res_div
         keep.append(residual)
     if fq is not None:
         mode, delta, zp, T, D, skip, bits = fq
@@ -322,10 +324,11 @@ def quant_linear(x: torch.Tensor, ab: ActBinding, pre_act=0, residual=None, fq=N
     return y.view(*x.shape[:-1], ab.pw.N)
 
 
-def quant_conv2d(x: torch.Tensor, ab: ActBinding, kh, kw, stride, pad, norm=None, residual=None):
+def quant_conv2d(x: torch.Tensor, ab: ActBinding, kh, kw, stride, pad, norm=None, residual=None, bias_rows=None):
     """x logical NCHW (any strides; made channels-last) -> logical NCHW output in channels-last storage.
     norm = (groups, eps, gamma, beta, act): GroupNorm (+SiLU) of x folded into the quantise-on-load pass;
-    residual (logical NCHW, same shape as the output) is added in the GEMM epilogue."""
+    residual (logical NCHW, same shape as the output) is added in the GEMM epilogue; bias_rows [B][N] likewise, one row
+    per image (conv1(...) + time_emb_proj(...)[:, :, None, None])."""
     B, C, H, W = x.shape
     xc = x.contiguous(memory_format=torch.channels_last)
     x_store = xc.permute(0, 2, 3, 1)                  # [B,H,W,C] view over the same storage, contiguous
@@ -335,10 +338,12 @@ def quant_conv2d(x: torch.Tensor, ab: ActBinding, kh, kw, stride, pad, norm=None
         sc, sh = groupnorm_scale_shift(x_store, B, H * W, C, groups, eps, gamma, beta)
         pre = (sc, sh, act)
     codes, rowsum, M = quant_act(x_store, B, H, W, C, kh, kw, stride, pad, ab, pre)
-    res2 = None
+    res2, res_div = None, 1
     if residual is not None:
         res2 = residual.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1).reshape(M, ab.pw.N)
-    y = gemm_wxa8(codes, rowsum, M, ab, x.dtype, extra=make_extra(res2))
+    elif bias_rows is not None:                       # [B][N]: one row per image, broadcast over its Ho*Wo positions
+        res2, res_div = bias_rows.contiguous(), M // B
+    y = gemm_wxa8(codes, rowsum, M, ab, x.dtype, extra=make_extra(res2, res_div=res_div))
     Ho = (H + 2 * pad - kh) // stride + 1
     Wo = (W + 2 * pad - kw) // stride + 1
     return y.view(B, Ho, Wo, ab.pw.N).permute(0, 3, 1, 2)

@@ -29,7 +29,7 @@ import os as _os
 # blocks).  While the GEMM grids under-fill the chip, moving elementwise work from full-width kernels into them does not
 # pay, so these three are OFF by default (bit-identical results either way, tests/test_gpu_unet.py::test_fused_equals_unfused
 # runs with them on); SiLU(temb) and GroupNorm+SiLU folding (-2.5 ms) stay on.
-_F_RES = _os.environ.get("DGQ_FUSE_RESIDUAL", "0") == "1"
+_F_RES = _os.environ.get("DGQ_FUSE_RESIDUAL", "1") == "1"
 _F_FQ = _os.environ.get("DGQ_FUSE_FQ", "0") == "1"
 _F_GEGLU = _os.environ.get("DGQ_FUSE_GEGLU", "0") == "1"
 _F_SILU = _os.environ.get("DGQ_FUSE_SILU", "1") == "1"
@@ -69,24 +69,27 @@ class QuantResnetBlock2D(BaseQuantBlock):
         self.nonlinearity = resnet.nonlinearity
         self.conv_shortcut = resnet.conv_shortcut
 
-    def _norm_act_conv(self, norm, conv, x, residual=None):
+    def _norm_act_conv(self, norm, conv, x, residual=None, bias_rows=None):
+        """conv(SiLU(norm(x))) + residual (same shape) or + bias_rows[:, :, None, None] ([B, C_out])"""
         if FUSION and FUSE_NORM and isinstance(conv, QuantLayer) and isinstance(norm, nn.GroupNorm) and conv.can_fuse_prenorm(x):
-            if _F_RES or residual is None:
-                return conv.forward_prenorm(x, norm, silu=True, residual=residual)
-            return residual + conv.forward_prenorm(x, norm, silu=True)
-        h = F.silu(norm(x))
-        if residual is not None and FUSION and _F_RES and isinstance(conv, QuantLayer):
-            return conv.forward_residual(h, residual)
-        y = conv(h)
+            if _F_RES:
+                return conv.forward_prenorm(x, norm, silu=True, residual=residual, bias_rows=bias_rows)
+            y = conv.forward_prenorm(x, norm, silu=True)
+        else:
+            h = F.silu(norm(x))
+            if residual is not None and FUSION and _F_RES and isinstance(conv, QuantLayer):
+                return conv.forward_residual(h, residual)
+            y = conv(h)
+        if bias_rows is not None:
+            y = y + bias_rows[:, :, None, None]
         return y if residual is None else residual + y
 
     def forward(self, input_tensor, temb):
-        h = self._norm_act_conv(self.norm1, self.conv1, input_tensor)
         if FUSION and _F_SILU and isinstance(self.time_emb_proj, QuantLayer):
             te = self.time_emb_proj.forward_fused(temb, pre_act=1)            # SiLU(temb) folded into the load
         else:
             te = self.time_emb_proj(F.silu(temb))
-        h = h + te[:, :, None, None]
+        h = self._norm_act_conv(self.norm1, self.conv1, input_tensor, bias_rows=te)   # + temb in conv1's epilogue
         sc = self.conv_shortcut(input_tensor) if self.conv_shortcut is not None else input_tensor
         return self._norm_act_conv(self.norm2, self.conv2, h, residual=sc)     # shortcut + conv2(...) in the epilogue
 
@@ -196,7 +199,10 @@ class QuantBasicTransformerBlock(BaseQuantBlock):
             if _F_GEGLU and isinstance(net[2], QuantLayer):
                 return net[2].forward_fused(h, pre_act=2, residual=x)   # a·gelu(g) happens in ff.net.2's load
             a, g = h.chunk(2, dim=-1)
-            return x + net[2](net[1](a * F.gelu(g)))
+            h2 = net[1](a * F.gelu(g))
+            if _F_RES and isinstance(net[2], QuantLayer):
+                return net[2].forward_fused(h2, residual=x)             # x + ff(x) in the epilogue
+            return x + net[2](h2)
         return x + self.ff(self.norm3(x))
 
 

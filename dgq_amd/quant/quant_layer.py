@@ -376,13 +376,13 @@ class QuantLayer(nn.Module):
                 and x.dtype == torch.float32
                 and (self.aqtizer.init or (self._slot_ref is not None and self._slot_ref.slot in self._act_tables)))
 
-    def forward_prenorm(self, x: torch.Tensor, norm: nn.GroupNorm, silu: bool = True, residual=None) -> torch.Tensor:
-        """conv(act(GroupNorm(x))) [+ residual] without materialising the normalised tensor."""
+    def forward_prenorm(self, x: torch.Tensor, norm: nn.GroupNorm, silu: bool = True, residual=None, bias_rows=None) -> torch.Tensor:
+        """conv(act(GroupNorm(x))) [+ residual | + bias_rows[b, :, None, None]] without materialising the normalised tensor."""
         ab = self._binding()
         kh, kw = self.w.shape[2], self.w.shape[3]
         return ops.quant_conv2d(x, ab, kh, kw, self.fwd_kwargs["stride"][0], self.fwd_kwargs["padding"][0],
                                 norm=(norm.num_groups, norm.eps, norm.weight.data, norm.bias.data, 1 if silu else 0),
-                                residual=residual)
+                                residual=residual, bias_rows=bias_rows)
 
     def forward_residual(self, x: torch.Tensor, residual) -> torch.Tensor:
         """conv(x) + residual with the add in the GEMM epilogue (integer path), else unfused."""

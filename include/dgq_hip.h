@@ -112,11 +112,13 @@ int dgq_groupnorm_scale_shift(const void* x, int x_dtype, int B, int HW, int C, 
  *   fq_mode != 0 : the attention-side quantizer of the projection output, aqtizer_{q,k,v} (sd.py:174-182,199):
  *                  y = δ·(clamp(rne(y/δ)+z, 0, fq_qmax) − z) with (δ,z) = table[0] (mode 1), table[(m % fq_T) − fq_skip]
  *                  (mode 2, per token; tokens < fq_skip bypass: start_peak) or table[n % fq_D] (mode 3, per head-dim);
- *   residual     : y += residual[m·ldr + n]  (x + attn(x), x + ff(x), shortcut + conv2(...) of the Quant blocks,
- *                  quant_block.py:98-119,165-186) — fp32, may alias nothing written by this call. */
+ *   residual     : y += residual[(m / res_div)·ldr + n]  (x + attn(x), x + ff(x), shortcut + conv2(...) of the Quant
+ *                  blocks, quant_block.py:98-119,165-186; res_div = Ho·Wo broadcasts one row per image: conv1(...) +
+ *                  time_emb_proj(...)[:, :, None, None]) — fp32, may alias nothing written by this call; res_div >= 1. */
 typedef struct dgq_gemm_extra {
     const float* residual;
     int ldr;
+    int res_div;
     int fq_mode;
     const float* fq_delta;
     const float* fq_zp;
