@@ -24,14 +24,16 @@ FUSION = True
 #: GroupNorm folding rounds differently from F.group_norm (x·(rstd·γ) + (β − mean·rstd·γ)); separate switch for tests.
 FUSE_NORM = True
 import os as _os
-# Measured on the SD1.4 step (MI355X, bench.py, ms/step): everything unfused 20.6; + residual-in-epilogue +0.3; + GEGLU-in-
-# load +0.3; + aqtizer_{q,k,v}-in-epilogue +1.1 (exact fp32 division per output element inside GEMM grids of 40-192
-# blocks).  While the GEMM grids under-fill the chip, moving elementwise work from full-width kernels into them does not
-# pay, so these three are OFF by default (bit-identical results either way, tests/test_gpu_unet.py::test_fused_equals_unfused
-# runs with them on); SiLU(temb) and GroupNorm+SiLU folding (-2.5 ms) stay on.
+# Kernel-level fusions, each measured A/B on one MI355X box with bench.py (SD1.4 step, all bit-identical to the unfused
+# sequence, tests/test_gpu_unet.py::test_fused_equals_unfused):
+#   residual / temb-broadcast adds in the GEMM epilogue (residual tile prefetched as 16-byte loads)   +3.3 %
+#   GEGLU a·gelu(g) inside ff.net.2's quantise-on-load pass                                           +1.5 %
+#   SiLU(temb), GroupNorm(+SiLU), LayerNorm folded into the load pass                                 (see FUSE_NORM)
+#   aqtizer_{q,k,v} in the attention pre-pass                                                         +0.3 %
+#   aqtizer_{q,k,v} in the projection GEMM's epilogue (exact division per output inside under-filled grids)  slower: off
 _F_RES = _os.environ.get("DGQ_FUSE_RESIDUAL", "1") == "1"
 _F_FQ = _os.environ.get("DGQ_FUSE_FQ", "0") == "1"
-_F_GEGLU = _os.environ.get("DGQ_FUSE_GEGLU", "0") == "1"
+_F_GEGLU = _os.environ.get("DGQ_FUSE_GEGLU", "1") == "1"
 _F_SILU = _os.environ.get("DGQ_FUSE_SILU", "1") == "1"
 # aqtizer_{q,k,v} applied inside the attention pre-pass (K/V while they are split into bf16 planes, Q into a scratch
 # copy by extra blocks of the same launch): three launches per attention saved, nothing added to a GEMM grid (-0.16 ms)

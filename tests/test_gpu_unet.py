@@ -259,7 +259,7 @@ def test_fused_equals_unfused(tmp_path_factory):
         with torch.no_grad():
             outs[name] = qnn(inp["sample"].cuda(), torch.tensor(999), inp["encoder_hidden_states"].cuda())[0].float().cpu()
     quant_block.FUSION, quant_block.FUSE_NORM = True, True
-    quant_block._F_RES = quant_block._F_FQ = quant_block._F_GEGLU = False                         # shipped defaults
+    quant_block._F_FQ = False                                                                    # shipped default
     e1 = rel_l2(outs["no_norm"], outs["none"])
     e2 = rel_l2(outs["all"], outs["none"])
     print("fused (without GN folding) vs unfused: rel-L2 %.3g ; with GN folding: %.3g" % (e1, e2))
