@@ -19,7 +19,7 @@ SIGNATURES = {
     "dgq_pack_w8": [_vp, _i, _i, _vp, _i, _vp, _vp],
     "dgq_quant_act": [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _i,
                       _vp, _vp, _i, _vp, _vp, _f, _vp],
-    "dgq_groupnorm_scale_shift": [_vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _i, _vp],
+    "dgq_groupnorm_scale_shift": [_vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp],
     "dgq_quant_act_parts": [_i, _i],
     "dgq_gemm_wxa8": [_vp, _vp, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _vp, _i, _i,
                       _vp, ctypes.c_size_t, _vp, _vp],

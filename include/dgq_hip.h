@@ -94,10 +94,13 @@ int dgq_quant_act_parts(int Kp, int ksplits);
 
 /* GroupNorm of a channels-last tensor x [B][HW][C] as per-(b,c) scale/shift (biased variance, eps as F.group_norm):
  * GN(x) = x·scale + shift.  Replaces norm1/norm2 of QuantResnetBlock2D.forward (quant_block.py:98-119) together with
- * the SiLU that follows, which dgq_quant_act applies while loading.  partial_ws: B·G·slices·3 floats. */
+ * the SiLU that follows, which dgq_quant_act applies while loading.  partial_ws: B·G·slices·3 floats.
+ * counters (optional): B·G zero-initialised uint32 owned by the caller; with it the statistic is ONE launch — the block
+ * that arrives last at a (batch, group) merges the slices in slice order and leaves its counter at zero again — otherwise
+ * a second merge kernel is launched.  Results are identical either way. */
 int dgq_groupnorm_scale_shift(const void* x, int x_dtype, int B, int HW, int C, int G, float eps,
                               const float* gamma, const float* beta, float* scale, float* shift,
-                              float* partial_ws, int slices, void* stream);
+                              float* partial_ws, int slices, unsigned* counters, void* stream);
 
 /* ---- the hot kernel: W4A8 / W8A8 MFMA GEMM with fused dequantisation ------------------------------
  * Replaces F.linear / `w.view(N,-1) @ unfolded` / F.conv2d on fake-quantised operands
