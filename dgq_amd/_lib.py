@@ -28,6 +28,7 @@ SIGNATURES = {
     "dgq_max_f32": [_vp, _i64, _i, _i, _vp, _vp],
     "dgq_logquant_f32": [_vp, _vp, _i64, _i, _i, _vp, _i, _vp],
     "dgq_attention_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _vp, _i, _vp, _vp, ctypes.c_size_t, _vp],
+    "dgq_attention": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _i, _vp, _i, _vp, _vp, ctypes.c_size_t, _vp],
     "dgq_attention_fuses_fakequant": [_i, _i],
     "dgq_attention_workspace_bytes": [_i, _i, _i, _i, _i],
 }
@@ -36,7 +37,7 @@ SIGNATURES = {
 
 class GemmExtra(ctypes.Structure):
     """dgq_gemm_extra_t of include/dgq_hip.h"""
-    _fields_ = [("residual", _vp), ("ldr", _i), ("res_div", _i), ("fq_mode", _i), ("fq_delta", _vp), ("fq_zp", _vp),
+    _fields_ = [("residual", _vp), ("ldr", _i), ("res_div", _i), ("res_dtype", _i), ("fq_mode", _i), ("fq_delta", _vp), ("fq_zp", _vp),
                 ("fq_T", _i), ("fq_D", _i), ("fq_skip", _i), ("fq_qmax", _f)]
 
 

@@ -61,10 +61,11 @@ __device__ __forceinline__ void fq_apply8(const FqDesc& f, float (&x)[8], int t,
 
 struct AttnParams {
     FqDesc fq[3];          // q, k, v
-    const float* q;
-    const float* k;
-    const float* v;
-    float* o;
+    const float* q;        // fp32 queries: the caller's tensor, or the scratch copy written by the pre-pass
+    const void* k;         // k / v / o in the caller's dtype (io_dtype)
+    const void* v;
+    void* o;
+    int io_dtype;
     int B, H, T, S;
     float scale;
     int mode;              // 1: log2 real-time δ, 2: log2 static δ, 3: uniform (δ, z = 0)
@@ -88,6 +89,34 @@ __device__ __forceinline__ void split3(float x, unsigned short& h, unsigned shor
     m = bf16_bits(r1);
     const float r2 = r1 - bf16_to_f(m);
     l = bf16_bits(r2);
+}
+
+template <typename TIn> __device__ __forceinline__ void load8(const TIn* p, float (&x)[8]);
+template <> __device__ __forceinline__ void load8<float>(const float* p, float (&x)[8]) {
+    const float4 a = *reinterpret_cast<const float4*>(p), c = *reinterpret_cast<const float4*>(p + 4);
+    x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = c.x; x[5] = c.y; x[6] = c.z; x[7] = c.w;
+}
+template <> __device__ __forceinline__ void load8<__half>(const __half* p, float (&x)[8]) {
+    const uint4 t = *reinterpret_cast<const uint4*>(p);
+    const __half* h = reinterpret_cast<const __half*>(&t);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] = __half2float(h[j]);
+}
+template <> __device__ __forceinline__ void load8<__hip_bfloat16>(const __hip_bfloat16* p, float (&x)[8]) {
+    const uint4 t = *reinterpret_cast<const uint4*>(p);
+    const unsigned short* h = reinterpret_cast<const unsigned short*>(&t);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] = __uint_as_float(((unsigned)h[j]) << 16);
+}
+__device__ __forceinline__ float load_any(const void* p, int dtype, int64_t i) {
+    if (dtype == DGQ_F16) return __half2float(reinterpret_cast<const __half*>(p)[i]);
+    if (dtype == DGQ_BF16) return __bfloat162float(reinterpret_cast<const __hip_bfloat16*>(p)[i]);
+    return reinterpret_cast<const float*>(p)[i];
+}
+__device__ __forceinline__ void store_any(void* p, int dtype, int64_t i, float v) {
+    if (dtype == DGQ_F16) reinterpret_cast<__half*>(p)[i] = __float2half(v);
+    else if (dtype == DGQ_BF16) reinterpret_cast<__hip_bfloat16*>(p)[i] = __float2bfloat16(v);
+    else reinterpret_cast<float*>(p)[i] = v;
 }
 
 template <int D> struct Geo {
@@ -146,11 +175,11 @@ __device__ __forceinline__ void wait_image(int wid) {
 // as the per-tile LDS images described above.  V is stored transposed with the keys of a tile permuted into the k
 // order of an accumulator tile used as the next MFMA's B operand: key 16s + 8a + 4h + b -> slot 16s + 8h + 4a + b.
 // Every Q block of a (batch, head) re-reads these images; splitting inside the main loop cost more than the MFMAs.
-template <int D>
-__global__ __launch_bounds__(256) void attn3_prep_kernel(const float* __restrict__ k, const float* __restrict__ v,
+template <int D, typename TIn>
+__global__ __launch_bounds__(256) void attn3_prep_kernel(const TIn* __restrict__ k, const TIn* __restrict__ v,
                                                          unsigned char* __restrict__ planes, int B, int H, int S, int NT,
                                                          FqDesc fk, FqDesc fv, float* __restrict__ delta_reset,
-                                                         const float* __restrict__ q, float* __restrict__ qfq, int T, FqDesc fqq) {
+                                                         const TIn* __restrict__ q, float* __restrict__ qfq, int T, FqDesc fqq) {
     using G = Geo<D>;
     static_assert(D % 8 == 0, "head_dim must be a multiple of 8");
     const int bh = blockIdx.y, b = bh / H, hd = bh - b * H;
@@ -164,8 +193,8 @@ __global__ __launch_bounds__(256) void attn3_prep_kernel(const float* __restrict
             const int t = t0 + r;
             if (t >= T) continue;
             const int64_t o = ((int64_t)(b * T + t) * H + hd) * D + 8 * c8;
-            const float4 a = *reinterpret_cast<const float4*>(q + o), c = *reinterpret_cast<const float4*>(q + o + 4);
-            float x[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+            float x[8];
+            load8<TIn>(q + o, x);
             fq_apply8(fqq, x, t, 8 * c8);
             *reinterpret_cast<float4*>(qfq + o) = make_float4(x[0], x[1], x[2], x[3]);
             *reinterpret_cast<float4*>(qfq + o + 4) = make_float4(x[4], x[5], x[6], x[7]);
@@ -174,8 +203,8 @@ __global__ __launch_bounds__(256) void attn3_prep_kernel(const float* __restrict
     }
     const int s0 = blockIdx.x * KT;
     if (delta_reset && blockIdx.x == 0 && bh == 0 && threadIdx.x == 0) *delta_reset = 0.0f;   // real-time δ: max starts at 0
-    const float* kbase = k + ((int64_t)(b * S) * H + hd) * D;
-    const float* vbase = v + ((int64_t)(b * S) * H + hd) * D;
+    const TIn* kbase = k + ((int64_t)(b * S) * H + hd) * D;
+    const TIn* vbase = v + ((int64_t)(b * S) * H + hd) * D;
     const int64_t HD = (int64_t)H * D;
     unsigned short* kimg = reinterpret_cast<unsigned short*>(planes + ((int64_t)bh * NT + blockIdx.x) * G::IMG_BYTES);
     unsigned short* vimg = kimg + G::K_ELEMS;
@@ -187,9 +216,7 @@ __global__ __launch_bounds__(256) void attn3_prep_kernel(const float* __restrict
         const bool live = sidx < S && 8 * c8 < D;
         float x[8];
         if (live) {
-            const float4 a = *reinterpret_cast<const float4*>(kbase + sidx * HD + 8 * c8);
-            const float4 c = *reinterpret_cast<const float4*>(kbase + sidx * HD + 8 * c8 + 4);
-            x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = c.x; x[5] = c.y; x[6] = c.z; x[7] = c.w;
+            load8<TIn>(kbase + sidx * HD + 8 * c8, x);
             fq_apply8(fk, x, sidx, 8 * c8);
         }
 #pragma unroll
@@ -220,7 +247,7 @@ __global__ __launch_bounds__(256) void attn3_prep_kernel(const float* __restrict
                 const int slot8 = 2 * j + e;                               // slot within the chunk = 4a + b
                 const int key = 16 * (c8 >> 1) + 8 * (slot8 >> 2) + 4 * (c8 & 1) + (slot8 & 3);
                 const int sidx = s0 + key;
-                if (c8 < 4 && sidx < S && d < D) split3(fq_apply(fv, vbase[sidx * HD + d], sidx, d), hh[e], mm[e], ll[e]);
+                if (c8 < 4 && sidx < S && d < D) split3(fq_apply(fv, dgq_to_float(vbase[sidx * HD + d]), sidx, d), hh[e], mm[e], ll[e]);
             }
             wh[j] = (unsigned)hh[0] | ((unsigned)hh[1] << 16);
             wm[j] = (unsigned)mm[0] | ((unsigned)mm[1] << 16);
@@ -479,8 +506,8 @@ __global__ __launch_bounds__(256) void attn3_pv_kernel(AttnParams p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // no DMA may outlive the block's LDS allocation
     if (p.skip > 0) p_bypass = __shfl(p_bypass, lane & 31, 64);   // key 0 lives in the lower half-wave
     if (t < p.T) {
-        float* op = p.o + ((int64_t)(b * p.T + t) * p.H + hd) * D;
-        const float* v0 = p.v + ((int64_t)(b * p.S) * p.H + hd) * D;
+        const int64_t ob = ((int64_t)(b * p.T + t) * p.H + hd) * D;
+        const int64_t vb = ((int64_t)(b * p.S) * p.H + hd) * D;
 #pragma unroll
         for (int j = 0; j < G::NDT; ++j)
 #pragma unroll
@@ -488,15 +515,15 @@ __global__ __launch_bounds__(256) void attn3_pv_kernel(AttnParams p) {
                 const int d = j * 32 + key_of(r, h32);
                 if (d < D) {
                     float o = delta * oacc[j][r];
-                    if (p.skip > 0) o += p_bypass * fq_apply(p.fq[2], v0[d], 0, d);
-                    op[d] = o;
+                    if (p.skip > 0) o += p_bypass * fq_apply(p.fq[2], load_any(p.v, p.io_dtype, vb + d), 0, d);
+                    store_any(p.o, p.io_dtype, ob + d, o);
                 }
             }
     }
 }
 
 template <int D>
-static int launch_attn3(AttnParams p, unsigned char* planes, float* qfq, hipStream_t st) {
+static int launch_attn3(AttnParams p, const void* q_raw, unsigned char* planes, float* qfq, hipStream_t st) {
     using G = Geo<D>;
     p.planes = planes;
     constexpr int stats_lds = G::STATS_STAGES * G::K_PIECES * 1024;
@@ -509,13 +536,22 @@ static int launch_attn3(AttnParams p, unsigned char* planes, float* qfq, hipStre
         return true;
     }();
     (void)lds_ok;
-    const bool q_copy = p.fq[0].mode >= 0 && qfq != nullptr;
-    hipLaunchKernelGGL((attn3_prep_kernel<D>), dim3(p.NT + (q_copy ? (p.T + 31) / 32 : 0), p.B * p.H), dim3(256), 0, st, p.k,
-                       p.v, planes, p.B, p.H, p.S, p.NT, p.fq[1], p.fq[2], p.mode == 1 ? p.delta : nullptr, p.q, qfq, p.T,
-                       p.fq[0]);
+    // the main kernels read fp32 queries: the caller's tensor when it is fp32 and aqtizer_q is not fused, else a scratch
+    // copy (converted / fake-quantised) written by extra blocks of the pre-pass
+    const bool q_copy = (p.fq[0].mode >= 0 || p.io_dtype != DGQ_F32) && qfq != nullptr;
+    const dim3 pgrid(p.NT + (q_copy ? (p.T + 31) / 32 : 0), p.B * p.H);
+    float* dreset = p.mode == 1 ? p.delta : nullptr;
+#define DGQ_PREP(TT) hipLaunchKernelGGL((attn3_prep_kernel<D, TT>), pgrid, dim3(256), 0, st, (const TT*)p.k, (const TT*)p.v, planes, \
+                                        p.B, p.H, p.S, p.NT, p.fq[1], p.fq[2], dreset, (const TT*)q_raw, qfq, p.T, p.fq[0])
+    if (p.io_dtype == DGQ_F16) DGQ_PREP(__half);
+    else if (p.io_dtype == DGQ_BF16) DGQ_PREP(__hip_bfloat16);
+    else DGQ_PREP(float);
+#undef DGQ_PREP
     if (q_copy) {
         p.q = qfq;
         p.fq[0].mode = -1;
+    } else {
+        p.q = reinterpret_cast<const float*>(q_raw);
     }
     dim3 grid((p.T + QROWS - 1) / QROWS, p.B * p.H), block(256);
     hipLaunchKernelGGL((attn3_stats_kernel<D>), grid, block, stats_lds, st, p);
@@ -541,7 +577,7 @@ size_t dgq_attention_bf16x3_bytes(int B, int H, int S, int D) {
 }
 
 // called from dgq_attention_f32 (attn_fused.hip) for the quantised modes; returns 1 when D is not instantiated here
-int dgq_attention_bf16x3(const float* q, const float* k, const float* v, float* o, int B, int H, int T, int S, int D,
+int dgq_attention_bf16x3(const void* q, const void* k, const void* v, void* o, int io_dtype, int B, int H, int T, int S, int D,
                          float scale, int mode, int skip, float qmax, float* stats_ws, float* delta_ws, void* planes,
                          float* qfq, const dgq_attn_fq_t* fq, hipStream_t st) {
     AttnParams p;
@@ -552,17 +588,18 @@ int dgq_attention_bf16x3(const float* q, const float* k, const float* v, float* 
             p.fq[i].delta = fq[i].delta; p.fq[i].zp = fq[i].zero_point;
         }
     }
-    p.q = q; p.k = k; p.v = v; p.o = o; p.B = B; p.H = H; p.T = T; p.S = S; p.scale = scale; p.mode = mode; p.skip = skip;
+    p.q = nullptr; p.k = k; p.v = v; p.o = o; p.io_dtype = io_dtype; p.B = B; p.H = H; p.T = T; p.S = S; p.scale = scale;
+    p.mode = mode; p.skip = skip;
     p.qmax = qmax; p.stats = stats_ws; p.delta = delta_ws;
     p.NT = (S + KT - 1) / KT;
     unsigned char* img = reinterpret_cast<unsigned char*>(planes);
     switch (D) {
-        case 8: return launch_attn3<8>(p, img, qfq, st);
-        case 16: return launch_attn3<16>(p, img, qfq, st);
-        case 40: return launch_attn3<40>(p, img, qfq, st);
-        case 64: return launch_attn3<64>(p, img, qfq, st);
-        case 80: return launch_attn3<80>(p, img, qfq, st);
-        case 160: return launch_attn3<160>(p, img, qfq, st);
+        case 8: return launch_attn3<8>(p, q, img, qfq, st);
+        case 16: return launch_attn3<16>(p, q, img, qfq, st);
+        case 40: return launch_attn3<40>(p, q, img, qfq, st);
+        case 64: return launch_attn3<64>(p, q, img, qfq, st);
+        case 80: return launch_attn3<80>(p, q, img, qfq, st);
+        case 160: return launch_attn3<160>(p, q, img, qfq, st);
         default: return 1;
     }
 }

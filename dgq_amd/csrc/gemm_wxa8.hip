@@ -79,7 +79,12 @@ __device__ __forceinline__ float dgq_extra(const dgq_gemm_extra_t& ex, float y, 
             y = d * (dgq_affine_code(y, d, z, ex.fq_qmax) - z);
         }
     }
-    if (ex.residual) y += ex.residual[(int64_t)(m / ex.res_div) * ex.ldr + n];
+    if (ex.residual) {
+        const int64_t i = (int64_t)(m / ex.res_div) * ex.ldr + n;
+        if (ex.res_dtype == DGQ_F16) y += __half2float(reinterpret_cast<const __half*>(ex.residual)[i]);
+        else if (ex.res_dtype == DGQ_BF16) y += __bfloat162float(reinterpret_cast<const __hip_bfloat16*>(ex.residual)[i]);
+        else y += reinterpret_cast<const float*>(ex.residual)[i];
+    }
     return y;
 }
 
@@ -354,14 +359,27 @@ __global__ __launch_bounds__(256, (STAGES <= 3 ? 2 : 1)) void gemm_wxa8_kernel(G
                         ((reinterpret_cast<uintptr_t>(p.y) & 15) == 0) && (sizeof(TOut) == 4 || (p.ldy & 3) == 0);
     // residual tile: all 16 rows of this lane fetched up front as 16-byte loads, so the epilogue pays one memory latency
     // (fetched row by row inside the store loop, the dependent loads made the fused add slower than a separate kernel)
+    const int res_es = p.ex.res_dtype == DGQ_F32 ? 4 : 2;
     const bool res_vec = p.ex.residual != nullptr && vec_ok && (p.ex.ldr & 3) == 0 &&
-                         (reinterpret_cast<uintptr_t>(p.ex.residual) & 15) == 0;
+                         (reinterpret_cast<uintptr_t>(p.ex.residual) & (4 * res_es - 1)) == 0;
     float4 res[16];
     if (res_vec) {
 #pragma unroll
         for (int rr = 0; rr < 16; ++rr) {
             const int m = min(m0 + wave_m * 64 + rr * 4 + (lane >> 4), p.M - 1);
-            res[rr] = *reinterpret_cast<const float4*>(p.ex.residual + (int64_t)(m / p.ex.res_div) * p.ex.ldr + nb);
+            const int64_t i = (int64_t)(m / p.ex.res_div) * p.ex.ldr + nb;
+            if (p.ex.res_dtype == DGQ_F32) {
+                res[rr] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.ex.residual) + i);
+            } else {
+                const uint2 t = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(p.ex.residual) + i);
+                if (p.ex.res_dtype == DGQ_F16) {
+                    const __half* h = reinterpret_cast<const __half*>(&t);
+                    res[rr] = make_float4(__half2float(h[0]), __half2float(h[1]), __half2float(h[2]), __half2float(h[3]));
+                } else {
+                    res[rr] = make_float4(__uint_as_float(t.x << 16), __uint_as_float(t.x & 0xFFFF0000u),
+                                          __uint_as_float(t.y << 16), __uint_as_float(t.y & 0xFFFF0000u));
+                }
+            }
         }
     }
     dgq_gemm_extra_t exl = p.ex;
@@ -532,9 +550,10 @@ extern "C" int dgq_gemm_wxa8(const int8_t* codes, const float* rowsum, int rowsu
         p.ex = *extra;
         DGQ_CHECK_ARG(p.ex.fq_mode >= 0 && p.ex.fq_mode <= 3, "dgq_gemm_wxa8: bad fq_mode");
         DGQ_CHECK_ARG(p.ex.fq_mode == 0 || (p.ex.fq_delta && p.ex.fq_zp && p.ex.fq_T > 0 && p.ex.fq_D > 0), "dgq_gemm_wxa8: fused quantizer needs tables");
-        DGQ_CHECK_ARG(!p.ex.residual || (p.ex.ldr >= N && p.ex.res_div >= 1), "dgq_gemm_wxa8: ldr < N or res_div < 1");
+        DGQ_CHECK_ARG(!p.ex.residual || (p.ex.ldr >= N && p.ex.res_div >= 1 && p.ex.res_dtype >= DGQ_F32 && p.ex.res_dtype <= DGQ_BF16),
+                      "dgq_gemm_wxa8: bad residual descriptor (ldr < N, res_div < 1 or unknown dtype)");
     } else {
-        p.ex.residual = nullptr; p.ex.ldr = 0; p.ex.res_div = 1; p.ex.fq_mode = 0; p.ex.fq_delta = nullptr; p.ex.fq_zp = nullptr;
+        p.ex.residual = nullptr; p.ex.ldr = 0; p.ex.res_div = 1; p.ex.res_dtype = DGQ_F32; p.ex.fq_mode = 0; p.ex.fq_delta = nullptr; p.ex.fq_zp = nullptr;
         p.ex.fq_T = 1; p.ex.fq_D = 1; p.ex.fq_skip = 0; p.ex.fq_qmax = 255.0f;
     }
     p.splits = workspace ? choose_splits(M, N, Kp, workspace_bytes) : 1;

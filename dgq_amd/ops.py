@@ -147,6 +147,25 @@ def act_ksplits(M, Kp):
     return _lib.load().dgq_quant_act_parts(Kp, ks)
 
 
+FLOAT_DTYPES = (torch.float32, torch.float16, torch.bfloat16)
+_F32_CACHE = {}
+
+
+def as_f32(t: torch.Tensor) -> torch.Tensor:
+    """fp32 view of a small parameter vector (norm γ/β ...) of a model that was cast with .half(): the kernels take
+    their per-channel vectors in fp32.  Cached per (storage, version)."""
+    if t.dtype == torch.float32:
+        return t
+    key = (t.data_ptr(), t._version, t.dtype, tuple(t.shape))
+    hit = _F32_CACHE.get(key)
+    if hit is None:
+        if len(_F32_CACHE) > 4096:
+            _F32_CACHE.clear()
+        hit = t.detach().float().contiguous()
+        _F32_CACHE[key] = hit
+    return hit
+
+
 #: one launch per GroupNorm statistic (last-arriving block merges the slices) instead of partial + merge kernels.
 #: Measured: 63.5 -> 57.8 steps/s — the agent-scope release/acquire each of the ~2000 blocks needs (the per-XCD L2s are
 #: not coherent) writes back / invalidates L2 every time and costs far more than the 6 us merge launch.  OFF.
@@ -178,8 +197,8 @@ def groupnorm_scale_shift(x_cl: torch.Tensor, B, HW, C, groups, eps, gamma, beta
     part = torch.empty((B * groups * slices * 3,), dtype=torch.float32, device=dev)
     counters = _gn_counters(dev, B * groups) if (GN_SINGLE_LAUNCH and slices > 1) else None
     _lib_call("dgq_groupnorm_scale_shift", _lib.ptr(x_cl), _lib.DTYPE_CODE[x_cl.dtype], B, HW, C, groups,
-              _c.c_float(eps), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(part),
-              slices, _lib.ptr(counters), _lib.stream())
+              _c.c_float(eps), _lib.ptr(as_f32(gamma)), _lib.ptr(as_f32(beta)), _lib.ptr(scale), _lib.ptr(shift),
+              _lib.ptr(part), slices, _lib.ptr(counters), _lib.stream())
     return scale, shift
 
 
@@ -203,7 +222,8 @@ def quant_act(x_cl: torch.Tensor, B, H, W, C, kh, kw, stride, pad, ab: ActBindin
               _lib.ptr(codes), _lib.ptr(rowsum), parts,
               _lib.ptr(pre[0]) if pre and pre[0] is not None else None,
               _lib.ptr(pre[1]) if pre and pre[1] is not None else None, pre[2] if pre else 0,
-              _lib.ptr(ln[0]) if ln else None, _lib.ptr(ln[1]) if ln else None, _c.c_float(ln[2] if ln else 0.0),
+              _lib.ptr(as_f32(ln[0])) if ln else None, _lib.ptr(as_f32(ln[1])) if ln else None,
+              _c.c_float(ln[2] if ln else 0.0),
               _lib.stream())
     return codes, rowsum, M
 
@@ -294,8 +314,9 @@ def make_extra(residual=None, fq=None, res_div=1):
     ex.res_div = 1
     keep = []
     if residual is not None:
-        assert residual.dtype == torch.float32 and residual.stride(-1) == 1
+        assert residual.dtype in _lib.DTYPE_CODE and residual.stride(-1) == 1
         ex.residual, ex.ldr, ex.res_div = residual.data_ptr(), residual.stride(0), res_div
+        ex.res_dtype = _lib.DTYPE_CODE[residual.dtype]
         keep.append(residual)
     if fq is not None:
         mode, delta, zp, T, D, skip, bits = fq
@@ -408,11 +429,12 @@ def attention_fuses_fakequant(D, mode):
     return bool(_lib.load().dgq_attention_fuses_fakequant(D, mode))
 
 
-def attention_f32(q, k, v, H, D, scale, mode, skip, delta, bits, fq=None):
-    """q [B,T,H*D], k/v [B,S,H*D] fp32 contiguous -> o [B,T,H*D]; see dgq_attention_f32.
+def attention(q, k, v, H, D, scale, mode, skip, delta, bits, fq=None):
+    """q [B,T,H*D], k/v [B,S,H*D] contiguous (fp32; fp16 / bf16 in the quantised modes) -> o [B,T,H*D]; see dgq_attention.
     fq: optional 3-tuple for q, k, v of None | (mode, delta, zp, skip, bits) — the aqtizer_q/k/v quantizers applied on
     load (only where ``attention_fuses_fakequant(D, mode)``)."""
-    assert q.dtype == torch.float32 and q.is_contiguous() and k.is_contiguous() and v.is_contiguous()
+    assert q.dtype in _lib.DTYPE_CODE and k.dtype == q.dtype and v.dtype == q.dtype
+    assert q.is_contiguous() and k.is_contiguous() and v.is_contiguous()
     B, T, _ = q.shape
     S = k.shape[1]
     o = torch.empty_like(q)
@@ -432,7 +454,10 @@ def attention_f32(q, k, v, H, D, scale, mode, skip, delta, bits, fq=None):
                 "q/k/v quantizer table has %d entries, kernel addresses %d" % (fd.numel(), need)
             desc[i].mode, desc[i].skip, desc[i].bits = fmode, fskip, fbits
             desc[i].delta, desc[i].zero_point = _lib.ptr(fd), _lib.ptr(fz)
-    _lib_call("dgq_attention_f32", _lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(o), B, H, T, S, D,
+    _lib_call("dgq_attention", _lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(o), _lib.DTYPE_CODE[q.dtype], B, H, T, S, D,
               _c.c_float(scale), mode, skip, _lib.ptr(delta), bits,
               _c.cast(desc, _c.c_void_p) if desc is not None else None, _lib.ptr(ws), nbytes, _lib.stream())
     return o
+
+
+attention_f32 = attention

@@ -140,7 +140,7 @@ def _fusable_ln(norm):
 
 
 def _prenorm(x, norm):
-    return PreLN(x, norm) if (_fusable_ln(norm) and x.is_cuda and x.dtype == torch.float32) else norm(x)
+    return PreLN(x, norm) if (_fusable_ln(norm) and x.is_cuda and x.dtype in ops.FLOAT_DTYPES) else norm(x)
 
 
 def _apply(layer, inp, **kw):
@@ -226,7 +226,7 @@ def quant_attention_forward(attn, hidden_states, encoder_hidden_states=None, res
     if use_aq:
         wq_ = attn.aqtizer_w
         mode_w = (1 if wq_.real_time else 2) if isinstance(wq_, T2ILogQuantizer) else 3
-    defer = (FUSION and _F_ATTN_FQ and use_aq and hidden_states.is_cuda and hidden_states.dtype == torch.float32
+    defer = (FUSION and _F_ATTN_FQ and use_aq and hidden_states.is_cuda and hidden_states.dtype in ops.FLOAT_DTYPES
              and D in ops.ATTN_HEAD_DIMS and (mode_w == 1 or attn.aqtizer_w.init)
              and ops.attention_fuses_fakequant(D, mode_w))
     pending = {}
@@ -240,7 +240,7 @@ def quant_attention_forward(attn, hidden_states, encoder_hidden_states=None, res
             pending[name] = (mode, dd, zz, skip, qz.bits)
             return _apply(layer, inp)
         if (FUSION and _F_FQ and qz is not None and qz.init and isinstance(layer, QuantLayer)
-                and layer.on_integer_path(inp.x if isinstance(inp, PreLN) else inp) and inp.dtype == torch.float32):
+                and layer.on_integer_path(inp.x if isinstance(inp, PreLN) else inp) and inp.dtype in ops.FLOAT_DTYPES):
             mode, dd, zz = _qparams(qz, inp.device)
             return _apply(layer, inp, fq=(mode + 1, dd, zz, ntok, D, skip, qz.bits))
         ten = _apply(layer, inp)
@@ -268,7 +268,9 @@ def quant_attention_forward(attn, hidden_states, encoder_hidden_states=None, res
         v = project(attn.to_v, "aqtizer_v", src, 0)
     b, t, c = q.shape
     s = k.shape[1]
-    if q.dtype == torch.float32 and D in ops.ATTN_HEAD_DIMS and q.is_cuda:
+    if (D in ops.ATTN_HEAD_DIMS and q.is_cuda and q.dtype == k.dtype == v.dtype
+            and (q.dtype == torch.float32
+                 or (q.dtype in ops.FLOAT_DTYPES and use_aq and ops.attention_fuses_fakequant(D, mode_w)))):
         # fused two-pass attention (dgq_attention_f32): probabilities are never materialised
         mode, delta, bits = 0, None, 8
         skip = 1 if (start_peak and use_aq) else 0
@@ -287,7 +289,7 @@ def quant_attention_forward(attn, hidden_states, encoder_hidden_states=None, res
                     _init_static_softmax_delta(attn, wq, q, k, b, t, s, H, D, skip)
                 mode, delta = 3, wq.delta.detach().reshape(1).float().to(q.device)
         fq = tuple(pending.get(n) for n in ("aqtizer_q", "aqtizer_k", "aqtizer_v")) if pending else None
-        o = ops.attention_f32(q.contiguous(), k.contiguous(), v.contiguous(), H, D, float(attn.scale), mode, skip,
+        o = ops.attention(q.contiguous(), k.contiguous(), v.contiguous(), H, D, float(attn.scale), mode, skip,
                               delta, bits, fq)
         return _attn_out(attn, o, residual)
     qh = q.view(b, t, H, D).transpose(1, 2)

@@ -350,11 +350,11 @@ class QuantLayer(nn.Module):
         attention-side quantizer, see ops.make_extra) and ``residual`` inside the GEMM epilogue.  Linear layers on the
         integer path only; anything else falls back to the unfused sequence of the same kernels/ops.  ``ln`` = an
         nn.LayerNorm module applied to x first, folded into the same load pass (per-row statistics in the kernel)."""
-        if ln is not None and (self.is_conv or not self.on_integer_path(x) or x.dtype != torch.float32 or pre_act
+        if ln is not None and (self.is_conv or not self.on_integer_path(x) or x.dtype not in ops.FLOAT_DTYPES or pre_act
                                or x.shape[-1] % 4 or x.shape[-1] > 2048):
             x = ln(x)                                           # nn.LayerNorm module: unfused
             ln = None
-        if self.is_conv or not self.on_integer_path(x) or x.dtype != torch.float32:
+        if self.is_conv or not self.on_integer_path(x) or x.dtype not in ops.FLOAT_DTYPES:
             if pre_act == 1:
                 x = F.silu(x)
             elif pre_act == 2:
@@ -373,7 +373,7 @@ class QuantLayer(nn.Module):
         """True when this layer runs on the integer path, so a preceding GroupNorm(+SiLU) can be folded into its
         quantise-on-load pass (dgq_groupnorm_scale_shift + dgq_quant_act prologue)."""
         return (self.is_conv and self.use_wq and self.use_aq and not self.disable_aq and x.is_cuda
-                and x.dtype == torch.float32
+                and x.dtype in ops.FLOAT_DTYPES
                 and (self.aqtizer.init or (self._slot_ref is not None and self._slot_ref.slot in self._act_tables)))
 
     def forward_prenorm(self, x: torch.Tensor, norm: nn.GroupNorm, silu: bool = True, residual=None, bias_rows=None) -> torch.Tensor:
@@ -386,7 +386,7 @@ class QuantLayer(nn.Module):
 
     def forward_residual(self, x: torch.Tensor, residual) -> torch.Tensor:
         """conv(x) + residual with the add in the GEMM epilogue (integer path), else unfused."""
-        if self.is_conv and self.on_integer_path(x) and x.dtype == torch.float32:
+        if self.is_conv and self.on_integer_path(x) and x.dtype in ops.FLOAT_DTYPES:
             kh, kw = self.w.shape[2], self.w.shape[3]
             return ops.quant_conv2d(x, self._binding(), kh, kw, self.fwd_kwargs["stride"][0],
                                     self.fwd_kwargs["padding"][0], residual=residual)

@@ -117,11 +117,13 @@ int dgq_groupnorm_scale_shift(const void* x, int x_dtype, int B, int HW, int C, 
  *                  (mode 2, per token; tokens < fq_skip bypass: start_peak) or table[n % fq_D] (mode 3, per head-dim);
  *   residual     : y += residual[(m / res_div)·ldr + n]  (x + attn(x), x + ff(x), shortcut + conv2(...) of the Quant
  *                  blocks, quant_block.py:98-119,165-186; res_div = Ho·Wo broadcasts one row per image: conv1(...) +
- *                  time_emb_proj(...)[:, :, None, None]) — fp32, may alias nothing written by this call; res_div >= 1. */
+ *                  time_emb_proj(...)[:, :, None, None]) — dtype res_dtype (DGQ_F32/F16/BF16; ldr in elements), may alias
+ *                  nothing written by this call; res_div >= 1. */
 typedef struct dgq_gemm_extra {
-    const float* residual;
+    const void* residual;
     int ldr;
     int res_div;
+    int res_dtype;
     int fq_mode;
     const float* fq_delta;
     const float* fq_zp;
@@ -183,6 +185,12 @@ typedef struct dgq_attn_fq {
 int dgq_attention_f32(const float* q, const float* k, const float* v, float* o, int B, int H, int T, int S, int D,
                       float scale, int mode, int skip, const float* delta_in, int bits, const dgq_attn_fq_t* fq,
                       void* workspace, size_t workspace_bytes, void* stream);
+/* The same for q/k/v/o of dtype DGQ_F32 / DGQ_F16 / DGQ_BF16 (the reference's --fp16 mode, quant_model.py:183-201):
+ * the arithmetic is unchanged (operands widened to fp32 and split exactly, fp32 accumulation), only the loads and the
+ * final store follow the tensors' dtype.  Half types are served where dgq_attention_fuses_fakequant(D, mode) is 1. */
+int dgq_attention(const void* q, const void* k, const void* v, void* o, int dtype, int B, int H, int T, int S, int D,
+                  float scale, int mode, int skip, const float* delta_in, int bits, const dgq_attn_fq_t* fq,
+                  void* workspace, size_t workspace_bytes, void* stream);
 int dgq_attention_fuses_fakequant(int D, int mode);
 size_t dgq_attention_workspace_bytes(int B, int H, int T, int S, int D);
 

@@ -378,3 +378,21 @@ def test_fused_layernorm_quant_codes(C, T, layout, dev):
     y_fus = ops.quant_linear(xg, ab, ln=(gamma.to(dev), beta.to(dev), 1e-5))
     torch.cuda.synchronize()
     assert rel_l2(y_fus.cpu(), y_ref.cpu()) < 2e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("D,T,S,H,mode,skip", [(40, 200, 200, 2, 1, 0), (80, 96, 77, 3, 1, 1), (160, 64, 77, 2, 3, 1)])
+def test_attention_half_io_equals_fp32_path(D, T, S, H, mode, skip, dtype, dev):
+    """dgq_attention on fp16 / bf16 tensors (the reference's --fp16 mode) == the fp32 entry point on the same values,
+    rounded once to the output dtype: only loads and the final store follow the tensor dtype."""
+    from dgq_amd import ops
+    g = torch.Generator().manual_seed(D + T)
+    B, bits = 2, 8
+    q, k, v = (torch.randn(B, n, H * D, generator=g).to(dev).to(dtype) for n in (T, S, S))
+    delta = torch.tensor([0.004], device=dev) if mode == 3 else None
+    fq = ((1, torch.full((T,), 0.03, device=dev), torch.full((T,), 128.0, device=dev), 0, bits), None, None)
+    o_h = ops.attention(q, k, v, H, D, D ** -0.5, mode, skip, delta, bits, fq=fq)
+    o_f = ops.attention(q.float(), k.float(), v.float(), H, D, D ** -0.5, mode, skip, delta, bits, fq=fq)
+    torch.cuda.synchronize()
+    assert o_h.dtype == dtype
+    assert torch.equal(o_h, o_f.to(dtype))

@@ -267,6 +267,31 @@ def test_fused_equals_unfused(tmp_path_factory):
     assert e2 < 1e-1, e2
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_half_mode_runs_on_the_fused_kernels(dtype, tmp_path_factory, monkeypatch):
+    """qnn.half() / bf16 (src/inference_qmodel.py:93, quant_model.py:183-201): the forward stays on the HIP kernels
+    (fused attention included — counted), stays finite and close to the fp32 run at the level the chaotic graph allows."""
+    from dgq_amd import ops
+    tmp = str(tmp_path_factory.mktemp("ck"))
+    qnn, _ = build_qnn("tiny", dict(C2, steps=2), 16, 2, 2, tmp)
+    inp = synth.synth_inputs("tiny", 2, 1, 16)
+    x, ctx = inp["sample"].cuda(), inp["encoder_hidden_states"].cuda()
+    with torch.no_grad():
+        ref = qnn(x, torch.tensor(999), ctx)[0].float().cpu()
+    qnn = qnn.half() if dtype == torch.float16 else qnn.to(torch.bfloat16)
+    calls = {"attn": 0, "mm": 0}
+    orig_attn, orig_mm = ops.attention, torch.matmul
+    monkeypatch.setattr(ops, "attention", lambda *a, **k: (calls.__setitem__("attn", calls["attn"] + 1), orig_attn(*a, **k))[1])
+    monkeypatch.setattr(torch, "matmul", lambda *a, **k: (calls.__setitem__("mm", calls["mm"] + 1), orig_mm(*a, **k))[1])
+    with torch.no_grad():
+        out = qnn(x.to(dtype), torch.tensor(999), ctx.to(dtype))[0]
+    assert out.dtype == dtype and torch.isfinite(out).all()
+    assert calls["attn"] > 0 and calls["mm"] == 0            # no materialised-attention fallback
+    e = rel_l2(out.float().cpu(), ref)
+    print("%s vs fp32 run: rel-L2 %.3g" % (dtype, e))
+    assert e < 0.5, e
+
+
 def test_cli_tiny(tmp_path):
     """The drop-in CLI (reference flag names) end to end on the tiny arch."""
     from dgq_amd import inference_qmodel as cli
