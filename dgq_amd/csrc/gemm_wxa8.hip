@@ -495,7 +495,19 @@ static int launch_gemm(const GemmParams& p, int y_dtype, hipStream_t st) {
 // K split factor from a small cost model (all times in us; constants measured on MI355X, tools/bench_gemm.py):
 //   a resident block retires one 128x128x128 K tile in ~0.6 us with 2 blocks/CU (0.35 us alone on its CU),
 //   512 block slots; a split adds S·M·N·4 B of slab writes + reads at ~3 TB/s and a ~2 us combine launch.
-static int choose_splits(int M, int N, int Kp, size_t ws_bytes) {
+// Fitted on the SD1.4 step with bench.py (A/B builds on one box): charging a split 2 us for its combine launch and a per-K
+// tile the same as a per-M tile left 1.7 % on the table — a per-K K tile costs 2-3x a per-M one (a fp32 flush of the 64x64
+// wave tile after every DGQ group), and inside a hipGraph the dependent combine launch costs well under 1 us.
+#ifndef SPLIT_LAUNCH_US
+#define SPLIT_LAUNCH_US 0.5
+#endif
+#ifndef PERK_TILE_SCALE
+#define PERK_TILE_SCALE 2.5
+#endif
+#ifndef PERM_TILE_SCALE
+#define PERM_TILE_SCALE 1.0
+#endif
+static int choose_splits(int M, int N, int Kp, size_t ws_bytes, bool per_m = true) {
     const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     const int nk = Kp / BK;
     if (nk < 4) return 1;
@@ -507,16 +519,16 @@ static int choose_splits(int M, int N, int Kp, size_t ws_bytes) {
         const int tps = (nk + s - 1) / s;
         const long blocks = (long)tiles * ((nk + tps - 1) / tps);
         const long waves = (blocks + 511) / 512;
-        const double per_tile = blocks <= 256 ? 0.35 : 0.6;
+        const double per_tile = (blocks <= 256 ? 0.35 : 0.6) * (per_m ? PERM_TILE_SCALE : PERK_TILE_SCALE);
         double t = waves * (tps * per_tile + 1.5);
-        if (s > 1) t += 2.0 + 2.0 * slab_bytes * s / 3.0e6;
+        if (s > 1) t += SPLIT_LAUNCH_US + 2.0 * slab_bytes * s / 3.0e6;
         if (t < best_t) { best_t = t; best = s; }
     }
     return best;
 }
 
 extern "C" size_t dgq_gemm_workspace_bytes(int M, int N, int Kp) {
-    const int s = choose_splits(M, N, Kp, (size_t)-1);
+    const int s = choose_splits(M, N, Kp, (size_t)-1, false);
     return s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
 }
 
@@ -556,7 +568,7 @@ extern "C" int dgq_gemm_wxa8(const int8_t* codes, const float* rowsum, int rowsu
         p.ex.residual = nullptr; p.ex.ldr = 0; p.ex.res_div = 1; p.ex.res_dtype = DGQ_F32; p.ex.fq_mode = 0; p.ex.fq_delta = nullptr; p.ex.fq_zp = nullptr;
         p.ex.fq_T = 1; p.ex.fq_D = 1; p.ex.fq_skip = 0; p.ex.fq_qmax = 255.0f;
     }
-    p.splits = workspace ? choose_splits(M, N, Kp, workspace_bytes) : 1;
+    p.splits = workspace ? choose_splits(M, N, Kp, workspace_bytes, per_m != 0) : 1;
     p.slab = p.splits > 1 ? reinterpret_cast<float*>(workspace) : nullptr;
     const int nk = Kp / BK;
     p.tiles_per_split = (nk + p.splits - 1) / p.splits;
