@@ -18,7 +18,6 @@
 typedef float v16f __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-#define QROWS 128
 #define KT 32
 #define LOG2E 1.4426950408889634f
 
@@ -152,22 +151,23 @@ __device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_addr) {
                  : "memory");
 }
 
-// this wave's share of one tile image: pieces wid, wid+4, ... < NP
-template <int NP>
+// this wave's share of one tile image: pieces wid, wid+NW, ... < NP (NW waves per block)
+template <int NP, int NW>
 __device__ __forceinline__ void issue_image(const unsigned char* img_lane, uint32_t lds_stage, int wid) {
 #pragma unroll
-    for (int i = 0; i < (NP + 3) / 4; ++i) {
-        const int j = wid + 4 * i;
+    for (int i = 0; i < (NP + NW - 1) / NW; ++i) {
+        const int j = wid + NW * i;
         if (j < NP) glds16(img_lane + 1024 * j, __builtin_amdgcn_readfirstlane(lds_stage + 1024 * j));
     }
 }
 
 // wait until all but the youngest YOUNGER tiles of this wave's DMA pieces have landed (vmcnt counts in issue order;
-// a wave issues ceil or floor of NP/4 pieces per tile depending on its index)
-template <int NP, int YOUNGER>
+// a wave issues ceil or floor of NP/NW pieces per tile depending on its index)
+template <int NP, int YOUNGER, int NW>
 __device__ __forceinline__ void wait_image(int wid) {
-    constexpr int HI = (NP + 3) / 4, LO = NP / 4;
-    if (HI == LO || wid < NP % 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(HI * YOUNGER) : "memory");
+    constexpr int HI = (NP + NW - 1) / NW, LO = NP / NW;
+    static_assert(HI * YOUNGER <= 63, "vmcnt immediate");
+    if (HI == LO || wid < NP % NW) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(HI * YOUNGER) : "memory");
     else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LO * YOUNGER) : "memory");
 }
 
@@ -332,14 +332,17 @@ __device__ __forceinline__ v16f score_tile(const unsigned short* kb, const bf16x
 
 __device__ __forceinline__ int key_of(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
-template <int D>
-__global__ __launch_bounds__(256) void attn3_stats_kernel(AttnParams p) {
+// NW waves of 32 query rows per block.  NW = 8 (256 rows, one block per CU, two waves per SIMD) where the grid still
+// fills the chip (T >= 2048 at B*H = 16): the K/V tile images are then staged once per 256 rows instead of once per
+// 128 — half the LDS-DMA pieces per wave per tile, the largest non-MFMA cost of the loop.
+template <int D, int NW>
+__global__ __launch_bounds__(64 * NW) void attn3_stats_kernel(AttnParams p) {
     using G = Geo<D>;
     constexpr int ST = G::STATS_STAGES, NP = G::K_PIECES, SB = NP * 1024;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds8[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, h32 = lane >> 5;
     const int bh = blockIdx.y, b = bh / p.H, hd = bh - b * p.H;
-    const int t = blockIdx.x * QROWS + wid * 32 + (lane & 31);
+    const int t = blockIdx.x * (32 * NW) + wid * 32 + (lane & 31);
     const int tq = min(t, p.T - 1);
     const unsigned char* img_lane = p.planes + (int64_t)bh * p.NT * G::IMG_BYTES + lane * 16;
     const uint32_t lds_base = (uint32_t)(uintptr_t)(lptr_t)lds8;
@@ -347,16 +350,16 @@ __global__ __launch_bounds__(256) void attn3_stats_kernel(AttnParams p) {
     // the in-flight count is the same in every iteration), tile i has landed
 #pragma unroll
     for (int i = 0; i < ST - 1; ++i)
-        issue_image<NP>(img_lane + (int64_t)min(i, p.NT - 1) * G::IMG_BYTES, lds_base + i * SB, wid);
+        issue_image<NP, NW>(img_lane + (int64_t)min(i, p.NT - 1) * G::IMG_BYTES, lds_base + i * SB, wid);
     bf16x8 qf[3][G::NKK];
     load_q<D>(qf, p.q + ((int64_t)(b * p.T + tq) * p.H + hd) * D, h32, p.fq[0], tq);
     const float sl2 = p.scale * LOG2E;                   // scores in log2 units: p = 2^(s2 − m)/l
     float mraw = -INFINITY, l = 0.0f, m2raw = -INFINITY; // running maxima of the UNSCALED scores (scale > 0)
-    wait_image<NP, ST - 2>(wid);
+    wait_image<NP, ST - 2, NW>(wid);
     __builtin_amdgcn_s_barrier();
     int stage = 0, istage = ST - 1;
     for (int i = 0; i < p.NT; ++i) {
-        issue_image<NP>(img_lane + (int64_t)min(i + ST - 1, p.NT - 1) * G::IMG_BYTES, lds_base + istage * SB, wid);
+        issue_image<NP, NW>(img_lane + (int64_t)min(i + ST - 1, p.NT - 1) * G::IMG_BYTES, lds_base + istage * SB, wid);
         const int s0 = i * KT;
         v16f acc = score_tile<D>(reinterpret_cast<const unsigned short*>(lds8 + stage * SB), qf, lane);
         const bool edge = (s0 + KT > p.S) || (s0 < p.skip);      // block-uniform: only the first / a partial last tile
@@ -385,7 +388,7 @@ __global__ __launch_bounds__(256) void attn3_stats_kernel(AttnParams p) {
         l = l * __builtin_amdgcn_exp2f(fmaf(mraw, sl2, nb)) + part;
         mraw = mn;
         m2raw = fmaxf(m2raw, tmax2);
-        wait_image<NP, ST - 2>(wid);                      // tile i+1 (this wave's pieces) has landed
+        wait_image<NP, ST - 2, NW>(wid);                      // tile i+1 (this wave's pieces) has landed
         __builtin_amdgcn_s_barrier();                     // ... everyone's; and everyone is done reading `stage`
         stage = (stage + 1 == ST) ? 0 : stage + 1;
         istage = (istage + 1 == ST) ? 0 : istage + 1;
@@ -405,20 +408,20 @@ __global__ __launch_bounds__(256) void attn3_stats_kernel(AttnParams p) {
     }
 }
 
-template <int D, bool UNIFORM>
-__global__ __launch_bounds__(256) void attn3_pv_kernel(AttnParams p) {
+template <int D, bool UNIFORM, int NW>
+__global__ __launch_bounds__(64 * NW) void attn3_pv_kernel(AttnParams p) {
     using G = Geo<D>;
     constexpr int ST = G::PV_STAGES, NP = G::IMG_PIECES, SB = G::IMG_BYTES;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds8[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, h32 = lane >> 5;
     const int bh = blockIdx.y, b = bh / p.H, hd = bh - b * p.H;
-    const int t = blockIdx.x * QROWS + wid * 32 + (lane & 31);
+    const int t = blockIdx.x * (32 * NW) + wid * 32 + (lane & 31);
     const int tq = min(t, p.T - 1);
     const unsigned char* img_lane = p.planes + (int64_t)bh * p.NT * G::IMG_BYTES + lane * 16;
     const uint32_t lds_base = (uint32_t)(uintptr_t)(lptr_t)lds8;
 #pragma unroll
     for (int i = 0; i < ST - 1; ++i)
-        issue_image<NP>(img_lane + (int64_t)min(i, p.NT - 1) * G::IMG_BYTES, lds_base + i * SB, wid);
+        issue_image<NP, NW>(img_lane + (int64_t)min(i, p.NT - 1) * G::IMG_BYTES, lds_base + i * SB, wid);
     bf16x8 qf[3][G::NKK];
     load_q<D>(qf, p.q + ((int64_t)(b * p.T + tq) * p.H + hd) * D, h32, p.fq[0], tq);
     const float m = p.stats[((int64_t)bh * p.T + tq) * 2], l = p.stats[((int64_t)bh * p.T + tq) * 2 + 1];
@@ -443,7 +446,7 @@ __global__ __launch_bounds__(256) void attn3_pv_kernel(AttnParams p) {
     __builtin_amdgcn_s_barrier();
     int stage = 0, istage = ST - 1;
     for (int i = 0; i < p.NT; ++i) {
-        issue_image<NP>(img_lane + (int64_t)min(i + ST - 1, p.NT - 1) * G::IMG_BYTES, lds_base + istage * SB, wid);
+        issue_image<NP, NW>(img_lane + (int64_t)min(i + ST - 1, p.NT - 1) * G::IMG_BYTES, lds_base + istage * SB, wid);
         const int s0 = i * KT;
         const unsigned short* kbc = reinterpret_cast<const unsigned short*>(lds8 + stage * SB);
         const unsigned short* vtc = kbc + G::K_ELEMS;
@@ -498,7 +501,7 @@ __global__ __launch_bounds__(256) void attn3_pv_kernel(AttnParams p) {
                 oacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pf[ks], oacc[j], 0, 0, 0);
             }
         }
-        wait_image<NP, ST - 2>(wid);
+        wait_image<NP, ST - 2, NW>(wid);
         __builtin_amdgcn_s_barrier();
         stage = (stage + 1 == ST) ? 0 : stage + 1;
         istage = (istage + 1 == ST) ? 0 : istage + 1;
@@ -530,9 +533,14 @@ static int launch_attn3(AttnParams p, const void* q_raw, unsigned char* planes, 
     constexpr int pv_lds = G::PV_STAGES * G::IMG_BYTES;
     static_assert(stats_lds <= 160 * 1024 && pv_lds <= 160 * 1024, "LDS ring too large");
     static const bool lds_ok = [] {                            // up to 138 KB of dynamic LDS (D = 160): opt in once
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn3_stats_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, stats_lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn3_pv_kernel<D, true>), hipFuncAttributeMaxDynamicSharedMemorySize, pv_lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn3_pv_kernel<D, false>), hipFuncAttributeMaxDynamicSharedMemorySize, pv_lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn3_stats_kernel<D, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, stats_lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn3_pv_kernel<D, true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, pv_lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn3_pv_kernel<D, false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, pv_lds);
+        if (D <= 64) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn3_stats_kernel<D, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, stats_lds);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn3_pv_kernel<D, true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, pv_lds);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn3_pv_kernel<D, false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, pv_lds);
+        }
         return true;
     }();
     (void)lds_ok;
@@ -553,10 +561,22 @@ static int launch_attn3(AttnParams p, const void* q_raw, unsigned char* planes, 
     } else {
         p.q = reinterpret_cast<const float*>(q_raw);
     }
-    dim3 grid((p.T + QROWS - 1) / QROWS, p.B * p.H), block(256);
-    hipLaunchKernelGGL((attn3_stats_kernel<D>), grid, block, stats_lds, st, p);
-    if (p.mode == 3) hipLaunchKernelGGL((attn3_pv_kernel<D, true>), grid, block, pv_lds, st, p);
-    else hipLaunchKernelGGL((attn3_pv_kernel<D, false>), grid, block, pv_lds, st, p);
+    // 8-wave blocks (256 query rows) when they still give one block per CU; register budgets allow it for D <= 64
+    static const bool force4 = getenv("DGQ_ATTN_NW4") != nullptr;
+    const bool wide = D <= 64 && !force4 && (long)((p.T + 255) / 256) * p.B * p.H >= 256;
+    if (wide) {
+        if constexpr (D <= 64) {
+            dim3 grid((p.T + 255) / 256, p.B * p.H), block(512);
+            hipLaunchKernelGGL((attn3_stats_kernel<D, 8>), grid, block, stats_lds, st, p);
+            if (p.mode == 3) hipLaunchKernelGGL((attn3_pv_kernel<D, true, 8>), grid, block, pv_lds, st, p);
+            else hipLaunchKernelGGL((attn3_pv_kernel<D, false, 8>), grid, block, pv_lds, st, p);
+        }
+    } else {
+        dim3 grid((p.T + 127) / 128, p.B * p.H), block(256);
+        hipLaunchKernelGGL((attn3_stats_kernel<D, 4>), grid, block, stats_lds, st, p);
+        if (p.mode == 3) hipLaunchKernelGGL((attn3_pv_kernel<D, true, 4>), grid, block, pv_lds, st, p);
+        else hipLaunchKernelGGL((attn3_pv_kernel<D, false, 4>), grid, block, pv_lds, st, p);
+    }
     return dgq_launch_status("dgq_attention_f32(bf16x3)");
 }
 
