@@ -297,16 +297,18 @@ __global__ __launch_bounds__(256) void quant_act_staged_kernel(QuantActParams p)
     const int l = row - b * L;
     const int ho = l / p.Wo, wo = l - ho * p.Wo;
     const int hbase = ho * p.stride - p.pad, wbase = wo * p.stride - p.pad;
-    const TIn* img = x + (int64_t)b * p.H * p.W * p.C;
+    const TIn* img = x + (int64_t)b * p.H * p.W * p.ldc;
     const int taps = p.kh * p.kw;
     float* strip = strips + wv * taps * p.C;
     const float* pre_sc = p.pre_scale ? p.pre_scale + (int64_t)b * p.C : nullptr;
     const float* pre_sh = p.pre_shift ? p.pre_shift + (int64_t)b * p.C : nullptr;
+    float ln_mu = 0.0f, ln_rstd = 1.0f;                 // Linear inputs (taps == 1): LayerNorm over the row, or GEGLU
+    if (p.ln_gamma) row_layernorm_stats<TIn>(img + (int64_t)(hbase * p.W + wbase) * p.ldc, p.C, p.ln_eps, lane, ln_mu, ln_rstd);
     for (int tap = 0; tap < taps; ++tap) {
         const int dh = tap / p.kw, dw = tap - dh * p.kw;
         const int hi = hbase + dh, wi = wbase + dw;
         const bool inb = hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;     // wave-uniform
-        const TIn* src = img + ((int64_t)hi * p.W + wi) * p.C;
+        const TIn* src = img + ((int64_t)hi * p.W + wi) * p.ldc;
         float* dst = strip + tap * p.C;
         for (int c = lane * 4; c < p.C; c += 256) {
             float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -317,9 +319,20 @@ __global__ __launch_bounds__(256) void quant_act_staged_kernel(QuantActParams p)
                     const float4 sh = *reinterpret_cast<const float4*>(pre_sh + c);
                     v[0] = v[0] * sc.x + sh.x; v[1] = v[1] * sc.y + sh.y; v[2] = v[2] * sc.z + sh.z; v[3] = v[3] * sc.w + sh.w;
                 }
+                if (p.ln_gamma) {
+                    const float4 ga = *reinterpret_cast<const float4*>(p.ln_gamma + c);
+                    const float4 be = *reinterpret_cast<const float4*>(p.ln_beta + c);
+                    v[0] = (v[0] - ln_mu) * ln_rstd * ga.x + be.x; v[1] = (v[1] - ln_mu) * ln_rstd * ga.y + be.y;
+                    v[2] = (v[2] - ln_mu) * ln_rstd * ga.z + be.z; v[3] = (v[3] - ln_mu) * ln_rstd * ga.w + be.w;
+                }
                 if (p.pre_act == 1) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] = dgq_silu(v[j]);
+                } else if (p.pre_act == 2) {
+                    float g[4];
+                    load4<TIn>(src + p.C + c, g);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = v[j] * (0.5f * g[j] * (1.0f + erff(g[j] * 0.70710678118654752f)));
                 }
             }
             *reinterpret_cast<float4*>(dst + c) = make_float4(v[0], v[1], v[2], v[3]);
@@ -384,8 +397,13 @@ static void launch_quant_act(const QuantActParams& p, bool table, bool per_m, hi
     const int ks = (p.Kp + p.kp_per_split - 1) / p.kp_per_split;
     const size_t strip_bytes = (size_t)p.kh * p.kw * p.C * sizeof(float);
     // measured (SD1.4 layers): staging wins at C = 320 (4 rows per block, 3 blocks per CU: 88 -> 64 us) and loses once the
-    // strips cut occupancy (C >= 640) or the K range is split over blocks that would each re-stage every tap
-    if (table && p.klds && p.kh * p.kw > 1 && p.C % 4 == 0 && p.pre_act != 2 && strip_bytes <= 16 * 1024 && ks == 1) {
+    // strips cut occupancy (C >= 640 at 3x3) or the K range is split over blocks that would each re-stage every tap.
+    // Linear inputs (one tap: the strip is the row itself, <= 16 KB) are always staged — the global gather pays one L1
+    // access per code (8192 x 320 -> Kp 1024: 20 us) — together with their LayerNorm / GEGLU prologue.
+    const int taps_ = p.kh * p.kw;
+    const bool stage_conv = taps_ > 1 && p.pre_act != 2 && !p.ln_gamma && ks == 1;
+    const bool stage_lin = taps_ == 1 && (!p.ln_gamma || p.C <= DGQ_LN_MAX_C);
+    if (table && p.klds && p.C % 4 == 0 && strip_bytes <= 16 * 1024 && (stage_conv || stage_lin)) {
         const int nw = 4;                                                       // waves (= rows) per block, <= 64 KB of LDS
         dim3 sgrid((p.M + nw - 1) / nw, ks), sblock(64 * nw);
         if (per_m) hipLaunchKernelGGL((quant_act_staged_kernel<TIn, true>), sgrid, sblock, nw * strip_bytes, st, p);

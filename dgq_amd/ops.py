@@ -105,8 +105,8 @@ class ActBinding:
         return self._koff[key]
 
     def klds(self, kw, C):
-        """ksrc resolved to indices (dh*kw + dw)*C + c into a [tap][C] strip (cached; conv layers only)."""
-        if self.ksrc is None or self.pw.taps <= 1:
+        """ksrc resolved to indices (dh*kw + dw)*C + c into the [tap][C] strip a wave stages in LDS (cached)."""
+        if self.ksrc is None:
             return None
         key = ("lds", kw, C)
         if key not in self._koff:
