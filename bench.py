@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one hipGraph per timestep slot")
+    ap.add_argument("--no-roofline", action="store_true", help="skip the per-launch GEMM replay pass (profiling runs)")
     ap.add_argument("--prompts-per-gpu", type=int, default=1,
                     help="prompts denoised together on each GPU (default 1 = the CFG-pair step the metric is defined on)")
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "fp16", "bf16"],
@@ -121,7 +122,7 @@ def main():
     # per-launch events would time the host-side launch gaps, not the kernels.  Sum over the step = the kernel time
     # rocprofv3 reports for gemm_wxa8_kernel + splitk_epilogue_kernel (profiles/).
     roofline = None
-    if rank == 0:
+    if rank == 0 and not args.no_roofline:
         REP = 5
         times_ms, algo_ops, algo_bytes = [], [], []
         orig = ops.gemm_wxa8

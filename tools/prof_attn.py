@@ -3,8 +3,8 @@ import collections, csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 pat = sys.argv[2] if len(sys.argv) > 2 else "attn"
-idx = [i for i, r in enumerate(rows) if "quant_act_kernel" in r["Kernel_Name"]]
-win = rows[idx[-275 * 2]:idx[-275]]
+idx = [i for i, r in enumerate(rows) if "gemm_wxa8_kernel" in r["Kernel_Name"]]
+win = rows[idx[-280 * 2]:idx[-280]]
 agg = collections.OrderedDict()
 for r in win:
     if pat in r["Kernel_Name"]:

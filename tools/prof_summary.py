@@ -1,6 +1,6 @@
 """Per-step kernel breakdown from a rocprofv3 --kernel-trace CSV of bench.py.
 usage: python tools/prof_summary.py <kernel_trace.csv> <timed_steps> <out.csv> [comment]
-The window = the timed steps (the last `timed_steps`+1 step-equivalents end with bench.py's roofline pass)."""
+Profile `bench.py --no-roofline --no-cpu-baseline`: the window = the last `timed_steps` forwards of the trace."""
 import collections
 import csv
 import sys
@@ -9,10 +9,13 @@ trace, steps, out = sys.argv[1], int(sys.argv[2]), sys.argv[3]
 comment = sys.argv[4] if len(sys.argv) > 4 else ""
 rows = list(csv.DictReader(open(trace)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-marker = "quant_act_kernel"                       # every quantized layer launches exactly one per forward
+marker = "gemm_wxa8_kernel"                       # every quantized layer launches exactly one per forward (280 in SD1.4)
 idx = [i for i, r in enumerate(rows) if marker in r["Kernel_Name"]]
-per = 275 if len(idx) >= 275 * (steps + 1) else len(idx) // (steps + 1)
-win = rows[idx[-per * (steps + 1)]:idx[-per]]
+per = 280 if len(idx) >= 280 * (steps + 1) else len(idx) // (steps + 1)
+first = idx[-per * steps]
+while first > 0 and "gemm_wxa8_kernel" not in rows[first - 1]["Kernel_Name"] and "splitk" not in rows[first - 1]["Kernel_Name"]:
+    first -= 1                                     # include the kernels in front of the step's first GEMM (conv_in, time embedding, its quant_act)
+win = rows[first:]
 agg = collections.defaultdict(lambda: [0, 0])
 for r in win:
     agg[r["Kernel_Name"]][0] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
