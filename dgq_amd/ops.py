@@ -148,22 +148,19 @@ def act_ksplits(M, Kp):
 
 
 FLOAT_DTYPES = (torch.float32, torch.float16, torch.bfloat16)
-_F32_CACHE = {}
-
-
 def as_f32(t: torch.Tensor) -> torch.Tensor:
-    """fp32 view of a small parameter vector (norm γ/β ...) of a model that was cast with .half(): the kernels take
-    their per-channel vectors in fp32.  Cached per (storage, version)."""
+    """fp32 copy of a small parameter vector (norm γ/β ...) of a model that was cast with .half(): the kernels take
+    their per-channel vectors in fp32.  The copy is cached ON the tensor object (pass the Parameter, not ``.data``) and
+    refreshed when the tensor is modified in place or moved; nothing is keyed by address, so a later model that
+    happens to reuse the same device memory can never see a stale vector."""
     if t.dtype == torch.float32:
-        return t
-    key = (t.data_ptr(), t._version, t.dtype, tuple(t.shape))
-    hit = _F32_CACHE.get(key)
-    if hit is None:
-        if len(_F32_CACHE) > 4096:
-            _F32_CACHE.clear()
-        hit = t.detach().float().contiguous()
-        _F32_CACHE[key] = hit
-    return hit
+        return t.detach()
+    key = (t._version, t.data_ptr(), t.dtype)
+    hit = t.__dict__.get("_dgq_f32")
+    if hit is None or hit[0] != key:
+        hit = (key, t.detach().float().contiguous())
+        t.__dict__["_dgq_f32"] = hit
+    return hit[1]
 
 
 #: one launch per GroupNorm statistic (last-arriving block merges the slices) instead of partial + merge kernels.

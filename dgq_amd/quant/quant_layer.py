@@ -366,7 +366,7 @@ class QuantLayer(nn.Module):
                 y = y.contiguous()
                 ops.fakequant_rows(y.view(-1, y.shape[-1]), T, D, mode - 1, dd, zz, skip, bits)
             return y if residual is None else y + residual
-        lnp = (ln.weight.data, ln.bias.data, float(ln.eps)) if ln is not None else None
+        lnp = (ln.weight, ln.bias, float(ln.eps)) if ln is not None else None
         return ops.quant_linear(x, self._binding(), pre_act=pre_act, residual=residual, fq=fq, ln=lnp)
 
     def can_fuse_prenorm(self, x: torch.Tensor) -> bool:
@@ -381,7 +381,7 @@ class QuantLayer(nn.Module):
         ab = self._binding()
         kh, kw = self.w.shape[2], self.w.shape[3]
         return ops.quant_conv2d(x, ab, kh, kw, self.fwd_kwargs["stride"][0], self.fwd_kwargs["padding"][0],
-                                norm=(norm.num_groups, norm.eps, norm.weight.data, norm.bias.data, 1 if silu else 0),
+                                norm=(norm.num_groups, norm.eps, norm.weight, norm.bias, 1 if silu else 0),
                                 residual=residual, bias_rows=bias_rows)
 
     def forward_residual(self, x: torch.Tensor, residual) -> torch.Tensor:

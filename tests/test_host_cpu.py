@@ -189,3 +189,19 @@ def test_shard_prompts_and_ddim():
     x, e = torch.randn(1, 4, 8, 8), torch.randn(1, 4, 8, 8)
     for t in (981, 501, 1):
         assert torch.allclose(sch.step(e, t, x), o.step(e, t, x), atol=1e-6)
+
+
+def test_as_f32_cache_lives_on_the_tensor():
+    """ops.as_f32: fp32 copies of half parameters are cached on the Parameter object itself (never by address), are
+    refreshed after an in-place update, and fp32 parameters are passed through without a copy."""
+    import torch
+    from dgq_amd import ops
+    p = torch.nn.Parameter(torch.randn(8).half())
+    a, b = ops.as_f32(p), ops.as_f32(p)
+    assert a is b and a.dtype == torch.float32
+    with torch.no_grad():
+        p.mul_(2)
+    c = ops.as_f32(p)
+    assert c is not a and torch.allclose(c, p.detach().float())
+    q = torch.nn.Parameter(torch.randn(8))
+    assert ops.as_f32(q).data_ptr() == q.data_ptr()
