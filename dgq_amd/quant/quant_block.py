@@ -6,6 +6,7 @@ diffusers_rewrite/sd.py:151-207); ``QuantResnetBlock2D`` (quant_block.py:79-119)
 submodules.  Wrapping is by duck-typing, so both this package's UNet and the reference's
 ``diffusers_rewrite`` UNet classes are accepted.
 """
+import os as _os
 from typing import Dict
 
 import torch
@@ -23,7 +24,6 @@ from .quant_layer_text import T2ILogQuantizer
 FUSION = True
 #: GroupNorm folding rounds differently from F.group_norm (x·(rstd·γ) + (β − mean·rstd·γ)); separate switch for tests.
 FUSE_NORM = True
-import os as _os
 # Kernel-level fusions, each measured A/B on one MI355X box with bench.py (SD1.4 step, all bit-identical to the unfused
 # sequence, tests/test_gpu_unet.py::test_fused_equals_unfused):
 #   residual / temb-broadcast adds in the GEMM epilogue (residual tile prefetched as 16-byte loads)   +3.3 %
@@ -35,10 +35,10 @@ _F_RES = _os.environ.get("DGQ_FUSE_RESIDUAL", "1") == "1"
 _F_FQ = _os.environ.get("DGQ_FUSE_FQ", "0") == "1"
 _F_GEGLU = _os.environ.get("DGQ_FUSE_GEGLU", "1") == "1"
 _F_SILU = _os.environ.get("DGQ_FUSE_SILU", "1") == "1"
-# aqtizer_{q,k,v} applied inside the attention pre-pass (K/V while they are split into bf16 planes, Q into a scratch
-# copy by extra blocks of the same launch): three launches per attention saved, nothing added to a GEMM grid (-0.16 ms)
 # norm1/2/3 of the transformer block folded into the quantise-on-load pass of the layers that consume them
 _F_LN = _os.environ.get("DGQ_FUSE_LN", "1") == "1"
+# aqtizer_{q,k,v} applied inside the attention pre-pass (K/V while they are split into bf16 planes, Q into a scratch
+# copy by extra blocks of the same launch): three launches per attention saved, nothing added to a GEMM grid
 _F_ATTN_FQ = _os.environ.get("DGQ_FUSE_ATTN_FQ", "1") == "1"
 
 
