@@ -1,55 +1,128 @@
-"""bench.py — denoise-step throughput of the quantized SD1.4 UNet on MI355X.
+"""bench.py — denoise-step throughput of the quantized SD1.4 / SDXL UNet on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
-    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+    python bench.py --gpus N --steps K --warmup W [--config c2|c4|c5]
 
-Metric (BASELINE.json): UNet denoise steps/sec @ SD1.4 512² W4A8 g16.  A "step" = one QuantModel.forward on a CFG
-pair ([2,4,64,64] latents, [2,77,768] context) inside the DDIM loop (CFG combine + scheduler update included),
-synthetic name-keyed weights and a synthetic reference-format cali_ckpt (time-aware act tables, 16 DGQ groups,
-log2-quantised softmax with real-time δ and start-peak — the reference's own preset for G>1,
-scripts/quantize_act.sh:16-19).  Inputs are resident in HBM when the timed region starts.  Each rank denoises
-its own prompts (weak scaling, no data-path collective); value = (steps × ranks) / max-over-ranks time.
+N > 1 without a torchrun environment: the parent process — before anything touches the GPU — checks that N devices
+are visible (fails loudly otherwise) and starts `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+--master-addr 127.0.0.1 --master-port P bench.py <same flags>` as a CHILD process (never an exec of a process that
+holds the GPU), then exits with its code.  Under torchrun every rank asserts WORLD_SIZE == --gpus.  This is the
+reference's only multi-GPU mode (one python process per GPU, rank-sliced prompt list: src/gen4eval_SDXL.py:116,
+scripts/gen4eval_SDXL.sh:53-100): ranks share nothing but the timing barrier and a MAX all-reduce of the elapsed time.
+
+Metric (BASELINE.json): UNet denoise steps/sec @ SD1.4 512² W4A8 g16 (config c2, the default).  A "step" = one
+QuantModel.forward on a CFG pair ([2,4,64,64] latents, [2,77,768] context) inside the DDIM loop (CFG combine +
+scheduler update included), synthetic name-keyed weights and a synthetic reference-format cali_ckpt (time-aware act
+tables, 16 DGQ groups, log2-quantised softmax with real-time δ and start-peak — the reference's own preset for G>1,
+scripts/quantize_act.sh:16-19).  Inputs are resident in HBM when the timed region starts.
+  c4 = SDXL-turbo W4A8 g16, 1024² (128² latents), batch 1, 4-step schedule, no CFG (BASELINE.json configs[3])
+  c5 = SDXL-turbo W4A6 g=1 (scalar scales, uniform softmax quantiser), 8 prompts per GPU (configs[4]: 64 prompts / 8 GPUs)
+
+Timing: W untimed warm-up steps, then `--windows` (default 5) windows of EXACTLY K steps, each bracketed by a barrier +
+torch.cuda.synchronize() on both sides, max over ranks per window; `value` / `ms_per_step` come from the MEDIAN window,
+the minimum and every window are printed beside it.
 
 The JSON line also carries
-  roofline     — the W4A8 MFMA GEMM (dgq_gemm_wxa8): algorithmic int8 ops of all 280 quantized layers of one
-                 step (2·M·N·K, SURVEY.md §8(d): 1.354 Top) ÷ the HIP-event time of those launches, against the
+  roofline     — the W4A8 MFMA GEMM path (dgq_gemm_wxa8): algorithmic int8 ops of all quantized layers of one step
+                 (2·M·N·K, SURVEY.md §8(d): 1.354 Top for c2) ÷ the HIP-event time of those launches, against the
                  dense int8 MFMA peak (≈5 Pop/s = 2× the 2.5 PF bf16 peak, MI355X_MICROARCH.md § Matrix cores);
   cpu_baseline — the reference's op sequence (oracle/, a pinned CPU port: re-quantised weights each call, F.unfold,
-                 fp32 GEMMs, materialised attention) timed for ONE step on this box's host cores.
+                 fp32 GEMMs, materialised attention) on this box's host cores: 1 warm-up + 3 timed steps (c2 only).
 """
 import argparse
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-CFG_C2 = dict(wbits=4, abits=8, use_aq=True, G=16, log=True, rt=True, sp=True, time_aware=True, steps=50)
 INT8_PEAK_TOPS = 5000.0
 
+CONFIGS = {
+    # SD v1.4 W4A8 g=16, DDIM-50 schedule, CFG pair per prompt
+    "c2": dict(arch="sd", res=64, cfg=dict(wbits=4, abits=8, use_aq=True, G=16, log=True, rt=True, sp=True, time_aware=True, steps=50),
+               guidance=7.5, prompts=1,
+               metric="UNet denoise steps/sec @ SD1.4 512^2 W4A8 g16",
+               workload="SD v1.4 UNet W4A8 g=16 (time-aware, log2 softmax real-time δ, start-peak), DDIM 50-step schedule, "
+                        "512x512 (64x64 latents), CFG pair per step per GPU"),
+    # SDXL-turbo W4A8 g=16, 4 steps, 1024x1024, batch 1, no CFG
+    "c4": dict(arch="sdxl", res=128, cfg=dict(wbits=4, abits=8, use_aq=True, G=16, log=True, rt=True, sp=True, time_aware=True, steps=4),
+               guidance=0.0, prompts=1,
+               metric="UNet denoise steps/sec @ SDXL-turbo 1024^2 W4A8 g16",
+               workload="SDXL-turbo UNet W4A8 g=16 (time-aware, log2 softmax real-time δ, start-peak), 4-step schedule, "
+                        "1024x1024 (128x128 latents), batch = prompts per GPU, no CFG"),
+    # SDXL-turbo W4A6 g=1 (scalar scales), prompts sharded over the GPUs (64 prompts over 8 GPUs = 8 per GPU)
+    "c5": dict(arch="sdxl", res=128, cfg=dict(wbits=4, abits=6, use_aq=True, G=1, log=False, rt=False, sp=False, time_aware=True, steps=4),
+               guidance=0.0, prompts=8,
+               metric="UNet denoise steps/sec @ SDXL-turbo 1024^2 W4A6 g1, prompts sharded over GPUs",
+               workload="SDXL-turbo UNet W4A6 g=1 (scalar activation scales, uniform softmax quantiser, time-aware), 4-step "
+                        "schedule, 1024x1024 (128x128 latents), batch = prompts per GPU, no CFG"),
+}
 
-def main():
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--windows", type=int, default=5, help="timed windows of --steps steps each (median reported)")
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline", action="store_true", help="force the CPU leg for c4/c5 too (minutes per SDXL step)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one hipGraph per timestep slot")
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-launch GEMM replay pass (profiling runs)")
-    ap.add_argument("--prompts-per-gpu", type=int, default=1,
-                    help="prompts denoised together on each GPU (default 1 = the CFG-pair step the metric is defined on)")
+    ap.add_argument("--prompts-per-gpu", type=int, default=0,
+                    help="prompts denoised together on each GPU (default: the config's own: c2/c4 1, c5 8)")
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "fp16", "bf16"],
                     help="inter-layer activation dtype (fp32 = the reference's default .float() mode)")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
 
+
+def launch_command(args, argv, port):
+    """The torchrun command the parent starts for --gpus N > 1 (one rank per GPU over RCCL)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def spawn_ranks(args, argv):
+    """Parent side of --gpus N > 1.  Nothing here initialises the GPU (torch.cuda.device_count() does not, on this
+    image); the ranks are child processes."""
+    import torch
+    visible = torch.cuda.device_count()
+    if visible < args.gpus:
+        sys.stderr.write("bench.py: --gpus %d requested but only %d GPU(s) visible; refusing to report a smaller run as "
+                         "n_gpus=%d\n" % (args.gpus, visible, args.gpus))
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(launch_command(args, argv, port), env=env)
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if args.gpus < 1:
+        sys.stderr.write("bench.py: --gpus must be >= 1\n")
+        return 2
+    if args.gpus > 1 and "RANK" not in os.environ:
+        return spawn_ranks(args, argv)
+
+    import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.stderr.write("bench.py: WORLD_SIZE=%d but --gpus %d; launch as `python bench.py --gpus N` or with "
+                         "--nproc-per-node equal to --gpus\n" % (world, args.gpus))
+        return 2
     dist = None
     torch.cuda.set_device(local_rank)
     if "RANK" in os.environ:          # launched by torch.distributed.run: one rank per GPU over RCCL (timing only)
@@ -66,13 +139,18 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    C = CONFIGS[args.config]
+    arch, res, qcfg, guidance = C["arch"], C["res"], C["cfg"], C["guidance"]
     K, W = args.steps, args.warmup
-    sch = DDIMScheduler(50)
-    n_ts = min(K + W, 50)
-    timesteps = [sch.timesteps[i % n_ts] for i in range(W + K)]
-    slots = sorted({(1000 - t) // 20 for t in timesteps})
-    P = args.prompts_per_gpu
-    qnn, ckpt_path = build_synthetic_qnn("sd", CFG_C2, 64, 2 * P, max(slots) + 1, rank=local_rank, barrier=barrier, device=dev)
+    P = args.prompts_per_gpu or C["prompts"]
+    nsteps = qcfg["steps"]
+    sch = DDIMScheduler(nsteps)
+    sched_ts = sch.timesteps if arch == "sd" else [999, 749, 499, 249]     # SDXL-turbo: src/inference_qmodel.py:49-54 trailing spacing
+    n_ts = min(K + W, len(sched_ts))
+    timesteps = [sched_ts[i % n_ts] for i in range(W + K)]
+    slots = sorted({(1000 - t) // (1000 // nsteps) for t in timesteps})
+    batch = (2 if guidance > 0 else 1) * P
+    qnn, ckpt_path = build_synthetic_qnn(arch, qcfg, res, batch, max(slots) + 1, rank=local_rank, barrier=barrier, device=dev)
     if args.dtype == "fp16":
         qnn.half()
     elif args.dtype == "bf16":
@@ -82,125 +160,174 @@ def main():
     if not args.no_graph:
         qnn.enable_graphs(True)
 
-    # this rank's prompt (seeded by rank: rank-sliced prompt list), resident on the device
-    lat = synth.named_randn("latent", (P, 4, 64, 64), 1 + rank).to(dev, adt)
-    ctx = synth.named_randn("ctx", (2 * P, 77, 768), 100 + rank).to(dev, adt)
-    guidance = 7.5
+    # this rank's prompts (seeded by rank: rank-sliced prompt list), resident on the device
+    ctx_dim = 768 if arch == "sd" else 2048
+    lat = synth.named_randn("latent", (P, 4, res, res), 1 + rank).to(dev, adt)
+    ctx = synth.named_randn("ctx", (batch, 77, ctx_dim), 100 + rank).to(dev, adt)
+    extra = {}
+    if arch == "sdxl":
+        te = synth.named_randn("text_embeds", (batch, 1280), 200 + rank).to(dev, adt)
+        tid = torch.tensor([[float(res * 8)] * 2 + [0.0, 0.0] + [float(res * 8)] * 2]).repeat(batch, 1).to(dev, adt)
+        extra = {"added_cond_kwargs": {"text_embeds": te, "time_ids": tid}}
 
     def one_step(x, t):
-        inp = torch.cat([x, x], dim=0)
-        eps = qnn(inp, t, ctx)[0]
-        e_u, e_c = eps.chunk(2)
-        return sch.step(e_u + guidance * (e_c - e_u), t, x)
+        if guidance > 0:
+            eps = qnn(torch.cat([x, x], dim=0), t, ctx, **extra)[0]
+            e_u, e_c = eps.chunk(2)
+            eps = e_u + guidance * (e_c - e_u)
+        else:
+            eps = qnn(x, t, ctx, **extra)[0]
+        if arch == "sd":
+            return sch.step(eps, t, x)
+        return x - 0.25 * eps                     # SDXL-turbo: a fixed-coefficient Euler-style update (scheduler arithmetic is not on the path)
 
-    x = lat
+    windows = []
     with torch.no_grad():
         if not args.no_graph:
             for t in sorted(set(timesteps), reverse=True):     # capture one graph per slot used (amortised over images)
                 one_step(lat, t)
+        x = lat
         for t in timesteps[:W]:
             x = one_step(x, t)
-        torch.cuda.synchronize()
-        barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for t in timesteps[W:]:
-            x = one_step(x, t)
-        torch.cuda.synchronize()
-        barrier()
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
+        x_w = x
+        for _ in range(max(1, args.windows)):
+            x = x_w
+            torch.cuda.synchronize()
+            barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for t in timesteps[W:]:
+                x = one_step(x, t)
+            torch.cuda.synchronize()
+            barrier()
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+            if dist is not None:
+                tt = torch.tensor([el], device=dev, dtype=torch.float64)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                el = float(tt.item())
+            windows.append(el)
     assert torch.isfinite(x).all()
-    if dist is not None:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = statistics.median(windows)
 
     # ---- roofline of the dominant north-star kernel (W4A8 GEMM), measured live with HIP events ------------------
-    # One eager step with ops.gemm_wxa8 wrapped: every one of the 280 launches (its split-K reduction included) is
-    # replayed REP times back to back from a hipGraph on the current stream and bracketed by HIP events — eager
+    # One eager step with the GEMM entry point wrapped: every launch (its split-K reduction included) is replayed REP
+    # times back to back from a hipGraph on the current stream and bracketed by HIP events on that stream — eager
     # per-launch events would time the host-side launch gaps, not the kernels.  Sum over the step = the kernel time
-    # rocprofv3 reports for gemm_wxa8_kernel + splitk_epilogue_kernel (profiles/).
+    # rocprofv3 reports for the GEMM kernels (profiles/).
     roofline = None
     if rank == 0 and not args.no_roofline:
-        REP = 5
-        times_ms, algo_ops, algo_bytes = [], [], []
-        orig = ops.gemm_wxa8
+        roofline = measure_gemm_roofline(torch, ops, qnn, lambda: one_step(lat, timesteps[W]), args)
 
-        def timed(codes, rowsum, M, ab, out_dtype, out=None, extra=None):
-            y = orig(codes, rowsum, M, ab, out_dtype, out, extra)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                for _ in range(REP):
-                    orig(codes, rowsum, M, ab, out_dtype, y, extra)
-            g.replay()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            g.replay()
-            e1.record()
-            e1.synchronize()
-            times_ms.append(e0.elapsed_time(e1) / REP)
-            algo_ops.append(2.0 * M * ab.pw.N * ab.pw.K)
-            # un-unfolded input counted once at 1 B/code, int4 weights, output at its dtype
-            algo_bytes.append(M * ab.pw.K / max(1, ab.pw.taps) + ab.pw.N * ab.pw.K / 2 + M * ab.pw.N * y.element_size())
-            return y
-        ops.gemm_wxa8 = timed
-        graphs_were = qnn._graphs
-        qnn._graphs = None
-        with torch.no_grad():
-            one_step(lat, timesteps[W])
-        torch.cuda.synchronize()
-        qnn._graphs = graphs_were
-        ops.gemm_wxa8 = orig
-        gemm_ms = sum(times_ms)
-        tops = sum(algo_ops) / (gemm_ms * 1e-3) / 1e12
-        traffic = None
-        tj = os.path.join(ROOT, "profiles", "r01_gemm_hbm_traffic.json")   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
-        if os.path.exists(tj):
-            traffic = round(json.load(open(tj))["traffic_bytes_per_launch"] / 1e6, 3)
-        n = len(times_ms)
-        roofline = {"kernel": "gemm_wxa8_kernel<4,*> + splitk_epilogue_kernel (dgq_gemm_wxa8)", "bound": "mfma",
-                    "achieved": round(tops, 2), "peak": INT8_PEAK_TOPS, "unit": "TOP/s", "frac": round(tops / INT8_PEAK_TOPS, 4),
-                    "traffic": traffic, "traffic_unit": "MB of HBM-side reads+writes per launch (PMC, profiles/r01_gemm_hbm_traffic.json)",
-                    "launches_per_step": n, "avg_launch_us": round(1e3 * gemm_ms / n, 2), "kernel_ms_per_step": round(gemm_ms, 3),
-                    "algorithmic_Gop_per_launch": round(sum(algo_ops) / n / 1e9, 3),
-                    "algorithmic_MB_per_launch": round(sum(algo_bytes) / n / 1e6, 3)}
-
-    # ---- CPU baseline: the reference's op sequence (oracle port) on this box's host cores, one step --------------
+    # ---- CPU baseline: the reference's op sequence (oracle port) on this box's host cores ----------------------------
     cpu_baseline = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    want_cpu = (args.config == "c2" and not args.no_cpu_baseline) or args.cpu_baseline
+    if rank == 0 and world == 1 and want_cpu:
         from oracle import dgq_oracle as orc
         ncores = min(os.cpu_count() or 1, 64)
         torch.set_num_threads(ncores)
         ck = torch.load(ckpt_path, map_location="cpu")
-        cfg = orc.OracleConfig("sd", 4, 8, True, True, 8, True, True, True, True, 50, True)
-        om = orc.OracleModel(ck, cfg, synth.synth_state_dict("sd", 0))
-        lat_c = synth.named_randn("latent", (1, 4, 64, 64), 1)[:1]
-        ctx_c = synth.named_randn("ctx", (2, 77, 768), 100)
+        cfg = orc.OracleConfig(arch, qcfg["wbits"], qcfg["abits"], True, True, qcfg["abits"], qcfg["log"], qcfg["rt"], qcfg["sp"],
+                               True, nsteps, qcfg["G"] > 1)
+        om = orc.OracleModel(ck, cfg, synth.synth_state_dict(arch, 0))
+        lat_c = synth.named_randn("latent", (1, 4, res, res), 1)
+        ctx_c = synth.named_randn("ctx", (2 if guidance > 0 else 1, 77, ctx_dim), 100)
+        okw = {}
+        if arch == "sdxl":
+            okw = dict(text_embeds=synth.named_randn("text_embeds", (1, 1280), 200),
+                       time_ids=torch.tensor([[float(res * 8)] * 2 + [0.0, 0.0] + [float(res * 8)] * 2]))
         t = timesteps[W]
-        tc0 = time.perf_counter()
-        om.forward(torch.cat([lat_c, lat_c]), t, ctx_c)
-        cpu_s = time.perf_counter() - tc0
+        xin = torch.cat([lat_c, lat_c]) if guidance > 0 else lat_c
+        n_cpu = 3 if args.config == "c2" else 1
+        secs = []
+        for i in range(1 + n_cpu):                             # first call = warm-up (allocator, thread pool), untimed
+            tc0 = time.perf_counter()
+            om.forward(xin, t, ctx_c, **okw)
+            if i:
+                secs.append(time.perf_counter() - tc0)
+        cpu_s = statistics.median(secs)
         cpu_baseline = {"value": round(1.0 / cpu_s, 5), "unit": "steps/s", "cores": ncores, "kind": "port",
-                        "sample": "1 UNet denoise step (CFG pair, t=%d) of the same SD1.4 W4A8 g16 workload, fp32, "
-                                  "torch.set_num_threads(%d); no warm-up (the port keeps no state)" % (t, ncores)}
+                        "seconds_per_step": [round(s, 2) for s in secs],
+                        "sample": "1 warm-up + %d timed UNet denoise steps (batch %d, t=%d) of the same workload, fp32, "
+                                  "torch.set_num_threads(%d); median reported" % (n_cpu, xin.shape[0], t, ncores)}
 
     if rank == 0:
         n = max(world, 1)
+        glue = None
+        gj = os.path.join(ROOT, "profiles", "r02_step_kernel_classes.json")    # from the rocprofv3 kernel trace of this command
+        if args.config == "c2" and os.path.exists(gj):
+            glue = json.load(open(gj))
         out = {
-            "metric": "UNet denoise steps/sec @ SD1.4 512^2 W4A8 g16", "value": round(K * n * P / elapsed, 4),
+            "metric": C["metric"], "value": round(K * n * P / elapsed, 4),
             "unit": "steps/s", "n_gpus": n, "steps": K, "warmup": W, "ms_per_step": round(1e3 * elapsed / (K * P), 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "int8 (W4A8 MFMA, int32 accumulate; %s between layers)" % args.dtype, "data": "synthetic",
-            "config": {"workload": "SD v1.4 UNet W4A8 g=16 (time-aware, log2 softmax real-time δ, start-peak), "
-                                   "DDIM 50-step schedule, 512x512 (64x64 latents), CFG pair per step per GPU",
-                       "prompts_per_gpu": P, "cfg_batch": 2 * P, "parallelism": "replicas x%d (no collectives)" % n},
+            "dtype": "int8 (W%dA%d MFMA, int32 accumulate; %s between layers)" % (qcfg["wbits"], qcfg["abits"], args.dtype),
+            "data": "synthetic",
+            "config": {"workload": C["workload"], "config_id": args.config,
+                       "prompts_per_gpu": P, "batch_per_gpu": batch, "parallelism": "replicas x%d (no collectives)" % n},
+            "windows": {"n": len(windows), "steps_each": K, "value_from": "median",
+                        "ms_per_step_min": round(1e3 * min(windows) / (K * P), 3),
+                        "ms_per_step_all": [round(1e3 * w / (K * P), 3) for w in windows]},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
+            "non_hip_kernels": glue,
         }
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+    return 0
+
+
+def measure_gemm_roofline(torch, ops, qnn, run_step, args):
+    REP = 5
+    times_ms, algo_ops, algo_bytes = [], [], []
+    orig = ops.gemm_wxa8
+
+    def timed(codes, rowsum, M, ab, out_dtype, out=None, extra=None, **kw):
+        y = orig(codes, rowsum, M, ab, out_dtype, out, extra, **kw)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(REP):
+                orig(codes, rowsum, M, ab, out_dtype, y, extra, **kw)
+        g.replay()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        g.replay()
+        e1.record()
+        e1.synchronize()
+        times_ms.append(e0.elapsed_time(e1) / REP)
+        algo_ops.append(2.0 * M * ab.pw.N * ab.pw.K)
+        # un-unfolded input counted once at 1 B/code, int4 weights, output at its dtype
+        algo_bytes.append(M * ab.pw.K / max(1, ab.pw.taps) + ab.pw.N * ab.pw.K * ab.pw.bits / 8 + M * ab.pw.N * y.element_size())
+        return y
+    ops.gemm_wxa8 = timed
+    graphs_were = qnn._graphs
+    qnn._graphs = None
+    try:
+        with torch.no_grad():
+            run_step()
+        torch.cuda.synchronize()
+    finally:
+        qnn._graphs = graphs_were
+        ops.gemm_wxa8 = orig
+    gemm_ms = sum(times_ms)
+    tops = sum(algo_ops) / (gemm_ms * 1e-3) / 1e12
+    n = len(times_ms)
+    # HBM-side bytes per launch come from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/pmc_traffic.py);
+    # a STATIC figure, valid only for the configuration it was profiled on — otherwise null
+    traffic, traffic_src = None, None
+    tj = os.path.join(ROOT, "profiles", "r02_gemm_hbm_traffic.json")
+    if os.path.exists(tj):
+        tjd = json.load(open(tj))
+        if tjd.get("config") == args.config and tjd.get("dtype") == args.dtype and tjd.get("prompts_per_gpu", 1) == (args.prompts_per_gpu or CONFIGS[args.config]["prompts"]):
+            traffic = round(tjd["traffic_bytes_per_launch"] / 1e6, 3)
+            traffic_src = "static: profiles/r02_gemm_hbm_traffic.json (rocprofv3 --pmc passes of this command, not this run)"
+    return {"kernel": "dgq_gemm_wxa8 (gemm_wxa8_kernel<...> tile family + split-K combine where used)", "bound": "mfma",
+            "achieved": round(tops, 2), "peak": INT8_PEAK_TOPS, "unit": "TOP/s", "frac": round(tops / INT8_PEAK_TOPS, 4),
+            "traffic": traffic, "traffic_unit": "MB of HBM-side reads+writes per launch", "traffic_source": traffic_src,
+            "launches_per_step": n, "avg_launch_us": round(1e3 * gemm_ms / n, 2), "kernel_ms_per_step": round(gemm_ms, 3),
+            "algorithmic_Gop_per_launch": round(sum(algo_ops) / n / 1e9, 3),
+            "algorithmic_MB_per_launch": round(sum(algo_bytes) / n / 1e6, 3)}
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

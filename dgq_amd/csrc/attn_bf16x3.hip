@@ -144,11 +144,9 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // LDS-DMA of 16 B per lane: LDS[lds_addr + lane*16] <- *gsrc (inline asm: see gemm_wxa8.hip — the builtin form makes
 // hipcc drain every DMA with vmcnt(0) before the next ds_read; the ring below is ordered by counted vmcnt + barrier).
 __device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_addr) {
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(gsrc), "s"(lds_addr)
-                 : "memory");
+    // M0 (the wave-uniform LDS base of the DMA) is an INPUT OPERAND bound to the physical register with "{m0}": hipcc
+    // materialises the s_mov_b32 m0 itself and tracks the register like any other — nothing is clobbered behind its back.
+    asm volatile("s_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc), "{m0}"(lds_addr) : "memory");
 }
 
 // this wave's share of one tile image: pieces wid, wid+NW, ... < NP (NW waves per block)

@@ -5,8 +5,10 @@
 //   W  = int4 packed [N][Kp/2]  or int8 [N][Kp]
 //   Y  = fp [M][N]
 //
-// Tiling (wave64, gfx950): 128x128 block tile, BK = 128 (two MFMA K-slices), 256 threads = 2x2 waves, each wave
-// owns 64x64 = 4x4 MFMA tiles: 64 int32 accumulators + (per-K mode) 64 fp32 accumulators.
+// Tiling (wave64, gfx950): BM x BN block tile with BM in {32,64,128}, BN in {64,128} (template parameters; the host picks
+// the pair per shape so that the grid fills the 256 CUs without a K split wherever it can), BK = 128 (two MFMA K-slices),
+// 256 threads = 2x2 waves, each wave owns (BM/2)x(BN/2) = TM x TN MFMA tiles: 4·TM·TN int32 accumulators + (per-K mode)
+// as many fp32 accumulators (128x128: 64 + 64).
 //
 // Operand staging is LDS-DMA only (global_load_lds_dwordx4: no staging VGPRs, no ds_write — ds_write_b128 runs at
 // ~79 B/clk/CU and was the bottleneck of the register-staged version): a 3-stage LDS ring, tile t+2 is issued
@@ -21,11 +23,12 @@
 // Small grids (most SD1.4 layers give 10..192 tiles on 256 CUs) use deterministic split-K: grid.z slices of the
 // K-tile range write fp32 partial slabs [S][M][N] to a caller-provided workspace; splitk_epilogue_kernel sums
 // them in a fixed order and applies the dequantisation epilogue (no float atomics: results are bit-reproducible).
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
 #include <type_traits>
 #include "dgq_common.h"
 
-#define BM 128
-#define BN 128
 #define BK 128
 
 struct GemmParams {
@@ -58,15 +61,14 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // LDS-DMA of 16 B per lane: LDS[lds_addr + lane*16] <- *gsrc.  Issued from inline asm on purpose: with the builtin
 // hipcc treats the DMA as an LDS store that every later ds_read may alias and drains it with s_waitcnt vmcnt(0)
 // before the first ds_read of each K step; here the ring is ordered by hand (counted vmcnt + barrier below).
-// M0 carries the wave-uniform LDS base, is written in the same statement that uses it (cdna guide §5.7) and is declared
-// clobbered rather than saved/restored.  Measured on 8192^3: each DMA piece costs ~4.5 % of the loop (skipping the two
-// weight pieces of the six per wave per K tile: 521 -> 474 us) — the largest non-MFMA cost, ~100 cycles per piece
-// against 512 cycles of MFMA per wave per K tile.
+// M0 carries the wave-uniform LDS base: it is passed as an INPUT OPERAND bound to the physical register ("{m0}"), so
+// hipcc emits the s_mov_b32 m0 itself and tracks the register like any other (defined behaviour; the round-1 form wrote
+// M0 inside the asm and listed it as a clobber, which clang rejects as a reserved register and does not honour).  The
+// s_nop covers the M0-write -> LDS-DMA wait state, which the hazard recogniser does not see inside an asm statement.
+// Measured on 8192^3: each DMA piece costs ~4.5 % of the loop (skipping the two weight pieces of the six per wave per K
+// tile: 521 -> 474 us) — the largest non-MFMA cost, ~100 cycles per piece against 512 cycles of MFMA per wave per K tile.
 __device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_addr) {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
-                 :
-                 : "v"(gsrc), "s"(lds_addr)
-                 : "memory", "m0");
+    asm volatile("s_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc), "{m0}"(lds_addr) : "memory");
 }
 
 // y -> [aqtizer_{q,k,v}(y)] -> [+ residual]; element (m, n) of the output
@@ -101,15 +103,28 @@ __device__ __forceinline__ float dgq_epilogue(const GemmParams& p, float acc, in
     return al * (acc - zw * rs) + ga;
 }
 
-template <int WBITS, bool PER_M, typename TOut, int STAGES>
-__global__ __launch_bounds__(256, (STAGES <= 3 ? 2 : 1)) void gemm_wxa8_kernel(GemmParams p) {
+// blocks per CU the LDS ring of a tile shape allows (3 stages + tables), capped at 4: the register budget follows from it
+constexpr int gemm_stage_bytes(int wbits, int bm, int bn) { return bm * BK + bn * (wbits == 4 ? BK / 2 : BK); }
+constexpr int gemm_occupancy(int wbits, int bm, int bn) {
+    const int per_block = 3 * gemm_stage_bytes(wbits, bm, bn) + 6 * 1024;
+    const int o = (160 * 1024) / per_block;
+    return o > 4 ? 4 : (o < 1 ? 1 : o);
+}
+
+template <int WBITS, bool PER_M, typename TOut, int BM, int BN>
+__global__ __launch_bounds__(256, gemm_occupancy(WBITS, BM, BN)) void gemm_wxa8_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    constexpr int A_BYTES = BM * BK;                       // 16 KiB
+    constexpr int STAGES = 3;
+    constexpr int WM = BM / 2, WN = BN / 2;                // per-wave output tile
+    constexpr int TM = WM / 16, TN = WN / 16;              // MFMA tiles per wave
+    static_assert(BM % 32 == 0 && BM <= 128 && BN % 64 == 0 && BN <= 128, "tile shape");
+    constexpr int A_BYTES = BM * BK;                       // 16 KiB at BM = 128
     constexpr int W_ROW = (WBITS == 4) ? BK / 2 : BK;      // bytes per n-row per stage
     constexpr int W_BYTES = BN * W_ROW;
     constexpr int STAGE_BYTES = A_BYTES + W_BYTES;
     constexpr int A_DMA = A_BYTES / 1024 / 4;              // DMA instructions per wave per tile (1 KiB each)
     constexpr int W_DMA = W_BYTES / 1024 / 4;
+    static_assert(A_DMA >= 1 && W_DMA >= 1, "every wave stages at least one piece of each operand");
     constexpr int DMA_PER_TILE = A_DMA + W_DMA;
 
     const int tid = threadIdx.x;
@@ -164,28 +179,28 @@ __global__ __launch_bounds__(256, (STAGES <= 3 ? 2 : 1)) void gemm_wxa8_kernel(G
             glds16(w_src[i] + kw, __builtin_amdgcn_readfirstlane(sw + (wid * W_DMA + i) * 1024));
     };
 
-    v4i acc[4][4];
-    v4f accf[4][4];
+    v4i acc[TM][TN];
+    v4f accf[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < TN; ++j) {
             acc[i][j] = (v4i){0, 0, 0, 0};
             accf[i][j] = (v4f){0.f, 0.f, 0.f, 0.f};
         }
 
     const int fr = lane & 15, fq = lane >> 4;
     // ds_read byte offsets inside a stage (h = K half adds its chunk index below)
-    int a_off[4][2], w_off[4][2];
+    int a_off[TM][2], w_off[TN][2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = wave_m * 64 + i * 16 + fr;
+    for (int i = 0; i < TM; ++i) {
+        const int row = wave_m * WM + i * 16 + fr;
 #pragma unroll
         for (int h = 0; h < 2; ++h) a_off[i][h] = row * BK + (((4 * h + fq) ^ ((row >> 1) & 7)) << 4);
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int row = wave_n * 64 + j * 16 + fr;
+    for (int j = 0; j < TN; ++j) {
+        const int row = wave_n * WN + j * 16 + fr;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             if (WBITS == 4) w_off[j][h] = row * W_ROW + (((4 * h + fq) ^ (((row >> 2) & 3) << 1)) << 3);
@@ -200,12 +215,13 @@ __global__ __launch_bounds__(256, (STAGES <= 3 ? 2 : 1)) void gemm_wxa8_kernel(G
 #pragma unroll
     for (int i = 0; i < STAGES - 1; ++i)
         if (i < nk) issue_tile(kt_begin + i, i);
-    float* vtab = reinterpret_cast<float*>(smem + STAGES * STAGE_BYTES);   // [7][128]: R0 R1 R2 | alpha zw gamma vn
-    float* ctab = vtab + 7 * 128;
+    float* vtab = reinterpret_cast<float*>(smem + STAGES * STAGE_BYTES);   // [3][BM]: R0 R1 R2 | [4][BN]: alpha zw gamma vn
+    float* vcol = vtab + 3 * BM;
+    float* ctab = vcol + 4 * BN;
     {
         const bool final_ep = (p.splits == 1);
         if (final_ep) {
-            if (tid < 128) {
+            if (tid < BM) {
                 const int m = min(m0 + tid, p.M - 1);
                 float rs = 0.0f;
                 for (int j = 0; j < p.rowsum_parts; ++j) rs += p.rowsum[(int64_t)j * p.M + m];
@@ -215,12 +231,12 @@ __global__ __launch_bounds__(256, (STAGES <= 3 ? 2 : 1)) void gemm_wxa8_kernel(G
                     const float md = p.mdelta[li], mz = p.mzp[li];
                     r0 = md; r1 = md * rs; r2 = md * (p.offset - mz);
                 }
-                vtab[tid] = r0; vtab[128 + tid] = r1; vtab[256 + tid] = r2;
-            } else {
+                vtab[tid] = r0; vtab[BM + tid] = r1; vtab[2 * BM + tid] = r2;
+            } else if (tid >= 128 && tid - 128 < BN) {
                 const int c = tid - 128;
                 const int n = min(n0 + c, p.N - 1);
-                vtab[384 + c] = p.alpha[n]; vtab[512 + c] = p.zw[n]; vtab[640 + c] = p.gamma[n];
-                vtab[768 + c] = PER_M ? p.vn[n] : 0.0f;
+                vcol[c] = p.alpha[n]; vcol[BN + c] = p.zw[n]; vcol[2 * BN + c] = p.gamma[n];
+                vcol[3 * BN + c] = PER_M ? p.vn[n] : 0.0f;
             }
         }
         if (!PER_M) {
@@ -242,16 +258,16 @@ __global__ __launch_bounds__(256, (STAGES <= 3 ? 2 : 1)) void gemm_wxa8_kernel(G
     // dropped: MFMAs with a constant-0 C operand after a flush instead of clearing the tile — a second copy of the
     // 16 MFMAs behind a wave-uniform branch; no gain.)
     typedef typename std::conditional<WBITS == 4, uint2, v4i>::type wfrag_t;
-    auto load_frags = [&](const uint8_t* sa, const uint8_t* sw, int h, v4i (&af)[4], wfrag_t (&wf)[4]) {
+    auto load_frags = [&](const uint8_t* sa, const uint8_t* sw, int h, v4i (&af)[TM], wfrag_t (&wf)[TN]) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const v4i*>(sa + a_off[i][h]);
+        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const v4i*>(sa + a_off[i][h]);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const wfrag_t*>(sw + w_off[j][h]);
+        for (int j = 0; j < TN; ++j) wf[j] = *reinterpret_cast<const wfrag_t*>(sw + w_off[j][h]);
     };
-    auto mma_half = [&](const v4i (&af)[4], const wfrag_t (&wf)[4], int chunk) {
-        v4i bf[4];
+    auto mma_half = [&](const v4i (&af)[TM], const wfrag_t (&wf)[TN], int chunk) {
+        v4i bf[TN];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < TN; ++j) {
             if constexpr (WBITS == 4) {
                 const uint2 v = wf[j];
                 bf[j] = (v4i){(int)(v.x & 0x0F0F0F0Fu), (int)((v.x >> 4) & 0x0F0F0F0Fu),
@@ -261,9 +277,9 @@ __global__ __launch_bounds__(256, (STAGES <= 3 ? 2 : 1)) void gemm_wxa8_kernel(G
             }
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < TN; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[i], bf[j], acc[i][j], 0, 0, 0);
         if (!PER_M) {
             // wave-uniform: > 0 on the last chunk of a DGQ group or of this K split
@@ -271,9 +287,9 @@ __global__ __launch_bounds__(256, (STAGES <= 3 ? 2 : 1)) void gemm_wxa8_kernel(G
                 __builtin_bit_cast(int, ctab[chunk])));
             if (sc > 0.0f) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
+                    for (int j = 0; j < TN; ++j) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) accf[i][j][r] += sc * (float)acc[i][j][r];
                         acc[i][j] = (v4i){0, 0, 0, 0};
@@ -281,8 +297,8 @@ __global__ __launch_bounds__(256, (STAGES <= 3 ? 2 : 1)) void gemm_wxa8_kernel(G
             }
         }
     };
-    v4i af0[4], af1[4];
-    wfrag_t wf0[4], wf1[4];
+    v4i af0[TM], af1[TM];
+    wfrag_t wf0[TN], wf1[TN];
     int stage = 0, istage = STAGES - 1;
     load_frags(smem, smem + A_BYTES, 0, af0, wf0);
     for (int t = 0; t < nk; ++t) {
@@ -315,28 +331,33 @@ __global__ __launch_bounds__(256, (STAGES <= 3 ? 2 : 1)) void gemm_wxa8_kernel(G
 
     // epilogue.  The MFMA C/D layout (col = lane&15, row = (lane>>4)*4 + reg) would give 4-byte stores in 64-byte
     // runs; measured, that store pattern (not the MFMAs) bounded every small-K layer (~1 TB/s).  Each wave
-    // therefore transposes its 64x64 fp32 tile through the (now idle) LDS ring and writes 16 bytes per lane, 256
-    // contiguous bytes per row.  Row stride 68 floats: conflict-free ds_write_b32, near conflict-free ds_read_b128.
-    constexpr int EP_LD = 68;
-    float* ep = reinterpret_cast<float*>(smem) + wid * 64 * EP_LD;
+    // therefore transposes its WM x WN fp32 tile through the (now idle) LDS ring and writes 16 bytes per lane, WN·4
+    // contiguous bytes per row.  Row stride WN + 4 floats: conflict-free ds_write_b32, near conflict-free ds_read_b128.
+    constexpr int EP_LD = WN + 4;
+    constexpr int LPR = WN / 4;                              // lanes per output row (4 consecutive n each)
+    constexpr int RPP = 64 / LPR;                            // rows per pass of the wave
+    constexpr int PASSES = WM / RPP;
+    static_assert(4 * WM * EP_LD * 4 <= STAGES * STAGE_BYTES, "epilogue staging must fit the LDS ring");
+    float* ep = reinterpret_cast<float*>(smem) + wid * WM * EP_LD;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 ep[(i * 16 + fq * 4 + r) * EP_LD + j * 16 + fr] = PER_M ? (float)acc[i][j][r] : accf[i][j][r];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // same-wave LDS round trip: no barrier needed
-    const int c4 = (lane & 15) * 4;                          // 4 consecutive n per lane
-    const int nb = n0 + wave_n * 64 + c4;
+    const int c4 = (lane % LPR) * 4;                         // 4 consecutive n per lane
+    const int lrow = lane / LPR;
+    const int nb = n0 + wave_n * WN + c4;
     const bool vec_ok = (nb + 3 < p.N);
     if (p.splits > 1) {
         float* slab = p.slab + (int64_t)blockIdx.z * p.M * p.N;
         const bool al16 = ((p.N & 3) == 0);
 #pragma unroll 4
-        for (int rr = 0; rr < 16; ++rr) {
-            const int row = rr * 4 + (lane >> 4);
-            const int m = m0 + wave_m * 64 + row;
+        for (int rr = 0; rr < PASSES; ++rr) {
+            const int row = rr * RPP + lrow;
+            const int m = m0 + wave_m * WM + row;
             if (m >= p.M || nb >= p.N) continue;
             const float4 v = *reinterpret_cast<const float4*>(ep + row * EP_LD + c4);
             float* dst = slab + (int64_t)m * p.N + nb;
@@ -350,23 +371,23 @@ __global__ __launch_bounds__(256, (STAGES <= 3 ? 2 : 1)) void gemm_wxa8_kernel(G
         return;
     }
     TOut* y = reinterpret_cast<TOut*>(p.y);
-    const float* vc = vtab + 384 + wave_n * 64 + c4;
+    const float* vc = vcol + wave_n * WN + c4;
     const float4 al = *reinterpret_cast<const float4*>(vc);
-    const float4 zw = *reinterpret_cast<const float4*>(vc + 128);
-    const float4 ga = *reinterpret_cast<const float4*>(vc + 256);
-    const float4 vn = *reinterpret_cast<const float4*>(vc + 384);
+    const float4 zw = *reinterpret_cast<const float4*>(vc + BN);
+    const float4 ga = *reinterpret_cast<const float4*>(vc + 2 * BN);
+    const float4 vn = *reinterpret_cast<const float4*>(vc + 3 * BN);
     const bool st_vec = vec_ok && ((p.ldy * (int)sizeof(TOut)) % 16 == 0) &&
                         ((reinterpret_cast<uintptr_t>(p.y) & 15) == 0) && (sizeof(TOut) == 4 || (p.ldy & 3) == 0);
-    // residual tile: all 16 rows of this lane fetched up front as 16-byte loads, so the epilogue pays one memory latency
+    // residual tile: all rows of this lane fetched up front as 16-byte loads, so the epilogue pays one memory latency
     // (fetched row by row inside the store loop, the dependent loads made the fused add slower than a separate kernel)
     const int res_es = p.ex.res_dtype == DGQ_F32 ? 4 : 2;
     const bool res_vec = p.ex.residual != nullptr && vec_ok && (p.ex.ldr & 3) == 0 &&
                          (reinterpret_cast<uintptr_t>(p.ex.residual) & (4 * res_es - 1)) == 0;
-    float4 res[16];
+    float4 res[PASSES];
     if (res_vec) {
 #pragma unroll
-        for (int rr = 0; rr < 16; ++rr) {
-            const int m = min(m0 + wave_m * 64 + rr * 4 + (lane >> 4), p.M - 1);
+        for (int rr = 0; rr < PASSES; ++rr) {
+            const int m = min(m0 + wave_m * WM + rr * RPP + lrow, p.M - 1);
             const int64_t i = (int64_t)(m / p.ex.res_div) * p.ex.ldr + nb;
             if (p.ex.res_dtype == DGQ_F32) {
                 res[rr] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.ex.residual) + i);
@@ -386,13 +407,13 @@ __global__ __launch_bounds__(256, (STAGES <= 3 ? 2 : 1)) void gemm_wxa8_kernel(G
     if (res_vec) exl.residual = nullptr;                 // added below from the prefetched tile
     const bool has_extra = exl.fq_mode != 0 || exl.residual != nullptr;
 #pragma unroll
-    for (int rr = 0; rr < 16; ++rr) {
-        const int row = rr * 4 + (lane >> 4);
-        const int m = m0 + wave_m * 64 + row;
+    for (int rr = 0; rr < PASSES; ++rr) {
+        const int row = rr * RPP + lrow;
+        const int m = m0 + wave_m * WM + row;
         if (m >= p.M || nb >= p.N) continue;
         const float4 v = *reinterpret_cast<const float4*>(ep + row * EP_LD + c4);
-        const float* vr = vtab + wave_m * 64 + row;
-        const float r0 = vr[0], r1 = vr[128], r2 = vr[256];
+        const float* vr = vtab + wave_m * WM + row;
+        const float r0 = vr[0], r1 = vr[BM], r2 = vr[2 * BM];
         // y = alpha·(R0·acc − zw·R1 + R2·vn) + gamma   (per-K: R0 = 1, R1 = rowsum, R2 = 0)
         float o[4];
         o[0] = al.x * (r0 * v.x - zw.x * r1 + r2 * vn.x) + ga.x;
@@ -452,83 +473,136 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(GemmParams p) {
     }
 }
 
-template <int WBITS, bool PER_M, typename TOut, int STAGES>
-static void launch_staged(const GemmParams& p, hipStream_t st) {
-    constexpr int lds_stages = STAGES * (BM * BK + BN * ((WBITS == 4) ? BK / 2 : BK));
-    constexpr int lds_max = lds_stages + 7 * 128 * 4 + 8192;    // + epilogue vectors + per-chunk scales (<= 2048 chunks)
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_wxa8_kernel<WBITS, PER_M, TOut, STAGES>),
+template <int WBITS, bool PER_M, typename TOut, int BM, int BN>
+static void launch_tile(const GemmParams& p, hipStream_t st) {
+    constexpr int lds_stages = 3 * gemm_stage_bytes(WBITS, BM, BN);
+    constexpr int lds_vec = (3 * BM + 4 * BN) * 4;
+    constexpr int lds_max = lds_stages + lds_vec + 8192;        // + epilogue vectors + per-chunk scales (<= 2048 chunks)
+    // the attribute is per device: one flag per device ordinal (set again by whichever thread gets there first — the
+    // call is idempotent, so a benign race at worst repeats it)
+    static std::atomic<bool> attr_set[64];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64 || !attr_set[dev].load(std::memory_order_acquire)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_wxa8_kernel<WBITS, PER_M, TOut, BM, BN>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
-        attr_set = true;
+        if (dev >= 0 && dev < 64) attr_set[dev].store(true, std::memory_order_release);
     }
-    const int lds = lds_stages + 7 * 128 * 4 + (PER_M ? 0 : ((2 * p.tiles_per_split * 4 + 15) & ~15));
+    const int lds = lds_stages + lds_vec + (PER_M ? 0 : ((2 * p.tiles_per_split * 4 + 15) & ~15));
     dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, p.splits), block(256);
-    hipLaunchKernelGGL((gemm_wxa8_kernel<WBITS, PER_M, TOut, STAGES>), grid, block, lds, st, p);
+    hipLaunchKernelGGL((gemm_wxa8_kernel<WBITS, PER_M, TOut, BM, BN>), grid, block, lds, st, p);
 }
 
-// STAGES is a template parameter, but only the 3-stage ring (2 blocks per CU) is launched: a 5-stage ring for grids
-// of <= 1 block per CU measured SLOWER (conv 64x64 320->320: 37 -> 52 us): a lone wave per SIMD is bound by its own
-// ds_read -> MFMA -> barrier chain (~0.6 us per K tile), not by DMA latency; co-resident blocks hide that chain.
+// Tile shapes the host may pick (BM, BN).  W8 (a secondary configuration) carries three of them.
+struct GemmTile { int bm, bn; };
+static const GemmTile kTilesW4[] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}, {32, 128}, {32, 64}};
+static const GemmTile kTilesW8[] = {{128, 128}, {64, 64}, {32, 64}};
+
 template <int WBITS, bool PER_M, typename TOut>
-static void launch_one(const GemmParams& p, hipStream_t st) {
-    launch_staged<WBITS, PER_M, TOut, 3>(p, st);
+static int launch_one(const GemmParams& p, int bm, int bn, hipStream_t st) {
+    const int key = bm * 1000 + bn;
+    switch (key) {
+        case 128128: launch_tile<WBITS, PER_M, TOut, 128, 128>(p, st); break;
+        case 64064: launch_tile<WBITS, PER_M, TOut, 64, 64>(p, st); break;
+        case 32064: launch_tile<WBITS, PER_M, TOut, 32, 64>(p, st); break;
+        default:
+            if constexpr (WBITS == 4) {
+                switch (key) {
+                    case 128064: launch_tile<WBITS, PER_M, TOut, 128, 64>(p, st); break;
+                    case 64128: launch_tile<WBITS, PER_M, TOut, 64, 128>(p, st); break;
+                    case 32128: launch_tile<WBITS, PER_M, TOut, 32, 128>(p, st); break;
+                    default: dgq_set_error("dgq_gemm_wxa8: no %dx%d tile", bm, bn); return DGQ_EINVAL;
+                }
+            } else {
+                dgq_set_error("dgq_gemm_wxa8: no %dx%d tile for W8", bm, bn);
+                return DGQ_EINVAL;
+            }
+    }
     if (p.splits > 1) {
         int64_t total = (int64_t)p.M * ((p.N + 3) / 4);
         int g = (int)((total + 255) / 256);
         if (g > 4096) g = 4096;
         hipLaunchKernelGGL((splitk_epilogue_kernel<PER_M, TOut>), dim3(g), dim3(256), 0, st, p);
     }
+    return DGQ_OK;
 }
 
 template <int WBITS, bool PER_M>
-static int launch_gemm(const GemmParams& p, int y_dtype, hipStream_t st) {
+static int launch_gemm(const GemmParams& p, int bm, int bn, int y_dtype, hipStream_t st) {
+    int rc;
     switch (y_dtype) {
-        case DGQ_F32: launch_one<WBITS, PER_M, float>(p, st); break;
-        case DGQ_F16: launch_one<WBITS, PER_M, __half>(p, st); break;
-        case DGQ_BF16: launch_one<WBITS, PER_M, __hip_bfloat16>(p, st); break;
+        case DGQ_F32: rc = launch_one<WBITS, PER_M, float>(p, bm, bn, st); break;
+        case DGQ_F16: rc = launch_one<WBITS, PER_M, __half>(p, bm, bn, st); break;
+        case DGQ_BF16: rc = launch_one<WBITS, PER_M, __hip_bfloat16>(p, bm, bn, st); break;
         default: dgq_set_error("dgq_gemm_wxa8: unknown y dtype %d", y_dtype); return DGQ_EINVAL;
     }
+    if (rc != DGQ_OK) return rc;
     return dgq_launch_status("dgq_gemm_wxa8");
 }
 
-// K split factor from a small cost model (all times in us; constants measured on MI355X, tools/bench_gemm.py):
-//   a resident block retires one 128x128x128 K tile in ~0.6 us with 2 blocks/CU (0.35 us alone on its CU),
-//   512 block slots; a split adds S·M·N·4 B of slab writes + reads at ~3 TB/s and a ~2 us combine launch.
-// Fitted on the SD1.4 step with bench.py (A/B builds on one box): charging a split 2 us for its combine launch and a per-K
-// tile the same as a per-M tile left 1.7 % on the table — a per-K K tile costs 2-3x a per-M one (a fp32 flush of the 64x64
-// wave tile after every DGQ group), and inside a hipGraph the dependent combine launch costs well under 1 us.
-#ifndef SPLIT_LAUNCH_US
-#define SPLIT_LAUNCH_US 0.5
+// Launch plan (tile shape + K split) from a small cost model, all times in us, constants measured on MI355X with
+// tools/bench_gemm_sweep.py (profiles/r02_gemm_tile_sweep.txt).  A block of tile (BM, BN) retires one K tile (BK = 128) in
+//   t_k = max(T_LAT, mfma) · (per-K ? 1 + flush share : 1)
+// where T_LAT is the ds_read -> MFMA -> barrier chain of a K tile (what a resident block pays however small its tile is)
+// and mfma the matrix time of the co-resident blocks of a CU: occ·(BM·BN·128 MACs)/(4 SIMDs · 1024 MAC/clk) at ~2 GHz.
+// Blocks run in rounds of 256·occ; a split adds S·M·N·4 B of slab traffic (written, then read by the combine kernel) and the
+// combine launch.  Larger tiles win when the grid fills the chip anyway (fewer L2 reads per MAC); otherwise the model
+// prefers the shape that fills it WITHOUT a K split, because slabs + combine cost more than small tiles lose.
+struct GemmPlan { int bm, bn, splits; double t; };
+#ifndef GEMM_T_LAT
+#define GEMM_T_LAT 0.22
 #endif
-#ifndef PERK_TILE_SCALE
-#define PERK_TILE_SCALE 2.5
+#ifndef GEMM_T_FIXED
+#define GEMM_T_FIXED 2.0
 #endif
-#ifndef PERM_TILE_SCALE
-#define PERM_TILE_SCALE 1.0
+#ifndef GEMM_T_SPLIT
+#define GEMM_T_SPLIT 1.5
 #endif
-static int choose_splits(int M, int N, int Kp, size_t ws_bytes, bool per_m = true) {
-    const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+#ifndef GEMM_FLUSH
+#define GEMM_FLUSH 1.2
+#endif
+static GemmPlan plan_gemm(int M, int N, int Kp, int w_bits, size_t ws_bytes, bool per_m) {
+    const GemmTile* tiles = w_bits == 4 ? kTilesW4 : kTilesW8;
+    const int ntiles = w_bits == 4 ? (int)(sizeof(kTilesW4) / sizeof(GemmTile)) : (int)(sizeof(kTilesW8) / sizeof(GemmTile));
     const int nk = Kp / BK;
-    if (nk < 4) return 1;
     const double slab_bytes = (double)M * N * 4.0;
-    double best_t = 1e30;
-    int best = 1;
-    for (int s = 1; s <= 32 && s * 2 <= nk; ++s) {
-        if (s > 1 && slab_bytes * s > (double)ws_bytes) break;
-        const int tps = (nk + s - 1) / s;
-        const long blocks = (long)tiles * ((nk + tps - 1) / tps);
-        const long waves = (blocks + 511) / 512;
-        const double per_tile = (blocks <= 256 ? 0.35 : 0.6) * (per_m ? PERM_TILE_SCALE : PERK_TILE_SCALE);
-        double t = waves * (tps * per_tile + 1.5);
-        if (s > 1) t += SPLIT_LAUNCH_US + 2.0 * slab_bytes * s / 3.0e6;
-        if (t < best_t) { best_t = t; best = s; }
+    GemmPlan best = {tiles[0].bm, tiles[0].bn, 1, 1e30};
+    for (int ti = 0; ti < ntiles; ++ti) {
+        const int bm = tiles[ti].bm, bn = tiles[ti].bn;
+        const long grid = (long)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
+        const int occ = gemm_occupancy(w_bits, bm, bn);
+        for (int s = 1; s <= 32 && (s == 1 || s * 2 <= nk); ++s) {
+            if (s > 1 && slab_bytes * s > (double)ws_bytes) break;
+            const int tps = (nk + s - 1) / s;
+            const long blocks = grid * ((nk + tps - 1) / tps);
+            const long slots = 256L * occ;
+            const long rounds = (blocks + slots - 1) / slots;
+            const double resident = (double)(blocks < slots ? blocks : slots) / 256.0;    // blocks per CU actually there
+            const double mfma = (resident < 1.0 ? 1.0 : resident) * (double)bm * bn * BK / (4.0 * 1024.0) / 2000.0;
+            double tk = mfma > GEMM_T_LAT ? mfma : GEMM_T_LAT;
+            // per-K: every group end flushes the wave's int32 tile to fp32 (VALU, ~3 ops per accumulator)
+            if (!per_m) tk *= 1.0 + GEMM_FLUSH * (mfma / (mfma > GEMM_T_LAT ? mfma : GEMM_T_LAT));
+            double t = rounds * (tps * tk + GEMM_T_FIXED);
+            if (s > 1) t += GEMM_T_SPLIT + 2.0 * slab_bytes * s / 3.0e6;
+            if (t < best.t) best = {bm, bn, s, t};
+        }
     }
     return best;
 }
 
+// Development hook: DGQ_GEMM_FORCE="BM,BN,S" overrides the plan (tile sweeps, tools/bench_gemm_sweep.py); read per call.
+static bool forced_plan(GemmPlan& pl) {
+    const char* e = getenv("DGQ_GEMM_FORCE");
+    if (!e || !*e) return false;
+    int bm = 0, bn = 0, s = 0;
+    if (sscanf(e, "%d,%d,%d", &bm, &bn, &s) != 3) return false;
+    pl.bm = bm; pl.bn = bn; pl.splits = s < 1 ? 1 : s;
+    return true;
+}
+
 extern "C" size_t dgq_gemm_workspace_bytes(int M, int N, int Kp) {
-    const int s = choose_splits(M, N, Kp, (size_t)-1, false);
+    const GemmPlan a = plan_gemm(M, N, Kp, 4, (size_t)-1, false), b = plan_gemm(M, N, Kp, 4, (size_t)-1, true);
+    const int s = a.splits > b.splits ? a.splits : b.splits;
     return s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
 }
 
@@ -568,13 +642,18 @@ extern "C" int dgq_gemm_wxa8(const int8_t* codes, const float* rowsum, int rowsu
         p.ex.residual = nullptr; p.ex.ldr = 0; p.ex.res_div = 1; p.ex.res_dtype = DGQ_F32; p.ex.fq_mode = 0; p.ex.fq_delta = nullptr; p.ex.fq_zp = nullptr;
         p.ex.fq_T = 1; p.ex.fq_D = 1; p.ex.fq_skip = 0; p.ex.fq_qmax = 255.0f;
     }
-    p.splits = workspace ? choose_splits(M, N, Kp, workspace_bytes, per_m != 0) : 1;
+    GemmPlan pl = plan_gemm(M, N, Kp, w_bits, workspace ? workspace_bytes : 0, per_m != 0);
+    if (forced_plan(pl)) {
+        DGQ_CHECK_ARG(pl.splits == 1 || (workspace && (size_t)pl.splits * M * N * 4 <= workspace_bytes),
+                      "dgq_gemm_wxa8: DGQ_GEMM_FORCE split does not fit the workspace");
+    }
+    p.splits = pl.splits;
     p.slab = p.splits > 1 ? reinterpret_cast<float*>(workspace) : nullptr;
     const int nk = Kp / BK;
     p.tiles_per_split = (nk + p.splits - 1) / p.splits;
     p.splits = (nk + p.tiles_per_split - 1) / p.tiles_per_split;      // no empty split
     if (p.splits == 1) p.slab = nullptr;
     hipStream_t st = (hipStream_t)stream;
-    if (w_bits == 4) return per_m ? launch_gemm<4, true>(p, y_dtype, st) : launch_gemm<4, false>(p, y_dtype, st);
-    return per_m ? launch_gemm<8, true>(p, y_dtype, st) : launch_gemm<8, false>(p, y_dtype, st);
+    if (w_bits == 4) return per_m ? launch_gemm<4, true>(p, pl.bm, pl.bn, y_dtype, st) : launch_gemm<4, false>(p, pl.bm, pl.bn, y_dtype, st);
+    return per_m ? launch_gemm<8, true>(p, pl.bm, pl.bn, y_dtype, st) : launch_gemm<8, false>(p, pl.bm, pl.bn, y_dtype, st);
 }

@@ -234,10 +234,16 @@ def workspace(device):
     """Persistent split-K scratch (caller-owned; one per device AND stream, so that layers running concurrently on
     forked streams never share it): the library never allocates."""
     cur = torch.cuda.current_stream(device).cuda_stream
-    branch = "main"                      # every stream that is not one of the forked side streams (incl. capture streams)
+    branch = None
     for i, st in enumerate(_SIDE_STREAMS.get(str(device), [])):
         if st.cuda_stream == cur:
             branch = i
+    if branch is None:
+        # the default stream and torch's graph-capture stream of a device are one serial chain (a capture runs while the
+        # default stream is idle) and share the "main" slab; any OTHER user stream gets a slab of its own, keyed by handle,
+        # so two user streams can never race on one split-K workspace
+        is_main = cur == torch.cuda.default_stream(device).cuda_stream or torch.cuda.is_current_stream_capturing()
+        branch = "main" if is_main else ("stream", cur)
     key = (str(device), branch)
     if key not in _WORKSPACE:
         if torch.cuda.is_current_stream_capturing():

@@ -162,4 +162,5 @@ def load_cali_model(qnn: QuantModel, init_data: Tuple[torch.Tensor], use_aq: boo
                     if ("%s.delta" % name) not in covered:
                         m.delta, m.zero_point, m.init = None, None, False
                     del m._placeholder
+    qnn._drop_graphs()                               # anything captured before the (re)load is stale
     logger.info("Loading calibration model done.")

@@ -186,6 +186,18 @@ class UniformAffineQuantizer(nn.Module):
         return self
 
 
+#: Test instrumentation (tests/test_gpu_unet.py::teacher-forced checks).  When set to a callable, every call of a quantized
+#: layer that runs on the integer path — the plain ``forward`` and the fused entry points the blocks use
+#: (``forward_fused`` / ``forward_prenorm`` / ``forward_residual``) — reports
+#: ``LAYER_TAP(layer, y, x=..., prologue=bool, residual=..., bias_rows=...)`` and continues with the tensor it returns,
+#: so a test can compare every operator of the FUSED graph with the oracle and teacher-force it.  None in production.
+LAYER_TAP = None
+
+
+def _tap(layer, y, **info):
+    return y if LAYER_TAP is None else LAYER_TAP(layer, y, **info)
+
+
 class SlotRef:
     """Shared by every layer of one QuantModel: which timestep slot's activation tables are live
     (time-aware mode, calibration.py:297-312). ``None`` = use the quantizer modules' own δ/z."""
@@ -298,7 +310,8 @@ class QuantLayer(nn.Module):
             key = slot
             if key not in self._bindings:
                 d, z = self._act_tables[slot]
-                lay = plan_act(d, z, "conv" if self.is_conv else "linear", self.in_channels, self.taps, self.aqtizer.bits)
+                lay = plan_act(d, z, "conv" if self.is_conv else "linear", self.in_channels, self.taps, self.aqtizer.bits,
+                               kw=self.w.shape[3] if self.is_conv else 1)
                 self._bindings[key] = ops.ActBinding(lay, pw, self.aqtizer.bits)
             return self._bindings[key]
         a = self.aqtizer
@@ -307,7 +320,8 @@ class QuantLayer(nn.Module):
         key = ("live", d.data_ptr(), d._version, z.data_ptr() if z.numel() else 0, z._version)
         if key not in self._bindings:
             self._bindings = {k: v for k, v in self._bindings.items() if not (isinstance(k, tuple) and k[0] == "live")}
-            lay = plan_act(d.data, z.data, "conv" if self.is_conv else "linear", self.in_channels, self.taps, a.bits)
+            lay = plan_act(d.data, z.data, "conv" if self.is_conv else "linear", self.in_channels, self.taps, a.bits,
+                           kw=self.w.shape[3] if self.is_conv else 1)
             self._bindings[key] = ops.ActBinding(lay, pw, a.bits)
         return self._bindings[key]
 
@@ -336,8 +350,9 @@ class QuantLayer(nn.Module):
         ab = self._binding()
         if self.is_conv:
             kh, kw = self.w.shape[2], self.w.shape[3]
-            return ops.quant_conv2d(x, ab, kh, kw, self.fwd_kwargs["stride"][0], self.fwd_kwargs["padding"][0])
-        return ops.quant_linear(x, ab)
+            return _tap(self, ops.quant_conv2d(x, ab, kh, kw, self.fwd_kwargs["stride"][0], self.fwd_kwargs["padding"][0]),
+                        x=x, prologue=False)
+        return _tap(self, ops.quant_linear(x, ab), x=x, prologue=False)
 
     def on_integer_path(self, x: torch.Tensor) -> bool:
         """True when forward(x) would run dgq_quant_act + dgq_gemm_wxa8 (weights and activations quantised, GPU)."""
@@ -367,7 +382,8 @@ class QuantLayer(nn.Module):
                 ops.fakequant_rows(y.view(-1, y.shape[-1]), T, D, mode - 1, dd, zz, skip, bits)
             return y if residual is None else y + residual
         lnp = (ln.weight, ln.bias, float(ln.eps)) if ln is not None else None
-        return ops.quant_linear(x, self._binding(), pre_act=pre_act, residual=residual, fq=fq, ln=lnp)
+        return _tap(self, ops.quant_linear(x, self._binding(), pre_act=pre_act, residual=residual, fq=fq, ln=lnp),
+                    x=x, prologue=bool(pre_act or lnp is not None), residual=residual, fq=fq)
 
     def can_fuse_prenorm(self, x: torch.Tensor) -> bool:
         """True when this layer runs on the integer path, so a preceding GroupNorm(+SiLU) can be folded into its
@@ -380,16 +396,18 @@ class QuantLayer(nn.Module):
         """conv(act(GroupNorm(x))) [+ residual | + bias_rows[b, :, None, None]] without materialising the normalised tensor."""
         ab = self._binding()
         kh, kw = self.w.shape[2], self.w.shape[3]
-        return ops.quant_conv2d(x, ab, kh, kw, self.fwd_kwargs["stride"][0], self.fwd_kwargs["padding"][0],
-                                norm=(norm.num_groups, norm.eps, norm.weight, norm.bias, 1 if silu else 0),
-                                residual=residual, bias_rows=bias_rows)
+        return _tap(self, ops.quant_conv2d(x, ab, kh, kw, self.fwd_kwargs["stride"][0], self.fwd_kwargs["padding"][0],
+                                           norm=(norm.num_groups, norm.eps, norm.weight, norm.bias, 1 if silu else 0),
+                                           residual=residual, bias_rows=bias_rows),
+                    x=x, prologue=True, residual=residual, bias_rows=bias_rows)
 
     def forward_residual(self, x: torch.Tensor, residual) -> torch.Tensor:
         """conv(x) + residual with the add in the GEMM epilogue (integer path), else unfused."""
         if self.is_conv and self.on_integer_path(x) and x.dtype in ops.FLOAT_DTYPES:
             kh, kw = self.w.shape[2], self.w.shape[3]
-            return ops.quant_conv2d(x, self._binding(), kh, kw, self.fwd_kwargs["stride"][0],
-                                    self.fwd_kwargs["padding"][0], residual=residual)
+            return _tap(self, ops.quant_conv2d(x, self._binding(), kh, kw, self.fwd_kwargs["stride"][0],
+                                               self.fwd_kwargs["padding"][0], residual=residual),
+                        x=x, prologue=False, residual=residual)
         return self.forward(x) + residual
 
     # -- state switches (quant_layer.py:663-686) -----------------------------------------------------------

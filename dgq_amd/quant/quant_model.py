@@ -73,13 +73,22 @@ class QuantModel(nn.Module):
                 self.quant_block(child, wq_params, aq_params, softmax_aq_params)
 
     # -- state switches ----------------------------------------------------------------------------------------
+    def _drop_graphs(self):
+        """Captured graphs bake in the quantisation state, the dtype and the buffers of the moment of capture: any change
+        of those invalidates them (they are re-captured on the next forward)."""
+        if self._graphs is not None:
+            self._graphs = {}
+            self._graph_pool = None
+
     def set_quant_state(self, use_wq: bool = False, use_aq: bool = False) -> None:
+        self._drop_graphs()
         for m in self.model.modules():
             if isinstance(m, (BaseQuantBlock, QuantLayer)):
                 m.set_quant_state(use_wq=use_wq, use_aq=use_aq)
 
     def disable_out_quantization(self) -> None:
         """conv_in / conv_out stay floating point (quant_model.py:118-124)."""
+        self._drop_graphs()
         self.model.conv_in.use_wq = False
         self.model.conv_in.disable_aq = True
         self.model.conv_out.use_wq = False
@@ -94,7 +103,8 @@ class QuantModel(nn.Module):
             n = self.time_aware["num_inference_steps"]
             slot = int((1000 - int(t)) // (1000 // n))
             self.activate_slot(slot)
-        if self._graphs is not None and torch.is_tensor(sample) and sample.is_cuda and not args:
+        if (self._graphs is not None and torch.is_tensor(sample) and sample.is_cuda and not args
+                and self._graphable_kwargs(kwargs)):
             return self._graph_forward(slot, sample, timesteps, encoder_hidden_states, kwargs)
         return self.model(sample, timesteps, encoder_hidden_states, *args, **kwargs)
 
@@ -107,16 +117,31 @@ class QuantModel(nn.Module):
         self._graph_pool = None
         return self
 
+    @staticmethod
+    def _graphable_kwargs(kwargs):
+        """Only the keyword arguments the diffusers pipelines pass with no effect on this UNet (None / False / empty) may
+        accompany a replayed graph; anything else runs eagerly instead of being silently frozen at its first value."""
+        for k, v in kwargs.items():
+            if k == "added_cond_kwargs":
+                if v is not None and not all(torch.is_tensor(t) for t in v.values()):
+                    return False
+            elif not (v is None or v is False or (isinstance(v, (dict, list, tuple)) and len(v) == 0)):
+                return False
+        return True
+
     def _graph_forward(self, slot, sample, timesteps, ehs, kwargs):
-        ack = kwargs.get("added_cond_kwargs")
+        ack = kwargs.get("added_cond_kwargs") or None
         extra = {k: v for k, v in kwargs.items() if k != "added_cond_kwargs"}
-        tval = int(timesteps if not torch.is_tensor(timesteps) else (timesteps if timesteps.dim() == 0 else timesteps[0]))
-        key = (slot, tuple(sample.shape), sample.dtype, tuple(ehs.shape),
-               tuple(sorted((k, tuple(v.shape)) for k, v in ack.items())) if ack else None)
+        traw = timesteps if not torch.is_tensor(timesteps) else (timesteps if timesteps.dim() == 0 else timesteps[0])
+        t_is_float = (torch.is_tensor(traw) and traw.is_floating_point()) or isinstance(traw, float)
+        tval = float(traw) if t_is_float else int(traw)
+        key = (slot, tuple(sample.shape), sample.dtype, tuple(ehs.shape), ehs.dtype, t_is_float,
+               tuple(sorted((k, tuple(v.shape), v.dtype) for k, v in ack.items())) if ack else None)
         ent = self._graphs.get(key)
         if ent is None:
             dev = sample.device
-            st = dict(sample=sample.clone(), ehs=ehs.clone(), t=torch.full((1,), tval, dtype=torch.int64, device=dev),
+            st = dict(sample=sample.clone(), ehs=ehs.clone(),
+                      t=torch.full((1,), tval, dtype=torch.float32 if t_is_float else torch.int64, device=dev),
                       ack={k: v.clone() for k, v in ack.items()} if ack else None)
             kw = dict(extra)
             if st["ack"] is not None:
@@ -185,6 +210,10 @@ class QuantModel(nn.Module):
         raise NotImplementedError("multi-GPU calibration is disabled in the reference too (src/quantize_weight.py:214)")
 
     # -- dtype / device ---------------------------------------------------------------------------------------
+    def _apply(self, fn, *a, **k):
+        self._drop_graphs()                       # .to() / .cuda() / .half() / .float() move or recast the captured buffers
+        return super()._apply(fn, *a, **k)
+
     def half(self):
         super().half()
         for m in self.model.modules():

@@ -205,3 +205,35 @@ def test_as_f32_cache_lives_on_the_tensor():
     assert c is not a and torch.allclose(c, p.detach().float())
     q = torch.nn.Parameter(torch.randn(8))
     assert ops.as_f32(q).data_ptr() == q.data_ptr()
+
+
+# ---------------------------------------------------------------------------------------------- bench.py launcher
+def test_bench_gpus_n_fails_loudly_without_n_devices():
+    """`python bench.py --gpus 2` must start 2 ranks or fail — never report a 1-GPU run as n_gpus 2.
+    In this container no GPU is visible, so the parent refuses before touching the GPU."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert p.returncode != 0
+    assert "--gpus 2 requested" in p.stderr and "n_gpus" not in p.stdout
+
+
+def test_bench_world_size_must_equal_gpus(monkeypatch):
+    import bench
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    monkeypatch.setenv("LOCAL_RANK", "0")
+    assert bench.main(["--gpus", "2"]) == 2            # a torchrun world that disagrees with --gpus is refused
+
+
+def test_bench_launch_command_is_one_rank_per_gpu():
+    import bench
+    a = bench.parse_args(["--gpus", "4", "--steps", "3", "--warmup", "1", "--config", "c5"])
+    cmd = bench.launch_command(a, ["--gpus", "4", "--steps", "3", "--warmup", "1", "--config", "c5"], 29511)
+    assert cmd[1:3] == ["-m", "torch.distributed.run"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-8:] == ["--gpus", "4", "--steps", "3", "--warmup", "1", "--config", "c5"]
+    assert bench.CONFIGS["c5"]["prompts"] == 8 and bench.CONFIGS["c5"]["cfg"]["G"] == 1 and bench.CONFIGS["c5"]["cfg"]["abits"] == 6
+    assert bench.CONFIGS["c4"]["arch"] == "sdxl" and bench.CONFIGS["c4"]["res"] == 128

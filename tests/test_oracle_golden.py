@@ -154,3 +154,63 @@ def test_slot_formula():
     assert [orc.slot_for_timestep(t, 50) for t in (981, 961, 21, 1)] == [0, 1, 48, 49]
     assert [orc.slot_for_timestep(t, 4) for t in (999, 749, 499, 249)] == [0, 1, 2, 3]
     assert orc.DDIM(50).timesteps[:3] == [981, 961, 941] and orc.DDIM(50).timesteps[-1] == 1
+
+
+# ---------------------------------------------------------------------------------------------- F5 (whole UNet)
+def test_f5_oracle_forward_matches_reference_unet_16x16(golden_dir):
+    """OracleModel.forward (the whole SD1.4 UNet: 280 quantized layers, W4A8 g16, log2 softmax with real-time δ,
+    start-peak, time-aware tables) against the REAL reference's output at 16x16 latents
+    (tests/golden/f5_unet_sd_c2_r16.pt, written by make_golden.py `unet c2 16`).  Same thread count as the golden run
+    => the same BLAS calls => expected bit-identical; on a host whose BLAS blocks differently the fake-quant graph is
+    chaotic (the golden file's own 1-thread vs 8-thread outputs differ by ~1e-1), so the fallback bound is that
+    self-deviation."""
+    import warnings
+    from oracle import dgq_oracle as orc
+    from dgq_amd import synth
+    g = torch.load(os.path.join(golden_dir, "f5_unet_sd_c2_r16.pt"))
+    m = g["meta"]
+    assert m["arch"] == "sd" and m["res"] == 16
+    ts = sorted(g["outputs"].keys(), reverse=True)
+    slots = sorted({(1000 - t) // (1000 // m["steps"]) for t in ts})
+    recs = synth.enumerate_act_quantizers("sd", m["batch"], m["res"])
+    ck = {"act_%d" % s: synth.synth_act_slot("sd", m["abits"], m["G"], s, 0, m["batch"], m["res"], m["sp"], False, recs)
+          for s in slots}
+    ck["weight"] = synth.synth_weight_ckpt("sd", m["wbits"], 0)
+    cfg = orc.OracleConfig("sd", m["wbits"], m["abits"], True, True, m["abits"], m["log"], m["rt"], m["sp"],
+                           m["time_aware"], m["steps"], m["G"] > 1)
+    fp_sd = {k[len("model."):].replace(".w", ".weight").replace(".b", ".bias"): v for k, v in ck["weight"].items()
+             if k.startswith("model.conv_in.") or k.startswith("model.conv_out.")}
+    fp_sd = {k: v for k, v in fp_sd.items() if k.endswith("weight") or k.endswith("bias")}
+    om = orc.OracleModel(ck, cfg, fp_sd)
+    inp = synth.synth_inputs("sd", m["batch"], m["input_seed"], m["res"])
+    nt = torch.get_num_threads()
+    torch.set_num_threads(m.get("threads", nt))
+    try:
+        for t in ts:
+            y = om.forward(inp["sample"], t, inp["encoder_hidden_states"])
+            ref = g["outputs"][t]
+            e = ((y.double() - ref.double()).norm() / ref.double().norm()).item()
+            self_dev = ((g["outputs_1thread"][t].double() - ref.double()).norm() / ref.double().norm()).item()
+            if e != 0.0:
+                warnings.warn("oracle vs reference golden at t=%d: rel-L2 %.3g (not bit-identical on this host; "
+                              "reference self-deviation %.3g)" % (t, e, self_dev))
+            assert e == 0.0 or e < 2.5 * self_dev, (t, e, self_dev)
+    finally:
+        torch.set_num_threads(nt)
+
+
+def test_oracle_exact_gemm_mode_is_a_rounding_level_change_per_layer():
+    """The float64-GEMM variant of the oracle (the "exact" target of the GPU parity statistics) differs from the
+    reference-faithful fp32 one only by the rounding of each contraction: on a single quantized layer the outputs
+    agree to ~1e-6; through the whole chaotic UNet they diverge like any two fp32 runs do."""
+    from oracle import dgq_oracle as orc
+    case = [c for c in recipes.f3_cases() if c["name"] == "linear_w4a8g16_perK"][0]
+    inp = recipes.f3_inputs(case)
+    wd, wz = orc.minmax_channel(inp["w"], 4)
+    ck = {"weight": {"model.l.w": inp["w"], "model.l.b": inp["b"], "model.l.wqtizer.delta": wd,
+                     "model.l.wqtizer.zero_point": wz},
+          "act_0": {"model.l.aqtizer.delta": inp["adelta"], "model.l.aqtizer.zero_point": inp["azp"]}}
+    y32 = orc.OracleModel(ck, orc.OracleConfig(wbits=4, abits=8)).linear("l", inp["x"])
+    y64 = orc.OracleModel(ck, orc.OracleConfig(wbits=4, abits=8, exact_gemm=True)).linear("l", inp["x"])
+    e = ((y32.double() - y64.double()).norm() / y64.double().norm()).item()
+    assert 0.0 <= e < 5e-6, e
