@@ -103,10 +103,15 @@ __device__ __forceinline__ float dgq_epilogue(const GemmParams& p, float acc, in
     return al * (acc - zw * rs) + ga;
 }
 
-// blocks per CU the LDS ring of a tile shape allows (3 stages + tables), capped at 4: the register budget follows from it
+// LDS ring depth: 3 stages for every tile shape.  Deeper rings for the small tiles (6 stages at 32x64, 4 at 64x64 — more
+// bytes in flight per block) measured 5-25 % SLOWER on the SD layer shapes (tools/tile_sweep.py: 2048x640x1408 per-K
+// 11.4 -> 12.4 us, 8192x320x1024 14.2 -> 17.9): the extra LDS costs a resident block per CU, which hides more latency than
+// the longer ring does.
 constexpr int gemm_stage_bytes(int wbits, int bm, int bn) { return bm * BK + bn * (wbits == 4 ? BK / 2 : BK); }
+constexpr int gemm_stages(int wbits, int bm, int bn) { return 3; }
+// blocks per CU the LDS ring of a tile shape allows (ring + tables), capped at 4: the register budget follows from it
 constexpr int gemm_occupancy(int wbits, int bm, int bn) {
-    const int per_block = 3 * gemm_stage_bytes(wbits, bm, bn) + 6 * 1024;
+    const int per_block = gemm_stages(wbits, bm, bn) * gemm_stage_bytes(wbits, bm, bn) + 6 * 1024;
     const int o = (160 * 1024) / per_block;
     return o > 4 ? 4 : (o < 1 ? 1 : o);
 }
@@ -114,7 +119,7 @@ constexpr int gemm_occupancy(int wbits, int bm, int bn) {
 template <int WBITS, bool PER_M, typename TOut, int BM, int BN>
 __global__ __launch_bounds__(256, gemm_occupancy(WBITS, BM, BN)) void gemm_wxa8_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    constexpr int STAGES = 3;
+    constexpr int STAGES = gemm_stages(WBITS, BM, BN);
     constexpr int WM = BM / 2, WN = BN / 2;                // per-wave output tile
     constexpr int TM = WM / 16, TN = WN / 16;              // MFMA tiles per wave
     static_assert(BM % 32 == 0 && BM <= 128 && BN % 64 == 0 && BN <= 128, "tile shape");
@@ -475,7 +480,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(GemmParams p) {
 
 template <int WBITS, bool PER_M, typename TOut, int BM, int BN>
 static void launch_tile(const GemmParams& p, hipStream_t st) {
-    constexpr int lds_stages = 3 * gemm_stage_bytes(WBITS, BM, BN);
+    constexpr int lds_stages = gemm_stages(WBITS, BM, BN) * gemm_stage_bytes(WBITS, BM, BN);
     constexpr int lds_vec = (3 * BM + 4 * BN) * 4;
     constexpr int lds_max = lds_stages + lds_vec + 8192;        // + epilogue vectors + per-chunk scales (<= 2048 chunks)
     // the attribute is per device: one flag per device ordinal (set again by whichever thread gets there first — the

@@ -41,6 +41,15 @@ ARCH = {
         up=(("plain", 0, True), ("xattn", 1, False)),
         addition_time_embed_dim=None, add_in=None, temb_dim=128,
     ),
+    # two-level model with the REFERENCE's hard-wired widths (temb 1280, ctx 768, 8 heads): the one shape that can be built
+    # from the reference's own block classes too — used to golden-check the calibration producer (tests/golden/make_golden.py calib)
+    "mini": dict(
+        sample_size=16, ctx_dim=768, heads=8, head_dim=None, proj="conv", mid_layers=1,
+        block_out=(64, 64),
+        down=(("xattn", 1, True), ("plain", 0, False)),
+        up=(("plain", 0, True), ("xattn", 1, False)),
+        addition_time_embed_dim=None, add_in=None, temb_dim=1280,
+    ),
     "sdxl": dict(
         sample_size=128, ctx_dim=2048, heads=None, head_dim=64, proj="linear", mid_layers=10,
         block_out=(320, 640, 1280),

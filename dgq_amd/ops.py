@@ -424,6 +424,26 @@ def logquant_f32(p: torch.Tensor, delta: torch.Tensor, bits, skip_cols=0, out=No
     return out
 
 
+def minmax_rows_cols(x2d: torch.Tensor, rows=True, cols=True):
+    """Row-wise and column-wise (min, max) of a contiguous [R][C] view — the statistics of DGQ's calibration producer
+    (dgq_minmax_rows_cols).  Returns (rowmin, rowmax, colmin, colmax), fp32, None for a pair that was not requested."""
+    assert x2d.dim() == 2 and x2d.stride(1) == 1 and x2d.dtype in _lib.DTYPE_CODE
+    R, C = x2d.shape
+    dev = x2d.device
+    rmin = rmax = cmin = cmax = part = None
+    slices = max(1, min(256, R // 64))
+    if rows:
+        rmin = torch.empty((R,), dtype=torch.float32, device=dev)
+        rmax = torch.empty((R,), dtype=torch.float32, device=dev)
+    if cols:
+        cmin = torch.empty((C,), dtype=torch.float32, device=dev)
+        cmax = torch.empty((C,), dtype=torch.float32, device=dev)
+        part = torch.empty((2 * slices * C,), dtype=torch.float32, device=dev)
+    _lib_call("dgq_minmax_rows_cols", _lib.ptr(x2d), _lib.DTYPE_CODE[x2d.dtype], R, C, x2d.stride(0),
+              _lib.ptr(rmin), _lib.ptr(rmax), _lib.ptr(cmin), _lib.ptr(cmax), _lib.ptr(part), slices, _lib.stream())
+    return rmin, rmax, cmin, cmax
+
+
 ATTN_HEAD_DIMS = (8, 16, 40, 64, 80, 160)
 
 

@@ -6,3 +6,4 @@ from .quant_block import BaseQuantBlock, QuantResnetBlock2D, QuantBasicTransform
 from .quant_model import QuantModel
 from .calibration import load_cali_model
 from .load_qmodel_util import get_qmodel
+from .calibration_group_quantization import act_group_quant, cali_model_aq

@@ -226,7 +226,9 @@ def quant_attention_forward(attn, hidden_states, encoder_hidden_states=None, res
     if use_aq:
         wq_ = attn.aqtizer_w
         mode_w = (1 if wq_.real_time else 2) if isinstance(wq_, T2ILogQuantizer) else 3
-    defer = (FUSION and _F_ATTN_FQ and use_aq and hidden_states.is_cuda and hidden_states.dtype in ops.FLOAT_DTYPES
+    calibrating = use_aq and any(getattr(attn, n).calibrating() for n in ("aqtizer_q", "aqtizer_k", "aqtizer_v"))
+    defer = (FUSION and _F_ATTN_FQ and use_aq and not calibrating and hidden_states.is_cuda
+             and hidden_states.dtype in ops.FLOAT_DTYPES
              and D in ops.ATTN_HEAD_DIMS and (mode_w == 1 or attn.aqtizer_w.init)
              and ops.attention_fuses_fakequant(D, mode_w))
     pending = {}
@@ -249,6 +251,9 @@ def quant_attention_forward(attn, hidden_states, encoder_hidden_states=None, res
             if not qz.init:                                          # first-forward scalar self-init
                 view = ten.view(bb, ntok, H, D)
                 qz.init_from(view[:, skip:] if skip else view)
+            if qz.calibrating():                                     # DGQ calibration: the quantizer sees [B,H,T−skip,D]
+                view = ten.view(bb, ntok, H, D)
+                qz.observe((view[:, skip:] if skip else view).transpose(1, 2))
             mode, dd, zz = _qparams(qz, ten.device)
             ten = ten.contiguous()
             ops.fakequant_rows(ten.view(bb * ntok, cc), ntok, D, mode, dd, zz, skip, qz.bits)

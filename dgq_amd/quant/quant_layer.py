@@ -87,8 +87,51 @@ def channel_minmax(w: torch.Tensor, level: int):
     return delta.view(shape), zp.view(shape)
 
 
+def group_params_from_ranges(in_min, in_max, out_min, out_max, group_num, mode, level, force_in_channel=None):
+    """The host half of ``done_group_num`` (quant_layer.py:338-418) as a pure function of the folded range vectors —
+    returns (δ, z, in_channel_wise) in the checkpoint's broadcast shapes.  Arithmetic follows the reference line by
+    line: numpy float32 ranges -> float64 K-Means -> per-cluster range in float64 -> δ rounded to fp32 by
+    ``torch.tensor`` -> z = rne(−min/δ) in fp32."""
+    import os
+    import numpy as np
+    from sklearn.cluster import KMeans
+    imin, imax = in_min.detach().cpu().numpy().flatten(), in_max.detach().cpu().numpy().flatten()
+    omin, omax = out_min.detach().cpu().numpy().flatten(), out_max.detach().cpu().numpy().flatten()
+    in_spread = imax.max() - imax.min() + imin.max() - imin.min()
+    out_spread = omax.max() - omax.min() + omin.max() - omin.min()
+    in_channel_wise = bool(in_spread > out_spread or os.environ.get("IN_CHANNEL_WISE", False))
+    if force_in_channel is not None:
+        in_channel_wise = force_in_channel
+    data = np.column_stack((imin, imax)) if in_channel_wise else np.column_stack((omin, omax))
+    km = KMeans(n_clusters=group_num, random_state=0).fit(data)
+    labels = km.labels_
+    if mode == "mean":
+        center = km.cluster_centers_
+    elif mode == "minmax":
+        center = []
+        for i in range(group_num):
+            cl = data[labels == i]
+            center.append([cl.min(), cl.max()] if cl.size else [0.0, 1.0])
+        center = np.array(center)
+    else:
+        raise NotImplementedError(mode)
+    base = (in_min if in_channel_wise else out_min).detach().clone().cpu().float().flatten()
+    delta, zero_point = base.clone(), base.clone()
+    lab = torch.from_numpy(labels.astype("int64"))
+    for i in range(group_num):
+        d = torch.tensor((center[i, 1] - center[i, 0]) / (level - 1))
+        if d < 1e-8:
+            d = torch.tensor(1e-8)
+        d = d.float()
+        delta[lab == i] = d
+        zero_point[lab == i] = torch.round(torch.tensor(-center[i, 0]).float() / d)
+    shape = (1, 1, -1) if in_channel_wise else (1, -1, 1)
+    return delta.view(shape), zero_point.view(shape), in_channel_wise
+
+
 class UniformAffineQuantizer(nn.Module):
-    """δ·(clamp(rne(x/δ)+z, 0, 2^b−1) − z)  — quant_layer.py:216-299 (inference branch)."""
+    """δ·(clamp(rne(x/δ)+z, 0, 2^b−1) − z)  — quant_layer.py:216-299 (inference branch; the calibration branches of
+    :284-293 are ``observe``)."""
 
     def __init__(self, bits: int = 8, symmetric: bool = False, channel_wise: bool = False,
                  scaler: Scaler = Scaler.MINMAX, leaf_param: bool = False, always_zero: bool = False,
@@ -110,10 +153,75 @@ class UniformAffineQuantizer(nn.Module):
         self.init = False
         self.quant_emb = quant_emb
         self.group_num = -1
+        # calibration producer state (quant_layer.py:247-248): one (min, max) pair of vectors per observed batch
+        self.min_max_per_in_channel = []
+        self.min_max_per_out_channel = []
 
     @property
     def bits(self):
         return int(self.level).bit_length() - 1
+
+    # -- calibration producer (DGQ activation calibration, quant_layer.py:284-293, 301-446) ------------------------
+    def calibrating(self) -> bool:
+        return self.running_stat or self.group_num != -1
+
+    def observe(self, x: torch.Tensor) -> None:
+        """The statistics side of the reference's forward (quant_layer.py:284-293), called with the tensor the quantizer
+        sees (the unfolded operand for grouped convs; [B,H,T,D] for the attention-side quantizers)."""
+        if not self.init:
+            self.init_from(x)
+        if self.running_stat:
+            self.act_momentum_update(x)
+        if 1 < self.group_num:
+            if x.dim() > 2:
+                self.record_min_max_ema(x)
+        elif self.group_num != -1:
+            self.act_momentum_update(x)
+
+    def record_min_max_ema(self, x: torch.Tensor, act_range_momentum: float = 0.95) -> None:
+        """quant_layer.py:301-313: per-"in-channel" (last dim) and per-"out-channel" (second-to-last dim; the token /
+        unfolded-row axis) minima and maxima of this batch, reduced over everything else — one pass of
+        dgq_minmax_rows_cols over the tensor viewed as [rows][C] plus a fold of the batch (/head) index."""
+        if x.dim() not in (3, 4):
+            raise NotImplementedError("DGQ statistics are defined for 3-D (Linear / unfolded conv) and 4-D (attention) inputs")
+        xc = x.detach().contiguous()
+        C, T = xc.shape[-1], xc.shape[-2]
+        rmin, rmax, cmin, cmax = ops.minmax_rows_cols(xc.view(-1, C))
+        self.min_max_per_in_channel.append((cmin, cmax))
+        self.min_max_per_out_channel.append((rmin.view(-1, T).min(dim=0)[0], rmax.view(-1, T).max(dim=0)[0]))
+
+    def act_momentum_update(self, x: torch.Tensor, act_range_momentum: float = 0.95) -> None:
+        """quant_layer.py:431-446: EMA of the scalar range, δ/z from the EMA range (the reference builds a clipped copy
+        of x whose min / max ARE the EMA values and feeds it to Scaler.MINMAX; the result depends on those two only)."""
+        assert self.init and self.leaf_param
+        x_min, x_max = x.data.min().float(), x.data.max().float()
+        self.x_min = self.x_min * act_range_momentum + x_min * (1.0 - act_range_momentum)
+        self.x_max = self.x_max * act_range_momentum + x_max * (1.0 - act_range_momentum)
+        rng = torch.stack([self.x_min, self.x_max]).to(x.dtype)
+        delta, self.zero_point = self.scaler(rng, self.symmetric, self.level, self.always_zero)
+        self.delta = nn.Parameter(delta)
+
+    def done_group_num(self, group_num, mode):
+        """quant_layer.py:315-429: fold the recorded batches (min of mins / max of maxes), pick the axis with the larger
+        spread, K-Means(group_num, random_state=0) on the (min, max) pairs (host, scikit-learn like the reference), one
+        (δ, z) per cluster from the cluster's range ('minmax') or centre ('mean'), broadcast shape (1,1,X) / (1,X,1)."""
+        if self.min_max_per_in_channel == []:
+            self.group_num = -1
+            return None
+        import numpy as np
+        from sklearn.cluster import KMeans
+        in_min = torch.stack([m[0] for m in self.min_max_per_in_channel]).min(dim=0)[0]
+        in_max = torch.stack([m[1] for m in self.min_max_per_in_channel]).max(dim=0)[0]
+        out_min = torch.stack([m[0] for m in self.min_max_per_out_channel]).min(dim=0)[0]
+        out_max = torch.stack([m[1] for m in self.min_max_per_out_channel]).max(dim=0)[0]
+        delta, zero_point, _ = group_params_from_ranges(in_min, in_max, out_min, out_max, group_num, mode, self.level)
+        dev = in_min.device
+        self.delta.data = delta.to(dev)
+        self.zero_point = zero_point.to(dev)
+        self.group_num = -1
+        self.min_max_per_in_channel = []
+        self.min_max_per_out_channel = []
+        return self.delta.data, self.zero_point
 
     # -- initialisation -------------------------------------------------------------------------
     def _init_quantization_param(self, x: torch.Tensor, channel_wise: bool = False):
@@ -148,8 +256,6 @@ class UniformAffineQuantizer(nn.Module):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if not self.init:
             self.init_from(x)
-        if self.running_stat or self.group_num != -1:
-            raise NotImplementedError("activation-statistics collection is calibration-time (SURVEY.md §8(f)-1)")
         if not x.is_cuda:
             raise RuntimeError("dgq_amd: quantizers execute on the GPU only (no CPU fallback)")
         xc = x.contiguous()
@@ -347,6 +453,12 @@ class QuantLayer(nn.Module):
             return F.linear(x, w, b)
         if not self.aqtizer.init and not (self._slot_ref is not None and self._slot_ref.slot in self._act_tables):
             self.aqtizer.init_from(x)           # first-forward self-initialisation (quant_layer.py:274-278)
+        if self.aqtizer.calibrating():          # DGQ calibration: statistics of what the quantizer sees (:284-293, :630-641)
+            seen = x
+            if self.is_conv and self.use_group_num:
+                seen = F.unfold(x, kernel_size=tuple(self.w.shape[2:]), dilation=1, padding=self.fwd_kwargs["padding"][0],
+                                stride=self.fwd_kwargs["stride"][0])
+            self.aqtizer.observe(seen)
         ab = self._binding()
         if self.is_conv:
             kh, kw = self.w.shape[2], self.w.shape[3]
@@ -416,16 +528,16 @@ class QuantLayer(nn.Module):
         self.use_aq = use_aq if not self.ignore_recon else False
 
     def set_running_stat(self, running_stat: bool) -> None:
-        if running_stat:
-            raise NotImplementedError("running statistics are calibration-time (SURVEY.md §8(f)-1)")
-        self.aqtizer.running_stat = False
+        self.aqtizer.running_stat = running_stat
 
     def set_group_num(self, group_num: int = 1) -> None:
-        raise NotImplementedError("DGQ activation calibration (set_group_num/done_group_num) is the producer side "
-                                  "of the cali_ckpt — SURVEY.md §8(f)-1, not part of the inference path")
+        """quant_layer.py:604-608: start collecting DGQ statistics; convs switch to the unfolded-operand semantics."""
+        self.aqtizer.group_num = group_num
+        self.use_group_num = True
 
     def done_group_num(self, group_num, mode) -> None:
-        self.set_group_num(group_num)
+        self.aqtizer.done_group_num(group_num, mode)
+        self._bindings = {}
 
     def half(self):
         super().half()

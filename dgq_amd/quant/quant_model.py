@@ -195,16 +195,45 @@ class QuantModel(nn.Module):
                     m._binding()
         self.slot_ref.slot = prev
 
-    # -- calibration-time API (producer side) -----------------------------------------------
+    # -- calibration-time API (producer side; quant_model.py:135-181) ---------------------------------
+    def _attn_quantizers(self, with_w=False):
+        for m in self.model.modules():
+            if isinstance(m, QuantBasicTransformerBlock):
+                for attn in (m.attn1, m.attn2):
+                    for n in ("aqtizer_q", "aqtizer_k", "aqtizer_v") + (("aqtizer_w",) if with_w else ()):
+                        yield getattr(attn, n)
+
     def set_group_num(self, group_num: int = 1) -> None:
-        raise NotImplementedError("DGQ activation calibration is not part of the inference path (SURVEY.md §8(f)-1)")
+        """Start DGQ statistics collection: every following forward records per-axis min / max in each activation
+        quantizer (QuantLayer inputs, unfolded for convs; attention q / k / v).  The blocks run unfused meanwhile."""
+        from . import quant_block
+        self._drop_graphs()
+        self._fusion_was = quant_block.FUSION
+        quant_block.FUSION = False
+        for m in self.model.modules():
+            if isinstance(m, QuantLayer):
+                m.set_group_num(group_num)
+        for q in self._attn_quantizers():
+            q.group_num = group_num
 
     def done_group_num(self, group_num, mode) -> None:
-        self.set_group_num(group_num)
+        """Turn the recorded statistics into grouped (δ, z) tables (K-Means on the host) and leave calibration mode."""
+        from . import quant_block
+        for m in self.model.modules():
+            if isinstance(m, QuantLayer):
+                m.done_group_num(group_num, mode=mode)
+        for q in self._attn_quantizers():
+            q.done_group_num(group_num, mode=mode)
+        quant_block.FUSION = getattr(self, "_fusion_was", True)
+        self._drop_graphs()
 
     def set_running_stat(self, running_stat: bool = False) -> None:
-        if running_stat:
-            raise NotImplementedError("running statistics are calibration-time (SURVEY.md §8(f)-1)")
+        self._drop_graphs()
+        for q in self._attn_quantizers(with_w=True):
+            q.running_stat = running_stat
+        for m in self.model.modules():
+            if isinstance(m, QuantLayer):
+                m.set_running_stat(running_stat)
 
     def synchorize_activation_statistics(self):
         raise NotImplementedError("multi-GPU calibration is disabled in the reference too (src/quantize_weight.py:214)")

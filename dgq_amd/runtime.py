@@ -50,25 +50,41 @@ def quant_params(Scaler, wbits, abits, use_aq, log, rt, sp):
 def build_synthetic_qnn(arch, cfg, res, batch, slots, ckpt_dir="/tmp", seed=0, device="cuda", rank=0, barrier=None):
     """Writes (once) a synthetic reference-format cali_ckpt and builds the QuantModel from it through the same
     entry point the reference's CLI uses (get_qmodel, src/inference_qmodel.py:91).
-    cfg keys: wbits, abits, use_aq, G, log, rt, sp, time_aware, steps."""
+    cfg keys: wbits, abits, use_aq, G, log, rt, sp, time_aware, steps.  ``slots``: how many act_<s> tables to write
+    (int) or the explicit slot ids (a test that visits t = 981 and t = 21 needs act_0 and act_48, not 49 tables)."""
+    import time
     from .diffusers_rewrite import UNet2DConditionModel
     from .quant import get_qmodel, Scaler
-    path = os.path.join(ckpt_dir, "dgq_synth_%s_w%da%dg%d_r%d_b%d_s%d_%s.pth" % (
-        arch, cfg["wbits"], cfg["abits"], cfg["G"], res, batch, slots, "sp" if cfg["sp"] else "nosp"))
+    verbose = os.environ.get("DGQ_BUILD_TIMING") == "1"
+    t_last = [time.time()]
+
+    def lap(what):
+        if verbose:
+            now = time.time()
+            print("[build %s] %-28s %.1f s" % (arch, what, now - t_last[0]), flush=True)
+            t_last[0] = now
+    path = os.path.join(ckpt_dir, "dgq_synth_%s_w%da%dg%d_r%d_b%d_s%s_%s.pth" % (
+        arch, cfg["wbits"], cfg["abits"], cfg["G"], res, batch,
+        ("%d" % slots) if isinstance(slots, int) else "x".join(str(s) for s in synth.slot_list(slots)),
+        "sp" if cfg["sp"] else "nosp"))
     if rank == 0 and not os.path.exists(path):
         tmp = path + ".tmp%d" % os.getpid()
         synth.write_cali_ckpt(tmp, arch, cfg["wbits"], cfg["abits"], cfg["G"], num_slots=slots, seed=seed, batch=batch,
                               res=res, start_peak=cfg["sp"], uniform_softmax=(cfg["use_aq"] and not cfg["log"]),
                               with_act=cfg["use_aq"])
         os.replace(tmp, path)
+    lap("write cali_ckpt")
     if barrier is not None:
         barrier()
     unet = UNet2DConditionModel(arch)
+    lap("construct FP UNet")
     synth.load_synth_weights(unet, arch, seed)
+    lap("synthetic FP weights")
     pipe = types.SimpleNamespace(unet=unet)
     wq, aq, sm = quant_params(Scaler, cfg["wbits"], cfg["abits"], cfg["use_aq"], cfg["log"], cfg["rt"], cfg["sp"])
     qnn = get_qmodel(arch, pipe, path, wq, cfg["use_aq"], aq, sm, cfg["G"] > 1, cfg["steps"],
                      cfg["time_aware"] and cfg["use_aq"], device=device)
+    lap("get_qmodel (wrap + load)")
     qnn.float()
     qnn = qnn.to(device)
     qnn.disable_out_quantization()

@@ -29,3 +29,64 @@ class DDIMScheduler:
         a_t, a_prev = self._coef[int(t)]
         pred_x0 = (sample - (1 - a_t) ** 0.5 * model_output) / a_t ** 0.5
         return a_prev ** 0.5 * pred_x0 + (1 - a_prev) ** 0.5 * model_output
+
+
+class PNDMScheduler:
+    """PLMS (PNDM with ``skip_prk_steps=True``) — the scheduler the reference actually runs SD with: its pipeline is
+    loaded from the SD-v1-4 repo whose scheduler_config is PNDM (src/inference_qmodel.py:56-63 -> prepare_pipe,
+    src/dataset_generation.py:70).  Restates diffusers scheduling_pndm.py: ``set_timesteps`` "leading" spacing with
+    steps_offset = 1 (:185-190) and the skip-PRK timestep list (:204-212), ``step_plms`` (:321-390), ``_get_prev_sample``
+    (:407-449); scaled_linear β 0.00085→0.012, set_alpha_to_one=False, ε-prediction.
+
+    N inference steps produce N + 1 UNet calls: the second timestep is visited twice (the first PLMS step is a two-stage
+    Heun-like step), e.g. N = 25: [961, 921, 921, 881, ..., 1] — 26 calls that alias onto the 25 time-aware slots."""
+
+    def __init__(self, num_inference_steps, num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, steps_offset=1):
+        betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
+        self.alphas_cumprod = torch.cumprod(1.0 - betas, dim=0)
+        self.final_alpha_cumprod = self.alphas_cumprod[0].clone()             # set_alpha_to_one=False
+        self.num_inference_steps = num_inference_steps
+        self.num_train_timesteps = num_train_timesteps
+        ratio = num_train_timesteps // num_inference_steps
+        base = [i * ratio + steps_offset for i in range(num_inference_steps)]
+        self.timesteps = (base[:-1] + base[-2:-1] + base[-1:])[::-1]
+        self.ets = []
+        self.counter = 0
+        self.cur_sample = None
+
+    def scale_model_input(self, sample, t=None):
+        return sample
+
+    def _prev_sample(self, sample, timestep, prev_timestep, model_output):
+        a_t = self.alphas_cumprod[timestep]
+        a_prev = self.alphas_cumprod[prev_timestep] if prev_timestep >= 0 else self.final_alpha_cumprod
+        b_t, b_prev = 1 - a_t, 1 - a_prev
+        sample_coeff = (a_prev / a_t) ** 0.5
+        denom = a_t * b_prev ** 0.5 + (a_t * b_t * a_prev) ** 0.5
+        return sample_coeff * sample - (a_prev - a_t) * model_output / denom
+
+    def step(self, model_output, t, sample):
+        t = int(t)
+        ratio = self.num_train_timesteps // self.num_inference_steps
+        prev_t = t - ratio
+        if self.counter != 1:
+            self.ets = self.ets[-3:]
+            self.ets.append(model_output)
+        else:
+            prev_t = t
+            t = t + ratio
+        if len(self.ets) == 1 and self.counter == 0:
+            self.cur_sample = sample
+        elif len(self.ets) == 1 and self.counter == 1:
+            model_output = (model_output + self.ets[-1]) / 2
+            sample = self.cur_sample
+            self.cur_sample = None
+        elif len(self.ets) == 2:
+            model_output = (3 * self.ets[-1] - self.ets[-2]) / 2
+        elif len(self.ets) == 3:
+            model_output = (23 * self.ets[-1] - 16 * self.ets[-2] + 5 * self.ets[-3]) / 12
+        else:
+            model_output = (1 / 24) * (55 * self.ets[-1] - 59 * self.ets[-2] + 37 * self.ets[-3] - 9 * self.ets[-4])
+        out = self._prev_sample(sample, t, prev_t, model_output)
+        self.counter += 1
+        return out

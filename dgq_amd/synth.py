@@ -48,9 +48,24 @@ def named_randint(name, low, high, shape, seed=0):
 
 
 # ----------------------------------------------------------------------------- model weights
+#: Test suites that build several models of one architecture set this to keep the generated state dicts (3.4 GB for SD,
+#: 10 GB for SDXL: the CPU normal generator is the slowest part of a build); the tensors are shared, never mutated.
+CACHE_STATE_DICTS = False
+_SD_CACHE = {}
+
+
 def synth_state_dict(arch="sd", seed=0):
     """FP32 state-dict for ``UNet2DConditionModel(arch)`` (HF key names). Weights N(0, 1/fan_in),
     so activations stay O(1) through the 860 M / 2.6 B-parameter graph."""
+    if CACHE_STATE_DICTS and (arch, seed) in _SD_CACHE:
+        return _SD_CACHE[(arch, seed)]
+    out = _synth_state_dict(arch, seed)
+    if CACHE_STATE_DICTS:
+        _SD_CACHE[(arch, seed)] = out
+    return out
+
+
+def _synth_state_dict(arch, seed):
     with torch.device("meta"):
         skel = UNet2DConditionModel(arch)
     out = OrderedDict()
@@ -277,13 +292,28 @@ def synth_weight_ckpt(arch="sd", wbits=4, seed=0, adaround=False, delta_jitter=T
     return out
 
 
-def write_cali_ckpt(path, arch="sd", wbits=4, abits=8, G=16, num_slots=1, seed=0, batch=2, res=None,
+def slot_list(num_slots):
+    """``num_slots`` as an int (act_0 .. act_{n-1}) or an explicit collection of slot ids (act_0 is always written:
+    load_act_ckpt_with_difference_shape reads it, calibration.py:268-291)."""
+    if isinstance(num_slots, int):
+        return list(range(num_slots))
+    return sorted(set(int(s) for s in num_slots) | {0})
+
+
+def build_cali_ckpt(arch="sd", wbits=4, abits=8, G=16, num_slots=1, seed=0, batch=2, res=None,
                     start_peak=False, uniform_softmax=False, adaround=False, with_act=True):
+    """The merged checkpoint as a dict (what write_cali_ckpt saves)."""
     ck = OrderedDict()
     if with_act:
         recs = enumerate_act_quantizers(arch, batch, res)
-        for s in range(num_slots):
+        for s in slot_list(num_slots):
             ck["act_%d" % s] = synth_act_slot(arch, abits, G, s, seed, batch, res, start_peak, uniform_softmax, recs)
     ck["weight"] = synth_weight_ckpt(arch, wbits, seed, adaround)
-    torch.save(ck, path)
+    return ck
+
+
+def write_cali_ckpt(path, arch="sd", wbits=4, abits=8, G=16, num_slots=1, seed=0, batch=2, res=None,
+                    start_peak=False, uniform_softmax=False, adaround=False, with_act=True):
+    torch.save(build_cali_ckpt(arch, wbits, abits, G, num_slots, seed, batch, res, start_peak, uniform_softmax,
+                               adaround, with_act), path)
     return path

@@ -194,6 +194,15 @@ int dgq_attention(const void* q, const void* k, const void* v, void* o, int dtyp
 int dgq_attention_fuses_fakequant(int D, int mode);
 size_t dgq_attention_workspace_bytes(int B, int H, int T, int S, int D);
 
+/* ---- calibration producer --------------------------------------------------------
+ * dgq_minmax_rows_cols: the statistics UniformAffineQuantizer.record_min_max_ema collects for DGQ's grouping
+ * (quant/quant_layer.py:301-313): for x viewed as [rows][C] (row stride ldx elements, any fp dtype) the row-wise
+ * (rowmin/rowmax [rows]) and column-wise (colmin/colmax [C]) minima / maxima, fp32.  Either pair may be NULL.
+ * partial_ws: 2·slices·C floats of caller-owned scratch for the column pass (slices = row slices reduced in parallel). */
+int dgq_minmax_rows_cols(const void* x, int dtype, int rows, int C, int64_t ldx,
+                         float* rowmin, float* rowmax, float* colmin, float* colmax,
+                         float* partial_ws, int slices, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -112,6 +112,8 @@ ORACLE_ARCH = {
                up=((0, True), (1, True), (1, True), (1, False)), proj="conv", heads=lambda c: 8, mid=1),
     "sdxl": dict(bo=(320, 640, 1280), down=((0, True), (2, True), (10, False)),
                  up=((10, True), (2, True), (0, False)), proj="linear", heads=lambda c: c // 64, mid=10),
+    "mini": dict(bo=(64, 64), down=((1, True), (0, False)), up=((0, True), (1, False)), proj="conv",
+                 heads=lambda c: 8, mid=1),
     "tiny": dict(bo=(64, 128), down=((1, True), (0, False)), up=((0, True), (1, False)), proj="conv",
                  heads=lambda c: 8, mid=1),
 }
@@ -191,6 +193,19 @@ class OracleModel:
                 self.lazy[qname] = minmax_scalar(x, self.cfg.abits)
             d, z = self.lazy[qname]
         return uaq(x, d, z, self.cfg.abits)
+
+    def act_codes(self, path, x, stride=1, padding=0):
+        """Integer codes the activation quantizer of layer ``path`` assigns to the layer input ``x`` (on the unfolded
+        operand for grouped convs, like ``conv``) — used by the parity statistics to count code flips between two runs."""
+        kd = "model.%s.aqtizer.delta" % path
+        if self.act is not None and kd in self.act:
+            d, z = self.act[kd], self.act["model.%s.aqtizer.zero_point" % path]
+        else:
+            d, z = self.lazy[path + ".aqtizer"]
+        if x.dim() == 4 and self.grouped(path):
+            w = self.P(path + ".w")
+            x = F.unfold(x, kernel_size=(w.shape[2], w.shape[3]), dilation=1, padding=padding, stride=stride)
+        return uaq_codes(x, d, z, self.cfg.abits)
 
     def grouped(self, path):
         """use_group_num is switched on by load_act_ckpt_with_difference_shape when the ckpt δ is

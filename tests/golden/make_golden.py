@@ -11,6 +11,7 @@ Fixtures are DATA: seeded inputs and the reference's outputs (``.pt`` files of p
 JSON).  Full-UNet inputs are not stored — they are regenerated from ``dgq_amd.synth`` (name-keyed).
 """
 import json
+import math
 import os
 import sys
 import time
@@ -323,8 +324,191 @@ def make_schema(ref, arch):
     print("wrote schema", arch)
 
 
+# --------------------------------------------------------------------------------------- calibration producer (f1)
+CALIB = dict(wbits=4, abits=8, G=4, n=32, interval=16, res=16, ts=(901, 301), np_seed=123, mode="minmax")
+
+
+def calib_data():
+    c = CALIB
+    xs = synth.named_randn("calib_x", (c["n"], 4, c["res"], c["res"]), 3)
+    ts = torch.tensor([c["ts"][i // c["interval"]] for i in range(c["n"])], dtype=torch.int64)
+    ctx = synth.named_randn("calib_ctx", (c["n"], 77, 768), 4)
+    return xs, ts, ctx
+
+
+def build_ref_mini(ref):
+    """ARCH['mini'] of dgq_amd.diffusers_rewrite composed from the REFERENCE's block classes (same state-dict keys)."""
+    import torch.nn as nn
+    S = sys.modules["diffusers_rewrite.sd"]
+
+    class RefMini(nn.Module):
+        def __init__(self):
+            super().__init__()
+            import types
+            self.config = types.SimpleNamespace(in_channels=4, sample_size=16, time_cond_proj_dim=None)
+            self.conv_in = nn.Conv2d(4, 64, kernel_size=3, stride=1, padding=1)
+            self.time_proj = S.Timesteps(64)
+            self.time_embedding = S.TimestepEmbedding(in_features=64, out_features=1280)
+            self.down_blocks = nn.ModuleList([S.CrossAttnDownBlock2D(64, 64, n_layers=1, has_shortcut=False),
+                                              S.DownBlock2D(64, 64, has_downsamplers=False)])
+            self.up_blocks = nn.ModuleList([S.UpBlock2D(in_channels=64, out_channels=64, prev_output_channel=64),
+                                            S.CrossAttnUpBlock2D(in_channels=64, out_channels=64, prev_output_channel=64,
+                                                                 n_layers=1, has_upsamplers=False)])
+            self.mid_block = S.UNetMidBlock2DCrossAttn(64)
+            self.conv_norm_out = nn.GroupNorm(32, 64, eps=1e-05, affine=True)
+            self.conv_act = nn.SiLU()
+            self.conv_out = nn.Conv2d(64, 4, kernel_size=3, stride=1, padding=1)
+
+        def forward(self, sample, timesteps, encoder_hidden_states=None, **kwargs):
+            timesteps = timesteps.expand(sample.shape[0])
+            emb = self.time_embedding(self.time_proj(timesteps).to(dtype=sample.dtype))
+            sample = self.conv_in(sample)
+            s0 = sample
+            sample, [s1, s2, s3] = self.down_blocks[0](sample, temb=emb, encoder_hidden_states=encoder_hidden_states)
+            sample, [s4, s5] = self.down_blocks[1](sample, temb=emb)
+            sample = self.mid_block(sample, emb, encoder_hidden_states=encoder_hidden_states)
+            sample = self.up_blocks[0](hidden_states=sample, temb=emb, res_hidden_states_tuple=[s3, s4, s5])
+            sample = self.up_blocks[1](hidden_states=sample, temb=emb, res_hidden_states_tuple=[s0, s1, s2],
+                                       encoder_hidden_states=encoder_hidden_states)
+            return [self.conv_out(self.conv_act(self.conv_norm_out(sample)))]
+    m = RefMini()
+    m.load_state_dict(synth.synth_state_dict("mini", 0))          # strict: the key sets must coincide
+    return m
+
+
+def make_calib(ref):
+    """F8: the reference's DGQ activation calibration (quant/calibration_group_quantization.py:44-129 cali_model_aq)
+    on the mini model: per quantizer the folded (min, max) vectors that enter done_group_num and the (δ, z) it
+    produces, plus the act_<t> dicts act_group_quant would save."""
+    import contextlib, io
+    import numpy as np
+    import quant.calibration_group_quantization as cgq
+    c = CALIB
+    unet = build_ref_mini(ref)
+    wq = {"bits": c["wbits"], "channel_wise": True, "scaler": ref.ql.Scaler.MINMAX}
+    aq = {"bits": c["abits"], "channel_wise": False, "scaler": ref.ql.Scaler.MINMAX, "leaf_param": True}
+    sm = {"softmax_a_bit": c["abits"], "t2i_log_quant": True, "t2i_real_time": True, "t2i_start_peak": True, "log_max_1": False}
+    wpath = "/tmp/golden_mini_weight_only.pth"
+    torch.save(synth.synth_weight_ckpt("mini", c["wbits"], 0), wpath)
+    xs, ts, ctx = calib_data()
+    with contextlib.redirect_stdout(io.StringIO()):
+        qnn = ref.qm.QuantModel(model=unet, wq_params=wq, aq_params=aq, softmax_aq_params=sm,
+                                aq_mode=[ref.ql.QMODE.NORMAL.value, ref.ql.QMODE.QDIFF.value], tib_recon=False).eval()
+        ref.cal.load_cali_model(qnn, init_data=(xs[:1], ts[:1], ctx[:1]), use_aq=False, path=wpath)
+    names = {id(m): n for n, m in qnn.model.named_modules()}
+    ranges = {}
+    cur = {"t": 0}
+    orig_done = ref.ql.UniformAffineQuantizer.done_group_num
+
+    def spy(self, group_num, mode):
+        if self.min_max_per_in_channel != []:
+            im = torch.stack([x[0] for x in self.min_max_per_in_channel]).min(dim=0)[0]
+            ix = torch.stack([x[1] for x in self.min_max_per_in_channel]).max(dim=0)[0]
+            om = torch.stack([x[0] for x in self.min_max_per_out_channel]).min(dim=0)[0]
+            ox = torch.stack([x[1] for x in self.min_max_per_out_channel]).max(dim=0)[0]
+            r = orig_done(self, group_num, mode)
+            ranges.setdefault(cur["t"], {})[names[id(self)]] = dict(
+                in_min=im.clone(), in_max=ix.clone(), out_min=om.clone(), out_max=ox.clone(),
+                delta=self.delta.data.clone(), zero_point=torch.as_tensor(self.zero_point).data.clone())
+            return r
+        return orig_done(self, group_num, mode)
+    ref.ql.UniformAffineQuantizer.done_group_num = spy
+    orig_qdone = ref.qm.QuantModel.done_group_num
+
+    def qdone(self, group_num, mode):
+        r = orig_qdone(self, group_num, mode)
+        cur["t"] += 1
+        return r
+    ref.qm.QuantModel.done_group_num = qdone
+    np.random.seed(c["np_seed"])
+    with contextlib.redirect_stdout(io.StringIO()):
+        model_dict = cgq.cali_model_aq("sd", qnn, (xs, ts, ctx), {}, c["G"], c["interval"], c["mode"])
+    ref.ql.UniformAffineQuantizer.done_group_num = orig_done
+    ref.qm.QuantModel.done_group_num = orig_qdone
+    act = {k: {kk: vv.detach().clone() for kk, vv in v.items()} for k, v in model_dict.items()}
+    print("intervals:", list(act), "keys per interval:", len(act["act_0"]), "grouped quantizers:", len(ranges[0]))
+    import sklearn
+    save("f8_calibration_mini.pt", dict(meta=dict(c, sklearn=sklearn.__version__), act=act, ranges=ranges))
+
+
+# --------------------------------------------------------------------------------------- scheduler (f3)
+def load_vendored_pndm():
+    """The reference's vendored diffusers 0.26.0 does not import as a package here; its
+    schedulers/scheduling_pndm.py is loaded on its own with minimal stand-ins for the three modules it imports from."""
+    import dataclasses, enum, importlib.util, types
+    import numpy  # noqa: F401
+    root = "/root/reference/diffusers/src/diffusers"
+    pk = types.ModuleType("vdiff"); pk.__path__ = [root]
+    cu = types.ModuleType("vdiff.configuration_utils")
+
+    class ConfigMixin:
+        pass
+
+    def register_to_config(init):
+        import functools, inspect
+
+        @functools.wraps(init)
+        def inner(self, *a, **k):
+            sig = inspect.signature(init)
+            ba = sig.bind(self, *a, **k); ba.apply_defaults()
+            kw = {n: v for n, v in ba.arguments.items() if n != "self"}
+            self.config = types.SimpleNamespace(**kw)
+            init(self, *a, **k)
+        return inner
+    cu.ConfigMixin, cu.register_to_config = ConfigMixin, register_to_config
+    ut = types.ModuleType("vdiff.utils"); ut.__path__ = []
+    tu = types.ModuleType("vdiff.utils.torch_utils"); tu.randn_tensor = lambda *a, **k: None
+    sc = types.ModuleType("vdiff.schedulers"); sc.__path__ = [root + "/schedulers"]
+    su = types.ModuleType("vdiff.schedulers.scheduling_utils")
+
+    class KarrasDiffusionSchedulers(enum.Enum):
+        PNDMScheduler = 1
+
+    class SchedulerMixin:
+        pass
+
+    @dataclasses.dataclass
+    class SchedulerOutput:
+        prev_sample: torch.Tensor
+    su.KarrasDiffusionSchedulers, su.SchedulerMixin, su.SchedulerOutput = KarrasDiffusionSchedulers, SchedulerMixin, SchedulerOutput
+    sys.modules.update({"vdiff": pk, "vdiff.configuration_utils": cu, "vdiff.utils": ut, "vdiff.utils.torch_utils": tu,
+                        "vdiff.schedulers": sc, "vdiff.schedulers.scheduling_utils": su})
+    spec = importlib.util.spec_from_file_location("vdiff.schedulers.scheduling_pndm", root + "/schedulers/scheduling_pndm.py")
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[spec.name] = mod
+    spec.loader.exec_module(mod)
+    return mod.PNDMScheduler
+
+
+def fake_eps(x, t):
+    """Deterministic stand-in for the UNet in the scheduler fixture."""
+    return 0.3 * x * math.cos(t / 100.0) + 0.1 * torch.sin(3.0 * x + t)
+
+
+def make_pndm():
+    """F7: the vendored PNDM scheduler (SD-v1-4 config: scaled_linear 0.00085-0.012, skip_prk_steps, steps_offset 1)
+    driven exactly like pipeline_stable_diffusion.py:1013-1044 with a closed-form ε model: timesteps + every latent."""
+    P = load_vendored_pndm()
+    out = {}
+    for n in (25, 50, 8):
+        sch = P(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
+                skip_prk_steps=True, set_alpha_to_one=False, steps_offset=1)
+        sch.set_timesteps(n)
+        x = torch.randn(2, 4, 8, 8, generator=g(77))
+        xs = [x.clone()]
+        for t in sch.timesteps:
+            x = sch.step(fake_eps(x, int(t)), int(t), x, return_dict=False)[0]
+            xs.append(x.clone())
+        out[n] = dict(timesteps=[int(t) for t in sch.timesteps], samples=torch.stack(xs))
+        print("pndm n=%d: %d unet calls, first timesteps %s" % (n, len(sch.timesteps), out[n]["timesteps"][:4]))
+    save("f7_pndm_schedule.pt", out)
+
+
 if __name__ == "__main__":
     what = sys.argv[1]
+    if what == "pndm":
+        make_pndm()
+        sys.exit(0)
     arch = os.environ.get("DIFFUSERS_REWRITE", "sd")
     ref = rh.import_reference(arch)
     if what == "small":
@@ -336,6 +520,8 @@ if __name__ == "__main__":
     elif what == "unet":
         res = int(sys.argv[3]) if len(sys.argv) > 3 else None
         make_unet(ref, arch, sys.argv[2], res=res)
+    elif what == "calib":
+        make_calib(ref)
     elif what == "ddim":
         make_ddim(ref, int(sys.argv[2]) if len(sys.argv) > 2 else 50,
                   int(sys.argv[3]) if len(sys.argv) > 3 else 64)

@@ -1,0 +1,125 @@
+"""SURVEY.md §8(f)-1 — the DGQ activation-calibration PRODUCER (quant/calibration_group_quantization.py:44-129,
+quant/quant_layer.py:301-429) against tests/golden/f8_calibration_mini.pt: the REAL reference's cali_model_aq run on a
+two-level UNet composed of the reference's own block classes (make_golden.py `calib`; ARCH['mini'] is the same model in
+this package).  The host half (spread-based axis choice, K-Means(G, random_state=0), per-cluster ranges -> δ, z) is
+checked exactly from the reference's recorded ranges on CPU; the whole producer (statistics kernel, calibration forwards
+on the integer path, writer) on the GPU.  scikit-learn is unpinned: the golden file records its version."""
+import os
+
+import pytest
+import torch
+
+from dgq_amd import synth
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "f8_calibration_mini.pt")
+
+
+def calib_data(c):
+    xs = synth.named_randn("calib_x", (c["n"], 4, c["res"], c["res"]), 3)
+    ts = torch.tensor([c["ts"][i // c["interval"]] for i in range(c["n"])], dtype=torch.int64)
+    ctx = synth.named_randn("calib_ctx", (c["n"], 77, 768), 4)
+    return xs, ts, ctx
+
+
+def test_grouping_from_reference_ranges_is_exact():
+    """done_group_num's host arithmetic: same axis, same δ, same z as the reference for every one of the 2 x 140 grouped
+    quantizers, given the (min, max) vectors the reference itself recorded."""
+    from dgq_amd.quant.quant_layer import group_params_from_ranges
+    g = torch.load(GOLD)
+    c = g["meta"]
+    n = 0
+    for t, qs in g["ranges"].items():
+        for name, r in qs.items():
+            d, z, in_wise = group_params_from_ranges(r["in_min"], r["in_max"], r["out_min"], r["out_max"], c["G"], c["mode"],
+                                                     2 ** c["abits"])
+            assert d.shape == r["delta"].shape, (name, d.shape, r["delta"].shape)       # the axis choice
+            assert torch.equal(d, r["delta"]), (t, name, (d - r["delta"]).abs().max())
+            assert torch.equal(z, r["zero_point"]), (t, name)
+            assert torch.unique(torch.stack([d.flatten(), z.flatten()], 1), dim=0).shape[0] <= c["G"]
+            n += 1
+    assert n == 2 * 140
+
+
+def test_mini_arch_matches_the_reference_composition():
+    """ARCH['mini'] has the state-dict keys the reference's block classes produce (the golden act tables are keyed by them)."""
+    g = torch.load(GOLD)
+    from dgq_amd.diffusers_rewrite import UNet2DConditionModel
+    with torch.device("meta"):
+        net = UNet2DConditionModel("mini")
+    paths = {n for n, m in net.named_modules() if isinstance(m, (torch.nn.Linear, torch.nn.Conv2d))}
+    for k in g["act"]["act_0"]:
+        p = k[len("model."):].rsplit(".", 2)[0]                       # '<path>.aqtizer' or '<blk>.attnN'
+        assert p in paths or any(q.startswith(p + ".") for q in paths), k
+
+
+@pytest.mark.gpu
+def test_minmax_statistics_kernel_vs_torch():
+    from dgq_amd import ops
+    for shape, dt in (((2, 37, 320), torch.float32), ((3, 8, 15, 40), torch.float32), ((4, 1152, 64), torch.float16),
+                      ((1, 4096, 77), torch.bfloat16)):
+        x = torch.randn(shape, generator=torch.Generator().manual_seed(len(shape))).to("cuda", dt)
+        C = shape[-1]
+        rmin, rmax, cmin, cmax = ops.minmax_rows_cols(x.view(-1, C))
+        x2 = x.float().view(-1, C)
+        assert torch.equal(rmin, x2.min(dim=1)[0]) and torch.equal(rmax, x2.max(dim=1)[0])
+        assert torch.equal(cmin, x2.min(dim=0)[0]) and torch.equal(cmax, x2.max(dim=0)[0])
+
+
+@pytest.mark.gpu
+def test_act_group_quant_producer_vs_reference_golden(tmp_path):
+    """The whole producer on the GPU: reset -> scalar self-init forward -> set_group_num -> recording forwards ->
+    done_group_num -> act_<t> dict, then the file is LOADED by load_cali_model and run.  Against the reference's result on
+    the same model / data / numpy seed: identical key set and shapes; the calibration forwards themselves are quantized
+    (scalar δ) and differ from the reference's CPU run at rounding level, so ranges agree closely, not bitwise."""
+    import numpy as np
+    from dgq_amd.diffusers_rewrite import UNet2DConditionModel
+    from dgq_amd.quant import QuantModel, Scaler, load_cali_model, act_group_quant
+    from dgq_amd.quant.quant_block import QuantBasicTransformerBlock
+    g = torch.load(GOLD)
+    c = g["meta"]
+    unet = UNet2DConditionModel("mini")
+    synth.load_synth_weights(unet, "mini", 0)
+    wq = {"bits": c["wbits"], "channel_wise": True, "scaler": Scaler.MINMAX}
+    aq = {"bits": c["abits"], "channel_wise": False, "scaler": Scaler.MINMAX, "leaf_param": True}
+    sm = {"softmax_a_bit": c["abits"], "t2i_log_quant": True, "t2i_real_time": True, "t2i_start_peak": True, "log_max_1": False}
+    qnn = QuantModel(model=unet, wq_params=wq, aq_params=aq, softmax_aq_params=sm, aq_mode=[1, 0], tib_recon=False).cuda().eval()
+    wpath = str(tmp_path / "w.pth")
+    torch.save(synth.synth_weight_ckpt("mini", c["wbits"], 0), wpath)
+    xs, ts, ctx = calib_data(c)
+    load_cali_model(qnn, (xs[:1], ts[:1], ctx[:1]), use_aq=False, path=wpath)
+    for m in qnn.modules():                                  # src/quantize_act.py flow: attentions quantise during calibration
+        if isinstance(m, QuantBasicTransformerBlock):
+            m.attn1.use_aq = m.attn2.use_aq = True
+    np.random.seed(c["np_seed"])
+    out = str(tmp_path / "act.pth")
+    act = act_group_quant("sd", qnn, (xs, ts, ctx), path=out, group_num=c["G"], interval=c["interval"], group_mode=c["mode"])
+    saved = torch.load(out)
+    assert sorted(saved) == sorted(g["act"]) == ["act_0", "act_1"]
+    same_axis = close = total = 0
+    worst = 0.0
+    for t in saved:
+        assert sorted(saved[t]) == sorted(g["act"][t]), set(saved[t]) ^ set(g["act"][t])
+        for k, v in saved[t].items():
+            ref = g["act"][t][k]
+            if not k.endswith(".delta"):
+                continue
+            total += 1
+            if v.shape == ref.shape:
+                same_axis += 1
+                rel = ((v.float() - ref.float()).abs().max() / ref.float().abs().max()).item()
+                worst = max(worst, rel)
+                close += rel < 5e-2
+            assert v.numel() == 1 or torch.unique(v).numel() <= c["G"]
+    print("producer vs reference: %d quantizers, same axis %d, δ within 5%% for %d (worst rel %.3g)" % (total, same_axis, close, worst))
+    assert same_axis >= 0.97 * total and close >= 0.9 * total
+    # the produced file is a valid cali_ckpt: merge with the weights (results/merge.py) and run it time-aware
+    merged = dict(saved)
+    merged["weight"] = torch.load(wpath)
+    mpath = str(tmp_path / "merged.pth")
+    torch.save(merged, mpath)
+    load_cali_model(qnn, (xs[:1], ts[:1], ctx[:1]), use_aq=True, path=mpath, time_aware_aqtizer=True, num_inference_steps=2,
+                    use_group=True)
+    qnn.disable_out_quantization()
+    with torch.no_grad():
+        y = qnn(xs[:2].cuda(), torch.tensor(901), ctx[:2].cuda())[0]
+    assert torch.isfinite(y).all()

@@ -233,6 +233,33 @@ def test_fakequant_rows_and_logquant(dev):
         assert (y != v["y"]).float().mean().item() < 1e-3
 
 
+def test_static_log_quantizer_init_and_forward_vs_reference_golden(dev):
+    """Non-real-time T2ILogQuantizer (quant_layer_text.py:49-76): first forward runs the 0.999 / 0.9999 / 0.99999
+    quantile search for δ on the device, later forwards reuse it.  Golden `logq_static_b*` = the REAL reference's δ and
+    output on the same probabilities; also through the fused attention kernel's static-δ mode (mode 2) with that δ."""
+    from dgq_amd import ops
+    from dgq_amd.quant.quant_layer_text import T2ILogQuantizer
+    f2 = gold("f2_quantizers.pt")
+    for bits in (6, 8):
+        v = f2["logq_static_b%d" % bits]
+        q = T2ILogQuantizer(bits=bits, always_zero=True, real_time=False)
+        x = v["x"].to(dev)
+        y = q(x.clone())
+        assert q.init and not q.real_time
+        d = float(torch.as_tensor(q.delta).detach().cpu())
+        # torch.quantile on the device interpolates like the CPU one; allow 1 ulp-level difference of the picked quantile
+        assert abs(d - float(v["delta"])) <= 2e-7 * abs(float(v["delta"])), (d, float(v["delta"]))
+        mism = (y.cpu() != v["y"]).float().mean().item()
+        assert mism < 1e-3, mism
+        assert rel_l2(y.cpu(), v["y"]) < 1e-2
+        y2 = q(x.clone())                                     # δ is frozen after the first call
+        assert torch.equal(y2.cpu(), y.cpu())
+        # a second tensor with a larger maximum must NOT move δ (that is what separates it from real-time mode)
+        x3 = (x * 0.5).contiguous()
+        q(x3.clone())
+        assert float(torch.as_tensor(q.delta).detach().cpu()) == d
+
+
 # ------------------------------------------------------------------------------------------ fused attention
 @pytest.mark.parametrize("D,T,S,H", [(40, 200, 200, 2), (8, 70, 77, 8), (16, 130, 40, 3), (64, 96, 77, 2),
                                      (80, 257, 257, 2), (160, 64, 77, 2), (160, 256, 256, 8)])

@@ -1,11 +1,17 @@
 """GPU parity of the whole hot path — QuantModel.forward built through the drop-in API
 (get_qmodel -> load_cali_model on a synthetic reference-format cali_ckpt) — against
-  (a) the CPU oracle at a small latent size (computed on the spot), and
-  (b) the REAL reference's outputs at full 64x64 latents (tests/golden/f5_*.pt).
-Tolerance: 1e-3 relative (L2 and max-abs/absmax) on the UNet output — BASELINE.json's bound for the
-final latent; weight codes and activation codes are bit-exact by the kernel tests."""
+  (a) the CPU oracle, operator by operator (teacher-forced), for the UNFUSED and for the FUSED (shipped) graph,
+  (b) the REAL reference's free-running outputs (tests/golden/f5_*.pt), and
+  (c) an exact (float64-GEMM) evaluation of the reference's arithmetic, in distribution over seeds x timesteps.
+Every BASELINE.json configuration runs here, shrunk where the full size would not fit the driver's 20-minute limit:
+  C1 SD W8 weight-only .......... free-running vs reference golden, 64x64
+  C2 SD W4A8 g16 ................ teacher-forced 16x16 (unfused + fused), free-running 64x64 golden, 8-step DDIM golden,
+                                  deviation statistics vs the exact oracle
+  C3 SD W4A6 g8 + log/rt/sp ..... free-running 64x64 golden, teacher-forced on the tiny arch
+  C4 SDXL W4A8 g16 .............. teacher-forced 32x32 (unfused + fused), free-running vs reference golden 32x32
+  C5 SDXL W4A6 g1 ............... teacher-forced 16x16 on the sdxl arch, batch 2 (a rank's shard of the prompt batch)
+Models, checkpoints and oracle runs are cached across the tests of this module."""
 import os
-import types
 
 import pytest
 import torch
@@ -14,46 +20,98 @@ from dgq_amd import synth
 
 pytestmark = pytest.mark.gpu
 
-# The SDXL / 32x32 / DDIM-50 cases build multi-GB synthetic checkpoints (the whole file takes ~18 min on an MI355X box);
-# they run with DGQ_SLOW_TESTS=1 and their last full output is kept in profiles/r01_parity_full_gpu_suite.txt.
-SLOW = pytest.mark.skipif(os.environ.get("DGQ_SLOW_TESTS") != "1", reason="set DGQ_SLOW_TESTS=1 (multi-GB checkpoints)")
-
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+synth.CACHE_STATE_DICTS = True          # one CPU generation of the 3.4 GB / 10 GB synthetic weights per architecture
 
 
 def rel_l2(a, b):
     return ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
 
 
-def build_qnn(arch, c, res, batch, slots, tmpdir):
-    from dgq_amd.runtime import build_synthetic_qnn
-    return build_synthetic_qnn(arch, c, res, batch, slots, ckpt_dir=tmpdir)
-
-
 C2 = dict(wbits=4, abits=8, use_aq=True, G=16, log=True, rt=True, sp=True, time_aware=True, steps=50)
+C2U = dict(wbits=4, abits=8, use_aq=True, G=1, log=False, rt=False, sp=False, time_aware=True, steps=50)
 C1 = dict(wbits=8, abits=8, use_aq=False, G=1, log=False, rt=False, sp=False, time_aware=False, steps=50)
 C3 = dict(wbits=4, abits=6, use_aq=True, G=8, log=True, rt=True, sp=True, time_aware=True, steps=50)
 C5 = dict(wbits=4, abits=6, use_aq=True, G=1, log=False, rt=False, sp=False, time_aware=True, steps=50)
+CFGS = {"C2": C2, "C3": C3, "C5": C5, "C1": C1, "C2U": C2U}
+
+_QNN = {}
+_ORACLE = {}
+
+
+@pytest.fixture(scope="module")
+def ckdir(tmp_path_factory):
+    return str(tmp_path_factory.mktemp("ck"))
+
+
+def get_qnn(arch, c, res, batch, slots, ckdir):
+    """(QuantModel, ckpt path) built once per module through get_qmodel (src/inference_qmodel.py:91)."""
+    from dgq_amd.runtime import build_synthetic_qnn
+    key = (arch, tuple(sorted(c.items())), res, batch, tuple(synth.slot_list(slots)))
+    if key not in _QNN:
+        _QNN[key] = build_synthetic_qnn(arch, c, res, batch, slots, ckpt_dir=ckdir)
+    return _QNN[key]
+
+
+def oracle_ckpt(arch, c, res, batch, slots):
+    """The same checkpoint content as the file the product loads, rebuilt in memory from the name-keyed generators
+    (shares the cached weight tensors instead of reading 10 GB back)."""
+    return synth.build_cali_ckpt(arch, c["wbits"], c["abits"], c["G"], num_slots=slots, seed=0, batch=batch, res=res,
+                                 start_peak=c["sp"], uniform_softmax=(c["use_aq"] and not c["log"]), with_act=c["use_aq"])
 
 
 class _Recorder:
-    """Wraps an OracleModel so that every quantized layer's (input, output) is recorded by path."""
+    """Wraps an OracleModel so that every quantized layer's (input, output, conv geometry) is recorded by path."""
 
     def __init__(self, om):
         self.io = {}
+        self.geom = {}
         for fn in ("linear", "conv"):
             orig = getattr(om, fn)
 
             def wrap(path, x, *a, _orig=orig, **k):
                 y = _orig(path, x, *a, **k)
                 self.io[path] = (x.detach().clone(), y.detach().clone())
+                self.geom[path] = a
                 return y
             setattr(om, fn, wrap)
 
 
+def oracle_run(arch, c, res, batch, slots, inp, t, exact=False, threads=None, cache_key=None):
+    """One OracleModel.forward with every layer's input/output recorded -> (output, recorder, model)."""
+    from oracle import dgq_oracle as orc
+    key = (arch, tuple(sorted(c.items())), res, batch, tuple(synth.slot_list(slots)), t, exact, threads, cache_key)
+    if cache_key is not None and key in _ORACLE:
+        return _ORACLE[key]
+    ck = oracle_ckpt(arch, c, res, batch, slots)
+    cfg = orc.OracleConfig(arch, c["wbits"], c["abits"], True, c["use_aq"], c["abits"], c["log"], c["rt"], c["sp"],
+                           c["time_aware"], c["steps"], c["G"] > 1, exact_gemm=exact)
+    om = orc.OracleModel(ck, cfg, synth.synth_state_dict(arch, 0))
+    rec = _Recorder(om)
+    okw = dict(text_embeds=inp["text_embeds"], time_ids=inp["time_ids"]) if arch == "sdxl" else {}
+    nt = torch.get_num_threads()
+    if threads:
+        torch.set_num_threads(threads)
+    try:
+        ref = om.forward(inp["sample"], t, inp["encoder_hidden_states"], **okw)
+    finally:
+        torch.set_num_threads(nt)
+    out = (ref, rec, om)
+    if cache_key is not None:
+        _ORACLE[key] = out
+    return out
+
+
+def product_kwargs(arch, inp):
+    if arch == "sdxl":
+        return dict(added_cond_kwargs={"text_embeds": inp["text_embeds"].cuda(), "time_ids": inp["time_ids"].cuda()})
+    return {}
+
+
+# ----------------------------------------------------------------------------------------------- teacher forcing
 def teacher_forced_check(qnn, io, run):
-    """One product forward in which every QuantLayer's input and output are (1) compared with the oracle's
-    tensors and (2) replaced by them.  Because the fake-quant UNet is chaotic (a 1e-7
+    """One product forward (UNFUSED graph) in which every QuantLayer's input and output are (1) compared with the
+    oracle's tensors and (2) replaced by them.  Because the fake-quant UNet is chaotic (a 1e-7
     perturbation grows to ~1e-1 through the quantizers — the reference differs from ITSELF by that much when
     only the BLAS thread count changes), this is how every operator of the path is pinned tightly:
       * layer outputs: integer GEMM vs the reference's fp32 GEMM on IDENTICAL inputs  -> tol 1e-4 rel-L2
@@ -102,56 +160,100 @@ def teacher_forced_check(qnn, io, run):
     return stats
 
 
-N_QUANT_LAYERS = {"sd": 280, "sdxl": 792, "tiny": None}
+def fused_teacher_forced_check(qnn, io, run):
+    """The same for the FUSED graph the benchmark runs (GroupNorm / LayerNorm / SiLU / GEGLU folded into the
+    quantise-on-load pass, residual / temb adds in the GEMM epilogue, q/k/v quantizers in the attention pre-pass): every
+    quantized-layer call reports through quant_layer.LAYER_TAP; its output is compared with
+        oracle layer output (+ the residual / per-image bias rows the epilogue added, taken from the product's own tensors)
+    and replaced by it.  Layers WITHOUT a folded prologue see the same operand as the oracle (compared: "in" / "attn").
+    Layers WITH a folded GroupNorm / LayerNorm / SiLU / GEGLU quantise values that are rounded differently from the
+    reference's separately materialised norm (x·(rstd·γ) + (β − μ·rstd·γ) vs ((x − μ)·rstd)·γ + β): a few codes per
+    thousand move by one step ("pro": measured median 4e-7 .. 2e-6, worst 4e-4 over SD / SDXL; asserted 2e-5 / 2e-3)."""
+    from dgq_amd.quant import QuantLayer, quant_layer
+    names = {id(m): n for n, m in qnn.model.named_modules() if isinstance(m, QuantLayer)}
+    stats = {"out": [], "pro": [], "in": [], "attn": [], "aout": []}
+    seen = []
+
+    def tap(layer, y, x=None, prologue=False, residual=None, bias_rows=None, fq=None):
+        name = names[id(layer)]
+        if name not in io or fq is not None:
+            return y
+        seen.append(name)
+        x_ref, y_ref = io[name]
+        exp = y_ref.to(y.device, torch.float32).reshape(y.shape)
+        if residual is not None:
+            exp = exp + residual.float().reshape(y.shape)
+        if bias_rows is not None:
+            exp = exp + bias_rows.float()[:, :, None, None]
+        e = rel_l2(y.detach().float().cpu(), exp.cpu())
+        # to_out.0 consumes the product's OWN attention output (the tap pins layer outputs; its input carries the isolated
+        # log2-code flips counted under "attn"), so its output inherits that deviation: its own class
+        stats["aout" if name.endswith("to_out.0") else ("pro" if prologue else "out")].append((e, name))
+        if not prologue and x is not None and x.numel() == x_ref.numel():
+            ex = rel_l2(x.detach().float().cpu().reshape(x_ref.shape), x_ref)
+            stats["attn" if name.endswith("to_out.0") else "in"].append((ex, name))
+        return exp.to(y.dtype)
+
+    quant_layer.LAYER_TAP = tap
+    try:
+        run()
+    finally:
+        quant_layer.LAYER_TAP = None
+    return stats, seen
 
 
-@pytest.mark.parametrize("arch,res,cname", [("tiny", 16, "C2"), ("sd", 16, "C2"), pytest.param("sd", 32, "C2", marks=SLOW),
-                                            ("tiny", 16, "C3"), ("tiny", 16, "C5"), pytest.param("sdxl", 16, "C2", marks=SLOW)])
-def test_unet_teacher_forced_vs_oracle(arch, res, cname, tmp_path_factory):
-    """Every operator of the HIP path against the CPU oracle (itself bit-identical to the reference,
+N_QUANT_LAYERS = {"sd": 280, "sdxl": 792, "tiny": 119}
+# arch, res, config, batch, timesteps (1 timestep for the 2.6 B-parameter SDXL graph: the oracle re-quantises every weight)
+TF_CASES = [("tiny", 16, "C2", 2, (999, 499)), ("sd", 16, "C2", 2, (999, 499)), ("tiny", 16, "C3", 2, (999, 499)),
+            ("tiny", 16, "C5", 2, (999, 499)), ("sdxl", 32, "C2", 1, (999,)), ("sdxl", 16, "C5", 2, (999,))]
+
+
+def _tf_setup(arch, res, cname, batch, ckdir):
+    steps = 4 if arch == "sdxl" else 2          # SDXL-turbo's 4-step schedule (slot = (1000 − t)//250); SD: 2 slots
+    c = dict(CFGS[cname], steps=steps)
+    slots = {"sdxl": [0, 3], "sd": 2, "tiny": 2}[arch] if not (arch == "sdxl" and cname == "C5") else [0]
+    qnn, _ = get_qnn(arch, c, res, batch, slots, ckdir)
+    return c, slots, qnn, synth.synth_inputs(arch, batch, 1, res)
+
+
+def _report(tag, stats, kinds):
+    fails = []
+    os.makedirs("gpurun_out", exist_ok=True)
+    for kind, tol, med_tol in kinds:
+        if not stats[kind]:
+            continue
+        worst = max(stats[kind])
+        errs = sorted(e for e, _ in stats[kind])
+        med = errs[len(errs) // 2]
+        print("%s %-4s n=%d median %.3g worst rel-L2 %.3g (%s)" % (tag, kind, len(stats[kind]), med, worst[0], worst[1]))
+        if worst[0] >= tol:
+            fails.append((kind, worst))
+        if med_tol is not None and med >= med_tol:
+            fails.append((kind + "-median", med))
+        with open("gpurun_out/tf_stats_%s_%s.txt" % (tag.replace("/", "_").replace(" ", "_").replace("=", ""), kind), "w") as fh:
+            for e, n in sorted(stats[kind], reverse=True):
+                fh.write("%.4e %s\n" % (e, n))
+    return fails
+
+
+@pytest.mark.parametrize("arch,res,cname,batch,ts", TF_CASES)
+def test_unet_teacher_forced_vs_oracle(arch, res, cname, batch, ts, ckdir):
+    """Every operator of the HIP path (unfused graph) against the CPU oracle (itself bit-identical to the reference,
     tests/test_oracle_golden.py) on identical inputs.  C2 = W4A8 g16 + log/real-time/start-peak + time-aware;
     C3 = W4A6 g8 (same switches); C5 = W4A6 g1: scalar scales, native-conv semantics, uniform softmax quantizer."""
-    from oracle import dgq_oracle as orc
-    tmp = str(tmp_path_factory.mktemp("ck"))
-    base = {"C2": C2, "C3": C3, "C5": C5}[cname]
-    c = dict(base, steps=2)
-    batch = 1 if arch == "sdxl" else 2
-    qnn, path = build_qnn(arch, c, res, batch, 2, tmp)
-    inp = synth.synth_inputs(arch, batch, 1, res)
-    ck = torch.load(path)
-    cfg = orc.OracleConfig(arch, c["wbits"], c["abits"], True, True, c["abits"], c["log"], c["rt"], c["sp"],
-                           c["time_aware"], 2, c["G"] > 1)
-    okw, pkw = {}, {}
-    if arch == "sdxl":
-        okw = dict(text_embeds=inp["text_embeds"], time_ids=inp["time_ids"])
-        pkw = dict(added_cond_kwargs={"text_embeds": inp["text_embeds"].cuda(), "time_ids": inp["time_ids"].cuda()})
-    for t in (999, 499):
-        om = orc.OracleModel(ck, cfg, synth.synth_state_dict(arch, 0))
-        rec = _Recorder(om)
-        ref = om.forward(inp["sample"], t, inp["encoder_hidden_states"], **okw)
+    c, slots, qnn, inp = _tf_setup(arch, res, cname, batch, ckdir)
+    pkw = product_kwargs(arch, inp)
+    for t in ts:
+        ref, rec, _ = oracle_run(arch, c, res, batch, slots, inp, t, cache_key="tf")
         out = {}
 
         def run():
             with torch.no_grad():
                 out["y"] = qnn(inp["sample"].cuda(), torch.tensor(t), inp["encoder_hidden_states"].cuda(), **pkw)[0]
         stats = teacher_forced_check(qnn, rec.io, run)
-        if N_QUANT_LAYERS[arch]:
-            assert len(stats["out"]) == N_QUANT_LAYERS[arch]     # every quantized layer was exercised
-        fails = []
-        for kind, tol in (("out", 1e-4), ("in", 2e-5), ("attn", 2e-2)):
-            worst = max(stats[kind])
-            errs = sorted(e for e, _ in stats[kind])
-            med = errs[len(errs) // 2]
-            if kind == "attn" and med >= 1e-5:
-                fails.append(("attn-median", med))
-            print("%s/%s res=%d t=%d %-4s n=%d median %.3g worst rel-L2 %.3g (%s)"
-                  % (arch, cname, res, t, kind, len(stats[kind]), med, worst[0], worst[1]))
-            if worst[0] >= tol:
-                fails.append((kind, worst))
-            os.makedirs("gpurun_out", exist_ok=True)
-            with open("gpurun_out/tf_stats_%s_%s_r%d_t%d_%s.txt" % (arch, cname, res, t, kind), "w") as fh:
-                for e, n in sorted(stats[kind], reverse=True):
-                    fh.write("%.4e %s\n" % (e, n))
+        assert len(stats["out"]) == N_QUANT_LAYERS[arch]         # every quantized layer was exercised
+        fails = _report("%s/%s res=%d t=%d" % (arch, cname, res, t), stats,
+                        (("out", 1e-4, None), ("in", 2e-5, None), ("attn", 2e-2, 1e-5)))
         assert not fails, fails
         # tail of the network after the last pinned tensor (conv_norm_out -> SiLU -> FP conv_out)
         e = rel_l2(out["y"].float().cpu(), ref)
@@ -159,23 +261,47 @@ def test_unet_teacher_forced_vs_oracle(arch, res, cname, tmp_path_factory):
         assert e < 2e-5, e
 
 
-@pytest.mark.parametrize("name,c", [("c2", C2), ("c1", C1), ("c3", C3)])
-def test_full_unet_free_running_vs_reference_golden(name, c, tmp_path_factory):
+@pytest.mark.parametrize("arch,res,cname,batch,ts", [c for c in TF_CASES if c[0] != "tiny" or c[2] == "C2"])
+def test_fused_unet_teacher_forced_vs_oracle(arch, res, cname, batch, ts, ckdir):
+    """Per-operator oracle check of the FUSED graph — the one bench.py times (the unfused test alone does not
+    pin the shipped path).  Same cached model and oracle run as the unfused test."""
+    from dgq_amd.quant import quant_block
+    assert quant_block.FUSION and quant_block.FUSE_NORM
+    c, slots, qnn, inp = _tf_setup(arch, res, cname, batch, ckdir)
+    pkw = product_kwargs(arch, inp)
+    t = ts[0]
+    ref, rec, _ = oracle_run(arch, c, res, batch, slots, inp, t, cache_key="tf")
+    out = {}
+
+    def run():
+        with torch.no_grad():
+            out["y"] = qnn(inp["sample"].cuda(), torch.tensor(t), inp["encoder_hidden_states"].cuda(), **pkw)[0]
+    stats, seen = fused_teacher_forced_check(qnn, rec.io, run)
+    assert sorted(seen) == sorted(rec.io.keys()), (len(seen), len(rec.io))     # every quantized layer, exactly once
+    assert len(stats["pro"]) > 0.3 * len(seen)                                   # the folded prologues really are in use
+    fails = _report("fused %s/%s res=%d t=%d" % (arch, cname, res, t), stats,
+                    (("out", 1e-4, None), ("pro", 2e-3, 2e-5), ("in", 2e-5, None), ("attn", 2e-2, 1e-5), ("aout", 2e-2, 1e-5)))
+    assert not fails, fails
+    e = rel_l2(out["y"].float().cpu(), ref)
+    print("fused %s/%s res=%d t=%d final (teacher-forced, folded conv_norm_out) rel-L2 %.3g" % (arch, cname, res, t, e))
+    assert e < 1e-3, e
+
+
+# ----------------------------------------------------------------------------------------------- free running
+@pytest.mark.parametrize("name,c", [("c2", C2), ("c1", C1), ("c3", C3), ("c2u", C2U)])
+def test_full_unet_free_running_vs_reference_golden(name, c, ckdir):
     """Free-running 64x64 forward against the REAL reference's output.  BASELINE.json asks for 1e-3 on the
     final latent; for the activation-quantised configs that bound is not attainable by ANY implementation
     that is not bit-identical to the reference's CPU BLAS: the golden file also holds the reference's own
     output with torch.set_num_threads(1) (same code, same inputs, different fp32 summation order), and the
-    two reference runs differ by 5e-2 (A8) to 1.4e-1 (A6).  The HIP path must sit within 2.5x of that self-deviation —
-    i.e. the same order: both are single samples of a chaotic divergence; measured ratios 1.0 (XL) … 1.5 (C2) — and
-    within 1e-3 for the weight-only config C1, which has no activation quantizers to amplify rounding (measured 6e-6)."""
-    f = os.path.join(GOLD, "f5_unet_sd_%s_r64.pt" % name)
-    if not os.path.exists(f):
-        pytest.skip("golden %s not generated" % f)
-    g = torch.load(f)
-    tmp = str(tmp_path_factory.mktemp("ck"))
+    two reference runs differ by 5e-2 (A8) to 1.4e-1 (A6).  Here the HIP path must sit within 2.5x of that self-deviation
+    (both are single samples of a chaotic divergence); the principled, distribution-level statement is
+    test_free_running_deviation_vs_exact_oracle below.  Weight-only C1 has no activation quantizers to amplify rounding:
+    1e-3 is asserted (measured 6e-6).  c2u = SD W4A8 g=1 with the uniform softmax quantiser (C5's switches on SD)."""
+    g = torch.load(os.path.join(GOLD, "f5_unet_sd_%s_r64.pt" % name))
     ts = sorted(g["outputs"].keys(), reverse=True)
-    slots = 1 + max((1000 - t) // 20 for t in ts) if c["time_aware"] else 1
-    qnn, _ = build_qnn("sd", c, 64, 2, slots, tmp)
+    slots = sorted({(1000 - t) // 20 for t in ts} | {0}) if c["time_aware"] else 1
+    qnn, _ = get_qnn("sd", c, 64, 2, slots, ckdir)
     inp = synth.synth_inputs("sd", 2, 1, 64)
     for t in ts:
         with torch.no_grad():
@@ -183,27 +309,26 @@ def test_full_unet_free_running_vs_reference_golden(name, c, tmp_path_factory):
         y = y.float().cpu()
         ref = g["outputs"][t]
         e = rel_l2(y, ref)
-        if c["use_aq"]:
+        if c["use_aq"] and "outputs_1thread" in g:
             self_dev = rel_l2(g["outputs_1thread"][t], ref)
             print("%s t=%d rel_l2=%.3g  (reference 1-thread vs 8-thread: %.3g)" % (name, t, e, self_dev))
             assert e < 2.5 * self_dev, (name, t, e, self_dev)
+        elif c["use_aq"]:
+            print("%s t=%d rel_l2=%.3g (no 1-thread reference run in this golden file)" % (name, t, e))
+            assert e < 0.25, (name, t, e)
         else:
             print("%s t=%d rel_l2=%.3g" % (name, t, e))
             assert e < 1e-3, (name, t, e)
 
 
-@SLOW
-def test_sdxl_free_running_vs_reference_golden(tmp_path_factory):
-    """C4: SDXL W4A8 g16 (log/real-time/start-peak, time-aware, 4 steps) at 128x128 latents, batch 1, against the REAL
-    reference's output; bounded by the reference's own 1-thread/8-thread deviation like the SD configs."""
-    f = os.path.join(GOLD, "f5_unet_sdxl_xl_r128.pt")
-    if not os.path.exists(f):
-        pytest.skip("golden %s not generated" % f)
-    g = torch.load(f)
-    tmp = str(tmp_path_factory.mktemp("ck"))
+def test_sdxl_free_running_vs_reference_golden(ckdir):
+    """C4: SDXL W4A8 g16 (log/real-time/start-peak, time-aware, 4 steps), batch 1, against the REAL reference's output
+    at 32x32 latents (tests/golden/f5_unet_sdxl_xl_r32.pt; the 128x128 golden of round 1 is kept for tools/, its ckpt
+    and run do not fit the driver's time limit); bounded by the reference's own 1-thread/8-thread deviation."""
+    g = torch.load(os.path.join(GOLD, "f5_unet_sdxl_xl_r32.pt"))
     c = dict(C2, steps=4)
-    qnn, _ = build_qnn("sdxl", c, 128, 1, 4, tmp)
-    inp = synth.synth_inputs("sdxl", 1, 1, 128)
+    qnn, _ = get_qnn("sdxl", c, 32, 1, [0, 3], ckdir)
+    inp = synth.synth_inputs("sdxl", 1, 1, 32)
     ack = {"text_embeds": inp["text_embeds"].cuda(), "time_ids": inp["time_ids"].cuda()}
     for t in sorted(g["outputs"].keys(), reverse=True):
         with torch.no_grad():
@@ -216,33 +341,100 @@ def test_sdxl_free_running_vs_reference_golden(tmp_path_factory):
         assert e < 2.5 * self_dev, (t, e, self_dev)
 
 
-@SLOW
-def test_ddim50_free_running_vs_reference_golden(tmp_path_factory):
-    """C2 end to end: 50-step DDIM (CFG 7.5) with one hipGraph per timestep slot against the REAL reference's final
-    latent.  Per DESIGN.md §5 the trajectory is chaotic (the reference deviates from itself by ~1e-1 per UNet call
-    when only its BLAS thread count changes), so this asserts sanity, not 1e-3: finite, same scale, and a relative
-    deviation below 1.0 (uncorrelated outputs give ~1.41); the measured value is printed for the record."""
-    f = os.path.join(GOLD, "f5_ddim50_sd_c2_r64.pt")
-    if not os.path.exists(f):
-        pytest.skip("golden %s not generated" % f)
+def test_ddim8_free_running_vs_reference_golden(ckdir):
+    """C2 end to end, shrunk from 50 to 8 DDIM steps (CFG 7.5, one hipGraph per timestep slot) against the REAL
+    reference's final latent of the same 8-step run.  Per DESIGN.md §5 the trajectory is chaotic (the reference deviates
+    from itself by ~1e-1 per UNet call when only its BLAS thread count changes), so this asserts sanity, not 1e-3:
+    finite, same scale, relative deviation well below the ~1.41 of uncorrelated outputs; the value is printed."""
     from dgq_amd.runtime import denoise_loop
-    g = torch.load(f)
-    tmp = str(tmp_path_factory.mktemp("ck"))
-    qnn, _ = build_qnn("sd", C2, 64, 2, 50, tmp)
+    g = torch.load(os.path.join(GOLD, "f5_ddim8_sd_c2_r64.pt"))
+    c = dict(C2, steps=8)
+    qnn, _ = get_qnn("sd", c, 64, 2, 8, ckdir)
     qnn.prepare_slots()
     qnn.enable_graphs(True)
-    lat = synth.named_randn("latent", (1, 4, 64, 64), 1).cuda()
-    ctx = synth.named_randn("ctx", (2, 77, 768), 2).cuda()
-    out = denoise_loop(lambda x, t, c: qnn(x, t, c)[0], lat, ctx, 50, guidance=7.5).float().cpu()
+    try:
+        lat = synth.named_randn("latent", (1, 4, 64, 64), 1).cuda()
+        ctx = synth.named_randn("ctx", (2, 77, 768), 2).cuda()
+        out = denoise_loop(lambda x, t, cc: qnn(x, t, cc)[0], lat, ctx, 8, guidance=7.5).float().cpu()
+    finally:
+        qnn.enable_graphs(False)
     ref = g["final_latent"]
     e = rel_l2(out, ref)
-    print("DDIM-50 final latent: rel-L2 vs reference %.3g, |out| %.3g |ref| %.3g" % (e, out.norm().item(), ref.norm().item()))
+    print("DDIM-8 final latent: rel-L2 vs reference %.3g, |out| %.3g |ref| %.3g" % (e, out.norm().item(), ref.norm().item()))
     assert torch.isfinite(out).all()
     assert 0.5 < out.norm().item() / ref.norm().item() < 2.0
-    assert e < 1.0, e
+    assert e < 0.5, e
 
 
-def test_fused_equals_unfused(tmp_path_factory):
+def test_free_running_deviation_vs_exact_oracle(ckdir):
+    """The principled end-to-end criterion: take the reference's arithmetic with every contraction
+    evaluated EXACTLY (float64 GEMMs rounded once, oracle exact_gemm) as the target E.  Two fp32 runs of the reference
+    (R: all host threads, R1: one thread) each deviate from E through nothing but the rounding of their GEMMs; the HIP
+    path H (integer-exact GEMMs + an fp32 epilogue) is acceptable if it is not farther from E than the reference's own
+    fp32 runs are — in distribution over seeds x timesteps, for the final output AND for the rate at which activation
+    codes flip layer by layer in free-running mode (the mechanism of the divergence)."""
+    from dgq_amd.quant import QuantLayer, quant_block
+    arch, res, batch = "sd", 16, 2
+    c, slots, qnn, _ = _tf_setup(arch, res, "C2", batch, ckdir)
+    rows, flipH_all, flipR_all = [], [], []
+    for seed, t in ((1, 999), (1, 499), (7, 999)):
+        inp = synth.synth_inputs(arch, batch, seed, res)
+        if True:
+            E, recE, omE = oracle_run(arch, c, res, batch, slots, inp, t, exact=True)
+            R, recR, _ = oracle_run(arch, c, res, batch, slots, inp, t)
+            dR1 = None
+            if (seed, t) == (1, 999):
+                R1, _, _ = oracle_run(arch, c, res, batch, slots, inp, t, threads=1)
+                dR1 = rel_l2(R1, E)
+            xs = {}
+            handles = [m.register_forward_pre_hook(lambda mod, args, _n=n: xs.__setitem__(_n, args[0].detach().float().cpu()))
+                       for n, m in qnn.model.named_modules() if isinstance(m, QuantLayer) and n in recE.io]
+            quant_block.FUSION = False
+            try:
+                with torch.no_grad():
+                    Hu = qnn(inp["sample"].cuda(), torch.tensor(t), inp["encoder_hidden_states"].cuda())[0].float().cpu()
+            finally:
+                quant_block.FUSION = True
+                for h in handles:
+                    h.remove()
+            with torch.no_grad():
+                Hf = qnn(inp["sample"].cuda(), torch.tensor(t), inp["encoder_hidden_states"].cuda())[0].float().cpu()
+            fH, fR = [], []
+            for name, (xE, _) in recE.io.items():
+                if name not in xs:
+                    continue
+                cE = omE.act_codes(name, xE, *recE.geom[name])
+                cH = omE.act_codes(name, xs[name].reshape(xE.shape), *recE.geom[name])
+                cR = omE.act_codes(name, recR.io[name][0], *recE.geom[name])
+                fH.append((cH != cE).float().mean().item())
+                fR.append((cR != cE).float().mean().item())
+            fH.sort(), fR.sort()
+            flipH_all += fH
+            flipR_all += fR
+            row = dict(seed=seed, t=t, dHf=rel_l2(Hf, E), dHu=rel_l2(Hu, E), dR=rel_l2(R, E), dR1=dR1,
+                       flipH_med=fH[len(fH) // 2], flipR_med=fR[len(fR) // 2], flipH_max=fH[-1], flipR_max=fR[-1])
+            rows.append(row)
+            print("seed %d t=%d: |H_fused−E| %.3g  |H_unfused−E| %.3g  |R−E| %.3g  |R1−E| %s ; code flips vs E per layer: "
+                  "HIP median %.3g max %.3g, reference-fp32 median %.3g max %.3g"
+                  % (seed, t, row["dHf"], row["dHu"], row["dR"], "%.3g" % dR1 if dR1 is not None else "-",
+                     row["flipH_med"], row["flipH_max"], row["flipR_med"], row["flipR_max"]))
+
+    def med(v):
+        v = sorted(v)
+        return v[len(v) // 2]
+    dH = [max(r["dHf"], r["dHu"]) for r in rows]
+    dRef = [max(r["dR"], r["dR1"] or 0.0) for r in rows]
+    print("medians: |H−E| %.3g  |R−E| %.3g ; per-layer flip rate HIP %.3g reference %.3g"
+          % (med(dH), med(dRef), med(flipH_all), med(flipR_all)))
+    # HIP is no farther from the exact target than the reference's own fp32 evaluations (25 % slack on 3 samples; every
+    # single sample within 2x of the largest reference deviation)
+    assert med(dH) <= 1.25 * med(dRef) + 1e-3, (med(dH), med(dRef))
+    assert max(dH) <= 2.0 * max(dRef), (max(dH), max(dRef))
+    assert med(flipH_all) <= 1.25 * med(flipR_all) + 1e-4, (med(flipH_all), med(flipR_all))
+
+
+# ----------------------------------------------------------------------------------------------- fusion / dtype / CLI
+def test_fused_equals_unfused(ckdir):
     """Free-running tiny UNet with the kernel-level fusions on vs off.  SiLU / GEGLU / residual / aqtizer_{q,k,v}
     fusions perform the same fp32 operations in the same order as the unfused kernels, so with the GroupNorm folding
     off the outputs must agree to rounding (asserted < 1e-5).  The folded GroupNorm rounds differently
@@ -250,16 +442,17 @@ def test_fused_equals_unfused(tmp_path_factory):
     (DESIGN.md §5): asserted only to stay below the reference's own thread-count sensitivity."""
     from dgq_amd.quant import quant_block
     quant_block._F_RES = quant_block._F_FQ = quant_block._F_GEGLU = quant_block._F_SILU = True   # exercise every fusion
-    tmp = str(tmp_path_factory.mktemp("ck"))
-    qnn, _ = build_qnn("tiny", dict(C2, steps=2), 16, 2, 2, tmp)
+    qnn, _ = get_qnn("tiny", dict(C2, steps=2), 16, 2, 2, ckdir)
     inp = synth.synth_inputs("tiny", 2, 1, 16)
     outs = {}
-    for name, fusion, fnorm in (("all", True, True), ("no_norm", True, False), ("none", False, False)):
-        quant_block.FUSION, quant_block.FUSE_NORM = fusion, fnorm
-        with torch.no_grad():
-            outs[name] = qnn(inp["sample"].cuda(), torch.tensor(999), inp["encoder_hidden_states"].cuda())[0].float().cpu()
-    quant_block.FUSION, quant_block.FUSE_NORM = True, True
-    quant_block._F_FQ = False                                                                    # shipped default
+    try:
+        for name, fusion, fnorm in (("all", True, True), ("no_norm", True, False), ("none", False, False)):
+            quant_block.FUSION, quant_block.FUSE_NORM = fusion, fnorm
+            with torch.no_grad():
+                outs[name] = qnn(inp["sample"].cuda(), torch.tensor(999), inp["encoder_hidden_states"].cuda())[0].float().cpu()
+    finally:
+        quant_block.FUSION, quant_block.FUSE_NORM = True, True
+        quant_block._F_FQ = False                                                                # shipped default
     e1 = rel_l2(outs["no_norm"], outs["none"])
     e2 = rel_l2(outs["all"], outs["none"])
     print("fused (without GN folding) vs unfused: rel-L2 %.3g ; with GN folding: %.3g" % (e1, e2))
@@ -272,8 +465,9 @@ def test_half_mode_runs_on_the_fused_kernels(dtype, tmp_path_factory, monkeypatc
     """qnn.half() / bf16 (src/inference_qmodel.py:93, quant_model.py:183-201): the forward stays on the HIP kernels
     (fused attention included — counted), stays finite and close to the fp32 run at the level the chaotic graph allows."""
     from dgq_amd import ops
-    tmp = str(tmp_path_factory.mktemp("ck"))
-    qnn, _ = build_qnn("tiny", dict(C2, steps=2), 16, 2, 2, tmp)
+    from dgq_amd.runtime import build_synthetic_qnn
+    tmp = str(tmp_path_factory.mktemp("ckh"))
+    qnn, _ = build_synthetic_qnn("tiny", dict(C2, steps=2), 16, 2, 2, ckpt_dir=tmp)      # not cached: the model is recast
     inp = synth.synth_inputs("tiny", 2, 1, 16)
     x, ctx = inp["sample"].cuda(), inp["encoder_hidden_states"].cuda()
     with torch.no_grad():
@@ -290,6 +484,26 @@ def test_half_mode_runs_on_the_fused_kernels(dtype, tmp_path_factory, monkeypatc
     e = rel_l2(out.float().cpu(), ref)
     print("%s vs fp32 run: rel-L2 %.3g" % (dtype, e))
     assert e < 0.5, e
+
+
+def test_graph_cache_is_invalidated_by_state_changes(ckdir):
+    """a captured hipGraph bakes in the quantisation state; set_quant_state / dtype casts must drop it."""
+    from dgq_amd.runtime import build_synthetic_qnn
+    qnn, _ = build_synthetic_qnn("tiny", dict(C2, steps=2), 16, 2, 2, ckpt_dir=ckdir)
+    inp = synth.synth_inputs("tiny", 2, 1, 16)
+    x, ctx = inp["sample"].cuda(), inp["encoder_hidden_states"].cuda()
+    qnn.enable_graphs(True)
+    with torch.no_grad():
+        y_q = qnn(x, torch.tensor(999), ctx)[0].clone()
+        assert len(qnn._graphs) == 1
+        qnn.set_quant_state(use_wq=True, use_aq=False)        # weight-only: a different graph
+        assert len(qnn._graphs) == 0
+        qnn.disable_out_quantization()
+        y_w = qnn(x, torch.tensor(999), ctx)[0].clone()
+        qnn.enable_graphs(False)
+        y_w_eager = qnn(x, torch.tensor(999), ctx)[0]
+    assert rel_l2(y_w.float().cpu(), y_w_eager.float().cpu()) < 1e-6          # the replayed graph is the NEW state
+    assert rel_l2(y_w.float().cpu(), y_q.float().cpu()) > 1e-4
 
 
 def test_cli_tiny(tmp_path):
