@@ -171,8 +171,13 @@ def test_load_cali_model_side_effects_cpu(tmp_path):
     assert torch.equal(q.delta.data, tab[2][0])
     with pytest.raises(KeyError):
         qnn.activate_slot(7)
-    with pytest.raises(NotImplementedError):
-        qnn.set_group_num(16)
+    # calibration-time API is implemented since round 2: flags propagate like quant_model.py:135-149
+    from dgq_amd.quant import quant_block
+    qnn.set_group_num(16)
+    assert all(m.aqtizer.group_num == 16 and m.use_group_num for m in qnn.modules() if isinstance(m, QuantLayer))
+    assert quant_block.FUSION is False
+    qnn.done_group_num(16, "minmax")                       # nothing recorded: every quantizer leaves calibration mode
+    assert all(m.aqtizer.group_num == -1 for m in qnn.modules() if isinstance(m, QuantLayer)) and quant_block.FUSION is True
 
 
 # ------------------------------------------------------------------------------------------ sharding / scheduler
