@@ -8,14 +8,25 @@
 //   * the quantised probabilities are EXACT single bf16 numbers: log2 quantiser p̂/δ = 2^-code, uniform quantiser
 //     p̂/δ = code ∈ [0,255]; so P̂·V needs only the three V terms, and δ multiplies the output once;
 //   * the start-peak column (an unquantised probability) is added as a rank-1 fp32 update.
+//
+// QI8 variant ("int8 attention"): when aqtizer_q and aqtizer_k are scalar or per-token quantizers the
+// operands of Q·K^T are integer codes times one scale per token, q̂ = δq(t)(cq − zq(t)), k̂ = δk(s)(ck − zk(s)), so
+//     Σ_d q̂k̂ = δq δk [ Σ_d c'q c'k  −  z'q Σ_d c'k  −  z'k (Σ_d c'q − D z'q) ]        (c' = c − 2^(b−1): centred int8)
+// is ONE exact int8 contraction on V_MFMA_I32_32X32X32_I8 (2x the bf16 rate, one product instead of six) plus a rank-1
+// correction per key and per query, applied in fp32 to the int32 accumulator (3 FMA/mul per score).  The K tile image
+// then holds int8 codes + a (δk, −z'k, −Σc'k) table per key, the pre-pass writes int8 Q codes + (δq, z'q, Σc'q − D z'q,
+// start-peak score) per query; δq is folded into the per-lane log2 scale.  Per-head-dim quantizers put a scale inside the
+// sum and stay on the bf16x3 products.  P̂·V is unchanged.
 // Work decomposition as attn_fused.hip: block = 4 waves = 128 query rows of one (batch, head), 32-key tiles, the
 // score tile is computed transposed (S^T = K·Q^T) so softmax statistics are in-register and the S^T accumulator is
 // directly the B operand of O^T = V^T·P̂^T (k order inside a 16-key step: element j of lane half h is key
 // 16s + 8(j>>2) + 4h + (j&3) — the V tile is stored transposed in exactly that key order).
+#include <atomic>
 #include <type_traits>
 #include "dgq_common.h"
 
 typedef float v16f __attribute__((ext_vector_type(16)));
+typedef int v16i __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 #define KT 32
@@ -74,6 +85,9 @@ struct AttnParams {
     float* delta;
     const unsigned char* planes;   // [B*H][NT] tile images of the bf16 split planes (Geo<D>::IMG_BYTES each)
     int NT;                        // 32-key tiles per (batch, head)
+    const int8_t* qcodes;          // QI8: [B][T][H][DP32] centred int8 codes of aqtizer_q(q), zero padded
+    const float* qtab;             // QI8: [B][T][H][4] = δq, z'q, Σ_d c'q − D·z'q, start-peak score / δq
+    int kskip;                     // QI8: leading keys that bypass aqtizer_k (start-peak key 0: exact fp32 rank-1 score)
 };
 
 __device__ __forceinline__ unsigned short bf16_bits(float x) {
@@ -118,14 +132,22 @@ __device__ __forceinline__ void store_any(void* p, int dtype, int64_t i, float v
     else reinterpret_cast<float*>(p)[i] = v;
 }
 
-template <int D> struct Geo {
+template <int D, bool QI8 = false> struct Geo {
     static constexpr int DP = (D + 15) / 16 * 16;      // K depth of the score product
     static constexpr int NKK = DP / 16;
     static constexpr int NDT = (D + 31) / 32;          // 32-wide d tiles of O^T
     static constexpr int DV = NDT * 32;
     static constexpr int KLD = DP + 8;                 // bf16 elements per K row (16-byte aligned, de-conflicted)
     static constexpr int VLD = KT + 8;                 // bf16 elements per V^T row
-    static constexpr int K_ELEMS = 3 * KT * KLD;
+    // QI8: int8 K codes [KT][K8_LD] (D zero-padded to a multiple of 32 = one MFMA_I32_32X32X32_I8 step, + 16 B of row
+    // padding) followed by the per-key table [3][KT] floats (δk, −z'k, −Σ_d c'k)
+    static constexpr int DP32 = (D + 31) / 32 * 32;
+    static constexpr int NK32 = DP32 / 32;
+    static constexpr int K8_LD = DP32 + 16;
+    static constexpr int K8_BYTES = KT * K8_LD;
+    static constexpr int KTAB_BYTES = 3 * KT * 4;
+    // bf16-element count of the K part of the image (QI8: bytes / 2, a multiple of 8 so that V stays 16-byte aligned)
+    static constexpr int K_ELEMS = QI8 ? (K8_BYTES + KTAB_BYTES) / 2 : 3 * KT * KLD;
     static constexpr int V_ELEMS = 3 * DV * VLD;
     // One 32-key tile of a (batch, head) is ONE contiguous image in global memory, laid out exactly as it sits in LDS
     // (K planes [3][KT][KLD] then V^T planes [3][DV][VLD], padding included), so staging is a flat LDS-DMA copy in
@@ -138,6 +160,8 @@ template <int D> struct Geo {
     static constexpr int STATS_STAGES = D <= 80 ? 4 : 3;
     static constexpr int PV_STAGES = (D <= 40 || D == 80) ? 3 : 2;
 };
+
+template <int D> using GeoI8 = Geo<D, true>;
 
 typedef __attribute__((address_space(3))) void* lptr_t;
 
@@ -173,14 +197,61 @@ __device__ __forceinline__ void wait_image(int wid) {
 // as the per-tile LDS images described above.  V is stored transposed with the keys of a tile permuted into the k
 // order of an accumulator tile used as the next MFMA's B operand: key 16s + 8a + 4h + b -> slot 16s + 8h + 4a + b.
 // Every Q block of a (batch, head) re-reads these images; splitting inside the main loop cost more than the MFMAs.
-template <int D, typename TIn>
+// centred integer code c' = clamp(rne(x/δ)+z, 0, qmax) − off of one element (the reference's code, bit for bit)
+__device__ __forceinline__ float fq_code(float x, float dl, float inv, float z, float qmax, float off) {
+    return dgq_affine_code_fast(x, dl, inv, z, qmax) - off;
+}
+
+template <int D, typename TIn, bool QI8>
 __global__ __launch_bounds__(256) void attn3_prep_kernel(const TIn* __restrict__ k, const TIn* __restrict__ v,
                                                          unsigned char* __restrict__ planes, int B, int H, int S, int NT,
                                                          FqDesc fk, FqDesc fv, float* __restrict__ delta_reset,
                                                          const TIn* __restrict__ q, float* __restrict__ qfq, int T, FqDesc fqq) {
-    using G = Geo<D>;
+    using G = Geo<D, QI8>;
     static_assert(D % 8 == 0, "head_dim must be a multiple of 8");
     const int bh = blockIdx.y, b = bh / H, hd = bh - b * H;
+    if (QI8 && (int)blockIdx.x >= NT) {
+        // QI8: int8 codes of aqtizer_q(q) for 32 query rows + (δq, z'q, Σc'q − D·z'q, start-peak score/δq) per query.
+        // One thread per query row (D <= 160 elements); the row is read as 8-element vectors.
+        const int t = ((int)blockIdx.x - NT) * 32 + (threadIdx.x >> 3);
+        const int part = threadIdx.x & 7;                       // 8 threads share a row: chunks part, part+8, ...
+        int8_t* qc = reinterpret_cast<int8_t*>(qfq);             // [B][T][H][DP32] codes, then the float table
+        float* qtab = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(qfq) + (size_t)B * T * H * G::DP32);
+        if (t < T) {
+            const int64_t row = (int64_t)(b * T + t) * H + hd;
+            const int idx = fqq.mode == 0 ? 0 : t - fqq.skip;     // per-token / scalar only (host-checked); q has no skip
+            const float dl = fqq.delta[idx], z = fqq.zp[idx], inv = dgq_rcp(dl);
+            const float off = 0.5f * (fqq.qmax + 1.0f);
+            const float zc = z - off;
+            const TIn* k0 = k + ((int64_t)(b * S) * H + hd) * D;   // raw key 0 (start-peak bypass)
+            float csum = 0.0f, sp = 0.0f;
+            for (int c8 = part; c8 < G::DP32 / 8; c8 += 8) {
+                float x[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                unsigned w0 = 0, w1 = 0;
+                if (8 * c8 < D) {
+                    load8<TIn>(q + row * D + 8 * c8, x);
+                    float kk[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    if (fk.skip > 0) load8<TIn>(k0 + 8 * c8, kk);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float c = fq_code(x[j], dl, inv, z, fqq.qmax, off);
+                        csum += c;
+                        sp += (c - zc) * kk[j];
+                        const unsigned byte = ((unsigned)(int)c) & 0xFFu;
+                        if (j < 4) w0 |= byte << (8 * j); else w1 |= byte << (8 * (j - 4));
+                    }
+                }
+                *reinterpret_cast<uint2*>(qc + row * G::DP32 + 8 * c8) = make_uint2(w0, w1);
+            }
+#pragma unroll
+            for (int o = 4; o > 0; o >>= 1) {
+                csum += __shfl_xor(csum, o, 64);
+                sp += __shfl_xor(sp, o, 64);
+            }
+            if (part == 0) *reinterpret_cast<float4*>(qtab + row * 4) = make_float4(dl, zc, csum - (float)D * zc, sp);
+        }
+        return;
+    }
     if ((int)blockIdx.x >= NT) {
         // extra blocks (only when aqtizer_q is fused): fake-quantised copy of 32 query rows of this (batch, head), so
         // that the Q-fragment loads of the two main kernels stay plain loads
@@ -206,8 +277,45 @@ __global__ __launch_bounds__(256) void attn3_prep_kernel(const TIn* __restrict__
     const int64_t HD = (int64_t)H * D;
     unsigned short* kimg = reinterpret_cast<unsigned short*>(planes + ((int64_t)bh * NT + blockIdx.x) * G::IMG_BYTES);
     unsigned short* vimg = kimg + G::K_ELEMS;
+    if (QI8) {
+        // int8 K codes + per-key table; 8 threads per key row like the Q rows above
+        int8_t* k8 = reinterpret_cast<int8_t*>(kimg);
+        float* ktab = reinterpret_cast<float*>(k8 + G::K8_BYTES);
+        const int r = threadIdx.x >> 3, part = threadIdx.x & 7;
+        const int sidx = s0 + r;
+        const bool quant = sidx < S && sidx >= fk.skip;          // key 0 under start-peak: zero row, scale 0 (rank-1 path)
+        float dl = 0.0f, z = 0.0f, inv = 0.0f;
+        if (quant) {
+            const int idx = fk.mode == 0 ? 0 : sidx - fk.skip;
+            dl = fk.delta[idx]; z = fk.zp[idx]; inv = dgq_rcp(dl);
+        }
+        const float off = 0.5f * (fk.qmax + 1.0f);
+        float csum = 0.0f;
+        for (int c8 = part; c8 < G::K8_LD / 8; c8 += 8) {
+            unsigned w0 = 0, w1 = 0;
+            if (quant && 8 * c8 < D) {
+                float x[8];
+                load8<TIn>(kbase + sidx * HD + 8 * c8, x);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float c = fq_code(x[j], dl, inv, z, fk.qmax, off);
+                    csum += c;
+                    const unsigned byte = ((unsigned)(int)c) & 0xFFu;
+                    if (j < 4) w0 |= byte << (8 * j); else w1 |= byte << (8 * (j - 4));
+                }
+            }
+            *reinterpret_cast<uint2*>(k8 + r * G::K8_LD + 8 * c8) = make_uint2(w0, w1);
+        }
+#pragma unroll
+        for (int o = 4; o > 0; o >>= 1) csum += __shfl_xor(csum, o, 64);
+        if (part == 0) {
+            ktab[r] = dl;                                        // 0 for padding keys and the bypassed key
+            ktab[KT + r] = quant ? -(z - off) : 0.0f;
+            ktab[2 * KT + r] = -csum;
+        }
+    }
     constexpr int KC = G::KLD / 8;                       // 16-byte chunks per K row (padding chunks are zero)
-    for (int i = threadIdx.x; i < KT * KC; i += 256) {
+    for (int i = threadIdx.x; !QI8 && i < KT * KC; i += 256) {
         const int r = i / KC, c8 = i - r * KC;
         const int sidx = s0 + r;
         unsigned wh[4], wm[4], wl[4];
@@ -330,12 +438,58 @@ __device__ __forceinline__ v16f score_tile(const unsigned short* kb, const bf16x
 
 __device__ __forceinline__ int key_of(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
+// QI8: this lane's query as B-operand fragments of V_MFMA_I32_32X32X32_I8 (lane l: column l&31, k = 16·(l>>5) + byte j)
+// and its table entry (δq, z'q, Σc'q − D·z'q, start-peak score / δq)
+template <int D>
+__device__ __forceinline__ void load_q_i8(v4i (&qc)[GeoI8<D>::NK32], float4& qt, const AttnParams& p, int64_t row, int h32) {
+    using G = Geo<D, true>;
+    const int8_t* src = p.qcodes + row * G::DP32 + 16 * h32;
+#pragma unroll
+    for (int kk = 0; kk < G::NK32; ++kk) qc[kk] = *reinterpret_cast<const v4i*>(src + 32 * kk);
+    qt = *reinterpret_cast<const float4*>(p.qtab + row * 4);
+}
+
+// QI8 S^T tile in units of δq: acc[r] = δk(s)·(Σ_d c'k c'q − z'q Σ_d c'k − z'k (Σ_d c'q − D z'q)), s = key_of(r, h);
+// the bypassed start-peak key (tile 0, key 0: r = 0 of the lower half-wave) gets its exact fp32 rank-1 score.
+template <int D>
+__device__ __forceinline__ v16f score_tile_i8(const unsigned char* kimg, const v4i (&qc)[GeoI8<D>::NK32], const float4& qt,
+                                              int lane, bool bypass_key0) {
+    using G = Geo<D, true>;
+    v16i acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0;
+    const unsigned char* kp = kimg + (lane & 31) * G::K8_LD + 16 * (lane >> 5);
+#pragma unroll
+    for (int kk = 0; kk < G::NK32; ++kk) {
+        const v4i kf = *reinterpret_cast<const v4i*>(kp + 32 * kk);
+        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(kf, qc[kk], acc, 0, 0, 0);
+    }
+    const float* ktab = reinterpret_cast<const float*>(kimg + G::K8_BYTES);
+    const int h32 = lane >> 5;
+    v16f out;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {                          // keys 8g + 4h .. +3: four consecutive table entries
+        const float4 dk = *reinterpret_cast<const float4*>(ktab + 8 * g + 4 * h32);
+        const float4 nz = *reinterpret_cast<const float4*>(ktab + KT + 8 * g + 4 * h32);
+        const float4 ns = *reinterpret_cast<const float4*>(ktab + 2 * KT + 8 * g + 4 * h32);
+        const float dks[4] = {dk.x, dk.y, dk.z, dk.w}, nzs[4] = {nz.x, nz.y, nz.z, nz.w}, nss[4] = {ns.x, ns.y, ns.z, ns.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v = fmaf(qt.y, nss[e], (float)acc[4 * g + e]);      // Σ c'k c'q − z'q·Σ c'k
+            v = fmaf(qt.z, nzs[e], v);                                // − z'k·(Σ c'q − D z'q)
+            out[4 * g + e] = v * dks[e];
+        }
+    }
+    if (bypass_key0 && h32 == 0) out[0] = qt.w;
+    return out;
+}
+
 // NW waves of 32 query rows per block.  NW = 8 (256 rows, one block per CU, two waves per SIMD) where the grid still
 // fills the chip (T >= 2048 at B*H = 16): the K/V tile images are then staged once per 256 rows instead of once per
 // 128 — half the LDS-DMA pieces per wave per tile, the largest non-MFMA cost of the loop.
-template <int D, int NW>
+template <int D, int NW, bool QI8>
 __global__ __launch_bounds__(64 * NW) void attn3_stats_kernel(AttnParams p) {
-    using G = Geo<D>;
+    using G = Geo<D, QI8>;
     constexpr int ST = G::STATS_STAGES, NP = G::K_PIECES, SB = NP * 1024;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds8[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, h32 = lane >> 5;
@@ -349,9 +503,12 @@ __global__ __launch_bounds__(64 * NW) void attn3_stats_kernel(AttnParams p) {
 #pragma unroll
     for (int i = 0; i < ST - 1; ++i)
         issue_image<NP, NW>(img_lane + (int64_t)min(i, p.NT - 1) * G::IMG_BYTES, lds_base + i * SB, wid);
-    bf16x8 qf[3][G::NKK];
-    load_q<D>(qf, p.q + ((int64_t)(b * p.T + tq) * p.H + hd) * D, h32, p.fq[0], tq);
-    const float sl2 = p.scale * LOG2E;                   // scores in log2 units: p = 2^(s2 − m)/l
+    bf16x8 qf[3][QI8 ? 1 : G::NKK];
+    v4i qc[G::NK32];
+    float4 qt = make_float4(1.0f, 0.0f, 0.0f, 0.0f);
+    if constexpr (QI8) load_q_i8<D>(qc, qt, p, (int64_t)(b * p.T + tq) * p.H + hd, h32);
+    else load_q<D>(qf, p.q + ((int64_t)(b * p.T + tq) * p.H + hd) * D, h32, p.fq[0], tq);
+    const float sl2 = p.scale * LOG2E * qt.x;            // scores in log2 units: p = 2^(s2 − m)/l  (QI8: δq folded in, > 0)
     float mraw = -INFINITY, l = 0.0f, m2raw = -INFINITY; // running maxima of the UNSCALED scores (scale > 0)
     wait_image<NP, ST - 2, NW>(wid);
     __builtin_amdgcn_s_barrier();
@@ -359,7 +516,9 @@ __global__ __launch_bounds__(64 * NW) void attn3_stats_kernel(AttnParams p) {
     for (int i = 0; i < p.NT; ++i) {
         issue_image<NP, NW>(img_lane + (int64_t)min(i + ST - 1, p.NT - 1) * G::IMG_BYTES, lds_base + istage * SB, wid);
         const int s0 = i * KT;
-        v16f acc = score_tile<D>(reinterpret_cast<const unsigned short*>(lds8 + stage * SB), qf, lane);
+        v16f acc;
+        if constexpr (QI8) acc = score_tile_i8<D>(lds8 + stage * SB, qc, qt, lane, i == 0 && p.kskip > 0);
+        else acc = score_tile<D>(reinterpret_cast<const unsigned short*>(lds8 + stage * SB), qf, lane);
         const bool edge = (s0 + KT > p.S) || (s0 < p.skip);      // block-uniform: only the first / a partial last tile
         float tmax = -INFINITY, tmax2 = -INFINITY;
         if (edge) {
@@ -406,9 +565,9 @@ __global__ __launch_bounds__(64 * NW) void attn3_stats_kernel(AttnParams p) {
     }
 }
 
-template <int D, bool UNIFORM, int NW>
+template <int D, bool UNIFORM, int NW, bool QI8>
 __global__ __launch_bounds__(64 * NW) void attn3_pv_kernel(AttnParams p) {
-    using G = Geo<D>;
+    using G = Geo<D, QI8>;
     constexpr int ST = G::PV_STAGES, NP = G::IMG_PIECES, SB = G::IMG_BYTES;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds8[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, h32 = lane >> 5;
@@ -420,11 +579,14 @@ __global__ __launch_bounds__(64 * NW) void attn3_pv_kernel(AttnParams p) {
 #pragma unroll
     for (int i = 0; i < ST - 1; ++i)
         issue_image<NP, NW>(img_lane + (int64_t)min(i, p.NT - 1) * G::IMG_BYTES, lds_base + i * SB, wid);
-    bf16x8 qf[3][G::NKK];
-    load_q<D>(qf, p.q + ((int64_t)(b * p.T + tq) * p.H + hd) * D, h32, p.fq[0], tq);
+    bf16x8 qf[3][QI8 ? 1 : G::NKK];
+    v4i qc[G::NK32];
+    float4 qt = make_float4(1.0f, 0.0f, 0.0f, 0.0f);
+    if constexpr (QI8) load_q_i8<D>(qc, qt, p, (int64_t)(b * p.T + tq) * p.H + hd, h32);
+    else load_q<D>(qf, p.q + ((int64_t)(b * p.T + tq) * p.H + hd) * D, h32, p.fq[0], tq);
     const float m = p.stats[((int64_t)bh * p.T + tq) * 2], l = p.stats[((int64_t)bh * p.T + tq) * 2 + 1];
     const float delta = p.delta[0];
-    const float sl2 = p.scale * LOG2E;
+    const float sl2 = p.scale * LOG2E * qt.x;
     const float nsl2 = -sl2;
     const float a0 = m + log2f(l) + log2f(delta);       // −log2(p/δ) = a0 − s2
     const float inv_l = 1.0f / l;
@@ -448,7 +610,9 @@ __global__ __launch_bounds__(64 * NW) void attn3_pv_kernel(AttnParams p) {
         const int s0 = i * KT;
         const unsigned short* kbc = reinterpret_cast<const unsigned short*>(lds8 + stage * SB);
         const unsigned short* vtc = kbc + G::K_ELEMS;
-        v16f acc = score_tile<D>(kbc, qf, lane);
+        v16f acc;
+        if constexpr (QI8) acc = score_tile_i8<D>(lds8 + stage * SB, qc, qt, lane, i == 0 && p.kskip > 0);
+        else acc = score_tile<D>(kbc, qf, lane);
         // interior tiles carry no per-key conditions; only the first tile (bypassed column) and a partial last tile do
         const bool edge = (s0 + KT > p.S) || (s0 < p.skip);      // block-uniform
         auto quantise = [&](auto edge_tag) {
@@ -523,37 +687,49 @@ __global__ __launch_bounds__(64 * NW) void attn3_pv_kernel(AttnParams p) {
     }
 }
 
-template <int D>
+template <int D, bool QI8>
 static int launch_attn3(AttnParams p, const void* q_raw, unsigned char* planes, float* qfq, hipStream_t st) {
-    using G = Geo<D>;
+    using G = Geo<D, QI8>;
     p.planes = planes;
     constexpr int stats_lds = G::STATS_STAGES * G::K_PIECES * 1024;
     constexpr int pv_lds = G::PV_STAGES * G::IMG_BYTES;
     static_assert(stats_lds <= 160 * 1024 && pv_lds <= 160 * 1024, "LDS ring too large");
-    static const bool lds_ok = [] {                            // up to 138 KB of dynamic LDS (D = 160): opt in once
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn3_stats_kernel<D, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, stats_lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn3_pv_kernel<D, true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, pv_lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn3_pv_kernel<D, false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, pv_lds);
-        if (D <= 64) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn3_stats_kernel<D, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, stats_lds);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn3_pv_kernel<D, true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, pv_lds);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn3_pv_kernel<D, false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, pv_lds);
+    // up to 138 KB of dynamic LDS (D = 160): opt in, once per device (the attribute is per device)
+    static std::atomic<bool> attr_set[64];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64 || !attr_set[dev].load(std::memory_order_acquire)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn3_stats_kernel<D, 4, QI8>), hipFuncAttributeMaxDynamicSharedMemorySize, stats_lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn3_pv_kernel<D, true, 4, QI8>), hipFuncAttributeMaxDynamicSharedMemorySize, pv_lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn3_pv_kernel<D, false, 4, QI8>), hipFuncAttributeMaxDynamicSharedMemorySize, pv_lds);
+        if constexpr (D <= 64) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn3_stats_kernel<D, 8, QI8>), hipFuncAttributeMaxDynamicSharedMemorySize, stats_lds);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn3_pv_kernel<D, true, 8, QI8>), hipFuncAttributeMaxDynamicSharedMemorySize, pv_lds);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn3_pv_kernel<D, false, 8, QI8>), hipFuncAttributeMaxDynamicSharedMemorySize, pv_lds);
         }
-        return true;
-    }();
-    (void)lds_ok;
+        if (dev >= 0 && dev < 64) attr_set[dev].store(true, std::memory_order_release);
+    }
     // the main kernels read fp32 queries: the caller's tensor when it is fp32 and aqtizer_q is not fused, else a scratch
-    // copy (converted / fake-quantised) written by extra blocks of the pre-pass
-    const bool q_copy = (p.fq[0].mode >= 0 || p.io_dtype != DGQ_F32) && qfq != nullptr;
+    // copy (converted / fake-quantised) written by extra blocks of the pre-pass; QI8: int8 codes + per-query table
+    const bool q_copy = QI8 || ((p.fq[0].mode >= 0 || p.io_dtype != DGQ_F32) && qfq != nullptr);
     const dim3 pgrid(p.NT + (q_copy ? (p.T + 31) / 32 : 0), p.B * p.H);
     float* dreset = p.mode == 1 ? p.delta : nullptr;
-#define DGQ_PREP(TT) hipLaunchKernelGGL((attn3_prep_kernel<D, TT>), pgrid, dim3(256), 0, st, (const TT*)p.k, (const TT*)p.v, planes, \
+#define DGQ_PREP(TT) hipLaunchKernelGGL((attn3_prep_kernel<D, TT, QI8>), pgrid, dim3(256), 0, st, (const TT*)p.k, (const TT*)p.v, planes, \
                                         p.B, p.H, p.S, p.NT, p.fq[1], p.fq[2], dreset, (const TT*)q_raw, qfq, p.T, p.fq[0])
     if (p.io_dtype == DGQ_F16) DGQ_PREP(__half);
     else if (p.io_dtype == DGQ_BF16) DGQ_PREP(__hip_bfloat16);
     else DGQ_PREP(float);
 #undef DGQ_PREP
-    if (q_copy) {
+    p.kskip = 0;
+    p.qcodes = nullptr;
+    p.qtab = nullptr;
+    if (QI8) {
+        p.qcodes = reinterpret_cast<const int8_t*>(qfq);
+        p.qtab = reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(qfq) + (size_t)p.B * p.T * p.H * G::DP32);
+        p.kskip = p.fq[1].skip;
+        p.q = nullptr;
+        p.fq[0].mode = -1;
+    } else if (q_copy) {
         p.q = qfq;
         p.fq[0].mode = -1;
     } else {
@@ -565,17 +741,23 @@ static int launch_attn3(AttnParams p, const void* q_raw, unsigned char* planes, 
     if (wide) {
         if constexpr (D <= 64) {
             dim3 grid((p.T + 255) / 256, p.B * p.H), block(512);
-            hipLaunchKernelGGL((attn3_stats_kernel<D, 8>), grid, block, stats_lds, st, p);
-            if (p.mode == 3) hipLaunchKernelGGL((attn3_pv_kernel<D, true, 8>), grid, block, pv_lds, st, p);
-            else hipLaunchKernelGGL((attn3_pv_kernel<D, false, 8>), grid, block, pv_lds, st, p);
+            hipLaunchKernelGGL((attn3_stats_kernel<D, 8, QI8>), grid, block, stats_lds, st, p);
+            if (p.mode == 3) hipLaunchKernelGGL((attn3_pv_kernel<D, true, 8, QI8>), grid, block, pv_lds, st, p);
+            else hipLaunchKernelGGL((attn3_pv_kernel<D, false, 8, QI8>), grid, block, pv_lds, st, p);
         }
     } else {
         dim3 grid((p.T + 127) / 128, p.B * p.H), block(256);
-        hipLaunchKernelGGL((attn3_stats_kernel<D, 4>), grid, block, stats_lds, st, p);
-        if (p.mode == 3) hipLaunchKernelGGL((attn3_pv_kernel<D, true, 4>), grid, block, pv_lds, st, p);
-        else hipLaunchKernelGGL((attn3_pv_kernel<D, false, 4>), grid, block, pv_lds, st, p);
+        hipLaunchKernelGGL((attn3_stats_kernel<D, 4, QI8>), grid, block, stats_lds, st, p);
+        if (p.mode == 3) hipLaunchKernelGGL((attn3_pv_kernel<D, true, 4, QI8>), grid, block, pv_lds, st, p);
+        else hipLaunchKernelGGL((attn3_pv_kernel<D, false, 4, QI8>), grid, block, pv_lds, st, p);
     }
     return dgq_launch_status("dgq_attention_f32(bf16x3)");
+}
+
+// bytes of the int8 query codes + per-query table of the QI8 path (0 when D is not instantiated here)
+size_t dgq_attention_qi8_bytes(int B, int H, int T, int D) {
+    const size_t dp32 = (size_t)(D + 31) / 32 * 32;
+    return (size_t)B * T * H * (dp32 + 16);
 }
 
 // bytes of the K/V tile images for one call (0 when D is not instantiated here)
@@ -610,14 +792,23 @@ int dgq_attention_bf16x3(const void* q, const void* k, const void* v, void* o, i
     p.mode = mode; p.skip = skip;
     p.qmax = qmax; p.stats = stats_ws; p.delta = delta_ws;
     p.NT = (S + KT - 1) / KT;
+    p.qcodes = nullptr; p.qtab = nullptr; p.kskip = 0;
     unsigned char* img = reinterpret_cast<unsigned char*>(planes);
+    // int8 score path: aqtizer_q and aqtizer_k both fused and scalar / per-token (one scale per token outside the d sum);
+    // DGQ_ATTN_I8=0 keeps every call on the bf16x3 products (A/B runs)
+    const char* i8_env = getenv("DGQ_ATTN_I8");                     // read per call: tests toggle it in-process
+    const bool i8_off = i8_env != nullptr && i8_env[0] == '0';
+    const bool qi8 = !i8_off && qfq != nullptr && p.fq[0].mode >= 0 && p.fq[0].mode <= 1 && p.fq[1].mode >= 0 && p.fq[1].mode <= 1 &&
+                     p.fq[0].skip == 0;
+#define DGQ_ATTN_CASE(DD) case DD: return qi8 ? launch_attn3<DD, true>(p, q, img, qfq, st) : launch_attn3<DD, false>(p, q, img, qfq, st)
     switch (D) {
-        case 8: return launch_attn3<8>(p, q, img, qfq, st);
-        case 16: return launch_attn3<16>(p, q, img, qfq, st);
-        case 40: return launch_attn3<40>(p, q, img, qfq, st);
-        case 64: return launch_attn3<64>(p, q, img, qfq, st);
-        case 80: return launch_attn3<80>(p, q, img, qfq, st);
-        case 160: return launch_attn3<160>(p, q, img, qfq, st);
+        DGQ_ATTN_CASE(8);
+        DGQ_ATTN_CASE(16);
+        DGQ_ATTN_CASE(40);
+        DGQ_ATTN_CASE(64);
+        DGQ_ATTN_CASE(80);
+        DGQ_ATTN_CASE(160);
         default: return 1;
     }
+#undef DGQ_ATTN_CASE
 }

@@ -218,14 +218,21 @@ int dgq_attention_bf16x3(const void* q, const void* k, const void* v, void* o, i
                          float scale, int mode, int skip, float qmax, float* stats_ws, float* delta_ws, void* planes,
                          float* qfq, const dgq_attn_fq_t* fq, hipStream_t st);
 size_t dgq_attention_bf16x3_bytes(int B, int H, int S, int D);
+size_t dgq_attention_qi8_bytes(int B, int H, int T, int D);
 
 // workspace layout: [0,256) δ scalar | stats B·H·T·2 floats (256-byte aligned) | tile images of the bf16 split planes of
 // K and V | fake-quantised copy of q (used when aqtizer_q is fused)
 static size_t attn_stats_off() { return 256; }
 static size_t attn_planes_off(int B, int H, int T) { return 256 + (((size_t)B * H * T * 2 * sizeof(float) + 255) / 256) * 256; }
 
+// query scratch: an fp32 (fake-quantised) copy of q, or the int8 codes + per-query table of the QI8 path
+static size_t attn_q_scratch(int B, int H, int T, int D) {
+    const size_t f32 = (size_t)B * T * H * D * sizeof(float), i8 = dgq_attention_qi8_bytes(B, H, T, D);
+    return ((f32 > i8 ? f32 : i8) + 255) / 256 * 256;
+}
+
 extern "C" size_t dgq_attention_workspace_bytes(int B, int H, int T, int S, int D) {
-    return attn_planes_off(B, H, T) + dgq_attention_bf16x3_bytes(B, H, S, D) + (size_t)B * T * H * D * sizeof(float);
+    return attn_planes_off(B, H, T) + dgq_attention_bf16x3_bytes(B, H, S, D) + attn_q_scratch(B, H, T, D);
 }
 
 extern "C" int dgq_attention_fuses_fakequant(int D, int mode) {
