@@ -87,6 +87,7 @@ struct AttnParams {
     int NT;                        // 32-key tiles per (batch, head)
     const int8_t* qcodes;          // QI8: [B][T][H][DP32] centred int8 codes of aqtizer_q(q), zero padded
     const float* qtab;             // QI8: [B][T][H][4] = δq, z'q, Σ_d c'q − D·z'q, start-peak score / δq
+    int img_bytes;                 // bytes of one tile image in global memory (depends on the K / V plane formats)
     int kskip;                     // QI8: leading keys that bypass aqtizer_k (start-peak key 0: exact fp32 rank-1 score)
 };
 
@@ -132,7 +133,7 @@ __device__ __forceinline__ void store_any(void* p, int dtype, int64_t i, float v
     else reinterpret_cast<float*>(p)[i] = v;
 }
 
-template <int D, bool QI8 = false> struct Geo {
+template <int D, bool QI8 = false, bool VINT = false> struct Geo {
     static constexpr int DP = (D + 15) / 16 * 16;      // K depth of the score product
     static constexpr int NKK = DP / 16;
     static constexpr int NDT = (D + 31) / 32;          // 32-wide d tiles of O^T
@@ -148,7 +149,10 @@ template <int D, bool QI8 = false> struct Geo {
     static constexpr int KTAB_BYTES = 3 * KT * 4;
     // bf16-element count of the K part of the image (QI8: bytes / 2, a multiple of 8 so that V stays 16-byte aligned)
     static constexpr int K_ELEMS = QI8 ? (K8_BYTES + KTAB_BYTES) / 2 : 3 * KT * KLD;
-    static constexpr int V_ELEMS = 3 * DV * VLD;
+    // VINT (scalar / per-head-dim aqtizer_v): ONE plane of centred integer codes c'v (exact bf16) instead of three planes
+    // of the dequantised values — P̂·V is then a single bf16 product, δv(d) and the zero point move to the epilogue
+    static constexpr int V_PLANES = VINT ? 1 : 3;
+    static constexpr int V_ELEMS = V_PLANES * DV * VLD;
     // One 32-key tile of a (batch, head) is ONE contiguous image in global memory, laid out exactly as it sits in LDS
     // (K planes [3][KT][KLD] then V^T planes [3][DV][VLD], padding included), so staging is a flat LDS-DMA copy in
     // 1-KB pieces (64 lanes x 16 B) with no registers in between.
@@ -161,7 +165,7 @@ template <int D, bool QI8 = false> struct Geo {
     static constexpr int PV_STAGES = (D <= 40 || D == 80) ? 3 : 2;
 };
 
-template <int D> using GeoI8 = Geo<D, true>;
+template <int D> using GeoI8 = Geo<D, true, false>;        // the K part does not depend on VINT
 
 typedef __attribute__((address_space(3))) void* lptr_t;
 
@@ -202,12 +206,12 @@ __device__ __forceinline__ float fq_code(float x, float dl, float inv, float z, 
     return dgq_affine_code_fast(x, dl, inv, z, qmax) - off;
 }
 
-template <int D, typename TIn, bool QI8>
+template <int D, typename TIn, bool QI8, bool VINT>
 __global__ __launch_bounds__(256) void attn3_prep_kernel(const TIn* __restrict__ k, const TIn* __restrict__ v,
                                                          unsigned char* __restrict__ planes, int B, int H, int S, int NT,
                                                          FqDesc fk, FqDesc fv, float* __restrict__ delta_reset,
                                                          const TIn* __restrict__ q, float* __restrict__ qfq, int T, FqDesc fqq) {
-    using G = Geo<D, QI8>;
+    using G = Geo<D, QI8, VINT>;
     static_assert(D % 8 == 0, "head_dim must be a multiple of 8");
     const int bh = blockIdx.y, b = bh / H, hd = bh - b * H;
     if (QI8 && (int)blockIdx.x >= NT) {
@@ -353,7 +357,16 @@ __global__ __launch_bounds__(256) void attn3_prep_kernel(const TIn* __restrict__
                 const int slot8 = 2 * j + e;                               // slot within the chunk = 4a + b
                 const int key = 16 * (c8 >> 1) + 8 * (slot8 >> 2) + 4 * (c8 & 1) + (slot8 & 3);
                 const int sidx = s0 + key;
-                if (c8 < 4 && sidx < S && d < D) split3(fq_apply(fv, dgq_to_float(vbase[sidx * HD + d]), sidx, d), hh[e], mm[e], ll[e]);
+                if (c8 < 4 && sidx < S && d < D) {
+                    const float xv = dgq_to_float(vbase[sidx * HD + d]);
+                    if (VINT) {                                            // centred code (|c'| <= 128: exact in bf16)
+                        const int idx = fv.mode == 0 ? 0 : d;
+                        const float dl = fv.delta[idx];
+                        hh[e] = bf16_bits(fq_code(xv, dl, dgq_rcp(dl), fv.zp[idx], fv.qmax, 0.5f * (fv.qmax + 1.0f)));
+                    } else {
+                        split3(fq_apply(fv, xv, sidx, d), hh[e], mm[e], ll[e]);
+                    }
+                }
             }
             wh[j] = (unsigned)hh[0] | ((unsigned)hh[1] << 16);
             wm[j] = (unsigned)mm[0] | ((unsigned)mm[1] << 16);
@@ -361,8 +374,10 @@ __global__ __launch_bounds__(256) void attn3_prep_kernel(const TIn* __restrict__
         }
         unsigned short* dst = vimg + d * G::VLD + 8 * c8;
         *reinterpret_cast<uint4*>(dst) = make_uint4(wh[0], wh[1], wh[2], wh[3]);
-        *reinterpret_cast<uint4*>(dst + G::DV * G::VLD) = make_uint4(wm[0], wm[1], wm[2], wm[3]);
-        *reinterpret_cast<uint4*>(dst + 2 * G::DV * G::VLD) = make_uint4(wl[0], wl[1], wl[2], wl[3]);
+        if (!VINT) {
+            *reinterpret_cast<uint4*>(dst + G::DV * G::VLD) = make_uint4(wm[0], wm[1], wm[2], wm[3]);
+            *reinterpret_cast<uint4*>(dst + 2 * G::DV * G::VLD) = make_uint4(wl[0], wl[1], wl[2], wl[3]);
+        }
     }
 }
 
@@ -496,13 +511,13 @@ __global__ __launch_bounds__(64 * NW) void attn3_stats_kernel(AttnParams p) {
     const int bh = blockIdx.y, b = bh / p.H, hd = bh - b * p.H;
     const int t = blockIdx.x * (32 * NW) + wid * 32 + (lane & 31);
     const int tq = min(t, p.T - 1);
-    const unsigned char* img_lane = p.planes + (int64_t)bh * p.NT * G::IMG_BYTES + lane * 16;
+    const unsigned char* img_lane = p.planes + (int64_t)bh * p.NT * p.img_bytes + lane * 16;
     const uint32_t lds_base = (uint32_t)(uintptr_t)(lptr_t)lds8;
     // ring invariant at the top of iteration i: tiles i .. i+ST-2 are issued (indices clamped to the last tile, so
     // the in-flight count is the same in every iteration), tile i has landed
 #pragma unroll
     for (int i = 0; i < ST - 1; ++i)
-        issue_image<NP, NW>(img_lane + (int64_t)min(i, p.NT - 1) * G::IMG_BYTES, lds_base + i * SB, wid);
+        issue_image<NP, NW>(img_lane + (int64_t)min(i, p.NT - 1) * p.img_bytes, lds_base + i * SB, wid);
     bf16x8 qf[3][QI8 ? 1 : G::NKK];
     v4i qc[G::NK32];
     float4 qt = make_float4(1.0f, 0.0f, 0.0f, 0.0f);
@@ -514,7 +529,7 @@ __global__ __launch_bounds__(64 * NW) void attn3_stats_kernel(AttnParams p) {
     __builtin_amdgcn_s_barrier();
     int stage = 0, istage = ST - 1;
     for (int i = 0; i < p.NT; ++i) {
-        issue_image<NP, NW>(img_lane + (int64_t)min(i + ST - 1, p.NT - 1) * G::IMG_BYTES, lds_base + istage * SB, wid);
+        issue_image<NP, NW>(img_lane + (int64_t)min(i + ST - 1, p.NT - 1) * p.img_bytes, lds_base + istage * SB, wid);
         const int s0 = i * KT;
         v16f acc;
         if constexpr (QI8) acc = score_tile_i8<D>(lds8 + stage * SB, qc, qt, lane, i == 0 && p.kskip > 0);
@@ -565,9 +580,9 @@ __global__ __launch_bounds__(64 * NW) void attn3_stats_kernel(AttnParams p) {
     }
 }
 
-template <int D, bool UNIFORM, int NW, bool QI8>
+template <int D, bool UNIFORM, int NW, bool QI8, bool VINT>
 __global__ __launch_bounds__(64 * NW) void attn3_pv_kernel(AttnParams p) {
-    using G = Geo<D, QI8>;
+    using G = Geo<D, QI8, VINT>;
     constexpr int ST = G::PV_STAGES, NP = G::IMG_PIECES, SB = G::IMG_BYTES;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds8[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, h32 = lane >> 5;
@@ -596,6 +611,7 @@ __global__ __launch_bounds__(64 * NW) void attn3_pv_kernel(AttnParams p) {
     constexpr int MAGIC_I = 0x4B400000;
     const int cmax_i = MAGIC_I + min((int)p.qmax, 127);
     float p_bypass = 0.0f;                               // unquantised probability of key 0 (start-peak)
+    float psum = 0.0f;                                   // VINT: Σ_s p̂/δ of this lane's keys (zero-point term of V)
     v16f oacc[G::NDT];
 #pragma unroll
     for (int j = 0; j < G::NDT; ++j)
@@ -638,6 +654,7 @@ __global__ __launch_bounds__(64 * NW) void attn3_pv_kernel(AttnParams p) {
                     }
                 }
                 acc[r] = ph;
+                if (VINT) psum += ph;
             }
         };
         if (edge) quantise(std::true_type{});
@@ -656,10 +673,12 @@ __global__ __launch_bounds__(64 * NW) void attn3_pv_kernel(AttnParams p) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 const bf16x8 vh = *reinterpret_cast<const bf16x8*>(vp + 16 * ks);
-                const bf16x8 vm = *reinterpret_cast<const bf16x8*>(vp + VPL + 16 * ks);
-                const bf16x8 vl = *reinterpret_cast<const bf16x8*>(vp + 2 * VPL + 16 * ks);
-                oacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, pf[ks], oacc[j], 0, 0, 0);
-                oacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vm, pf[ks], oacc[j], 0, 0, 0);
+                if constexpr (!VINT) {
+                    const bf16x8 vm = *reinterpret_cast<const bf16x8*>(vp + VPL + 16 * ks);
+                    const bf16x8 vl = *reinterpret_cast<const bf16x8*>(vp + 2 * VPL + 16 * ks);
+                    oacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, pf[ks], oacc[j], 0, 0, 0);
+                    oacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vm, pf[ks], oacc[j], 0, 0, 0);
+                }
                 oacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pf[ks], oacc[j], 0, 0, 0);
             }
         }
@@ -670,27 +689,49 @@ __global__ __launch_bounds__(64 * NW) void attn3_pv_kernel(AttnParams p) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // no DMA may outlive the block's LDS allocation
     if (p.skip > 0) p_bypass = __shfl(p_bypass, lane & 31, 64);   // key 0 lives in the lower half-wave
+    if (VINT) psum += __shfl_xor(psum, 32, 64);          // both half-waves hold keys of the same query
+    // VINT: (δv, z'v) per head-dim element staged once through the (now idle) LDS ring — read per output element from
+    // global memory they were 5·16 dependent round trips between the stores (D = 160: +10 us on a 64-row call)
+    // likewise the (fake-quantised) value row of the bypassed start-peak key
+    float* vtab = reinterpret_cast<float*>(lds8);
+    if (VINT || p.skip > 0) {
+        for (int d = tid; d < G::DV; d += 64 * NW) {
+            if (VINT) {
+                const int idx = (p.fq[2].mode == 0 || d >= D) ? 0 : d;
+                vtab[d] = p.fq[2].delta[idx];
+                vtab[G::DV + d] = p.fq[2].zp[idx] - 0.5f * (p.fq[2].qmax + 1.0f);
+            }
+            if (p.skip > 0)
+                vtab[2 * G::DV + d] = d < D ? fq_apply(p.fq[2], load_any(p.v, p.io_dtype, ((int64_t)(b * p.S) * p.H + hd) * D + d), 0, d) : 0.0f;
+        }
+        __syncthreads();
+    }
     if (t < p.T) {
         const int64_t ob = ((int64_t)(b * p.T + t) * p.H + hd) * D;
-        const int64_t vb = ((int64_t)(b * p.S) * p.H + hd) * D;
 #pragma unroll
         for (int j = 0; j < G::NDT; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int d = j * 32 + key_of(r, h32);
                 if (d < D) {
-                    float o = delta * oacc[j][r];
-                    if (p.skip > 0) o += p_bypass * fq_apply(p.fq[2], load_any(p.v, p.io_dtype, vb + d), 0, d);
+                    float o;
+                    if (VINT) {                              // o = δw·δv(d)·(Σ p̂'·c'v − z'v(d)·Σ p̂')
+                        o = delta * (vtab[d] * (oacc[j][r] - vtab[G::DV + d] * psum));
+                    } else {
+                        o = delta * oacc[j][r];
+                    }
+                    if (p.skip > 0) o += p_bypass * vtab[2 * G::DV + d];
                     store_any(p.o, p.io_dtype, ob + d, o);
                 }
             }
     }
 }
 
-template <int D, bool QI8>
+template <int D, bool QI8, bool VINT>
 static int launch_attn3(AttnParams p, const void* q_raw, unsigned char* planes, float* qfq, hipStream_t st) {
-    using G = Geo<D, QI8>;
+    using G = Geo<D, QI8, VINT>;
     p.planes = planes;
+    p.img_bytes = G::IMG_BYTES;
     constexpr int stats_lds = G::STATS_STAGES * G::K_PIECES * 1024;
     constexpr int pv_lds = G::PV_STAGES * G::IMG_BYTES;
     static_assert(stats_lds <= 160 * 1024 && pv_lds <= 160 * 1024, "LDS ring too large");
@@ -700,12 +741,12 @@ static int launch_attn3(AttnParams p, const void* q_raw, unsigned char* planes, 
     (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= 64 || !attr_set[dev].load(std::memory_order_acquire)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn3_stats_kernel<D, 4, QI8>), hipFuncAttributeMaxDynamicSharedMemorySize, stats_lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn3_pv_kernel<D, true, 4, QI8>), hipFuncAttributeMaxDynamicSharedMemorySize, pv_lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn3_pv_kernel<D, false, 4, QI8>), hipFuncAttributeMaxDynamicSharedMemorySize, pv_lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn3_pv_kernel<D, true, 4, QI8, VINT>), hipFuncAttributeMaxDynamicSharedMemorySize, pv_lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn3_pv_kernel<D, false, 4, QI8, VINT>), hipFuncAttributeMaxDynamicSharedMemorySize, pv_lds);
         if constexpr (D <= 64) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn3_stats_kernel<D, 8, QI8>), hipFuncAttributeMaxDynamicSharedMemorySize, stats_lds);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn3_pv_kernel<D, true, 8, QI8>), hipFuncAttributeMaxDynamicSharedMemorySize, pv_lds);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn3_pv_kernel<D, false, 8, QI8>), hipFuncAttributeMaxDynamicSharedMemorySize, pv_lds);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn3_pv_kernel<D, true, 8, QI8, VINT>), hipFuncAttributeMaxDynamicSharedMemorySize, pv_lds);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn3_pv_kernel<D, false, 8, QI8, VINT>), hipFuncAttributeMaxDynamicSharedMemorySize, pv_lds);
         }
         if (dev >= 0 && dev < 64) attr_set[dev].store(true, std::memory_order_release);
     }
@@ -714,7 +755,7 @@ static int launch_attn3(AttnParams p, const void* q_raw, unsigned char* planes, 
     const bool q_copy = QI8 || ((p.fq[0].mode >= 0 || p.io_dtype != DGQ_F32) && qfq != nullptr);
     const dim3 pgrid(p.NT + (q_copy ? (p.T + 31) / 32 : 0), p.B * p.H);
     float* dreset = p.mode == 1 ? p.delta : nullptr;
-#define DGQ_PREP(TT) hipLaunchKernelGGL((attn3_prep_kernel<D, TT, QI8>), pgrid, dim3(256), 0, st, (const TT*)p.k, (const TT*)p.v, planes, \
+#define DGQ_PREP(TT) hipLaunchKernelGGL((attn3_prep_kernel<D, TT, QI8, VINT>), pgrid, dim3(256), 0, st, (const TT*)p.k, (const TT*)p.v, planes, \
                                         p.B, p.H, p.S, p.NT, p.fq[1], p.fq[2], dreset, (const TT*)q_raw, qfq, p.T, p.fq[0])
     if (p.io_dtype == DGQ_F16) DGQ_PREP(__half);
     else if (p.io_dtype == DGQ_BF16) DGQ_PREP(__hip_bfloat16);
@@ -742,14 +783,14 @@ static int launch_attn3(AttnParams p, const void* q_raw, unsigned char* planes, 
         if constexpr (D <= 64) {
             dim3 grid((p.T + 255) / 256, p.B * p.H), block(512);
             hipLaunchKernelGGL((attn3_stats_kernel<D, 8, QI8>), grid, block, stats_lds, st, p);
-            if (p.mode == 3) hipLaunchKernelGGL((attn3_pv_kernel<D, true, 8, QI8>), grid, block, pv_lds, st, p);
-            else hipLaunchKernelGGL((attn3_pv_kernel<D, false, 8, QI8>), grid, block, pv_lds, st, p);
+            if (p.mode == 3) hipLaunchKernelGGL((attn3_pv_kernel<D, true, 8, QI8, VINT>), grid, block, pv_lds, st, p);
+            else hipLaunchKernelGGL((attn3_pv_kernel<D, false, 8, QI8, VINT>), grid, block, pv_lds, st, p);
         }
     } else {
         dim3 grid((p.T + 127) / 128, p.B * p.H), block(256);
         hipLaunchKernelGGL((attn3_stats_kernel<D, 4, QI8>), grid, block, stats_lds, st, p);
-        if (p.mode == 3) hipLaunchKernelGGL((attn3_pv_kernel<D, true, 4, QI8>), grid, block, pv_lds, st, p);
-        else hipLaunchKernelGGL((attn3_pv_kernel<D, false, 4, QI8>), grid, block, pv_lds, st, p);
+        if (p.mode == 3) hipLaunchKernelGGL((attn3_pv_kernel<D, true, 4, QI8, VINT>), grid, block, pv_lds, st, p);
+        else hipLaunchKernelGGL((attn3_pv_kernel<D, false, 4, QI8, VINT>), grid, block, pv_lds, st, p);
     }
     return dgq_launch_status("dgq_attention_f32(bf16x3)");
 }
@@ -800,7 +841,10 @@ int dgq_attention_bf16x3(const void* q, const void* k, const void* v, void* o, i
     const bool i8_off = i8_env != nullptr && i8_env[0] == '0';
     const bool qi8 = !i8_off && qfq != nullptr && p.fq[0].mode >= 0 && p.fq[0].mode <= 1 && p.fq[1].mode >= 0 && p.fq[1].mode <= 1 &&
                      p.fq[0].skip == 0;
-#define DGQ_ATTN_CASE(DD) case DD: return qi8 ? launch_attn3<DD, true>(p, q, img, qfq, st) : launch_attn3<DD, false>(p, q, img, qfq, st)
+    // single-plane integer V: aqtizer_v fused and scalar / per-head-dim (its scale is outside the sum over keys)
+    const bool vint = qi8 && (p.fq[2].mode == 0 || p.fq[2].mode == 2);
+#define DGQ_ATTN_CASE(DD) case DD: return !qi8 ? launch_attn3<DD, false, false>(p, q, img, qfq, st) : \
+                                          (vint ? launch_attn3<DD, true, true>(p, q, img, qfq, st) : launch_attn3<DD, true, false>(p, q, img, qfq, st))
     switch (D) {
         DGQ_ATTN_CASE(8);
         DGQ_ATTN_CASE(16);

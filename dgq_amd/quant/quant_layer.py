@@ -215,6 +215,7 @@ class UniformAffineQuantizer(nn.Module):
         out_min = torch.stack([m[0] for m in self.min_max_per_out_channel]).min(dim=0)[0]
         out_max = torch.stack([m[1] for m in self.min_max_per_out_channel]).max(dim=0)[0]
         delta, zero_point, _ = group_params_from_ranges(in_min, in_max, out_min, out_max, group_num, mode, self.level)
+        self.last_ranges = tuple(t.detach().cpu() for t in (in_min, in_max, out_min, out_max))    # kept for inspection / tests
         dev = in_min.device
         self.delta.data = delta.to(dev)
         self.zero_point = zero_point.to(dev)

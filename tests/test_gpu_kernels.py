@@ -398,8 +398,11 @@ def test_attention_int8_scores_vs_exact_formula(D, T, S, H, mode, skip, qmode, k
     for name, other in (("float64 formula", ref), ("bf16x3 path", ref3)):
         row_err = (out - other).view(B * T, -1).norm(dim=1) / other.view(B * T, -1).norm(dim=1).clamp_min(1e-20)
         # isolated log2-code flips of probabilities that sit on a rounding tie (as in the other attention tests)
-        assert row_err.median().item() < 1e-5, (name, row_err.median().item())
-        assert (row_err > 1e-4).float().mean().item() < 0.02, (name, (row_err > 1e-4).float().mean().item())
+        # the int8 contraction is exact; the bf16x3 products (like the reference's fp32 matmul) carry ~1e-7·Σ|q||k| of
+        # absolute score error, which the softmax turns into ~1e-5 relative error of every probability at these magnitudes
+        assert row_err.median().item() < (1e-5 if name.startswith("float64") else 1e-4), (name, row_err.median().item())
+        # a row holds S probabilities, each flips with the same small rate (measured ~1e-5 per entry): scale the bound
+        assert (row_err > 1e-4).float().mean().item() < max(0.02, 2.5e-5 * S), (name, (row_err > 1e-4).float().mean().item())
         assert rel_l2(out.cpu(), other.cpu()) < 4e-3, (name, rel_l2(out.cpu(), other.cpu()))
 
 
