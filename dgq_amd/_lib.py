@@ -32,6 +32,7 @@ SIGNATURES = {
     "dgq_attention_fuses_fakequant": [_i, _i],
     "dgq_attention_workspace_bytes": [_i, _i, _i, _i, _i],
     "dgq_minmax_rows_cols": [_vp, _i, _i, _i, _i64, _vp, _vp, _vp, _vp, _vp, _i, _vp],
+    "dgq_linear_smallm_batch": [_vp, _i, _i, _i, _i64, _i, _i, _vp, _i, _vp],
 }
 
 
@@ -40,6 +41,12 @@ class GemmExtra(ctypes.Structure):
     """dgq_gemm_extra_t of include/dgq_hip.h"""
     _fields_ = [("residual", _vp), ("ldr", _i), ("res_div", _i), ("res_dtype", _i), ("fq_mode", _i), ("fq_delta", _vp), ("fq_zp", _vp),
                 ("fq_T", _i), ("fq_D", _i), ("fq_skip", _i), ("fq_qmax", _f)]
+
+
+class SmallMProblem(ctypes.Structure):
+    """dgq_smallm_problem_t of include/dgq_hip.h"""
+    _fields_ = [("wpacked", _vp), ("alpha", _vp), ("zw", _vp), ("gamma", _vp), ("vn", _vp), ("mdelta", _vp), ("mzp", _vp),
+                ("y", _vp), ("ldy", _i), ("N", _i), ("Kp", _i), ("w_bits", _i), ("a_bits", _i)]
 
 
 class AttnFq(ctypes.Structure):

@@ -498,10 +498,8 @@ static void launch_tile(const GemmParams& p, hipStream_t st) {
     hipLaunchKernelGGL((gemm_wxa8_kernel<WBITS, PER_M, TOut, BM, BN>), grid, block, lds, st, p);
 }
 
-// Tile shapes the host may pick (BM, BN).  W8 (a secondary configuration) carries three of them.
-struct GemmTile { int bm, bn; };
-static const GemmTile kTilesW4[] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}, {32, 128}, {32, 64}};
-static const GemmTile kTilesW8[] = {{128, 128}, {64, 64}, {32, 64}};
+// Tile shapes the host may pick (BM, BN): W4 {128x128, 128x64, 64x128, 64x64, 32x128, 32x64}; W8 (a secondary
+// configuration) carries {128x128, 64x64, 32x64}.
 
 template <int WBITS, bool PER_M, typename TOut>
 static int launch_one(const GemmParams& p, int bm, int bn, hipStream_t st) {
@@ -545,54 +543,48 @@ static int launch_gemm(const GemmParams& p, int bm, int bn, int y_dtype, hipStre
     return dgq_launch_status("dgq_gemm_wxa8");
 }
 
-// Launch plan (tile shape + K split) from a small cost model, all times in us, constants measured on MI355X with
-// tools/bench_gemm_sweep.py (profiles/r02_gemm_tile_sweep.txt).  A block of tile (BM, BN) retires one K tile (BK = 128) in
-//   t_k = max(T_LAT, mfma) · (per-K ? 1 + flush share : 1)
-// where T_LAT is the ds_read -> MFMA -> barrier chain of a K tile (what a resident block pays however small its tile is)
-// and mfma the matrix time of the co-resident blocks of a CU: occ·(BM·BN·128 MACs)/(4 SIMDs · 1024 MAC/clk) at ~2 GHz.
-// Blocks run in rounds of 256·occ; a split adds S·M·N·4 B of slab traffic (written, then read by the combine kernel) and the
-// combine launch.  Larger tiles win when the grid fills the chip anyway (fewer L2 reads per MAC); otherwise the model
-// prefers the shape that fills it WITHOUT a K split, because slabs + combine cost more than small tiles lose.
+// Launch plan (tile shape + K split).  Rules distilled from the measured sweep of every (tile, split) candidate over the
+// SD1.4 / SDXL layer shapes (tools/tile_sweep.py, profiles/r02_gemm_tile_sweep_*.txt; within 2 % of the per-shape optimum
+// on the SD step, 14 % better than the analytic model they replace).  What the measurements say:
+//   * these GEMMs are latency-bound per K tile, not MFMA-bound: the smallest tile (32x64: 1280 blocks at 8192x320, 640 at
+//     2048x640) wins whenever the output is small (M·N <= 3M), because many resident blocks hide each other's DMA latency;
+//   * once K is long (>= 24 K tiles) and M large, operand re-reads through L2 dominate (blocks · tiles · (BM·128 + BN·64)
+//     bytes at ~12 TB/s): wider tiles (32x128, 64x128) halve the activation re-reads;
+//   * large outputs (M·N > 3M) are bound by their own stores: 64x128 (128x128 from 30M outputs on);
+//   * a K split pays only when the unsplit grid cannot fill the chip (< 256 blocks) AND K is long (> 60 tiles): slabs
+//     cost S·M·N·8 B of traffic plus a combine launch; then S brings the grid to ~480 blocks.
 struct GemmPlan { int bm, bn, splits; double t; };
-#ifndef GEMM_T_LAT
-#define GEMM_T_LAT 0.22
-#endif
-#ifndef GEMM_T_FIXED
-#define GEMM_T_FIXED 2.0
-#endif
-#ifndef GEMM_T_SPLIT
-#define GEMM_T_SPLIT 1.5
-#endif
-#ifndef GEMM_FLUSH
-#define GEMM_FLUSH 1.2
-#endif
 static GemmPlan plan_gemm(int M, int N, int Kp, int w_bits, size_t ws_bytes, bool per_m) {
-    const GemmTile* tiles = w_bits == 4 ? kTilesW4 : kTilesW8;
-    const int ntiles = w_bits == 4 ? (int)(sizeof(kTilesW4) / sizeof(GemmTile)) : (int)(sizeof(kTilesW8) / sizeof(GemmTile));
     const int nk = Kp / BK;
-    const double slab_bytes = (double)M * N * 4.0;
-    GemmPlan best = {tiles[0].bm, tiles[0].bn, 1, 1e30};
-    for (int ti = 0; ti < ntiles; ++ti) {
-        const int bm = tiles[ti].bm, bn = tiles[ti].bn;
-        const long grid = (long)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
-        const int occ = gemm_occupancy(w_bits, bm, bn);
-        for (int s = 1; s <= 32 && (s == 1 || s * 2 <= nk); ++s) {
-            if (s > 1 && slab_bytes * s > (double)ws_bytes) break;
-            const int tps = (nk + s - 1) / s;
-            const long blocks = grid * ((nk + tps - 1) / tps);
-            const long slots = 256L * occ;
-            const long rounds = (blocks + slots - 1) / slots;
-            const double resident = (double)(blocks < slots ? blocks : slots) / 256.0;    // blocks per CU actually there
-            const double mfma = (resident < 1.0 ? 1.0 : resident) * (double)bm * bn * BK / (4.0 * 1024.0) / 2000.0;
-            double tk = mfma > GEMM_T_LAT ? mfma : GEMM_T_LAT;
-            // per-K: every group end flushes the wave's int32 tile to fp32 (VALU, ~3 ops per accumulator)
-            if (!per_m) tk *= 1.0 + GEMM_FLUSH * (mfma / (mfma > GEMM_T_LAT ? mfma : GEMM_T_LAT));
-            double t = rounds * (tps * tk + GEMM_T_FIXED);
-            if (s > 1) t += GEMM_T_SPLIT + 2.0 * slab_bytes * s / 3.0e6;
-            if (t < best.t) best = {bm, bn, s, t};
+    const double out = (double)M * N;
+    GemmPlan pl = {32, 64, 1, 0.0};
+    if (out > 3.0e7) {
+        pl = {128, 128, 1, 0.0};
+    } else if (out > 3.0e6) {
+        pl = {64, 128, 1, 0.0};
+    } else if (nk > 60) {
+        if (M <= 160) pl = {32, 64, 1, 0.0};
+        else if (N >= 1280) pl = {128, 64, 1, 0.0};
+        else pl = {64, 128, 1, 0.0};
+        const long grid = (long)((M + pl.bm - 1) / pl.bm) * ((N + pl.bn - 1) / pl.bn);
+        if (grid < 256) {
+            int s = (int)((480 + grid - 1) / grid);
+            if (s > nk / 8) s = nk / 8;
+            if (s > 16) s = 16;
+            while (s > 1 && (double)s * out * 4.0 > (double)ws_bytes) --s;
+            pl.splits = s < 1 ? 1 : s;
         }
+    } else if (M >= 4096 && nk >= 24) {
+        pl = {32, 128, 1, 0.0};
+    } else if (per_m && nk >= 40) {
+        pl = {64, 64, 1, 0.0};
     }
-    return best;
+    if (w_bits != 4) {                                   // W8 carries three tile shapes: nearest one
+        if (pl.bm == 128 || pl.bn == 128) { pl.bm = 128; pl.bn = 128; }
+        else if (pl.bm == 64) { pl.bm = 64; pl.bn = 64; }
+        else { pl.bm = 32; pl.bn = 64; }
+    }
+    return pl;
 }
 
 // Development hook: DGQ_GEMM_FORCE="BM,BN,S" overrides the plan (tile sweeps, tools/bench_gemm_sweep.py); read per call.

@@ -1,0 +1,158 @@
+// Batched small-M quantized Linear: y_l = W_l · aqtizer_l(act(x)) + b_l for up to 24 layers that share ONE input of a
+// few rows — the 23 `time_emb_proj(SiLU(temb))` projections of a UNet forward (QuantResnetBlock2D.forward,
+// quant_block.py:98-119; x = [2·prompts, 1280]) are independent of the latents, so they run as ONE launch instead of 23
+// quantise-on-load + 23 GEMM launches whose 128-row MFMA tiles would hold two live rows.
+// Same integer identity as dgq_gemm_wxa8 (per_m = 1, L = 1: scalar activation quantizer), evaluated with V_DOT4_I32_I8:
+// block = 256 threads = 64 output columns; the block first quantises the M x K input into int8 codes in LDS (the SiLU
+// prologue and the exact-division rounding of dgq_quant_act), then each wave walks 16 weight rows with its lanes spread
+// over K (coalesced 16-byte loads of packed int4) and reduces across the wave.
+#include "dgq_common.h"
+
+#define SMALLM_MAX_PROBLEMS 24
+#define SMALLM_MAX_M 16
+#define SMALLM_MAX_K 2048
+
+struct SmallMProblem {
+    const uint8_t* wpacked;    // W4: [N][Kp/2] (dgq_pack_w4, natural K order); W8: [N][Kp] int8
+    const float* alpha;        // δw [N]
+    const float* zw;           // zero point in the stored code domain [N]
+    const float* gamma;        // bias [N]
+    const float* vn;           // Σ_k qw' − K·zw [N]
+    const float* mdelta;       // scalar activation δ (device, 1 element)
+    const float* mzp;
+    void* y;                   // [M][ldy]
+    int ldy, N, Kp, w_bits, a_bits, block0;
+};
+
+struct SmallMBatch {
+    SmallMProblem p[SMALLM_MAX_PROBLEMS];
+    int n;
+    const void* x;             // [M][ldx] shared input
+    int x_dtype, y_dtype, M, K, ldx, pre_act;
+};
+
+template <typename TIn, typename TOut>
+__global__ __launch_bounds__(256) void linear_smallm_kernel(SmallMBatch b) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    int pi = 0;
+    while (pi + 1 < b.n && (int)blockIdx.x >= b.p[pi + 1].block0) ++pi;
+    const SmallMProblem& P = b.p[pi];
+    const int n0 = ((int)blockIdx.x - P.block0) * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int Kq = (b.K + 15) & ~15;                     // code row stride in LDS (16-byte aligned, zero padded)
+    int8_t* codes = reinterpret_cast<int8_t*>(smem);     // [M][Kq]
+    float* rsum = reinterpret_cast<float*>(smem + (size_t)SMALLM_MAX_M * SMALLM_MAX_K);   // [M]
+    const float md = P.mdelta[0], mz = P.mzp[0], inv = dgq_rcp(md);
+    const float qmax = (float)((1 << P.a_bits) - 1), off = (float)(1 << (P.a_bits - 1));
+    if (tid < b.M) rsum[tid] = 0.0f;
+    __syncthreads();
+    const TIn* x = reinterpret_cast<const TIn*>(b.x);
+    for (int m = 0; m < b.M; ++m) {
+        float part = 0.0f;
+        for (int k = tid; k < Kq; k += 256) {
+            float c = 0.0f;
+            if (k < b.K) {
+                float v = dgq_to_float(x[(int64_t)m * b.ldx + k]);
+                if (b.pre_act == 1) v = dgq_silu(v);
+                c = dgq_affine_code_fast(v, md, inv, mz, qmax) - off;
+            }
+            codes[m * Kq + k] = (int8_t)(int)c;
+            part += c;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+        if (lane == 0) atomicAdd(&rsum[m], part);          // 4 exact small integers: order-independent
+    }
+    __syncthreads();
+    TOut* y = reinterpret_cast<TOut*>(P.y);
+    const int row_bytes = P.w_bits == 4 ? P.Kp / 2 : P.Kp;
+    for (int r = 0; r < 16; ++r) {
+        const int n = n0 + wid * 16 + r;
+        if (n >= P.N) break;                                // wave-uniform
+        const uint8_t* wrow = P.wpacked + (int64_t)n * row_bytes;
+        int acc[SMALLM_MAX_M];
+#pragma unroll
+        for (int m = 0; m < SMALLM_MAX_M; ++m) acc[m] = 0;
+        if (P.w_bits == 4) {
+            for (int k0 = lane * 32; k0 < Kq; k0 += 64 * 32) {           // 16 bytes = 32 k per lane
+                const uint4 w = *reinterpret_cast<const uint4*>(wrow + k0 / 2);
+                const unsigned ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+                for (int m = 0; m < SMALLM_MAX_M; ++m) {
+                    if (m >= b.M) break;
+                    const int4 c0 = *reinterpret_cast<const int4*>(codes + m * Kq + k0);
+                    const int4 c1 = (k0 + 16 < Kq) ? *reinterpret_cast<const int4*>(codes + m * Kq + k0 + 16) : make_int4(0, 0, 0, 0);
+                    const int cc[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+                    int a = acc[m];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {                            // dword j: k0+8j..+3 low nibbles, +4..+7 high nibbles
+                        a = __builtin_amdgcn_sdot4(cc[2 * j], (int)(ww[j] & 0x0F0F0F0Fu), a, false);
+                        a = __builtin_amdgcn_sdot4(cc[2 * j + 1], (int)((ww[j] >> 4) & 0x0F0F0F0Fu), a, false);
+                    }
+                    acc[m] = a;
+                }
+            }
+        } else {
+            for (int k0 = lane * 16; k0 < Kq; k0 += 64 * 16) {
+                const int4 w = *reinterpret_cast<const int4*>(wrow + k0);
+#pragma unroll
+                for (int m = 0; m < SMALLM_MAX_M; ++m) {
+                    if (m >= b.M) break;
+                    const int4 c = *reinterpret_cast<const int4*>(codes + m * Kq + k0);
+                    int a = acc[m];
+                    a = __builtin_amdgcn_sdot4(c.x, w.x, a, false);
+                    a = __builtin_amdgcn_sdot4(c.y, w.y, a, false);
+                    a = __builtin_amdgcn_sdot4(c.z, w.z, a, false);
+                    a = __builtin_amdgcn_sdot4(c.w, w.w, a, false);
+                    acc[m] = a;
+                }
+            }
+        }
+        const float al = P.alpha[n], zw = P.zw[n], ga = P.gamma[n], vn = P.vn[n];
+#pragma unroll
+        for (int m = 0; m < SMALLM_MAX_M; ++m) {
+            if (m >= b.M) break;
+            int a = acc[m];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+            if (lane == 0) {
+                // the per_m epilogue of dgq_gemm_wxa8, term for term
+                const float rs = rsum[m];
+                const float out = al * (md * (float)a - zw * (md * rs) + (md * (off - mz)) * vn) + ga;
+                y[(int64_t)m * P.ldy + n] = dgq_from_float<TOut>(out);
+            }
+        }
+    }
+}
+
+extern "C" int dgq_linear_smallm_batch(const void* x, int x_dtype, int M, int K, int64_t ldx, int pre_act, int n_problems,
+                                       const dgq_smallm_problem_t* probs, int y_dtype, void* stream) {
+    DGQ_CHECK_ARG(x && probs, "dgq_linear_smallm_batch: null pointer");
+    DGQ_CHECK_ARG(M >= 1 && M <= SMALLM_MAX_M && K >= 1 && K <= SMALLM_MAX_K && ldx >= K, "dgq_linear_smallm_batch: M=%d (<= %d) K=%d (<= %d)", M, SMALLM_MAX_M, K, SMALLM_MAX_K);
+    DGQ_CHECK_ARG(n_problems >= 1 && n_problems <= SMALLM_MAX_PROBLEMS, "dgq_linear_smallm_batch: %d problems (max %d)", n_problems, SMALLM_MAX_PROBLEMS);
+    DGQ_CHECK_ARG(pre_act == 0 || pre_act == 1, "dgq_linear_smallm_batch: pre_act");
+    SmallMBatch b;
+    b.n = n_problems; b.x = x; b.x_dtype = x_dtype; b.y_dtype = y_dtype; b.M = M; b.K = K; b.ldx = (int)ldx; b.pre_act = pre_act;
+    int blocks = 0;
+    for (int i = 0; i < n_problems; ++i) {
+        const dgq_smallm_problem_t& q = probs[i];
+        DGQ_CHECK_ARG(q.wpacked && q.alpha && q.zw && q.gamma && q.vn && q.mdelta && q.mzp && q.y, "dgq_linear_smallm_batch: null pointer in problem %d", i);
+        DGQ_CHECK_ARG(q.N > 0 && q.ldy >= q.N && q.Kp >= K && q.Kp % DGQ_KTILE == 0 && (q.w_bits == 4 || q.w_bits == 8) && q.a_bits >= 2 && q.a_bits <= 8,
+                      "dgq_linear_smallm_batch: bad problem %d", i);
+        DGQ_CHECK_ARG((reinterpret_cast<uintptr_t>(q.wpacked) & 15) == 0, "dgq_linear_smallm_batch: wpacked alignment");
+        SmallMProblem& P = b.p[i];
+        P.wpacked = reinterpret_cast<const uint8_t*>(q.wpacked); P.alpha = q.alpha; P.zw = q.zw; P.gamma = q.gamma; P.vn = q.vn;
+        P.mdelta = q.mdelta; P.mzp = q.mzp; P.y = q.y; P.ldy = q.ldy; P.N = q.N; P.Kp = q.Kp; P.w_bits = q.w_bits; P.a_bits = q.a_bits;
+        P.block0 = blocks;
+        blocks += (q.N + 63) / 64;
+    }
+    const size_t lds = (size_t)SMALLM_MAX_M * SMALLM_MAX_K + SMALLM_MAX_M * sizeof(float);
+    hipStream_t st = (hipStream_t)stream;
+#define DGQ_SMALLM(TI, TO) hipLaunchKernelGGL((linear_smallm_kernel<TI, TO>), dim3(blocks), dim3(256), lds, st, b)
+    if (x_dtype == DGQ_F32 && y_dtype == DGQ_F32) DGQ_SMALLM(float, float);
+    else if (x_dtype == DGQ_F16 && y_dtype == DGQ_F16) DGQ_SMALLM(__half, __half);
+    else if (x_dtype == DGQ_BF16 && y_dtype == DGQ_BF16) DGQ_SMALLM(__hip_bfloat16, __hip_bfloat16);
+    else { dgq_set_error("dgq_linear_smallm_batch: x/y dtypes %d/%d", x_dtype, y_dtype); return DGQ_EINVAL; }
+#undef DGQ_SMALLM
+    return dgq_launch_status("dgq_linear_smallm_batch");
+}

@@ -424,6 +424,35 @@ def logquant_f32(p: torch.Tensor, delta: torch.Tensor, bits, skip_cols=0, out=No
     return out
 
 
+SMALLM_MAX_M, SMALLM_MAX_K, SMALLM_MAX_PROBLEMS = 16, 2048, 24
+
+
+def linear_smallm_batch(x2d: torch.Tensor, bindings, pre_act=0):
+    """[ab.pw(aqtizer(act(x2d))) for ab in bindings] for scalar-quantizer Linear layers sharing the input x2d [M <= 16][K]
+    in ONE launch per 24 layers (dgq_linear_smallm_batch): the time-embedding projections of a UNet forward."""
+    assert x2d.dim() == 2 and x2d.stride(1) == 1 and x2d.dtype in _lib.DTYPE_CODE
+    M, K = x2d.shape
+    outs = []
+    for i0 in range(0, len(bindings), SMALLM_MAX_PROBLEMS):
+        chunk = bindings[i0:i0 + SMALLM_MAX_PROBLEMS]
+        probs = (_lib.SmallMProblem * len(chunk))()
+        keep = []
+        for j, ab in enumerate(chunk):
+            pw = ab.pw
+            assert ab.mode != "perK" and ab.L == 1 and pw.K == K and pw.taps == 1
+            y = torch.empty((M, pw.N), dtype=x2d.dtype, device=x2d.device)
+            q = probs[j]
+            q.wpacked, q.alpha, q.zw = ab.wpacked.data_ptr(), pw.alpha.data_ptr(), pw.zw.data_ptr()
+            q.gamma, q.vn = ab.gamma.data_ptr(), ab.vn.data_ptr()
+            q.mdelta, q.mzp = ab.mdelta.data_ptr(), ab.mzp.data_ptr()
+            q.y, q.ldy, q.N, q.Kp, q.w_bits, q.a_bits = y.data_ptr(), y.stride(0), pw.N, ab.Kp, pw.bits, ab.abits
+            keep.append(y)
+        _lib_call("dgq_linear_smallm_batch", _lib.ptr(x2d), _lib.DTYPE_CODE[x2d.dtype], M, K, x2d.stride(0), pre_act,
+                  len(chunk), _c.cast(probs, _c.c_void_p), _lib.DTYPE_CODE[x2d.dtype], _lib.stream())
+        outs += keep
+    return outs
+
+
 def minmax_rows_cols(x2d: torch.Tensor, rows=True, cols=True):
     """Row-wise and column-wise (min, max) of a contiguous [R][C] view — the statistics of DGQ's calibration producer
     (dgq_minmax_rows_cols).  Returns (rowmin, rowmax, colmin, colmax), fp32, None for a pair that was not requested."""

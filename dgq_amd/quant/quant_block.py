@@ -37,6 +37,8 @@ _F_GEGLU = _os.environ.get("DGQ_FUSE_GEGLU", "1") == "1"
 _F_SILU = _os.environ.get("DGQ_FUSE_SILU", "1") == "1"
 # norm1/2/3 of the transformer block folded into the quantise-on-load pass of the layers that consume them
 _F_LN = _os.environ.get("DGQ_FUSE_LN", "1") == "1"
+# the time_emb_proj(SiLU(temb)) projections of ALL resnet blocks in one launch (they depend on temb only): 46 launches -> 1
+_F_TEMB_BATCH = _os.environ.get("DGQ_TEMB_BATCH", "1") == "1"
 # aqtizer_{q,k,v} applied inside the attention pre-pass (K/V while they are split into bf16 planes, Q into a scratch
 # copy by extra blocks of the same launch): three launches per attention saved, nothing added to a GEMM grid
 _F_ATTN_FQ = _os.environ.get("DGQ_FUSE_ATTN_FQ", "1") == "1"
@@ -57,6 +59,31 @@ class BaseQuantBlock(nn.Module):
                 m.set_quant_state(use_wq=use_wq, use_aq=use_aq)
             if hasattr(m, "aqtizer_q") and hasattr(m, "to_q"):
                 m.use_aq = use_aq
+
+
+class TembGroup:
+    """The time_emb_proj layers of one QuantModel.  The first resnet block that asks for its projection of a given
+    ``temb`` tensor triggers ONE batched launch (ops.linear_smallm_batch) for every layer of the group; the others pick
+    their result up.  Keyed by tensor identity, so it holds within one forward (and one graph capture) only."""
+
+    def __init__(self, layers):
+        self.layers = list(layers)
+        self._src = None
+        self._out = {}
+
+    def eligible(self, temb):
+        return (temb.is_cuda and temb.dim() == 2 and temb.shape[0] <= ops.SMALLM_MAX_M and temb.shape[1] <= ops.SMALLM_MAX_K
+                and temb.dtype in ops.FLOAT_DTYPES and temb.stride(1) == 1
+                and all(l.on_integer_path(temb) and not l.aqtizer.calibrating() for l in self.layers))
+
+    def get(self, layer, temb):
+        if self._src is not temb:
+            binds = [l._binding() for l in self.layers]
+            if any(b.mode == "perK" or b.L != 1 for b in binds):
+                return None                                   # a grouped table on a 2-D input does not occur; be safe
+            self._out = dict(zip((id(l) for l in self.layers), ops.linear_smallm_batch(temb, binds, pre_act=1)))
+            self._src = temb
+        return self._out[id(layer)]
 
 
 class QuantResnetBlock2D(BaseQuantBlock):
@@ -87,7 +114,16 @@ class QuantResnetBlock2D(BaseQuantBlock):
         return y if residual is None else residual + y
 
     def forward(self, input_tensor, temb):
-        if FUSION and _F_SILU and isinstance(self.time_emb_proj, QuantLayer):
+        grp = getattr(self.time_emb_proj, "_temb_group", None)
+        te = None
+        if FUSION and _F_SILU and _F_TEMB_BATCH and grp is not None and grp.eligible(temb):
+            te = grp.get(self.time_emb_proj, temb)                            # all resnet blocks' projections: one launch
+            if te is not None:
+                from .quant_layer import _tap
+                te = _tap(self.time_emb_proj, te, x=temb, prologue=True)
+        if te is not None:
+            pass
+        elif FUSION and _F_SILU and isinstance(self.time_emb_proj, QuantLayer):
             te = self.time_emb_proj.forward_fused(temb, pre_act=1)            # SiLU(temb) folded into the load
         else:
             te = self.time_emb_proj(F.silu(temb))

@@ -44,6 +44,13 @@ class QuantModel(nn.Module):
         self.quant_module(self.model, wq_params, aq_params, aq_mode=kwargs.get("aq_mode", [QMODE.NORMAL.value]),
                           prev_name=None)
         self.quant_block(self.model, wq_params, aq_params, softmax_aq_params)
+        from .quant_block import TembGroup
+        temb_layers = [m.time_emb_proj for m in self.model.modules()
+                       if isinstance(m, QuantResnetBlock2D) and isinstance(m.time_emb_proj, QuantLayer)]
+        if temb_layers:
+            grp = TembGroup(temb_layers)
+            for l in temb_layers:
+                l.__dict__["_temb_group"] = grp          # plain attribute: not a submodule, not in the state dict
         self.time_aware = None          # set by load_cali_model(time_aware_aqtizer=True)
         self._graphs = None
         self._graph_pool = None

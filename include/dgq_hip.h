@@ -194,6 +194,27 @@ int dgq_attention(const void* q, const void* k, const void* v, void* o, int dtyp
 int dgq_attention_fuses_fakequant(int D, int mode);
 size_t dgq_attention_workspace_bytes(int B, int H, int T, int S, int D);
 
+/* ---- batched small-M Linear ------------------------------------------------------------------------
+ * dgq_linear_smallm_batch: y_l = W_l·aqtizer_l(act(x)) + b_l for up to 24 quantized Linear layers that share one input
+ * x [M][K] of M <= 16 rows — the time_emb_proj(SiLU(temb)) projections of every resnet block of a forward
+ * (quant_block.py:98-119), which do not depend on the latents — in ONE launch: quantise-on-load (scalar activation
+ * quantizer of each layer, SiLU prologue when pre_act == 1) + integer dot products + the per_m epilogue of dgq_gemm_wxa8
+ * (same arithmetic, term for term).  Weights in the natural K order (dgq_pack_w4 / dgq_pack_w8 with kperm == NULL... Kp
+ * padded to DGQ_KTILE); K <= 2048.  probs: host array, copied into the kernel arguments. */
+typedef struct dgq_smallm_problem {
+    const void* wpacked;
+    const float* alpha;
+    const float* zw;
+    const float* gamma;
+    const float* vn;
+    const float* mdelta;
+    const float* mzp;
+    void* y;
+    int ldy, N, Kp, w_bits, a_bits;
+} dgq_smallm_problem_t;
+int dgq_linear_smallm_batch(const void* x, int x_dtype, int M, int K, int64_t ldx, int pre_act, int n_problems,
+                            const dgq_smallm_problem_t* probs, int y_dtype, void* stream);
+
 /* ---- calibration producer --------------------------------------------------------
  * dgq_minmax_rows_cols: the statistics UniformAffineQuantizer.record_min_max_ema collects for DGQ's grouping
  * (quant/quant_layer.py:301-313): for x viewed as [rows][C] (row stride ldx elements, any fp dtype) the row-wise

@@ -524,3 +524,29 @@ def test_attention_wide_blocks(D, mode, skip, dev):
         row_err = (o - ref).view(B * T, -1).norm(dim=1) / ref.view(B * T, -1).norm(dim=1)
         assert row_err.median().item() < 1e-5
         assert (row_err > 1e-4).float().mean().item() < 0.05      # a row holds 16 heads x 333 probabilities: more tie flips per row
+
+
+# ------------------------------------------------------------------------------------------ batched small-M linear
+@pytest.mark.parametrize("M,K,wbits,abits,dtype", [(2, 1280, 4, 8, torch.float32), (8, 1280, 4, 6, torch.float32),
+                                                     (16, 128, 8, 8, torch.float32), (2, 320, 4, 8, torch.float16)])
+def test_linear_smallm_batch_equals_the_gemm_path(M, K, wbits, abits, dtype, dev):
+    """dgq_linear_smallm_batch (every time_emb_proj of a forward in one launch) against the regular two-kernel path
+    (dgq_quant_act with the SiLU prologue + dgq_gemm_wxa8) layer by layer: the same integer sums and the same epilogue
+    expression, so the outputs are bit-identical."""
+    from dgq_amd import ops
+    from dgq_amd.plan import plan_act
+    g = torch.Generator().manual_seed(M + K)
+    x = (torch.randn(M, K, generator=g) * 2).to(dev, dtype)
+    binds = []
+    for N in (320, 640, 1280, 77, 1280):
+        w = torch.randn(N, K, generator=g) * 0.05
+        wd, wz = orc.minmax_channel(w, wbits)
+        pw = ops.PackedWeight(w.to(dev), wd.to(dev), wz.to(dev), None, torch.randn(N, generator=g).to(dev), wbits, K, 1)
+        d = torch.tensor(0.01 + 0.03 * float(torch.rand(1, generator=g)))
+        z = torch.tensor(float(torch.randint(int(2 ** abits * 0.3), int(2 ** abits * 0.7), (1,), generator=g)))
+        binds.append(ops.ActBinding(plan_act(d, z, "linear", K, 1, abits), pw, abits))
+    outs = ops.linear_smallm_batch(x, binds, pre_act=1)
+    for ab, y in zip(binds, outs):
+        ref = ops.quant_linear(x, ab, pre_act=1)
+        assert y.shape == ref.shape and y.dtype == dtype
+        assert torch.equal(y, ref), (ab.pw.N, (y.float() - ref.float()).abs().max().item())
