@@ -33,6 +33,9 @@ SIGNATURES = {
     "dgq_attention_workspace_bytes": [_i, _i, _i, _i, _i],
     "dgq_minmax_rows_cols": [_vp, _i, _i, _i, _i64, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "dgq_linear_smallm_batch": [_vp, _i, _i, _i, _i64, _i, _i, _vp, _i, _vp],
+    "dgq_quant_act_batch": [_i, _vp, _vp],
+    "dgq_quant_act_variant": [_vp],
+    "dgq_gemm_wxa8_batch": [_i, _vp, _vp],
 }
 
 
@@ -47,6 +50,22 @@ class SmallMProblem(ctypes.Structure):
     """dgq_smallm_problem_t of include/dgq_hip.h"""
     _fields_ = [("wpacked", _vp), ("alpha", _vp), ("zw", _vp), ("gamma", _vp), ("vn", _vp), ("mdelta", _vp), ("mzp", _vp),
                 ("y", _vp), ("ldy", _i), ("N", _i), ("Kp", _i), ("w_bits", _i), ("a_bits", _i)]
+
+
+class QuantActArgs(ctypes.Structure):
+    """dgq_quant_act_args_t of include/dgq_hip.h"""
+    _fields_ = [("x", _vp), ("x_dtype", _i), ("B", _i), ("H", _i), ("W", _i), ("C", _i), ("kh", _i), ("kw", _i), ("stride", _i),
+                ("pad", _i), ("ksrc", _vp), ("koff", _vp), ("klds", _vp), ("Kp", _i), ("per_m", _i), ("delta", _vp), ("zp", _vp),
+                ("L", _i), ("bits", _i), ("codes", _vp), ("rowsum", _vp), ("ksplits", _i), ("pre_scale", _vp), ("pre_shift", _vp),
+                ("pre_act", _i), ("ln_gamma", _vp), ("ln_beta", _vp), ("ln_eps", _f)]
+
+
+class GemmArgs(ctypes.Structure):
+    """dgq_gemm_args_t of include/dgq_hip.h"""
+    _fields_ = [("codes", _vp), ("rowsum", _vp), ("rowsum_parts", _i), ("M", _i), ("Kp", _i), ("wpacked", _vp), ("w_bits", _i),
+                ("N", _i), ("per_m", _i), ("cdelta", _vp), ("cflush", _vp), ("mdelta", _vp), ("mzp", _vp), ("L", _i),
+                ("offset", _f), ("alpha", _vp), ("zw", _vp), ("gamma", _vp), ("vn", _vp), ("y", _vp), ("y_dtype", _i), ("ldy", _i),
+                ("extra", _vp)]
 
 
 class AttnFq(ctypes.Structure):

@@ -55,6 +55,14 @@ struct GemmParams {
     dgq_gemm_extra_t ex;  // optional epilogue extras (residual add, fused attention-side quantizer)
 };
 
+// Up to DGQ_GEMM_BATCH problems of one kernel instance (tile shape, weight bits, scale mode, output dtype; no K split) in
+// ONE launch: blockIdx.z = problem.  Grid x / y cover the widest problem; blocks outside a problem's tile grid exit.
+#define DGQ_GEMM_BATCH 8
+struct GemmBatch {
+    GemmParams p[DGQ_GEMM_BATCH];
+    int n;                 // 1: p[0], blockIdx.z = K split;  > 1: blockIdx.z = problem, no split
+};
+
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
@@ -117,7 +125,10 @@ constexpr int gemm_occupancy(int wbits, int bm, int bn) {
 }
 
 template <int WBITS, bool PER_M, typename TOut, int BM, int BN>
-__global__ __launch_bounds__(256, gemm_occupancy(WBITS, BM, BN)) void gemm_wxa8_kernel(GemmParams p) {
+__global__ __launch_bounds__(256, gemm_occupancy(WBITS, BM, BN)) void gemm_wxa8_kernel(GemmBatch bt) {
+    const GemmParams& p = bt.p[bt.n > 1 ? blockIdx.z : 0];
+    const int zsplit = bt.n > 1 ? 0 : blockIdx.z;
+    if ((int)blockIdx.x * BN >= p.N || (int)blockIdx.y * BM >= p.M) return;   // batch: a narrower problem than the grid (whole block)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr int STAGES = gemm_stages(WBITS, BM, BN);
     constexpr int WM = BM / 2, WN = BN / 2;                // per-wave output tile
@@ -139,7 +150,7 @@ __global__ __launch_bounds__(256, gemm_occupancy(WBITS, BM, BN)) void gemm_wxa8_
     const int n0 = blockIdx.x * BN;
     const int m0 = blockIdx.y * BM;
     const int nk_total = p.Kp / BK;
-    const int kt_begin = blockIdx.z * p.tiles_per_split;
+    const int kt_begin = zsplit * p.tiles_per_split;
     const int kt_end = min(nk_total, kt_begin + p.tiles_per_split);
     const int nk = kt_end - kt_begin;
 
@@ -357,7 +368,7 @@ __global__ __launch_bounds__(256, gemm_occupancy(WBITS, BM, BN)) void gemm_wxa8_
     const int nb = n0 + wave_n * WN + c4;
     const bool vec_ok = (nb + 3 < p.N);
     if (p.splits > 1) {
-        float* slab = p.slab + (int64_t)blockIdx.z * p.M * p.N;
+        float* slab = p.slab + (int64_t)zsplit * p.M * p.N;
         const bool al16 = ((p.N & 3) == 0);
 #pragma unroll 4
         for (int rr = 0; rr < PASSES; ++rr) {
@@ -479,7 +490,8 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(GemmParams p) {
 }
 
 template <int WBITS, bool PER_M, typename TOut, int BM, int BN>
-static void launch_tile(const GemmParams& p, hipStream_t st) {
+static void launch_tile(const GemmBatch& bt, hipStream_t st) {
+    const GemmParams& p = bt.p[0];
     constexpr int lds_stages = gemm_stages(WBITS, BM, BN) * gemm_stage_bytes(WBITS, BM, BN);
     constexpr int lds_vec = (3 * BM + 4 * BN) * 4;
     constexpr int lds_max = lds_stages + lds_vec + 8192;        // + epilogue vectors + per-chunk scales (<= 2048 chunks)
@@ -493,27 +505,34 @@ static void launch_tile(const GemmParams& p, hipStream_t st) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
         if (dev >= 0 && dev < 64) attr_set[dev].store(true, std::memory_order_release);
     }
-    const int lds = lds_stages + lds_vec + (PER_M ? 0 : ((2 * p.tiles_per_split * 4 + 15) & ~15));
-    dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, p.splits), block(256);
-    hipLaunchKernelGGL((gemm_wxa8_kernel<WBITS, PER_M, TOut, BM, BN>), grid, block, lds, st, p);
+    int maxN = 0, maxM = 0, max_tps = 0;
+    for (int i = 0; i < bt.n; ++i) {
+        maxN = bt.p[i].N > maxN ? bt.p[i].N : maxN;
+        maxM = bt.p[i].M > maxM ? bt.p[i].M : maxM;
+        max_tps = bt.p[i].tiles_per_split > max_tps ? bt.p[i].tiles_per_split : max_tps;
+    }
+    const int lds = lds_stages + lds_vec + (PER_M ? 0 : ((2 * max_tps * 4 + 15) & ~15));
+    dim3 grid((maxN + BN - 1) / BN, (maxM + BM - 1) / BM, bt.n > 1 ? bt.n : p.splits), block(256);
+    hipLaunchKernelGGL((gemm_wxa8_kernel<WBITS, PER_M, TOut, BM, BN>), grid, block, lds, st, bt);
 }
 
 // Tile shapes the host may pick (BM, BN): W4 {128x128, 128x64, 64x128, 64x64, 32x128, 32x64}; W8 (a secondary
 // configuration) carries {128x128, 64x64, 32x64}.
 
 template <int WBITS, bool PER_M, typename TOut>
-static int launch_one(const GemmParams& p, int bm, int bn, hipStream_t st) {
+static int launch_one(const GemmBatch& bt, int bm, int bn, hipStream_t st) {
+    const GemmParams& p = bt.p[0];
     const int key = bm * 1000 + bn;
     switch (key) {
-        case 128128: launch_tile<WBITS, PER_M, TOut, 128, 128>(p, st); break;
-        case 64064: launch_tile<WBITS, PER_M, TOut, 64, 64>(p, st); break;
-        case 32064: launch_tile<WBITS, PER_M, TOut, 32, 64>(p, st); break;
+        case 128128: launch_tile<WBITS, PER_M, TOut, 128, 128>(bt, st); break;
+        case 64064: launch_tile<WBITS, PER_M, TOut, 64, 64>(bt, st); break;
+        case 32064: launch_tile<WBITS, PER_M, TOut, 32, 64>(bt, st); break;
         default:
             if constexpr (WBITS == 4) {
                 switch (key) {
-                    case 128064: launch_tile<WBITS, PER_M, TOut, 128, 64>(p, st); break;
-                    case 64128: launch_tile<WBITS, PER_M, TOut, 64, 128>(p, st); break;
-                    case 32128: launch_tile<WBITS, PER_M, TOut, 32, 128>(p, st); break;
+                    case 128064: launch_tile<WBITS, PER_M, TOut, 128, 64>(bt, st); break;
+                    case 64128: launch_tile<WBITS, PER_M, TOut, 64, 128>(bt, st); break;
+                    case 32128: launch_tile<WBITS, PER_M, TOut, 32, 128>(bt, st); break;
                     default: dgq_set_error("dgq_gemm_wxa8: no %dx%d tile", bm, bn); return DGQ_EINVAL;
                 }
             } else {
@@ -521,7 +540,7 @@ static int launch_one(const GemmParams& p, int bm, int bn, hipStream_t st) {
                 return DGQ_EINVAL;
             }
     }
-    if (p.splits > 1) {
+    if (bt.n == 1 && p.splits > 1) {
         int64_t total = (int64_t)p.M * ((p.N + 3) / 4);
         int g = (int)((total + 255) / 256);
         if (g > 4096) g = 4096;
@@ -531,7 +550,7 @@ static int launch_one(const GemmParams& p, int bm, int bn, hipStream_t st) {
 }
 
 template <int WBITS, bool PER_M>
-static int launch_gemm(const GemmParams& p, int bm, int bn, int y_dtype, hipStream_t st) {
+static int launch_gemm(const GemmBatch& p, int bm, int bn, int y_dtype, hipStream_t st) {
     int rc;
     switch (y_dtype) {
         case DGQ_F32: rc = launch_one<WBITS, PER_M, float>(p, bm, bn, st); break;
@@ -603,6 +622,64 @@ extern "C" size_t dgq_gemm_workspace_bytes(int M, int N, int Kp) {
     return s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
 }
 
+static int fill_gemm(const dgq_gemm_args_t& a, GemmParams& p) {
+    DGQ_CHECK_ARG(a.codes && a.rowsum && a.wpacked && a.alpha && a.zw && a.gamma && a.y, "dgq_gemm_wxa8: null pointer");
+    DGQ_CHECK_ARG(a.M > 0 && a.N > 0 && a.Kp > 0 && a.Kp % DGQ_KTILE == 0, "dgq_gemm_wxa8: bad shape M=%d N=%d Kp=%d", a.M, a.N, a.Kp);
+    DGQ_CHECK_ARG(a.w_bits == 4 || a.w_bits == 8, "dgq_gemm_wxa8: w_bits=%d unsupported", a.w_bits);
+    DGQ_CHECK_ARG(a.rowsum_parts >= 1 && a.rowsum_parts <= 64, "dgq_gemm_wxa8: rowsum_parts=%d", a.rowsum_parts);
+    DGQ_CHECK_ARG(a.ldy >= a.N, "dgq_gemm_wxa8: ldy < N");
+    DGQ_CHECK_ARG(a.Kp / DGQ_KCHUNK <= 2048, "dgq_gemm_wxa8: Kp=%d too large (max %d)", a.Kp, 2048 * DGQ_KCHUNK);
+    DGQ_CHECK_ARG((reinterpret_cast<uintptr_t>(a.codes) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.wpacked) & 15) == 0,
+                  "dgq_gemm_wxa8: codes/wpacked must be 16-byte aligned");
+    if (a.per_m) {
+        DGQ_CHECK_ARG(a.mdelta && a.mzp && a.vn && a.L >= 1, "dgq_gemm_wxa8: per_m needs mdelta/mzp/vn/L");
+    } else {
+        DGQ_CHECK_ARG(a.cdelta && a.cflush, "dgq_gemm_wxa8: per-K mode needs cdelta/cflush");
+    }
+    p.codes = a.codes; p.rowsum = a.rowsum; p.rowsum_parts = a.rowsum_parts; p.M = a.M; p.Kp = a.Kp; p.N = a.N;
+    p.wpacked = reinterpret_cast<const uint8_t*>(a.wpacked);
+    p.cdelta = a.cdelta; p.cflush = a.cflush; p.mdelta = a.mdelta; p.mzp = a.mzp; p.L = a.per_m ? a.L : 1; p.offset = a.offset;
+    p.alpha = a.alpha; p.zw = a.zw; p.gamma = a.gamma; p.vn = a.vn; p.y = a.y; p.ldy = a.ldy;
+    if (a.extra) {
+        p.ex = *a.extra;
+        DGQ_CHECK_ARG(p.ex.fq_mode >= 0 && p.ex.fq_mode <= 3, "dgq_gemm_wxa8: bad fq_mode");
+        DGQ_CHECK_ARG(p.ex.fq_mode == 0 || (p.ex.fq_delta && p.ex.fq_zp && p.ex.fq_T > 0 && p.ex.fq_D > 0), "dgq_gemm_wxa8: fused quantizer needs tables");
+        DGQ_CHECK_ARG(!p.ex.residual || (p.ex.ldr >= a.N && p.ex.res_div >= 1 && p.ex.res_dtype >= DGQ_F32 && p.ex.res_dtype <= DGQ_BF16),
+                      "dgq_gemm_wxa8: bad residual descriptor (ldr < N, res_div < 1 or unknown dtype)");
+    } else {
+        p.ex.residual = nullptr; p.ex.ldr = 0; p.ex.res_div = 1; p.ex.res_dtype = DGQ_F32; p.ex.fq_mode = 0; p.ex.fq_delta = nullptr; p.ex.fq_zp = nullptr;
+        p.ex.fq_T = 1; p.ex.fq_D = 1; p.ex.fq_skip = 0; p.ex.fq_qmax = 255.0f;
+    }
+    p.splits = 1; p.slab = nullptr;
+    p.tiles_per_split = a.Kp / BK;
+    return DGQ_OK;
+}
+
+template <typename B>
+static int dispatch_gemm(const B& bt, int w_bits, bool per_m, int bm, int bn, int y_dtype, hipStream_t st) {
+    if (w_bits == 4) return per_m ? launch_gemm<4, true>(bt, bm, bn, y_dtype, st) : launch_gemm<4, false>(bt, bm, bn, y_dtype, st);
+    return per_m ? launch_gemm<8, true>(bt, bm, bn, y_dtype, st) : launch_gemm<8, false>(bt, bm, bn, y_dtype, st);
+}
+
+// 2..8 problems in one launch: same weight bits, scale mode, output dtype and launch plan (tile shape) — the plan of the
+// FIRST problem is used and must not split K (batches exist for small, launch-bound layers); DGQ_EINVAL otherwise.
+extern "C" int dgq_gemm_wxa8_batch(int n, const dgq_gemm_args_t* args, void* stream) {
+    DGQ_CHECK_ARG(args && n >= 1 && n <= DGQ_GEMM_BATCH, "dgq_gemm_wxa8_batch: n=%d (1..%d)", n, DGQ_GEMM_BATCH);
+    GemmBatch bt;
+    bt.n = n;
+    for (int i = 0; i < n; ++i) {
+        const int rc = fill_gemm(args[i], bt.p[i]);
+        if (rc != DGQ_OK) return rc;
+        DGQ_CHECK_ARG(args[i].w_bits == args[0].w_bits && (args[i].per_m != 0) == (args[0].per_m != 0) && args[i].y_dtype == args[0].y_dtype,
+                      "dgq_gemm_wxa8_batch: problem %d differs from problem 0 in weight bits / scale mode / output dtype", i);
+    }
+    const dgq_gemm_args_t& a0 = args[0];
+    GemmPlan pl = plan_gemm(a0.M, a0.N, a0.Kp, a0.w_bits, 0, a0.per_m != 0);
+    forced_plan(pl);
+    pl.splits = 1;
+    return dispatch_gemm(bt, a0.w_bits, a0.per_m != 0, pl.bm, pl.bn, a0.y_dtype, (hipStream_t)stream);
+}
+
 extern "C" int dgq_gemm_wxa8(const int8_t* codes, const float* rowsum, int rowsum_parts, int M, int Kp,
                              const void* wpacked, int w_bits, int N,
                              int per_m, const float* cdelta, const uint8_t* cflush,
@@ -610,35 +687,16 @@ extern "C" int dgq_gemm_wxa8(const int8_t* codes, const float* rowsum, int rowsu
                              const float* alpha, const float* zw, const float* gamma, const float* vn,
                              void* y, int y_dtype, int ldy, void* workspace, size_t workspace_bytes,
                              const dgq_gemm_extra_t* extra, void* stream) {
-    DGQ_CHECK_ARG(codes && rowsum && wpacked && alpha && zw && gamma && y, "dgq_gemm_wxa8: null pointer");
-    DGQ_CHECK_ARG(M > 0 && N > 0 && Kp > 0 && Kp % DGQ_KTILE == 0, "dgq_gemm_wxa8: bad shape M=%d N=%d Kp=%d", M, N, Kp);
-    DGQ_CHECK_ARG(w_bits == 4 || w_bits == 8, "dgq_gemm_wxa8: w_bits=%d unsupported", w_bits);
-    DGQ_CHECK_ARG(rowsum_parts >= 1 && rowsum_parts <= 64, "dgq_gemm_wxa8: rowsum_parts=%d", rowsum_parts);
-    DGQ_CHECK_ARG(ldy >= N, "dgq_gemm_wxa8: ldy < N");
-    DGQ_CHECK_ARG(Kp / DGQ_KCHUNK <= 2048, "dgq_gemm_wxa8: Kp=%d too large (max %d)", Kp, 2048 * DGQ_KCHUNK);
-    DGQ_CHECK_ARG((reinterpret_cast<uintptr_t>(codes) & 15) == 0 && (reinterpret_cast<uintptr_t>(wpacked) & 15) == 0,
-                  "dgq_gemm_wxa8: codes/wpacked must be 16-byte aligned");
     DGQ_CHECK_ARG(!workspace || (reinterpret_cast<uintptr_t>(workspace) & 15) == 0, "dgq_gemm_wxa8: workspace alignment");
-    if (per_m) {
-        DGQ_CHECK_ARG(mdelta && mzp && vn && L >= 1, "dgq_gemm_wxa8: per_m needs mdelta/mzp/vn/L");
-    } else {
-        DGQ_CHECK_ARG(cdelta && cflush, "dgq_gemm_wxa8: per-K mode needs cdelta/cflush");
-    }
-    GemmParams p;
-    p.codes = codes; p.rowsum = rowsum; p.rowsum_parts = rowsum_parts; p.M = M; p.Kp = Kp; p.N = N;
-    p.wpacked = reinterpret_cast<const uint8_t*>(wpacked);
-    p.cdelta = cdelta; p.cflush = cflush; p.mdelta = mdelta; p.mzp = mzp; p.L = per_m ? L : 1; p.offset = offset;
-    p.alpha = alpha; p.zw = zw; p.gamma = gamma; p.vn = vn; p.y = y; p.ldy = ldy;
-    if (extra) {
-        p.ex = *extra;
-        DGQ_CHECK_ARG(p.ex.fq_mode >= 0 && p.ex.fq_mode <= 3, "dgq_gemm_wxa8: bad fq_mode");
-        DGQ_CHECK_ARG(p.ex.fq_mode == 0 || (p.ex.fq_delta && p.ex.fq_zp && p.ex.fq_T > 0 && p.ex.fq_D > 0), "dgq_gemm_wxa8: fused quantizer needs tables");
-        DGQ_CHECK_ARG(!p.ex.residual || (p.ex.ldr >= N && p.ex.res_div >= 1 && p.ex.res_dtype >= DGQ_F32 && p.ex.res_dtype <= DGQ_BF16),
-                      "dgq_gemm_wxa8: bad residual descriptor (ldr < N, res_div < 1 or unknown dtype)");
-    } else {
-        p.ex.residual = nullptr; p.ex.ldr = 0; p.ex.res_div = 1; p.ex.res_dtype = DGQ_F32; p.ex.fq_mode = 0; p.ex.fq_delta = nullptr; p.ex.fq_zp = nullptr;
-        p.ex.fq_T = 1; p.ex.fq_D = 1; p.ex.fq_skip = 0; p.ex.fq_qmax = 255.0f;
-    }
+    dgq_gemm_args_t a;
+    a.codes = codes; a.rowsum = rowsum; a.rowsum_parts = rowsum_parts; a.M = M; a.Kp = Kp; a.wpacked = wpacked; a.w_bits = w_bits; a.N = N;
+    a.per_m = per_m; a.cdelta = cdelta; a.cflush = cflush; a.mdelta = mdelta; a.mzp = mzp; a.L = L; a.offset = offset;
+    a.alpha = alpha; a.zw = zw; a.gamma = gamma; a.vn = vn; a.y = y; a.y_dtype = y_dtype; a.ldy = ldy; a.extra = extra;
+    GemmBatch bt;
+    bt.n = 1;
+    GemmParams& p = bt.p[0];
+    const int rc = fill_gemm(a, p);
+    if (rc != DGQ_OK) return rc;
     GemmPlan pl = plan_gemm(M, N, Kp, w_bits, workspace ? workspace_bytes : 0, per_m != 0);
     if (forced_plan(pl)) {
         DGQ_CHECK_ARG(pl.splits == 1 || (workspace && (size_t)pl.splits * M * N * 4 <= workspace_bytes),
@@ -650,7 +708,5 @@ extern "C" int dgq_gemm_wxa8(const int8_t* codes, const float* rowsum, int rowsu
     p.tiles_per_split = (nk + p.splits - 1) / p.splits;
     p.splits = (nk + p.tiles_per_split - 1) / p.tiles_per_split;      // no empty split
     if (p.splits == 1) p.slab = nullptr;
-    hipStream_t st = (hipStream_t)stream;
-    if (w_bits == 4) return per_m ? launch_gemm<4, true>(p, pl.bm, pl.bn, y_dtype, st) : launch_gemm<4, false>(p, pl.bm, pl.bn, y_dtype, st);
-    return per_m ? launch_gemm<8, true>(p, pl.bm, pl.bn, y_dtype, st) : launch_gemm<8, false>(p, pl.bm, pl.bn, y_dtype, st);
+    return dispatch_gemm(bt, w_bits, per_m != 0, pl.bm, pl.bn, y_dtype, (hipStream_t)stream);
 }

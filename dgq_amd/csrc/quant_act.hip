@@ -28,6 +28,14 @@ struct QuantActParams {
     float ln_eps;
 };
 
+// Up to DGQ_QA_BATCH problems of ONE kernel variant and the same row count in one launch (blockIdx.z = problem): the
+// q / k / v projections of an attention quantise the same input three ways, the to_k / to_v of every cross-attention
+// quantise the same text context — one launch each instead of one per layer.
+#define DGQ_QA_BATCH 8
+struct QuantActBatch {
+    QuantActParams p[DGQ_QA_BATCH];
+};
+
 
 
 template <typename TIn>
@@ -102,7 +110,9 @@ __device__ __forceinline__ uint32_t dgq_pack4(const float (&biased)[4], float& f
 // table read (int4), the gathered loads (lane stride 16 B within a (group, tap) run) and the code store (256 B per
 // wave instruction) are all coalesced.  The 4 kp of a lane share one 64-wide chunk, hence one (δ, z).
 template <typename TIn, bool HAS_TABLE, bool PER_M>
-__global__ __launch_bounds__(256) void quant_act_kernel(QuantActParams p) {
+__global__ __launch_bounds__(256) void quant_act_kernel(QuantActBatch bt) {
+    const QuantActParams& p = bt.p[blockIdx.z];
+    if ((int)blockIdx.y * p.kp_per_split >= p.Kp) return;     // this problem has fewer K splits than the widest of the batch
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= p.M) return;                                 // whole wave leaves; no barriers below
@@ -286,7 +296,9 @@ __global__ __launch_bounds__(256) void quant_act_kernel(QuantActParams p) {
 // GroupNorm / SiLU applied and zeros for taps outside the image — into its own LDS strip with coalesced 16-byte loads
 // and gathers from LDS.  No block-level sync: a wave only reads what it wrote.
 template <typename TIn, bool PER_M>
-__global__ __launch_bounds__(256) void quant_act_staged_kernel(QuantActParams p) {
+__global__ __launch_bounds__(256) void quant_act_staged_kernel(QuantActBatch bt) {
+    const QuantActParams& p = bt.p[blockIdx.z];
+    if ((int)blockIdx.y * p.kp_per_split >= p.Kp) return;
     extern __shared__ __attribute__((aligned(16))) float strips[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int row = blockIdx.x * (blockDim.x >> 6) + wv;
@@ -392,8 +404,8 @@ __global__ __launch_bounds__(256) void quant_act_staged_kernel(QuantActParams p)
     if (lane == 0) p.rowsum[(int64_t)blockIdx.y * p.M + row] = partial;
 }
 
-template <typename TIn>
-static void launch_quant_act(const QuantActParams& p, bool table, bool per_m, hipStream_t st) {
+// kernel variant of one problem: 0 = LDS-staged strips, 1 = table gather from global, 2 = natural order
+static int quant_act_variant(const QuantActParams& p, bool table) {
     const int ks = (p.Kp + p.kp_per_split - 1) / p.kp_per_split;
     const size_t strip_bytes = (size_t)p.kh * p.kw * p.C * sizeof(float);
     // measured (SD1.4 layers): staging wins at C = 320 (4 rows per block, 3 blocks per CU: 88 -> 64 us) and loses once the
@@ -403,20 +415,35 @@ static void launch_quant_act(const QuantActParams& p, bool table, bool per_m, hi
     const int taps_ = p.kh * p.kw;
     const bool stage_conv = taps_ > 1 && p.pre_act != 2 && !p.ln_gamma && ks == 1;
     const bool stage_lin = taps_ == 1 && (!p.ln_gamma || p.C <= DGQ_LN_MAX_C);
-    if (table && p.klds && p.C % 4 == 0 && strip_bytes <= 16 * 1024 && (stage_conv || stage_lin)) {
+    if (table && p.klds && p.C % 4 == 0 && strip_bytes <= 16 * 1024 && (stage_conv || stage_lin)) return 0;
+    return table ? 1 : 2;
+}
+
+// all n problems: same variant, same per_m, same M (checked by the caller)
+template <typename TIn>
+static void launch_quant_act(const QuantActBatch& bt, int n, int variant, bool per_m, hipStream_t st) {
+    const QuantActParams& p0 = bt.p[0];
+    int ks = 1;
+    size_t strip_bytes = 0;
+    for (int i = 0; i < n; ++i) {
+        const QuantActParams& p = bt.p[i];
+        ks = std::max(ks, (p.Kp + p.kp_per_split - 1) / p.kp_per_split);
+        strip_bytes = std::max(strip_bytes, (size_t)p.kh * p.kw * p.C * sizeof(float));
+    }
+    if (variant == 0) {
         const int nw = 4;                                                       // waves (= rows) per block, <= 64 KB of LDS
-        dim3 sgrid((p.M + nw - 1) / nw, ks), sblock(64 * nw);
-        if (per_m) hipLaunchKernelGGL((quant_act_staged_kernel<TIn, true>), sgrid, sblock, nw * strip_bytes, st, p);
-        else hipLaunchKernelGGL((quant_act_staged_kernel<TIn, false>), sgrid, sblock, nw * strip_bytes, st, p);
+        dim3 sgrid((p0.M + nw - 1) / nw, ks, n), sblock(64 * nw);
+        if (per_m) hipLaunchKernelGGL((quant_act_staged_kernel<TIn, true>), sgrid, sblock, nw * strip_bytes, st, bt);
+        else hipLaunchKernelGGL((quant_act_staged_kernel<TIn, false>), sgrid, sblock, nw * strip_bytes, st, bt);
         return;
     }
-    dim3 grid((p.M + 3) / 4, ks), block(256);
-    if (table) {
-        if (per_m) hipLaunchKernelGGL((quant_act_kernel<TIn, true, true>), grid, block, 0, st, p);
-        else hipLaunchKernelGGL((quant_act_kernel<TIn, true, false>), grid, block, 0, st, p);
+    dim3 grid((p0.M + 3) / 4, ks, n), block(256);
+    if (variant == 1) {
+        if (per_m) hipLaunchKernelGGL((quant_act_kernel<TIn, true, true>), grid, block, 0, st, bt);
+        else hipLaunchKernelGGL((quant_act_kernel<TIn, true, false>), grid, block, 0, st, bt);
     } else {
-        if (per_m) hipLaunchKernelGGL((quant_act_kernel<TIn, false, true>), grid, block, 0, st, p);
-        else hipLaunchKernelGGL((quant_act_kernel<TIn, false, false>), grid, block, 0, st, p);
+        if (per_m) hipLaunchKernelGGL((quant_act_kernel<TIn, false, true>), grid, block, 0, st, bt);
+        else hipLaunchKernelGGL((quant_act_kernel<TIn, false, false>), grid, block, 0, st, bt);
     }
 }
 
@@ -426,6 +453,71 @@ extern "C" int dgq_quant_act_parts(int Kp, int ksplits) {
     return (Kp + per - 1) / per;
 }
 
+static int fill_quant_act(const dgq_quant_act_args_t& a, QuantActParams& p) {
+    DGQ_CHECK_ARG(a.x && a.delta && a.zp && a.codes && a.rowsum, "dgq_quant_act: null pointer");
+    DGQ_CHECK_ARG(a.B > 0 && a.H > 0 && a.W > 0 && a.C > 0 && a.kh > 0 && a.kw > 0 && a.stride > 0 && a.pad >= 0,
+                  "dgq_quant_act: bad geometry");
+    DGQ_CHECK_ARG(a.kh <= 0x7F && a.kw <= 0xFF && a.C <= 0xFFFF, "dgq_quant_act: kernel/channel count out of range");
+    DGQ_CHECK_ARG(a.Kp > 0 && a.Kp % DGQ_KTILE == 0, "dgq_quant_act: Kp=%d must be a multiple of %d", a.Kp, DGQ_KTILE);
+    DGQ_CHECK_ARG(a.bits >= 2 && a.bits <= 8, "dgq_quant_act: bits=%d", a.bits);
+    DGQ_CHECK_ARG(!a.per_m || a.L >= 1, "dgq_quant_act: per_m needs L >= 1");
+    DGQ_CHECK_ARG(a.ksplits >= 1 && a.ksplits <= 64, "dgq_quant_act: ksplits=%d", a.ksplits);
+    DGQ_CHECK_ARG((a.pre_scale == nullptr) == (a.pre_shift == nullptr) && a.pre_act >= 0 && a.pre_act <= 2, "dgq_quant_act: bad prologue");
+    DGQ_CHECK_ARG(a.pre_act != 2 || (a.kh == 1 && a.kw == 1 && !a.pre_scale), "dgq_quant_act: GEGLU prologue is for Linear inputs");
+    DGQ_CHECK_ARG((a.ln_gamma == nullptr) == (a.ln_beta == nullptr), "dgq_quant_act: LayerNorm prologue needs gamma and beta");
+    DGQ_CHECK_ARG(!a.ln_gamma || (a.kh == 1 && a.kw == 1 && !a.pre_scale && a.pre_act == 0 && a.C % 4 == 0 && a.C <= DGQ_LN_MAX_C && a.ln_eps > 0.0f),
+                  "dgq_quant_act: LayerNorm prologue is for Linear inputs (1x1, C %% 4 == 0, C <= 2048, no other prologue)");
+    const int K = a.C * a.kh * a.kw;
+    if (!a.ksrc) {
+        DGQ_CHECK_ARG(a.C % 4 == 0, "dgq_quant_act: natural K order needs C %% 4 == 0 (C=%d)", a.C);
+        DGQ_CHECK_ARG(a.Kp >= K, "dgq_quant_act: natural K order needs Kp >= K");
+    }
+    const int Ho = (a.H + 2 * a.pad - a.kh) / a.stride + 1, Wo = (a.W + 2 * a.pad - a.kw) / a.stride + 1;
+    DGQ_CHECK_ARG(Ho > 0 && Wo > 0, "dgq_quant_act: empty output");
+    p.x = a.x; p.B = a.B; p.H = a.H; p.W = a.W; p.C = a.C; p.kh = a.kh; p.kw = a.kw; p.stride = a.stride; p.pad = a.pad;
+    p.Ho = Ho; p.Wo = Wo; p.ksrc = a.ksrc; p.koff = a.ksrc ? a.koff : nullptr; p.klds = a.ksrc ? a.klds : nullptr;
+    p.Kp = a.Kp; p.K = K; p.delta = a.delta; p.zp = a.zp; p.L = a.per_m ? a.L : 1;
+    p.qmax = (float)((1 << a.bits) - 1);
+    p.offset = (float)(1 << (a.bits - 1));
+    p.codes = a.codes; p.rowsum = a.rowsum; p.M = a.B * Ho * Wo;
+    p.kp_per_split = (((a.Kp + a.ksplits - 1) / a.ksplits) + 255) / 256 * 256;
+    p.pre_scale = a.pre_scale; p.pre_shift = a.pre_shift; p.pre_act = a.pre_act;
+    p.ln_gamma = a.ln_gamma; p.ln_beta = a.ln_beta; p.ln_eps = a.ln_eps;
+    p.ldc = a.pre_act == 2 ? 2 * a.C : a.C;
+    return DGQ_OK;
+}
+
+extern "C" int dgq_quant_act_batch(int n, const dgq_quant_act_args_t* args, void* stream) {
+    DGQ_CHECK_ARG(args && n >= 1 && n <= DGQ_QA_BATCH, "dgq_quant_act_batch: n=%d (1..%d)", n, DGQ_QA_BATCH);
+    QuantActBatch bt;
+    int variant = -1;
+    for (int i = 0; i < n; ++i) {
+        const int rc = fill_quant_act(args[i], bt.p[i]);
+        if (rc != DGQ_OK) return rc;
+        const int v = quant_act_variant(bt.p[i], args[i].ksrc != nullptr);
+        if (i == 0) variant = v;
+        DGQ_CHECK_ARG(v == variant && args[i].x_dtype == args[0].x_dtype && (args[i].per_m != 0) == (args[0].per_m != 0) &&
+                      bt.p[i].M == bt.p[0].M,
+                      "dgq_quant_act_batch: problem %d differs from problem 0 in kernel variant / dtype / scale mode / row count", i);
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const bool per_m = args[0].per_m != 0;
+    switch (args[0].x_dtype) {
+        case DGQ_F32: launch_quant_act<float>(bt, n, variant, per_m, st); break;
+        case DGQ_F16: launch_quant_act<__half>(bt, n, variant, per_m, st); break;
+        case DGQ_BF16: launch_quant_act<__hip_bfloat16>(bt, n, variant, per_m, st); break;
+        default: dgq_set_error("dgq_quant_act: unknown dtype %d", args[0].x_dtype); return DGQ_EINVAL;
+    }
+    return dgq_launch_status("dgq_quant_act");
+}
+
+// which problems may share a launch: the kernel variant the library would pick for this problem (0 staged, 1 gather, 2 natural)
+extern "C" int dgq_quant_act_variant(const dgq_quant_act_args_t* a) {
+    QuantActParams p;
+    if (!a || fill_quant_act(*a, p) != DGQ_OK) return -1;
+    return quant_act_variant(p, a->ksrc != nullptr);
+}
+
 extern "C" int dgq_quant_act(const void* x, int x_dtype, int B, int H, int W, int C,
                              int kh, int kw, int stride, int pad,
                              const int32_t* ksrc, const int32_t* koff, const int32_t* klds, int Kp,
@@ -433,42 +525,10 @@ extern "C" int dgq_quant_act(const void* x, int x_dtype, int B, int H, int W, in
                              int bits, int8_t* codes, float* rowsum, int ksplits,
                              const float* pre_scale, const float* pre_shift, int pre_act,
                              const float* ln_gamma, const float* ln_beta, float ln_eps, void* stream) {
-    DGQ_CHECK_ARG(x && delta && zp && codes && rowsum, "dgq_quant_act: null pointer");
-    DGQ_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && kh > 0 && kw > 0 && stride > 0 && pad >= 0,
-                  "dgq_quant_act: bad geometry");
-    DGQ_CHECK_ARG(kh <= 0x7F && kw <= 0xFF && C <= 0xFFFF, "dgq_quant_act: kernel/channel count out of range");
-    DGQ_CHECK_ARG(Kp > 0 && Kp % DGQ_KTILE == 0, "dgq_quant_act: Kp=%d must be a multiple of %d", Kp, DGQ_KTILE);
-    DGQ_CHECK_ARG(bits >= 2 && bits <= 8, "dgq_quant_act: bits=%d", bits);
-    DGQ_CHECK_ARG(!per_m || L >= 1, "dgq_quant_act: per_m needs L >= 1");
-    DGQ_CHECK_ARG(ksplits >= 1 && ksplits <= 64, "dgq_quant_act: ksplits=%d", ksplits);
-    DGQ_CHECK_ARG((pre_scale == nullptr) == (pre_shift == nullptr) && pre_act >= 0 && pre_act <= 2, "dgq_quant_act: bad prologue");
-    DGQ_CHECK_ARG(pre_act != 2 || (kh == 1 && kw == 1 && !pre_scale), "dgq_quant_act: GEGLU prologue is for Linear inputs");
-    DGQ_CHECK_ARG((ln_gamma == nullptr) == (ln_beta == nullptr), "dgq_quant_act: LayerNorm prologue needs gamma and beta");
-    DGQ_CHECK_ARG(!ln_gamma || (kh == 1 && kw == 1 && !pre_scale && pre_act == 0 && C % 4 == 0 && C <= DGQ_LN_MAX_C && ln_eps > 0.0f),
-                  "dgq_quant_act: LayerNorm prologue is for Linear inputs (1x1, C %% 4 == 0, C <= 2048, no other prologue)");
-    int K = C * kh * kw;
-    if (!ksrc) {
-        DGQ_CHECK_ARG(C % 4 == 0, "dgq_quant_act: natural K order needs C %% 4 == 0 (C=%d)", C);
-        DGQ_CHECK_ARG(Kp >= K, "dgq_quant_act: natural K order needs Kp >= K");
-    }
-    int Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W + 2 * pad - kw) / stride + 1;
-    DGQ_CHECK_ARG(Ho > 0 && Wo > 0, "dgq_quant_act: empty output");
-    QuantActParams p;
-    p.x = x; p.B = B; p.H = H; p.W = W; p.C = C; p.kh = kh; p.kw = kw; p.stride = stride; p.pad = pad;
-    p.Ho = Ho; p.Wo = Wo; p.ksrc = ksrc; p.koff = ksrc ? koff : nullptr; p.klds = ksrc ? klds : nullptr; p.Kp = Kp; p.K = K; p.delta = delta; p.zp = zp; p.L = per_m ? L : 1;
-    p.qmax = (float)((1 << bits) - 1);
-    p.offset = (float)(1 << (bits - 1));
-    p.codes = codes; p.rowsum = rowsum; p.M = B * Ho * Wo;
-    p.kp_per_split = (((Kp + ksplits - 1) / ksplits) + 255) / 256 * 256;
-    p.pre_scale = pre_scale; p.pre_shift = pre_shift; p.pre_act = pre_act;
-    p.ln_gamma = ln_gamma; p.ln_beta = ln_beta; p.ln_eps = ln_eps;
-    p.ldc = pre_act == 2 ? 2 * C : C;
-    hipStream_t st = (hipStream_t)stream;
-    switch (x_dtype) {
-        case DGQ_F32: launch_quant_act<float>(p, ksrc != nullptr, per_m != 0, st); break;
-        case DGQ_F16: launch_quant_act<__half>(p, ksrc != nullptr, per_m != 0, st); break;
-        case DGQ_BF16: launch_quant_act<__hip_bfloat16>(p, ksrc != nullptr, per_m != 0, st); break;
-        default: dgq_set_error("dgq_quant_act: unknown dtype %d", x_dtype); return DGQ_EINVAL;
-    }
-    return dgq_launch_status("dgq_quant_act");
+    dgq_quant_act_args_t a;
+    a.x = x; a.x_dtype = x_dtype; a.B = B; a.H = H; a.W = W; a.C = C; a.kh = kh; a.kw = kw; a.stride = stride; a.pad = pad;
+    a.ksrc = ksrc; a.koff = koff; a.klds = klds; a.Kp = Kp; a.per_m = per_m; a.delta = delta; a.zp = zp; a.L = L; a.bits = bits;
+    a.codes = codes; a.rowsum = rowsum; a.ksplits = ksplits; a.pre_scale = pre_scale; a.pre_shift = pre_shift; a.pre_act = pre_act;
+    a.ln_gamma = ln_gamma; a.ln_beta = ln_beta; a.ln_eps = ln_eps;
+    return dgq_quant_act_batch(1, &a, stream);
 }

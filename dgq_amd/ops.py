@@ -332,6 +332,12 @@ def make_extra(residual=None, fq=None, res_div=1):
     return ex
 
 
+#: measurement hook (bench.py's roofline leg): when set, every GEMM launch of the dgq_gemm_wxa8 family is issued through
+#: ``GEMM_LAUNCH_HOOK(issue, problems)`` — ``issue()`` launches it (again) on the current stream, ``problems`` lists the
+#: (M, ActBinding, out_element_size) of the layers the launch computes.  None in production.
+GEMM_LAUNCH_HOOK = None
+
+
 def gemm_wxa8(codes, rowsum, M, ab: ActBinding, out_dtype, out: Optional[torch.Tensor] = None, extra=None):
     pw = ab.pw
     ws = workspace(codes.device)
@@ -339,14 +345,18 @@ def gemm_wxa8(codes, rowsum, M, ab: ActBinding, out_dtype, out: Optional[torch.T
         out = torch.empty((M, pw.N), dtype=out_dtype, device=codes.device)
     per_m = 0 if ab.mode == "perK" else 1
     parts = rowsum.shape[0] if rowsum.dim() == 2 else 1
-    _lib_call("dgq_gemm_wxa8", _lib.ptr(codes), _lib.ptr(rowsum), parts, M, ab.Kp, _lib.ptr(ab.wpacked), pw.bits, pw.N,
-              per_m,
-              _lib.ptr(ab.cdelta) if not per_m else None, _lib.ptr(ab.cflush) if not per_m else None,
-              _lib.ptr(ab.mdelta) if per_m else None, _lib.ptr(ab.mzp) if per_m else None,
-              ab.L if per_m else 1, _c.c_float(ab.offset),
-              _lib.ptr(pw.alpha), _lib.ptr(pw.zw), _lib.ptr(ab.gamma), _lib.ptr(ab.vn) if per_m else None,
-              _lib.ptr(out), _lib.DTYPE_CODE[out.dtype], out.stride(0), _lib.ptr(ws), ws.numel(),
-              _c.byref(extra) if extra is not None else None, _lib.stream())
+    def issue():
+        _lib_call("dgq_gemm_wxa8", _lib.ptr(codes), _lib.ptr(rowsum), parts, M, ab.Kp, _lib.ptr(ab.wpacked), pw.bits, pw.N,
+                  per_m,
+                  _lib.ptr(ab.cdelta) if not per_m else None, _lib.ptr(ab.cflush) if not per_m else None,
+                  _lib.ptr(ab.mdelta) if per_m else None, _lib.ptr(ab.mzp) if per_m else None,
+                  ab.L if per_m else 1, _c.c_float(ab.offset),
+                  _lib.ptr(pw.alpha), _lib.ptr(pw.zw), _lib.ptr(ab.gamma), _lib.ptr(ab.vn) if per_m else None,
+                  _lib.ptr(out), _lib.DTYPE_CODE[out.dtype], out.stride(0), _lib.ptr(ws), ws.numel(),
+                  _c.byref(extra) if extra is not None else None, _lib.stream())
+    issue()
+    if GEMM_LAUNCH_HOOK is not None:
+        GEMM_LAUNCH_HOOK(issue, [(M, ab, out.element_size())])
     return out
 
 
@@ -368,6 +378,79 @@ def quant_linear(x: torch.Tensor, ab: ActBinding, pre_act=0, residual=None, fq=N
             res2 = res2.contiguous()
     y = gemm_wxa8(codes, rowsum, M, ab, x.dtype, extra=make_extra(res2, fq))
     return y.view(*x.shape[:-1], ab.pw.N)
+
+
+def _dp(t):
+    return t.data_ptr() if t is not None else None
+
+
+def quant_linear_multi(x: torch.Tensor, bindings, ln=None):
+    """[quant_linear(x, ab, ln=ln) for ab in bindings] with the launches shared: layers that consume the SAME input — the
+    q / k / v projections of a self-attention, the to_k / to_v of every cross-attention (one text context) — are quantised
+    by one dgq_quant_act_batch per (kernel variant, scale mode) and multiplied by one dgq_gemm_wxa8_batch per scale mode,
+    8 problems per launch.  Same kernels, same arithmetic, same results as the one-layer calls."""
+    Kin = x.shape[-1]
+    x2 = x.reshape(-1, Kin)
+    if not x2.is_contiguous():
+        x2 = x2.contiguous()
+    M = x2.shape[0]
+    dev = x2.device
+    lib = _lib.load()
+    lnp = (as_f32(ln[0]), as_f32(ln[1]), float(ln[2])) if ln else None
+    qa, keep = [], []
+    for ab in bindings:
+        assert ab.pw.K == Kin and ab.pw.taps == 1
+        parts = act_ksplits(M, ab.Kp)
+        codes = torch.empty((M, ab.Kp), dtype=torch.int8, device=dev)
+        rowsum = torch.empty((parts, M), dtype=torch.float32, device=dev)
+        per_m = 0 if ab.mode == "perK" else 1
+        a = _lib.QuantActArgs()
+        a.x, a.x_dtype, a.B, a.H, a.W, a.C, a.kh, a.kw, a.stride, a.pad = x2.data_ptr(), _lib.DTYPE_CODE[x2.dtype], M, 1, 1, Kin, 1, 1, 1, 0
+        a.ksrc, a.koff, a.klds = _dp(ab.ksrc), _dp(ab.koff(1, Kin)), _dp(ab.klds(1, Kin))
+        a.Kp, a.per_m = ab.Kp, per_m
+        a.delta, a.zp = (ab.cdelta.data_ptr(), ab.czp.data_ptr()) if not per_m else (ab.mdelta.data_ptr(), ab.mzp.data_ptr())
+        a.L, a.bits = (1 if not per_m else ab.L), ab.abits
+        a.codes, a.rowsum, a.ksplits = codes.data_ptr(), rowsum.data_ptr(), parts
+        a.pre_scale = a.pre_shift = None
+        a.pre_act = 0
+        a.ln_gamma, a.ln_beta, a.ln_eps = (lnp[0].data_ptr(), lnp[1].data_ptr(), lnp[2]) if lnp else (None, None, 0.0)
+        variant = lib.dgq_quant_act_variant(_c.byref(a))
+        qa.append((variant, per_m, a, codes, rowsum, parts))
+    groups = {}
+    for i, (variant, per_m, a, *_rest) in enumerate(qa):
+        groups.setdefault((variant, per_m), []).append(i)
+    for idxs in groups.values():
+        for j0 in range(0, len(idxs), 8):
+            chunk = idxs[j0:j0 + 8]
+            arr = (_lib.QuantActArgs * len(chunk))(*[qa[i][2] for i in chunk])
+            _lib_call("dgq_quant_act_batch", len(chunk), _c.cast(arr, _c.c_void_p), _lib.stream())
+    outs = [torch.empty((M, ab.pw.N), dtype=x.dtype, device=dev) for ab in bindings]
+    ggroups = {}
+    for i, ab in enumerate(bindings):
+        ggroups.setdefault((qa[i][1], ab.pw.bits), []).append(i)
+    for (per_m, _bits), idxs in ggroups.items():
+        for j0 in range(0, len(idxs), 8):
+            chunk = idxs[j0:j0 + 8]
+            arr = (_lib.GemmArgs * len(chunk))()
+            for g, i in zip(arr, chunk):
+                ab, pw = bindings[i], bindings[i].pw
+                _v, _pm, _a, codes, rowsum, parts = qa[i]
+                g.codes, g.rowsum, g.rowsum_parts, g.M, g.Kp = codes.data_ptr(), rowsum.data_ptr(), parts, M, ab.Kp
+                g.wpacked, g.w_bits, g.N, g.per_m = ab.wpacked.data_ptr(), pw.bits, pw.N, per_m
+                g.cdelta, g.cflush = (ab.cdelta.data_ptr(), ab.cflush.data_ptr()) if not per_m else (None, None)
+                g.mdelta, g.mzp = (ab.mdelta.data_ptr(), ab.mzp.data_ptr()) if per_m else (None, None)
+                g.L, g.offset = (ab.L if per_m else 1), ab.offset
+                g.alpha, g.zw, g.gamma, g.vn = pw.alpha.data_ptr(), pw.zw.data_ptr(), ab.gamma.data_ptr(), (ab.vn.data_ptr() if per_m else None)
+                g.y, g.y_dtype, g.ldy, g.extra = outs[i].data_ptr(), _lib.DTYPE_CODE[outs[i].dtype], outs[i].stride(0), None
+            n_chunk = len(chunk)
+
+            def issue(arr=arr, n_chunk=n_chunk):
+                _lib_call("dgq_gemm_wxa8_batch", n_chunk, _c.cast(arr, _c.c_void_p), _lib.stream())
+            issue()
+            if GEMM_LAUNCH_HOOK is not None:
+                GEMM_LAUNCH_HOOK(issue, [(M, bindings[i], outs[i].element_size()) for i in chunk])
+    keep.append(qa)
+    return [o.view(*x.shape[:-1], o.shape[-1]) for o in outs]
 
 
 def quant_conv2d(x: torch.Tensor, ab: ActBinding, kh, kw, stride, pad, norm=None, residual=None, bias_rows=None):

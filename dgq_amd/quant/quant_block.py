@@ -37,6 +37,10 @@ _F_GEGLU = _os.environ.get("DGQ_FUSE_GEGLU", "1") == "1"
 _F_SILU = _os.environ.get("DGQ_FUSE_SILU", "1") == "1"
 # norm1/2/3 of the transformer block folded into the quantise-on-load pass of the layers that consume them
 _F_LN = _os.environ.get("DGQ_FUSE_LN", "1") == "1"
+# layers that consume the same tensor share their launches (dgq_quant_act_batch / dgq_gemm_wxa8_batch): to_q/to_k/to_v of a
+# self-attention (one input, three quantizer tables) and the to_k/to_v of EVERY cross-attention (one text context)
+_F_QKV_BATCH = _os.environ.get("DGQ_QKV_BATCH", "1") == "1"
+_F_CTX_BATCH = _os.environ.get("DGQ_CTX_BATCH", "1") == "1"
 # the time_emb_proj(SiLU(temb)) projections of ALL resnet blocks in one launch (they depend on temb only): 46 launches -> 1
 _F_TEMB_BATCH = _os.environ.get("DGQ_TEMB_BATCH", "1") == "1"
 # aqtizer_{q,k,v} applied inside the attention pre-pass (K/V while they are split into bf16 planes, Q into a scratch
@@ -83,6 +87,27 @@ class TembGroup:
                 return None                                   # a grouped table on a 2-D input does not occur; be safe
             self._out = dict(zip((id(l) for l in self.layers), ops.linear_smallm_batch(temb, binds, pre_act=1)))
             self._src = temb
+        return self._out[id(layer)]
+
+
+class CtxGroup:
+    """The attn2.to_k / attn2.to_v layers of one QuantModel: they all project the same encoder_hidden_states tensor, so the
+    first cross-attention of a forward computes every one of them with shared launches (ops.quant_linear_multi)."""
+
+    def __init__(self, layers):
+        self.layers = list(layers)
+        self._src = None
+        self._out = {}
+
+    def eligible(self, ctx):
+        return (torch.is_tensor(ctx) and ctx.is_cuda and ctx.dtype in ops.FLOAT_DTYPES
+                and all(l.on_integer_path(ctx) and not l.aqtizer.calibrating() for l in self.layers))
+
+    def get(self, layer, ctx):
+        if self._src is not ctx:
+            binds = [l._binding() for l in self.layers]
+            self._out = dict(zip((id(l) for l in self.layers), ops.quant_linear_multi(ctx, binds)))
+            self._src = ctx
         return self._out[id(layer)]
 
 
@@ -269,10 +294,38 @@ def quant_attention_forward(attn, hidden_states, encoder_hidden_states=None, res
              and ops.attention_fuses_fakequant(D, mode_w))
     pending = {}
 
+    # projections that share their launches: q/k/v of a self-attention (same input, LayerNorm folded once per problem) ...
+    pre = {}
+    from .quant_layer import _tap
+    if (FUSION and _F_QKV_BATCH and not _F_FQ and encoder_hidden_states is None and not calibrating
+            and all(isinstance(l, QuantLayer) and not l.is_conv for l in (attn.to_q, attn.to_k, attn.to_v))):
+        xin = hidden_states.x if isinstance(hidden_states, PreLN) else hidden_states
+        lnm = hidden_states.norm if isinstance(hidden_states, PreLN) else None
+        if (all(l.on_integer_path(xin) for l in (attn.to_q, attn.to_k, attn.to_v)) and xin.dtype in ops.FLOAT_DTYPES
+                and (lnm is None or (xin.shape[-1] % 4 == 0 and xin.shape[-1] <= 2048))):
+            ys = ops.quant_linear_multi(xin, [l._binding() for l in (attn.to_q, attn.to_k, attn.to_v)],
+                                        ln=(lnm.weight, lnm.bias, float(lnm.eps)) if lnm is not None else None)
+            for nm, l, y in zip(("aqtizer_q", "aqtizer_k", "aqtizer_v"), (attn.to_q, attn.to_k, attn.to_v), ys):
+                pre[nm] = _tap(l, y, x=xin, prologue=lnm is not None)
+    # ... and the k/v projections of the text context, shared by every cross-attention of the model
+    grp = getattr(attn.to_k, "_ctx_group", None)
+    if (FUSION and _F_CTX_BATCH and not _F_FQ and encoder_hidden_states is not None and not calibrating and grp is not None
+            and not isinstance(src, PreLN) and grp.eligible(src)):
+        for nm, l in (("aqtizer_k", attn.to_k), ("aqtizer_v", attn.to_v)):
+            pre[nm] = _tap(l, grp.get(l, src), x=src, prologue=False)
+
     def project(layer, name, inp, skip):
         """projection + its attention-side quantizer (fused into the attention kernel's loads when possible)"""
         qz = getattr(attn, name) if use_aq else None
         ntok = inp.shape[1]
+        if name in pre:
+            ten = pre[name]
+            if defer and qz.init:
+                mode, dd, zz = _qparams(qz, ten.device)
+                pending[name] = (mode, dd, zz, skip, qz.bits)
+                return ten
+            layer = lambda _x, _t=ten: _t                             # already projected: only the quantizer is left
+            inp = ten
         if defer and qz.init:
             mode, dd, zz = _qparams(qz, inp.device)
             pending[name] = (mode, dd, zz, skip, qz.bits)

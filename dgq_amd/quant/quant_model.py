@@ -44,7 +44,13 @@ class QuantModel(nn.Module):
         self.quant_module(self.model, wq_params, aq_params, aq_mode=kwargs.get("aq_mode", [QMODE.NORMAL.value]),
                           prev_name=None)
         self.quant_block(self.model, wq_params, aq_params, softmax_aq_params)
-        from .quant_block import TembGroup
+        from .quant_block import TembGroup, CtxGroup
+        ctx_layers = [l for m in self.model.modules() if isinstance(m, QuantBasicTransformerBlock)
+                      for l in (m.attn2.to_k, m.attn2.to_v) if isinstance(l, QuantLayer)]
+        if ctx_layers:
+            cgrp = CtxGroup(ctx_layers)
+            for l in ctx_layers:
+                l.__dict__["_ctx_group"] = cgrp
         temb_layers = [m.time_emb_proj for m in self.model.modules()
                        if isinstance(m, QuantResnetBlock2D) and isinstance(m.time_emb_proj, QuantLayer)]
         if temb_layers:

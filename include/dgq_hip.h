@@ -91,6 +91,20 @@ int dgq_quant_act(const void* x, int x_dtype, int B, int H, int W, int C,
                   const float* pre_scale, const float* pre_shift, int pre_act,
                   const float* ln_gamma, const float* ln_beta, float ln_eps, void* stream);
 int dgq_quant_act_parts(int Kp, int ksplits);
+/* The same with the arguments in a struct, for 1..8 problems in ONE launch (dgq_quant_act_batch): the q / k / v
+ * projections of an attention quantise one input with three tables, the to_k / to_v of every cross-attention quantise
+ * the one text context.  All problems of a batch must have the same row count M, dtype, scale mode (per_m) and kernel
+ * variant (dgq_quant_act_variant: 0 LDS-staged, 1 table gather, 2 natural order) — DGQ_EINVAL otherwise. */
+typedef struct dgq_quant_act_args {
+    const void* x; int x_dtype; int B, H, W, C, kh, kw, stride, pad;
+    const int32_t* ksrc; const int32_t* koff; const int32_t* klds; int Kp;
+    int per_m; const float* delta; const float* zp; int L; int bits;
+    int8_t* codes; float* rowsum; int ksplits;
+    const float* pre_scale; const float* pre_shift; int pre_act;
+    const float* ln_gamma; const float* ln_beta; float ln_eps;
+} dgq_quant_act_args_t;
+int dgq_quant_act_batch(int n, const dgq_quant_act_args_t* args, void* stream);
+int dgq_quant_act_variant(const dgq_quant_act_args_t* args);
 
 /* GroupNorm of a channels-last tensor x [B][HW][C] as per-(b,c) scale/shift (biased variance, eps as F.group_norm):
  * GN(x) = x·scale + shift.  Replaces norm1/norm2 of QuantResnetBlock2D.forward (quant_block.py:98-119) together with
@@ -138,6 +152,18 @@ int dgq_gemm_wxa8(const int8_t* codes, const float* rowsum, int rowsum_parts, in
                   const float* alpha, const float* zw, const float* gamma, const float* vn,
                   void* y, int y_dtype, int ldy, void* workspace, size_t workspace_bytes,
                   const dgq_gemm_extra_t* extra, void* stream);
+/* The same with the arguments in a struct, for 1..8 problems in ONE launch (dgq_gemm_wxa8_batch): problems that share
+ * weight bits, scale mode (per_m) and output dtype, e.g. the q / k / v projections of one attention or the to_k / to_v of
+ * every cross-attention (same text context).  The launch plan (tile shape) of problem 0 serves all; no K split. */
+typedef struct dgq_gemm_args {
+    const int8_t* codes; const float* rowsum; int rowsum_parts; int M, Kp;
+    const void* wpacked; int w_bits; int N;
+    int per_m; const float* cdelta; const uint8_t* cflush; const float* mdelta; const float* mzp; int L; float offset;
+    const float* alpha; const float* zw; const float* gamma; const float* vn;
+    void* y; int y_dtype; int ldy;
+    const dgq_gemm_extra_t* extra;
+} dgq_gemm_args_t;
+int dgq_gemm_wxa8_batch(int n, const dgq_gemm_args_t* args, void* stream);
 /* Small tile grids are split along K (deterministic: fp32 partial slabs [S][M][N] in the caller's `workspace`,
  * summed in a fixed order by a second kernel). dgq_gemm_workspace_bytes returns what the preferred split of a
  * shape needs; with workspace == NULL (or too small) fewer / no splits are used — results do not depend on it

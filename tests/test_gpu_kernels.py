@@ -550,3 +550,37 @@ def test_linear_smallm_batch_equals_the_gemm_path(M, K, wbits, abits, dtype, dev
         ref = ops.quant_linear(x, ab, pre_act=1)
         assert y.shape == ref.shape and y.dtype == dtype
         assert torch.equal(y, ref), (ab.pw.N, (y.float() - ref.float()).abs().max().item())
+
+
+@pytest.mark.parametrize("M,K,with_ln", [(154, 768, False), (512, 320, True), (64, 1280, True)])
+def test_quant_linear_multi_equals_single_calls(M, K, with_ln, dev):
+    """dgq_quant_act_batch + dgq_gemm_wxa8_batch (layers sharing one input: q/k/v, the cross-attention k/v of the text
+    context) against one dgq_quant_act + dgq_gemm_wxa8 per layer: same kernels, same arithmetic -> bit-identical,
+    for mixed per-K (grouped) and per-token / scalar tables and mixed widths in one call."""
+    from dgq_amd import ops, synth
+    from dgq_amd.plan import plan_act
+    g = torch.Generator().manual_seed(M + K)
+    x = torch.randn(2, M // 2, K, generator=g).to(dev)
+    ln = None
+    if with_ln:
+        ln = ((1 + 0.1 * torch.randn(K, generator=g)).to(dev), (0.05 * torch.randn(K, generator=g)).to(dev), 1e-5)
+    binds = []
+    for i, (N, mode) in enumerate(((320, "perK"), (640, "perM"), (320, "perK"), (1280, "scalar"), (640, "perK"), (320, "perM"),
+                                   (320, "perK"), (320, "perK"), (640, "perK"), (320, "perK"), (1280, "perK"))):
+        w = torch.randn(N, K, generator=g) * 0.05
+        wd, wz = orc.minmax_channel(w, 4)
+        pw = ops.PackedWeight(w.to(dev), wd.to(dev), wz.to(dev), None, torch.randn(N, generator=g).to(dev), 4, K, 1)
+        if mode == "perK":
+            d, z = synth._group_params(K, 16, 8, "multi|%d" % i, 0)
+            lay = plan_act(d.view(1, 1, -1), z.view(1, 1, -1), "linear", K, 1, 8)
+        elif mode == "perM":
+            d, z = synth._group_params(M // 2, 16, 8, "multi|%d" % i, 0)
+            lay = plan_act(d.view(1, -1, 1), z.view(1, -1, 1), "linear", K, 1, 8)
+        else:
+            lay = plan_act(torch.tensor(0.03), torch.tensor(120.0), "linear", K, 1, 8)
+        binds.append(ops.ActBinding(lay, pw, 8))
+    outs = ops.quant_linear_multi(x, binds, ln=ln)
+    for ab, y in zip(binds, outs):
+        ref = ops.quant_linear(x, ab, ln=ln)
+        assert y.shape == ref.shape
+        assert torch.equal(y, ref), (ab.pw.N, ab.mode, (y - ref).abs().max().item())
