@@ -2,6 +2,7 @@
 // operand in the packed weight's K order, + one float per row.  HBM-bound; one wave per output row, 4 consecutive
 // kp (one packed dword) per lane per 256-wide step; rounding bit-identical to fp32 true division (see below).
 #include <algorithm>
+#include <atomic>
 #include "dgq_common.h"
 
 struct QuantActParams {
@@ -10,6 +11,7 @@ struct QuantActParams {
     const int32_t* ksrc;      // [Kp] (dh<<24 | dw<<16 | c) or -1, or NULL (natural order kp = tap*C + c)
     const int32_t* koff;      // optional [Kp]: (dh*W + dw)*ldc + c for THIS geometry, -1 for padding (interior rows)
     const int32_t* klds;      // optional [Kp]: (dh*kw + dw)*C + c, -1 for padding (LDS-staged conv path)
+    const int32_t* kdst;      // optional [taps*C]: packed position kp of element (tap, c) — the inverse of ksrc (scatter path)
     int Kp, K;
     const float* delta;       // per_m: [L]; else [Kp/64]
     const float* zp;
@@ -404,7 +406,92 @@ __global__ __launch_bounds__(256) void quant_act_staged_kernel(QuantActBatch bt)
     if (lane == 0) p.rowsum[(int64_t)blockIdx.y * p.M + row] = partial;
 }
 
-// kernel variant of one problem: 0 = LDS-staged strips, 1 = table gather from global, 2 = natural order
+// Per-K conv layers with many input channels (3x3 on C >= 640, or any layer whose tap strips do not fit a wave's LDS
+// share): the gather above reads one scattered 4-byte element per code straight from global memory and runs at the L1's
+// access rate (8192 x 9088: 257 us, 0.3 TB/s).  Turned around: every tap's C contiguous channels are READ coalesced
+// (16 bytes per lane, GroupNorm / SiLU applied on the way), quantised with the (δ, 1/δ, z) of the element's destination
+// chunk (tables staged in LDS once per block), and the code byte is SCATTERED into the row's image in LDS at its packed
+// position kdst[tap][c]; the finished row leaves LDS as 16-byte coalesced stores.  RPB rows per block: 4 (one wave per
+// row) for large M; 1 (the four waves take the taps round-robin and share the row image) where M alone cannot fill the chip.
+template <typename TIn, int RPB>
+__global__ __launch_bounds__(256) void quant_act_scatter_kernel(QuantActBatch bt) {
+    const QuantActParams& p = bt.p[blockIdx.z];
+    extern __shared__ __attribute__((aligned(16))) uint8_t sc_smem[];
+    constexpr int WPR = 4 / RPB;                             // waves per row
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int nch = p.Kp >> 6;
+    float* tdelta = reinterpret_cast<float*>(sc_smem);
+    float* tinv = tdelta + nch;
+    float* tzp = tinv + nch;
+    float* psum = tzp + nch;                                 // [4] per-wave partial row sums (RPB == 1)
+    uint8_t* images = sc_smem + (((3 * nch + 4) * 4 + 15) & ~15);
+    for (int i = tid; i < nch; i += 256) {
+        const float d = p.delta[i];
+        tdelta[i] = d; tinv[i] = dgq_rcp(d); tzp[i] = p.zp[i];
+    }
+    for (int i = tid; i < RPB * (p.Kp >> 4); i += 256) reinterpret_cast<uint4*>(images)[i] = make_uint4(0, 0, 0, 0);   // padding = code 0
+    __syncthreads();
+    const int rslot = wv / WPR, wsub = wv % WPR;
+    const int row = blockIdx.x * RPB + rslot;
+    uint8_t* image = images + (size_t)rslot * p.Kp;
+    float partial = 0.0f;
+    if (row < p.M) {
+        const TIn* x = reinterpret_cast<const TIn*>(p.x);
+        const int L = p.Ho * p.Wo;
+        const int b = row / L, l = row - b * L;
+        const int ho = l / p.Wo, wo = l - ho * p.Wo;
+        const int hbase = ho * p.stride - p.pad, wbase = wo * p.stride - p.pad;
+        const TIn* img = x + (int64_t)b * p.H * p.W * p.ldc;
+        const float* pre_sc = p.pre_scale ? p.pre_scale + (int64_t)b * p.C : nullptr;
+        const float* pre_sh = p.pre_shift ? p.pre_shift + (int64_t)b * p.C : nullptr;
+        const int taps = p.kh * p.kw;
+        for (int tap = wsub; tap < taps; tap += WPR) {
+            const int dh = tap / p.kw, dw = tap - dh * p.kw;
+            const int hi = hbase + dh, wi = wbase + dw;
+            const bool inb = hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;     // wave-uniform
+            const TIn* src = img + ((int64_t)hi * p.W + wi) * p.ldc;
+            const int32_t* kd = p.kdst + tap * p.C;
+            for (int c = lane * 4; c < p.C; c += 256) {
+                float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (inb) {
+                    load4<TIn>(src + c, v);
+                    if (pre_sc) {
+                        const float4 sc = *reinterpret_cast<const float4*>(pre_sc + c);
+                        const float4 sh = *reinterpret_cast<const float4*>(pre_sh + c);
+                        v[0] = v[0] * sc.x + sh.x; v[1] = v[1] * sc.y + sh.y; v[2] = v[2] * sc.z + sh.z; v[3] = v[3] * sc.w + sh.w;
+                    }
+                    if (p.pre_act == 1) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = dgq_silu(v[j]);
+                    }
+                }
+                const int4 d4 = *reinterpret_cast<const int4*>(kd + c);
+                const int dst[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int ch = dst[j] >> 6;
+                    const float d = tdelta[ch];
+                    const float sc = dgq_affine_code_fast(v[j], d, tinv[ch], tzp[ch], p.qmax) - p.offset;
+                    image[dst[j]] = (uint8_t)(int)sc;
+                    partial += d * sc;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) partial += __shfl_down(partial, o, 64);
+    if (RPB == 1 && lane == 0) psum[wv] = partial;
+    __syncthreads();                                        // every wave's bytes of the shared image(s) are in LDS
+    if (row < p.M) {
+        uint4* out = reinterpret_cast<uint4*>(p.codes + (int64_t)row * p.Kp);
+        const uint4* im = reinterpret_cast<const uint4*>(image);
+        for (int i = wsub * 64 + lane; i < (p.Kp >> 4); i += 64 * WPR) out[i] = im[i];
+        if (lane == 0 && wsub == 0) p.rowsum[row] = RPB == 1 ? ((psum[0] + psum[1]) + (psum[2] + psum[3])) : partial;
+    }
+}
+
+// kernel variant of one problem: 0 = LDS-staged strips, 1 = table gather from global, 2 = natural order, 3 / 4 = scatter
+// through an LDS row image with 4 rows / 1 row per block
 static int quant_act_variant(const QuantActParams& p, bool table) {
     const int ks = (p.Kp + p.kp_per_split - 1) / p.kp_per_split;
     const size_t strip_bytes = (size_t)p.kh * p.kw * p.C * sizeof(float);
@@ -416,6 +503,10 @@ static int quant_act_variant(const QuantActParams& p, bool table) {
     const bool stage_conv = taps_ > 1 && p.pre_act != 2 && !p.ln_gamma && ks == 1;
     const bool stage_lin = taps_ == 1 && (!p.ln_gamma || p.C <= DGQ_LN_MAX_C);
     if (table && p.klds && p.C % 4 == 0 && strip_bytes <= 16 * 1024 && (stage_conv || stage_lin)) return 0;
+    // scatter path: per-K table, more than one tap, the whole row in one wave/block (no K split), no LN / GEGLU prologue
+    const size_t sc_tab = (((size_t)3 * (p.Kp >> 6) + 4) * 4 + 15) & ~(size_t)15;
+    if (table && p.kdst && taps_ > 1 && p.C % 4 == 0 && ks == 1 && p.pre_act != 2 && !p.ln_gamma && sc_tab + (size_t)p.Kp <= 150 * 1024)
+        return (p.M >= 2048 && sc_tab + 4 * (size_t)p.Kp <= 150 * 1024) ? 3 : 4;
     return table ? 1 : 2;
 }
 
@@ -429,6 +520,24 @@ static void launch_quant_act(const QuantActBatch& bt, int n, int variant, bool p
         const QuantActParams& p = bt.p[i];
         ks = std::max(ks, (p.Kp + p.kp_per_split - 1) / p.kp_per_split);
         strip_bytes = std::max(strip_bytes, (size_t)p.kh * p.kw * p.C * sizeof(float));
+    }
+    if (variant == 3 || variant == 4) {
+        size_t lds = 0;
+        for (int i = 0; i < n; ++i) {
+            const size_t tab = (((size_t)3 * (bt.p[i].Kp >> 6) + 4) * 4 + 15) & ~(size_t)15;
+            lds = std::max(lds, tab + (variant == 3 ? 4 : 1) * (size_t)bt.p[i].Kp);
+        }
+        static std::atomic<bool> attr_set[64];
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (dev < 0 || dev >= 64 || !attr_set[dev].load(std::memory_order_acquire)) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&quant_act_scatter_kernel<TIn, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&quant_act_scatter_kernel<TIn, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+            if (dev >= 0 && dev < 64) attr_set[dev].store(true, std::memory_order_release);
+        }
+        if (variant == 3) hipLaunchKernelGGL((quant_act_scatter_kernel<TIn, 4>), dim3((p0.M + 3) / 4, 1, n), dim3(256), lds, st, bt);
+        else hipLaunchKernelGGL((quant_act_scatter_kernel<TIn, 1>), dim3(p0.M, 1, n), dim3(256), lds, st, bt);
+        return;
     }
     if (variant == 0) {
         const int nw = 4;                                                       // waves (= rows) per block, <= 64 KB of LDS
@@ -476,6 +585,7 @@ static int fill_quant_act(const dgq_quant_act_args_t& a, QuantActParams& p) {
     DGQ_CHECK_ARG(Ho > 0 && Wo > 0, "dgq_quant_act: empty output");
     p.x = a.x; p.B = a.B; p.H = a.H; p.W = a.W; p.C = a.C; p.kh = a.kh; p.kw = a.kw; p.stride = a.stride; p.pad = a.pad;
     p.Ho = Ho; p.Wo = Wo; p.ksrc = a.ksrc; p.koff = a.ksrc ? a.koff : nullptr; p.klds = a.ksrc ? a.klds : nullptr;
+    p.kdst = a.ksrc ? a.kdst : nullptr;
     p.Kp = a.Kp; p.K = K; p.delta = a.delta; p.zp = a.zp; p.L = a.per_m ? a.L : 1;
     p.qmax = (float)((1 << a.bits) - 1);
     p.offset = (float)(1 << (a.bits - 1));
@@ -527,7 +637,7 @@ extern "C" int dgq_quant_act(const void* x, int x_dtype, int B, int H, int W, in
                              const float* ln_gamma, const float* ln_beta, float ln_eps, void* stream) {
     dgq_quant_act_args_t a;
     a.x = x; a.x_dtype = x_dtype; a.B = B; a.H = H; a.W = W; a.C = C; a.kh = kh; a.kw = kw; a.stride = stride; a.pad = pad;
-    a.ksrc = ksrc; a.koff = koff; a.klds = klds; a.Kp = Kp; a.per_m = per_m; a.delta = delta; a.zp = zp; a.L = L; a.bits = bits;
+    a.ksrc = ksrc; a.koff = koff; a.klds = klds; a.kdst = nullptr; a.Kp = Kp; a.per_m = per_m; a.delta = delta; a.zp = zp; a.L = L; a.bits = bits;
     a.codes = codes; a.rowsum = rowsum; a.ksplits = ksplits; a.pre_scale = pre_scale; a.pre_shift = pre_shift; a.pre_act = pre_act;
     a.ln_gamma = ln_gamma; a.ln_beta = ln_beta; a.ln_eps = ln_eps;
     return dgq_quant_act_batch(1, &a, stream);

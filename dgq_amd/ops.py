@@ -115,6 +115,21 @@ class ActBinding:
             self._koff[key] = torch.where(e >= 0, idx, torch.full_like(idx, -1)).to(torch.int32).contiguous()
         return self._koff[key]
 
+    def kdst(self, kw, C, taps):
+        """inverse of ksrc: packed position kp of element (tap, c), [taps*C] int32 (cached) — dgq_quant_act's scatter path"""
+        if self.ksrc is None:
+            return None
+        key = ("dst", kw, C, taps)
+        if key not in self._koff:
+            e = self.ksrc
+            valid = e >= 0
+            idx = ((((e >> 24) & 0x7F) * kw + ((e >> 16) & 0xFF)) * C + (e & 0xFFFF))[valid].long()
+            out = torch.full((taps * C,), -1, dtype=torch.int32, device=e.device)
+            out[idx] = torch.nonzero(valid).flatten().to(torch.int32)
+            assert int((out < 0).sum()) == 0, "per-K table does not cover every (tap, channel)"
+            self._koff[key] = out.contiguous()
+        return self._koff[key]
+
     def __init__(self, layout: ActLayout, pw: PackedWeight, abits: int):
         dev = pw.codes.device
         self.mode, self.abits, self.offset = layout.mode, abits, act_offset(abits)
@@ -206,23 +221,36 @@ def quant_act(x_cl: torch.Tensor, B, H, W, C, kh, kw, stride, pad, ab: ActBindin
     Ho = (H + 2 * pad - kh) // stride + 1
     Wo = (W + 2 * pad - kw) // stride + 1
     M = B * Ho * Wo
-    parts = act_ksplits(M, ab.Kp)
+    per_m = 0 if ab.mode == "perK" else 1
+    ldc = 2 * C if (pre and pre[2] == 2) else C
+    a = _lib.QuantActArgs()
+    a.x, a.x_dtype, a.B, a.H, a.W, a.C, a.kh, a.kw, a.stride, a.pad = x_cl.data_ptr(), _lib.DTYPE_CODE[x_cl.dtype], B, H, W, C, kh, kw, stride, pad
+    a.ksrc, a.koff, a.klds = _dp(ab.ksrc), _dp(ab.koff(W, ldc)), _dp(ab.klds(kw, C))
+    a.kdst = _dp(ab.kdst(kw, C, kh * kw)) if (ab.ksrc is not None and kh * kw > 1) else None
+    a.Kp, a.per_m = ab.Kp, per_m
+    a.delta, a.zp = (ab.cdelta.data_ptr(), ab.czp.data_ptr()) if not per_m else (ab.mdelta.data_ptr(), ab.mzp.data_ptr())
+    a.L, a.bits = (1 if not per_m else ab.L), ab.abits
+    a.pre_scale = _dp(pre[0]) if pre and pre[0] is not None else None
+    a.pre_shift = _dp(pre[1]) if pre and pre[1] is not None else None
+    a.pre_act = pre[2] if pre else 0
+    lnp = (as_f32(ln[0]), as_f32(ln[1]), float(ln[2])) if ln else None
+    a.ln_gamma, a.ln_beta, a.ln_eps = (lnp[0].data_ptr(), lnp[1].data_ptr(), lnp[2]) if lnp else (None, None, 0.0)
+    # the LDS-scatter path (per-K convs) takes the whole row in one wave / block: ask for it with one K split first
+    parts = 1
+    a.ksplits = 1
+    a.codes = a.rowsum = 1                                   # placeholders: dgq_quant_act_variant only validates non-NULL
+    if a.kdst is None or _lib.load().dgq_quant_act_variant(_c.byref(a)) not in (3, 4):
+        parts = act_ksplits(M, ab.Kp)
+        a.ksplits = parts
     codes = torch.empty((M, ab.Kp), dtype=torch.int8, device=x_cl.device)
     rowsum = torch.empty((parts, M), dtype=torch.float32, device=x_cl.device)
-    per_m = 0 if ab.mode == "perK" else 1
-    delta = ab.cdelta if ab.mode == "perK" else ab.mdelta
-    zp = ab.czp if ab.mode == "perK" else ab.mzp
-    L = 1 if ab.mode == "perK" else ab.L
-    ldc = 2 * C if (pre and pre[2] == 2) else C
-    _lib_call("dgq_quant_act", _lib.ptr(x_cl), _lib.DTYPE_CODE[x_cl.dtype], B, H, W, C, kh, kw, stride, pad,
-              _lib.ptr(ab.ksrc), _lib.ptr(ab.koff(W, ldc)), _lib.ptr(ab.klds(kw, C)), ab.Kp, per_m, _lib.ptr(delta), _lib.ptr(zp), L, ab.abits,
-              _lib.ptr(codes), _lib.ptr(rowsum), parts,
-              _lib.ptr(pre[0]) if pre and pre[0] is not None else None,
-              _lib.ptr(pre[1]) if pre and pre[1] is not None else None, pre[2] if pre else 0,
-              _lib.ptr(as_f32(ln[0])) if ln else None, _lib.ptr(as_f32(ln[1])) if ln else None,
-              _c.c_float(ln[2] if ln else 0.0),
-              _lib.stream())
+    a.codes, a.rowsum = codes.data_ptr(), rowsum.data_ptr()
+    _lib_call("dgq_quant_act_batch", 1, _c.byref(a), _lib.stream())
     return codes, rowsum, M
+
+
+def _dp(t):
+    return t.data_ptr() if t is not None else None
 
 
 _WORKSPACE = {}
@@ -380,10 +408,6 @@ def quant_linear(x: torch.Tensor, ab: ActBinding, pre_act=0, residual=None, fq=N
     return y.view(*x.shape[:-1], ab.pw.N)
 
 
-def _dp(t):
-    return t.data_ptr() if t is not None else None
-
-
 def quant_linear_multi(x: torch.Tensor, bindings, ln=None):
     """[quant_linear(x, ab, ln=ln) for ab in bindings] with the launches shared: layers that consume the SAME input — the
     q / k / v projections of a self-attention, the to_k / to_v of every cross-attention (one text context) — are quantised
@@ -406,7 +430,7 @@ def quant_linear_multi(x: torch.Tensor, bindings, ln=None):
         per_m = 0 if ab.mode == "perK" else 1
         a = _lib.QuantActArgs()
         a.x, a.x_dtype, a.B, a.H, a.W, a.C, a.kh, a.kw, a.stride, a.pad = x2.data_ptr(), _lib.DTYPE_CODE[x2.dtype], M, 1, 1, Kin, 1, 1, 1, 0
-        a.ksrc, a.koff, a.klds = _dp(ab.ksrc), _dp(ab.koff(1, Kin)), _dp(ab.klds(1, Kin))
+        a.ksrc, a.koff, a.klds, a.kdst = _dp(ab.ksrc), _dp(ab.koff(1, Kin)), _dp(ab.klds(1, Kin)), None
         a.Kp, a.per_m = ab.Kp, per_m
         a.delta, a.zp = (ab.cdelta.data_ptr(), ab.czp.data_ptr()) if not per_m else (ab.mdelta.data_ptr(), ab.mzp.data_ptr())
         a.L, a.bits = (1 if not per_m else ab.L), ab.abits

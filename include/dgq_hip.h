@@ -94,10 +94,13 @@ int dgq_quant_act_parts(int Kp, int ksplits);
 /* The same with the arguments in a struct, for 1..8 problems in ONE launch (dgq_quant_act_batch): the q / k / v
  * projections of an attention quantise one input with three tables, the to_k / to_v of every cross-attention quantise
  * the one text context.  All problems of a batch must have the same row count M, dtype, scale mode (per_m) and kernel
- * variant (dgq_quant_act_variant: 0 LDS-staged, 1 table gather, 2 natural order) — DGQ_EINVAL otherwise. */
+ * variant (dgq_quant_act_variant: 0 LDS-staged, 1 table gather, 2 natural order, 3 / 4 LDS scatter) — DGQ_EINVAL otherwise. */
 typedef struct dgq_quant_act_args {
     const void* x; int x_dtype; int B, H, W, C, kh, kw, stride, pad;
-    const int32_t* ksrc; const int32_t* koff; const int32_t* klds; int Kp;
+    const int32_t* ksrc; const int32_t* koff; const int32_t* klds;
+    const int32_t* kdst;      /* optional [kh·kw·C]: packed position kp of element (tap, c) — the inverse of ksrc; enables the
+                                 coalesced-read / LDS-scatter path for per-K conv layers (ksplits must be 1) */
+    int Kp;
     int per_m; const float* delta; const float* zp; int L; int bits;
     int8_t* codes; float* rowsum; int ksplits;
     const float* pre_scale; const float* pre_shift; int pre_act;

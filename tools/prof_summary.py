@@ -9,13 +9,16 @@ trace, steps, out = sys.argv[1], int(sys.argv[2]), sys.argv[3]
 comment = sys.argv[4] if len(sys.argv) > 4 else ""
 rows = list(csv.DictReader(open(trace)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-marker = "gemm_wxa8_kernel"                       # every quantized layer launches exactly one per forward (280 in SD1.4)
+# step boundaries: the batched time-embedding projection (dgq_linear_smallm_batch) runs exactly once per forward; the window
+# is the kernels between its occurrence `steps` forwards before the last one and the last one = `steps` whole periods
+marker = "linear_smallm_kernel"
 idx = [i for i, r in enumerate(rows) if marker in r["Kernel_Name"]]
-per = 280 if len(idx) >= 280 * (steps + 1) else len(idx) // (steps + 1)
-first = idx[-per * steps]
-while first > 0 and "gemm_wxa8_kernel" not in rows[first - 1]["Kernel_Name"] and "splitk" not in rows[first - 1]["Kernel_Name"]:
-    first -= 1                                     # include the kernels in front of the step's first GEMM (conv_in, time embedding, its quant_act)
-win = rows[first:]
+if len(idx) > steps:
+    win = rows[idx[-steps - 1] + 1: idx[-1] + 1]
+else:                                              # older builds: one gemm_wxa8_kernel per quantized layer (280 in SD1.4)
+    idx = [i for i, r in enumerate(rows) if "gemm_wxa8_kernel" in r["Kernel_Name"]]
+    per = 280 if len(idx) >= 280 * (steps + 1) else len(idx) // (steps + 1)
+    win = rows[idx[-per * steps]:]
 agg = collections.defaultdict(lambda: [0, 0])
 for r in win:
     agg[r["Kernel_Name"]][0] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
