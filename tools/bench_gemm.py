@@ -31,9 +31,22 @@ SHAPES_ALL = [
     ("big 8192x8192x8192 perM", 8192, 8192, 8192, 1, "perM"),
     ("big 8192x8192x8192 perK g16", 8192, 8192, 8192, 1, "perK"),
 ]
-SHAPES = SHAPES_ALL[-2:] if os.environ.get("BIG_ONLY") else SHAPES_ALL
-print("%-40s %6s %6s %6s  %9s %9s %7s" % ("shape", "M", "N", "K", "us", "TOP/s", "frac"))
-for name, M, N, C, taps, mode in SHAPES:
+# SURVEY.md §8(d) headline shapes: GEGLU-class Linear layers at B = 1 and at the batch a GPU holds in config C5 (8 prompts),
+# the compute-bound convs, 8192^3 — per-K g16 and per-M, fp32 and bf16 outputs
+HEADLINE = [
+    ("sd geglu 16x16 1280->10240", 512, 10240, 1280, 1), ("xl geglu 32x32 1280->10240 B=1", 1024, 10240, 1280, 1),
+    ("xl geglu 32x32 1280->10240 B=8", 8192, 10240, 1280, 1), ("xl ff.2 32x32 5120->1280 B=8", 8192, 1280, 5120, 1),
+    ("sd conv3x3 64x64 320->320", 8192, 320, 320, 9), ("sd conv3x3 16x16 1280->1280", 512, 1280, 1280, 9),
+    ("xl conv3x3 32x32 1280->1280 B=8", 8192, 1280, 1280, 9), ("big 8192^3", 8192, 8192, 8192, 1),
+]
+OUT_DTYPES = {"fp32": torch.float32, "bf16": torch.bfloat16}
+if os.environ.get("HEADLINE"):
+    SHAPES = [(n, M, N, C, t, mode, od) for (n, M, N, C, t) in HEADLINE for mode in ("perK", "perM") for od in ("fp32", "bf16")]
+else:
+    SHAPES = [s + ("fp32",) for s in (SHAPES_ALL[-2:] if os.environ.get("BIG_ONLY") else SHAPES_ALL)]
+print("%-40s %6s %6s %6s %5s %5s %9s %9s %7s" % ("shape", "M", "N", "K", "mode", "out", "us", "TOP/s", "frac"))
+for name, M, N, C, taps, mode, od in SHAPES:
+    odt = OUT_DTYPES[od]
     K = C * taps
     g = torch.Generator().manual_seed(0)
     w = torch.randn(N, K, generator=g) * 0.05
@@ -50,15 +63,15 @@ for name, M, N, C, taps, mode in SHAPES:
     ab = ops.ActBinding(lay, pw, 8)
     codes = torch.randint(-128, 128, (M, ab.Kp), dtype=torch.int8, device=dev)
     rowsum = torch.randn(M, device=dev)
-    out = torch.empty(M, N, device=dev)
+    out = torch.empty(M, N, device=dev, dtype=odt)
     for _ in range(3):
-        ops.gemm_wxa8(codes, rowsum, M, ab, torch.float32, out)
+        ops.gemm_wxa8(codes, rowsum, M, ab, odt, out)
     torch.cuda.synchronize()
     # capture `iters` launches in a hipGraph so that host launch overhead (python + ctypes ~15 us/call) is excluded
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph):
         for _ in range(iters):
-            ops.gemm_wxa8(codes, rowsum, M, ab, torch.float32, out)
+            ops.gemm_wxa8(codes, rowsum, M, ab, odt, out)
     graph.replay()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -68,5 +81,5 @@ for name, M, N, C, taps, mode in SHAPES:
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / iters
     tops = 2.0 * M * N * K / (us * 1e-6) / 1e12
-    print("%-40s %6d %6d %6d  %9.1f %9.1f %6.1f%%  Kp=%d" % (name, M, N, K, us, tops, 100 * tops / PEAK, ab.Kp))
+    print("%-40s %6d %6d %6d %5s %5s %9.1f %9.1f %6.1f%%  Kp=%d" % (name, M, N, K, mode, od, us, tops, 100 * tops / PEAK, ab.Kp))
     del pw, ab, codes, out

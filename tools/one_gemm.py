@@ -1,4 +1,4 @@
-"""Runs ONE dgq_gemm_wxa8 shape a few times (for rocprofv3 --pmc passes).  usage: one_gemm.py M N K mode [iters]"""
+"""Runs ONE dgq_gemm_wxa8 shape a few times (for rocprofv3 --pmc passes).  usage: one_gemm.py M N K mode [iters] [fp32|bf16]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -19,8 +19,9 @@ else:
 ab = ops.ActBinding(lay, pw, 8)
 codes = torch.randint(-128, 128, (M, ab.Kp), dtype=torch.int8, device=dev)
 rowsum = torch.randn(M, device=dev)
-out = torch.empty(M, N, device=dev)
+odt = torch.bfloat16 if (len(sys.argv) > 6 and sys.argv[6] == "bf16") else torch.float32
+out = torch.empty(M, N, device=dev, dtype=odt)
 for _ in range(iters):
-    ops.gemm_wxa8(codes, rowsum, M, ab, torch.float32, out)
+    ops.gemm_wxa8(codes, rowsum, M, ab, odt, out)
 torch.cuda.synchronize()
 print("done", M, N, K, ab.Kp)
