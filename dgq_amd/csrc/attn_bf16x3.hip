@@ -133,7 +133,11 @@ __device__ __forceinline__ void store_any(void* p, int dtype, int64_t i, float v
     else reinterpret_cast<float*>(p)[i] = v;
 }
 
-template <int D, bool QI8 = false, bool VINT = false> struct Geo {
+// QM: how Q·K^T is formed — 0: three bf16 planes each (six products); 1 (QI8): int8 codes on both sides; 2 (Q1K3): ONE
+// plane of centred Q codes (exact in bf16) against three K planes (pre-scaled by δq(d) for a per-head-dim aqtizer_q) with a
+// rank-1 zero-point correction per key — three products, for every aqtizer_q the int8 path cannot take.
+template <int D, int QM = 0, bool VINT = false> struct Geo {
+    static constexpr bool QI8 = QM == 1;
     static constexpr int DP = (D + 15) / 16 * 16;      // K depth of the score product
     static constexpr int NKK = DP / 16;
     static constexpr int NDT = (D + 31) / 32;          // 32-wide d tiles of O^T
@@ -148,7 +152,8 @@ template <int D, bool QI8 = false, bool VINT = false> struct Geo {
     static constexpr int K8_BYTES = KT * K8_LD;
     static constexpr int KTAB_BYTES = 3 * KT * 4;
     // bf16-element count of the K part of the image (QI8: bytes / 2, a multiple of 8 so that V stays 16-byte aligned)
-    static constexpr int K_ELEMS = QI8 ? (K8_BYTES + KTAB_BYTES) / 2 : 3 * KT * KLD;
+    // Q1K3 appends one float per key (Σ_d w(d)·K̃[s][d], the zero-point correction) to the three planes
+    static constexpr int K_ELEMS = QI8 ? (K8_BYTES + KTAB_BYTES) / 2 : 3 * KT * KLD + (QM == 2 ? 2 * KT : 0);
     // VINT (scalar / per-head-dim aqtizer_v): ONE plane of centred integer codes c'v (exact bf16) instead of three planes
     // of the dequantised values — P̂·V is then a single bf16 product, δv(d) and the zero point move to the epilogue
     static constexpr int V_PLANES = VINT ? 1 : 3;
@@ -165,7 +170,7 @@ template <int D, bool QI8 = false, bool VINT = false> struct Geo {
     static constexpr int PV_STAGES = (D <= 40 || D == 80) ? 3 : 2;
 };
 
-template <int D> using GeoI8 = Geo<D, true, false>;        // the K part does not depend on VINT
+template <int D> using GeoI8 = Geo<D, 1, false>;        // the K part does not depend on VINT
 
 typedef __attribute__((address_space(3))) void* lptr_t;
 
@@ -206,14 +211,46 @@ __device__ __forceinline__ float fq_code(float x, float dl, float inv, float z, 
     return dgq_affine_code_fast(x, dl, inv, z, qmax) - off;
 }
 
-template <int D, typename TIn, bool QI8, bool VINT>
+template <int D, typename TIn, int QM, bool VINT>
 __global__ __launch_bounds__(256) void attn3_prep_kernel(const TIn* __restrict__ k, const TIn* __restrict__ v,
                                                          unsigned char* __restrict__ planes, int B, int H, int S, int NT,
                                                          FqDesc fk, FqDesc fv, float* __restrict__ delta_reset,
                                                          const TIn* __restrict__ q, float* __restrict__ qfq, int T, FqDesc fqq) {
-    using G = Geo<D, QI8, VINT>;
+    using G = Geo<D, QM, VINT>;
+    constexpr bool QI8 = QM == 1;
     static_assert(D % 8 == 0, "head_dim must be a multiple of 8");
     const int bh = blockIdx.y, b = bh / H, hd = bh - b * H;
+    if (QM == 2 && (int)blockIdx.x >= NT) {
+        // Q1K3: centred codes c'q = c − 2^(b−1) of aqtizer_q(q) as fp32 (exact), + (q scale, zero-point multiplier) per query
+        const int t0 = ((int)blockIdx.x - NT) * 32;
+        constexpr int QC = D / 8;
+        float* qtab = qfq + (size_t)B * T * H * D;
+        const float off = 0.5f * (fqq.qmax + 1.0f);
+        for (int i = threadIdx.x; i < 32 * QC; i += 256) {
+            const int r = i / QC, c8 = i - r * QC;
+            const int t = t0 + r;
+            if (t >= T) continue;
+            const int64_t row = (int64_t)(b * T + t) * H + hd;
+            float x[8];
+            load8<TIn>(q + row * D + 8 * c8, x);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int idx = fqq.mode == 0 ? 0 : (fqq.mode == 1 ? t - fqq.skip : 8 * c8 + j);
+                const float dl = fqq.delta[idx];
+                x[j] = fq_code(x[j], dl, dgq_rcp(dl), fqq.zp[idx], fqq.qmax, off);
+            }
+            *reinterpret_cast<float4*>(qfq + row * D + 8 * c8) = make_float4(x[0], x[1], x[2], x[3]);
+            *reinterpret_cast<float4*>(qfq + row * D + 8 * c8 + 4) = make_float4(x[4], x[5], x[6], x[7]);
+            if (c8 == 0) {
+                // per-d table: δq(d) lives in the K planes and z'q(d) in the per-key correction (multiplier 1);
+                // scalar / per-token: scale δq(t) outside, correction z'q(t)·Σ_d K[s][d]
+                const int idx = fqq.mode == 0 ? 0 : t - fqq.skip;
+                qtab[row * 2] = fqq.mode == 2 ? 1.0f : fqq.delta[idx];
+                qtab[row * 2 + 1] = fqq.mode == 2 ? 1.0f : fqq.zp[idx] - off;
+            }
+        }
+        return;
+    }
     if (QI8 && (int)blockIdx.x >= NT) {
         // QI8: int8 codes of aqtizer_q(q) for 32 query rows + (δq, z'q, Σc'q − D·z'q, start-peak score/δq) per query.
         // One thread per query row (D <= 160 elements); the row is read as 8-element vectors.
@@ -319,7 +356,48 @@ __global__ __launch_bounds__(256) void attn3_prep_kernel(const TIn* __restrict__
         }
     }
     constexpr int KC = G::KLD / 8;                       // 16-byte chunks per K row (padding chunks are zero)
-    for (int i = threadIdx.x; !QI8 && i < KT * KC; i += 256) {
+    if (QM == 2) {
+        // Q1K3: three planes of K̃[s][d] = aqtizer_k(k)[s][d]·(δq(d) for a per-head-dim aqtizer_q) and, per key,
+        // Σ_d w(d)·K̃[s][d] with w = z'q(d) (per-head-dim) or 1; 8 threads per key row, deterministic shuffle reduction
+        const int r = threadIdx.x >> 3, part = threadIdx.x & 7;
+        const int sidx = s0 + r;
+        const float offq = 0.5f * (fqq.qmax + 1.0f);
+        float corr = 0.0f;
+        for (int c8 = part; c8 < KC; c8 += 8) {
+            unsigned wh[4] = {0, 0, 0, 0}, wm[4] = {0, 0, 0, 0}, wl[4] = {0, 0, 0, 0};
+            if (sidx < S && 8 * c8 < D) {
+                float x[8];
+                load8<TIn>(kbase + sidx * HD + 8 * c8, x);
+                fq_apply8(fk, x, sidx, 8 * c8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    if (fqq.mode == 2) {
+                        x[j] *= fqq.delta[8 * c8 + j];
+                        corr += (fqq.zp[8 * c8 + j] - offq) * x[j];
+                    } else {
+                        corr += x[j];
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    unsigned short h0, m0, l0, h1, m1, l1;
+                    split3(x[2 * j], h0, m0, l0);
+                    split3(x[2 * j + 1], h1, m1, l1);
+                    wh[j] = (unsigned)h0 | ((unsigned)h1 << 16);
+                    wm[j] = (unsigned)m0 | ((unsigned)m1 << 16);
+                    wl[j] = (unsigned)l0 | ((unsigned)l1 << 16);
+                }
+            }
+            unsigned short* dst = kimg + r * G::KLD + 8 * c8;
+            *reinterpret_cast<uint4*>(dst) = make_uint4(wh[0], wh[1], wh[2], wh[3]);
+            *reinterpret_cast<uint4*>(dst + KT * G::KLD) = make_uint4(wm[0], wm[1], wm[2], wm[3]);
+            *reinterpret_cast<uint4*>(dst + 2 * KT * G::KLD) = make_uint4(wl[0], wl[1], wl[2], wl[3]);
+        }
+#pragma unroll
+        for (int o = 4; o > 0; o >>= 1) corr += __shfl_xor(corr, o, 64);
+        if (part == 0) reinterpret_cast<float*>(kimg + 3 * KT * G::KLD)[r] = corr;
+    }
+    for (int i = threadIdx.x; QM == 0 && i < KT * KC; i += 256) {
         const int r = i / KC, c8 = i - r * KC;
         const int sidx = s0 + r;
         unsigned wh[4], wm[4], wl[4];
@@ -499,12 +577,45 @@ __device__ __forceinline__ v16f score_tile_i8(const unsigned char* kimg, const v
     return out;
 }
 
+// Q1K3 S^T tile in units of the query scale: acc[r] = Σ_d c'q[t][d]·K̃[s][d] − zmul·tv[s] (three bf16 products per 16-deep
+// step: the Q plane is exact, K̃ is split three ways)
+template <int D>
+__device__ __forceinline__ v16f score_tile_q1(const unsigned short* kb, const bf16x8 (&qf)[3][Geo<D>::NKK], float zmul, int lane) {
+    using G = Geo<D, 2, false>;
+    v16f acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    const unsigned short* kp = kb + (lane & 31) * G::KLD + 8 * (lane >> 5);
+    constexpr int PL = KT * G::KLD;
+#pragma unroll
+    for (int kk = 0; kk < G::NKK; ++kk) {
+        const bf16x8 kh = *reinterpret_cast<const bf16x8*>(kp + 16 * kk);
+        const bf16x8 km = *reinterpret_cast<const bf16x8*>(kp + PL + 16 * kk);
+        const bf16x8 kl = *reinterpret_cast<const bf16x8*>(kp + 2 * PL + 16 * kk);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qf[0][kk], acc, 0, 0, 0);     // smallest terms first
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(km, qf[0][kk], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qf[0][kk], acc, 0, 0, 0);
+    }
+    const float* tv = reinterpret_cast<const float*>(kb + 3 * PL);
+    const int h32 = lane >> 5;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float4 t4 = *reinterpret_cast<const float4*>(tv + 8 * g + 4 * h32);
+        acc[4 * g + 0] = fmaf(-zmul, t4.x, acc[4 * g + 0]);
+        acc[4 * g + 1] = fmaf(-zmul, t4.y, acc[4 * g + 1]);
+        acc[4 * g + 2] = fmaf(-zmul, t4.z, acc[4 * g + 2]);
+        acc[4 * g + 3] = fmaf(-zmul, t4.w, acc[4 * g + 3]);
+    }
+    return acc;
+}
+
 // NW waves of 32 query rows per block.  NW = 8 (256 rows, one block per CU, two waves per SIMD) where the grid still
 // fills the chip (T >= 2048 at B*H = 16): the K/V tile images are then staged once per 256 rows instead of once per
 // 128 — half the LDS-DMA pieces per wave per tile, the largest non-MFMA cost of the loop.
-template <int D, int NW, bool QI8>
+template <int D, int NW, int QM>
 __global__ __launch_bounds__(64 * NW) void attn3_stats_kernel(AttnParams p) {
-    using G = Geo<D, QI8>;
+    using G = Geo<D, QM>;
+    constexpr bool QI8 = QM == 1;
     constexpr int ST = G::STATS_STAGES, NP = G::K_PIECES, SB = NP * 1024;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds8[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, h32 = lane >> 5;
@@ -523,6 +634,11 @@ __global__ __launch_bounds__(64 * NW) void attn3_stats_kernel(AttnParams p) {
     float4 qt = make_float4(1.0f, 0.0f, 0.0f, 0.0f);
     if constexpr (QI8) load_q_i8<D>(qc, qt, p, (int64_t)(b * p.T + tq) * p.H + hd, h32);
     else load_q<D>(qf, p.q + ((int64_t)(b * p.T + tq) * p.H + hd) * D, h32, p.fq[0], tq);
+    if constexpr (QM == 2) {                              // (query scale, zero-point multiplier) written by the pre-pass
+        const float2 t2 = *reinterpret_cast<const float2*>(p.qtab + ((int64_t)(b * p.T + tq) * p.H + hd) * 2);
+        qt.x = t2.x;
+        qt.y = t2.y;
+    }
     const float sl2 = p.scale * LOG2E * qt.x;            // scores in log2 units: p = 2^(s2 − m)/l  (QI8: δq folded in, > 0)
     float mraw = -INFINITY, l = 0.0f, m2raw = -INFINITY; // running maxima of the UNSCALED scores (scale > 0)
     wait_image<NP, ST - 2, NW>(wid);
@@ -533,6 +649,7 @@ __global__ __launch_bounds__(64 * NW) void attn3_stats_kernel(AttnParams p) {
         const int s0 = i * KT;
         v16f acc;
         if constexpr (QI8) acc = score_tile_i8<D>(lds8 + stage * SB, qc, qt, lane, i == 0 && p.kskip > 0);
+        else if constexpr (QM == 2) acc = score_tile_q1<D>(reinterpret_cast<const unsigned short*>(lds8 + stage * SB), qf, qt.y, lane);
         else acc = score_tile<D>(reinterpret_cast<const unsigned short*>(lds8 + stage * SB), qf, lane);
         const bool edge = (s0 + KT > p.S) || (s0 < p.skip);      // block-uniform: only the first / a partial last tile
         float tmax = -INFINITY, tmax2 = -INFINITY;
@@ -580,9 +697,10 @@ __global__ __launch_bounds__(64 * NW) void attn3_stats_kernel(AttnParams p) {
     }
 }
 
-template <int D, bool UNIFORM, int NW, bool QI8, bool VINT>
+template <int D, bool UNIFORM, int NW, int QM, bool VINT>
 __global__ __launch_bounds__(64 * NW) void attn3_pv_kernel(AttnParams p) {
-    using G = Geo<D, QI8, VINT>;
+    using G = Geo<D, QM, VINT>;
+    constexpr bool QI8 = QM == 1;
     constexpr int ST = G::PV_STAGES, NP = G::IMG_PIECES, SB = G::IMG_BYTES;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds8[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, h32 = lane >> 5;
@@ -599,6 +717,11 @@ __global__ __launch_bounds__(64 * NW) void attn3_pv_kernel(AttnParams p) {
     float4 qt = make_float4(1.0f, 0.0f, 0.0f, 0.0f);
     if constexpr (QI8) load_q_i8<D>(qc, qt, p, (int64_t)(b * p.T + tq) * p.H + hd, h32);
     else load_q<D>(qf, p.q + ((int64_t)(b * p.T + tq) * p.H + hd) * D, h32, p.fq[0], tq);
+    if constexpr (QM == 2) {                              // (query scale, zero-point multiplier) written by the pre-pass
+        const float2 t2 = *reinterpret_cast<const float2*>(p.qtab + ((int64_t)(b * p.T + tq) * p.H + hd) * 2);
+        qt.x = t2.x;
+        qt.y = t2.y;
+    }
     const float m = p.stats[((int64_t)bh * p.T + tq) * 2], l = p.stats[((int64_t)bh * p.T + tq) * 2 + 1];
     const float delta = p.delta[0];
     const float sl2 = p.scale * LOG2E * qt.x;
@@ -628,6 +751,7 @@ __global__ __launch_bounds__(64 * NW) void attn3_pv_kernel(AttnParams p) {
         const unsigned short* vtc = kbc + G::K_ELEMS;
         v16f acc;
         if constexpr (QI8) acc = score_tile_i8<D>(lds8 + stage * SB, qc, qt, lane, i == 0 && p.kskip > 0);
+        else if constexpr (QM == 2) acc = score_tile_q1<D>(kbc, qf, qt.y, lane);
         else acc = score_tile<D>(kbc, qf, lane);
         // interior tiles carry no per-key conditions; only the first tile (bypassed column) and a partial last tile do
         const bool edge = (s0 + KT > p.S) || (s0 < p.skip);      // block-uniform
@@ -727,9 +851,10 @@ __global__ __launch_bounds__(64 * NW) void attn3_pv_kernel(AttnParams p) {
     }
 }
 
-template <int D, bool QI8, bool VINT>
+template <int D, int QM, bool VINT>
 static int launch_attn3(AttnParams p, const void* q_raw, unsigned char* planes, float* qfq, hipStream_t st) {
-    using G = Geo<D, QI8, VINT>;
+    using G = Geo<D, QM, VINT>;
+    constexpr bool QI8 = QM == 1;
     p.planes = planes;
     p.img_bytes = G::IMG_BYTES;
     constexpr int stats_lds = G::STATS_STAGES * G::K_PIECES * 1024;
@@ -740,22 +865,22 @@ static int launch_attn3(AttnParams p, const void* q_raw, unsigned char* planes, 
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= 64 || !attr_set[dev].load(std::memory_order_acquire)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn3_stats_kernel<D, 4, QI8>), hipFuncAttributeMaxDynamicSharedMemorySize, stats_lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn3_pv_kernel<D, true, 4, QI8, VINT>), hipFuncAttributeMaxDynamicSharedMemorySize, pv_lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn3_pv_kernel<D, false, 4, QI8, VINT>), hipFuncAttributeMaxDynamicSharedMemorySize, pv_lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn3_stats_kernel<D, 4, QM>), hipFuncAttributeMaxDynamicSharedMemorySize, stats_lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn3_pv_kernel<D, true, 4, QM, VINT>), hipFuncAttributeMaxDynamicSharedMemorySize, pv_lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn3_pv_kernel<D, false, 4, QM, VINT>), hipFuncAttributeMaxDynamicSharedMemorySize, pv_lds);
         if constexpr (D <= 64) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn3_stats_kernel<D, 8, QI8>), hipFuncAttributeMaxDynamicSharedMemorySize, stats_lds);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn3_pv_kernel<D, true, 8, QI8, VINT>), hipFuncAttributeMaxDynamicSharedMemorySize, pv_lds);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn3_pv_kernel<D, false, 8, QI8, VINT>), hipFuncAttributeMaxDynamicSharedMemorySize, pv_lds);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn3_stats_kernel<D, 8, QM>), hipFuncAttributeMaxDynamicSharedMemorySize, stats_lds);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn3_pv_kernel<D, true, 8, QM, VINT>), hipFuncAttributeMaxDynamicSharedMemorySize, pv_lds);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn3_pv_kernel<D, false, 8, QM, VINT>), hipFuncAttributeMaxDynamicSharedMemorySize, pv_lds);
         }
         if (dev >= 0 && dev < 64) attr_set[dev].store(true, std::memory_order_release);
     }
     // the main kernels read fp32 queries: the caller's tensor when it is fp32 and aqtizer_q is not fused, else a scratch
     // copy (converted / fake-quantised) written by extra blocks of the pre-pass; QI8: int8 codes + per-query table
-    const bool q_copy = QI8 || ((p.fq[0].mode >= 0 || p.io_dtype != DGQ_F32) && qfq != nullptr);
+    const bool q_copy = QM != 0 || ((p.fq[0].mode >= 0 || p.io_dtype != DGQ_F32) && qfq != nullptr);
     const dim3 pgrid(p.NT + (q_copy ? (p.T + 31) / 32 : 0), p.B * p.H);
     float* dreset = p.mode == 1 ? p.delta : nullptr;
-#define DGQ_PREP(TT) hipLaunchKernelGGL((attn3_prep_kernel<D, TT, QI8, VINT>), pgrid, dim3(256), 0, st, (const TT*)p.k, (const TT*)p.v, planes, \
+#define DGQ_PREP(TT) hipLaunchKernelGGL((attn3_prep_kernel<D, TT, QM, VINT>), pgrid, dim3(256), 0, st, (const TT*)p.k, (const TT*)p.v, planes, \
                                         p.B, p.H, p.S, p.NT, p.fq[1], p.fq[2], dreset, (const TT*)q_raw, qfq, p.T, p.fq[0])
     if (p.io_dtype == DGQ_F16) DGQ_PREP(__half);
     else if (p.io_dtype == DGQ_BF16) DGQ_PREP(__hip_bfloat16);
@@ -770,6 +895,10 @@ static int launch_attn3(AttnParams p, const void* q_raw, unsigned char* planes, 
         p.kskip = p.fq[1].skip;
         p.q = nullptr;
         p.fq[0].mode = -1;
+    } else if (QM == 2) {
+        p.q = qfq;                                             // centred codes as fp32
+        p.qtab = qfq + (size_t)p.B * p.T * p.H * D;            // (query scale, zero-point multiplier) per query
+        p.fq[0].mode = -1;
     } else if (q_copy) {
         p.q = qfq;
         p.fq[0].mode = -1;
@@ -782,15 +911,15 @@ static int launch_attn3(AttnParams p, const void* q_raw, unsigned char* planes, 
     if (wide) {
         if constexpr (D <= 64) {
             dim3 grid((p.T + 255) / 256, p.B * p.H), block(512);
-            hipLaunchKernelGGL((attn3_stats_kernel<D, 8, QI8>), grid, block, stats_lds, st, p);
-            if (p.mode == 3) hipLaunchKernelGGL((attn3_pv_kernel<D, true, 8, QI8, VINT>), grid, block, pv_lds, st, p);
-            else hipLaunchKernelGGL((attn3_pv_kernel<D, false, 8, QI8, VINT>), grid, block, pv_lds, st, p);
+            hipLaunchKernelGGL((attn3_stats_kernel<D, 8, QM>), grid, block, stats_lds, st, p);
+            if (p.mode == 3) hipLaunchKernelGGL((attn3_pv_kernel<D, true, 8, QM, VINT>), grid, block, pv_lds, st, p);
+            else hipLaunchKernelGGL((attn3_pv_kernel<D, false, 8, QM, VINT>), grid, block, pv_lds, st, p);
         }
     } else {
         dim3 grid((p.T + 127) / 128, p.B * p.H), block(256);
-        hipLaunchKernelGGL((attn3_stats_kernel<D, 4, QI8>), grid, block, stats_lds, st, p);
-        if (p.mode == 3) hipLaunchKernelGGL((attn3_pv_kernel<D, true, 4, QI8, VINT>), grid, block, pv_lds, st, p);
-        else hipLaunchKernelGGL((attn3_pv_kernel<D, false, 4, QI8, VINT>), grid, block, pv_lds, st, p);
+        hipLaunchKernelGGL((attn3_stats_kernel<D, 4, QM>), grid, block, stats_lds, st, p);
+        if (p.mode == 3) hipLaunchKernelGGL((attn3_pv_kernel<D, true, 4, QM, VINT>), grid, block, pv_lds, st, p);
+        else hipLaunchKernelGGL((attn3_pv_kernel<D, false, 4, QM, VINT>), grid, block, pv_lds, st, p);
     }
     return dgq_launch_status("dgq_attention_f32(bf16x3)");
 }
@@ -798,22 +927,26 @@ static int launch_attn3(AttnParams p, const void* q_raw, unsigned char* planes, 
 // bytes of the int8 query codes + per-query table of the QI8 path (0 when D is not instantiated here)
 size_t dgq_attention_qi8_bytes(int B, int H, int T, int D) {
     const size_t dp32 = (size_t)(D + 31) / 32 * 32;
-    return (size_t)B * T * H * (dp32 + 16);
+    const size_t i8 = (size_t)B * T * H * (dp32 + 16), q1 = (size_t)B * T * H * (D + 2) * sizeof(float);
+    return i8 > q1 ? i8 : q1;
 }
 
 // bytes of the K/V tile images for one call (0 when D is not instantiated here)
 size_t dgq_attention_bf16x3_bytes(int B, int H, int S, int D) {
     const size_t NT = (size_t)(S + KT - 1) / KT;
     size_t img;
+    // the largest image of any operand format (Q1K3 appends a per-key table to the three K planes)
+#define DGQ_IMG(DD) case DD: img = Geo<DD, 2, false>::IMG_BYTES > Geo<DD, 0, false>::IMG_BYTES ? Geo<DD, 2, false>::IMG_BYTES : Geo<DD, 0, false>::IMG_BYTES; break
     switch (D) {
-        case 8: img = Geo<8>::IMG_BYTES; break;
-        case 16: img = Geo<16>::IMG_BYTES; break;
-        case 40: img = Geo<40>::IMG_BYTES; break;
-        case 64: img = Geo<64>::IMG_BYTES; break;
-        case 80: img = Geo<80>::IMG_BYTES; break;
-        case 160: img = Geo<160>::IMG_BYTES; break;
+        DGQ_IMG(8);
+        DGQ_IMG(16);
+        DGQ_IMG(40);
+        DGQ_IMG(64);
+        DGQ_IMG(80);
+        DGQ_IMG(160);
         default: return 0;
     }
+#undef DGQ_IMG
     return (size_t)B * H * NT * img;
 }
 
@@ -841,10 +974,13 @@ int dgq_attention_bf16x3(const void* q, const void* k, const void* v, void* o, i
     const bool i8_off = i8_env != nullptr && i8_env[0] == '0';
     const bool qi8 = !i8_off && qfq != nullptr && p.fq[0].mode >= 0 && p.fq[0].mode <= 1 && p.fq[1].mode >= 0 && p.fq[1].mode <= 1 &&
                      p.fq[0].skip == 0;
+    // any other fused aqtizer_q (a per-head-dim table on q or k, or an unquantised k): one exact plane of centred Q codes
+    // against three K planes — three products instead of six
+    const int qm = qi8 ? 1 : ((!i8_off && qfq != nullptr && p.fq[0].mode >= 0 && p.fq[0].skip == 0) ? 2 : 0);
     // single-plane integer V: aqtizer_v fused and scalar / per-head-dim (its scale is outside the sum over keys)
-    const bool vint = qi8 && (p.fq[2].mode == 0 || p.fq[2].mode == 2);
-#define DGQ_ATTN_CASE(DD) case DD: return !qi8 ? launch_attn3<DD, false, false>(p, q, img, qfq, st) : \
-                                          (vint ? launch_attn3<DD, true, true>(p, q, img, qfq, st) : launch_attn3<DD, true, false>(p, q, img, qfq, st))
+    const bool vint = !i8_off && (p.fq[2].mode == 0 || p.fq[2].mode == 2);
+#define DGQ_ATTN_V(DD, QQ) (vint ? launch_attn3<DD, QQ, true>(p, q, img, qfq, st) : launch_attn3<DD, QQ, false>(p, q, img, qfq, st))
+#define DGQ_ATTN_CASE(DD) case DD: return qm == 1 ? DGQ_ATTN_V(DD, 1) : (qm == 2 ? DGQ_ATTN_V(DD, 2) : DGQ_ATTN_V(DD, 0))
     switch (D) {
         DGQ_ATTN_CASE(8);
         DGQ_ATTN_CASE(16);
@@ -855,4 +991,5 @@ int dgq_attention_bf16x3(const void* q, const void* k, const void* v, void* o, i
         default: return 1;
     }
 #undef DGQ_ATTN_CASE
+#undef DGQ_ATTN_V
 }

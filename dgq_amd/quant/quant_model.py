@@ -45,16 +45,17 @@ class QuantModel(nn.Module):
                           prev_name=None)
         self.quant_block(self.model, wq_params, aq_params, softmax_aq_params)
         from .quant_block import TembGroup, CtxGroup
+        self._epoch = [0]               # one tick per run of the wrapped UNet: scopes the shared-launch caches below
         ctx_layers = [l for m in self.model.modules() if isinstance(m, QuantBasicTransformerBlock)
                       for l in (m.attn2.to_k, m.attn2.to_v) if isinstance(l, QuantLayer)]
         if ctx_layers:
-            cgrp = CtxGroup(ctx_layers)
+            cgrp = CtxGroup(ctx_layers, self._epoch)
             for l in ctx_layers:
                 l.__dict__["_ctx_group"] = cgrp
         temb_layers = [m.time_emb_proj for m in self.model.modules()
                        if isinstance(m, QuantResnetBlock2D) and isinstance(m.time_emb_proj, QuantLayer)]
         if temb_layers:
-            grp = TembGroup(temb_layers)
+            grp = TembGroup(temb_layers, self._epoch)
             for l in temb_layers:
                 l.__dict__["_temb_group"] = grp          # plain attribute: not a submodule, not in the state dict
         self.time_aware = None          # set by load_cali_model(time_aware_aqtizer=True)
@@ -119,7 +120,11 @@ class QuantModel(nn.Module):
         if (self._graphs is not None and torch.is_tensor(sample) and sample.is_cuda and not args
                 and self._graphable_kwargs(kwargs)):
             return self._graph_forward(slot, sample, timesteps, encoder_hidden_states, kwargs)
-        return self.model(sample, timesteps, encoder_hidden_states, *args, **kwargs)
+        return self._run_model(sample, timesteps, encoder_hidden_states, *args, **kwargs)
+
+    def _run_model(self, *args, **kwargs):
+        self._epoch[0] += 1
+        return self.model(*args, **kwargs)
 
     # -- hipGraph replay of a whole denoise step -------------------------------------------------------------------
     def enable_graphs(self, enabled: bool = True):
@@ -162,13 +167,13 @@ class QuantModel(nn.Module):
             from .. import ops
             ops.prepare_side_streams(dev, 2)
             with torch.no_grad():
-                self.model(st["sample"], st["t"], st["ehs"], **kw)          # eager warm-up: lazy inits, caches
+                self._run_model(st["sample"], st["t"], st["ehs"], **kw)     # eager warm-up: lazy inits, caches
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
                 if self._graph_pool is None:
                     self._graph_pool = torch.cuda.graph_pool_handle()
                 with torch.cuda.graph(g, pool=self._graph_pool):
-                    out = self.model(st["sample"], st["t"], st["ehs"], **kw)
+                    out = self._run_model(st["sample"], st["t"], st["ehs"], **kw)
             ent = (g, st, out)
             self._graphs[key] = ent
         g, st, out = ent

@@ -340,7 +340,9 @@ def test_attention_fused_qkv_quantizers_bit_identical(D, T, S, H, mode, dev):
 @pytest.mark.parametrize("D,T,S,H", [(40, 200, 200, 2), (8, 70, 77, 8), (64, 300, 77, 2), (80, 257, 257, 2), (160, 64, 77, 2),
                                      (40, 4096, 4096, 1)])
 @pytest.mark.parametrize("mode,skip,qmode,kmode,vmode,bits", [(1, 1, 1, 1, 2, 8), (1, 0, 0, 1, 1, 8), (3, 0, 0, 0, 0, 6),
-                                                               (2, 1, 1, 0, 2, 6)])
+                                                               (2, 1, 1, 0, 2, 6),
+                                                               # a per-head-dim table on q or k: one exact Q plane x three K planes
+                                                               (1, 1, 2, 1, 2, 8), (1, 0, 1, 2, 0, 8), (3, 0, 2, 2, 1, 6), (2, 1, 2, 0, 2, 6)])
 def test_attention_int8_scores_vs_exact_formula(D, T, S, H, mode, skip, qmode, kmode, vmode, bits, dev):
     """with scalar / per-token aqtizer_q and aqtizer_k, Q·K^T runs as ONE int8 contraction
     (V_MFMA_I32_32X32X32_I8) with the zero-point / scale algebra in the epilogue.  Checked against (a) the attention
