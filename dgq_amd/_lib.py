@@ -36,6 +36,11 @@ SIGNATURES = {
     "dgq_quant_act_batch": [_i, _vp, _vp],
     "dgq_quant_act_variant": [_vp],
     "dgq_gemm_wxa8_batch": [_i, _vp, _vp],
+    "dgq_adaround_soft_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp],
+    "dgq_adaround_soft_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp],
+    "dgq_adaround_reg_blocks": [_i64],
+    "dgq_adaround_reg_fwd": [_vp, _i64, _f, _vp, _vp],
+    "dgq_adaround_reg_bwd": [_vp, _i64, _f, _vp, _vp, _vp],
 }
 
 

@@ -247,7 +247,8 @@ class _Stage(nn.Module):
 
     def __init__(self, res_io, tf_layers, a, sampler=None):
         super().__init__()
-        self.resnets = nn.ModuleList([ResnetBlock2D(i, o, a.get("temb_dim", 1280)) for i, o in res_io])
+        # registration order as the reference's block classes (attentions, resnets, samplers — sd.py:362-376,400-416): the
+        # weight-PTQ driver walks named_children() and reconstructs in that order (calibration.py:113-141)
         if tf_layers:
             n_att = len(res_io) if sampler != "mid" else len(res_io) - 1
             self.attentions = nn.ModuleList(
@@ -255,6 +256,7 @@ class _Stage(nn.Module):
                  for _ in range(n_att)])
         else:
             self.attentions = None
+        self.resnets = nn.ModuleList([ResnetBlock2D(i, o, a.get("temb_dim", 1280)) for i, o in res_io])
         c = res_io[-1][1]
         self.downsamplers = nn.ModuleList([Downsample2D(c)]) if sampler == "down" else None
         self.upsamplers = nn.ModuleList([Upsample2D(c)]) if sampler == "up" else None
@@ -322,7 +324,6 @@ class UNet2DConditionModel(nn.Module):
             skip_ch += [cout, cout] + ([cout] if has_down else [])
             cin = cout
         self.down_blocks = nn.ModuleList(downs)
-        self.mid_block = _Stage([(cin, cin), (cin, cin)], a["mid_layers"], a, "mid")
         ups, prev = [], cin
         for (kind, nl, has_up), cout in zip(a["up"], reversed(bo)):
             io = []
@@ -330,7 +331,8 @@ class UNet2DConditionModel(nn.Module):
                 io.append((prev + skip_ch.pop(), cout))
                 prev = cout
             ups.append(_Stage(io, nl if kind == "xattn" else 0, a, "up" if has_up else None))
-        self.up_blocks = nn.ModuleList(ups)
+        self.up_blocks = nn.ModuleList(ups)                         # registered before mid_block, as sd.py:509-541
+        self.mid_block = _Stage([(cin, cin), (cin, cin)], a["mid_layers"], a, "mid")
         self.conv_norm_out = nn.GroupNorm(32, bo[0], eps=1e-5)
         self.conv_act = nn.SiLU()
         self.conv_out = nn.Conv2d(bo[0], 4, 3, 1, 1)

@@ -34,6 +34,76 @@ def quantize_weight(w: torch.Tensor, delta: torch.Tensor, zp: torch.Tensor, alph
     return codes
 
 
+class _AdaRoundSoft(torch.autograd.Function):
+    """ŵ(α) of the AdaRound soft quantiser (adaptive_rounding.py:39-70, soft_tgt) — dgq_adaround_soft_fwd / _bwd.
+    Only α receives a gradient: it is the only tensor the reconstruction optimiser owns (reconstruction.py:37-41)."""
+
+    @staticmethod
+    def forward(ctx, w2, d, z, alpha2, bits):
+        N, K = w2.shape
+        out = torch.empty_like(w2)
+        _lib_call("dgq_adaround_soft_fwd", _lib.ptr(w2), _lib.ptr(d), _lib.ptr(z), _lib.ptr(alpha2), N, K, bits,
+                  _lib.ptr(out), _lib.stream())
+        ctx.save_for_backward(w2, d, z, alpha2)
+        ctx.bits = bits
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        w2, d, z, alpha2 = ctx.saved_tensors
+        N, K = w2.shape
+        g = gout.contiguous().float()
+        galpha = torch.empty_like(alpha2)
+        _lib_call("dgq_adaround_soft_bwd", _lib.ptr(g), _lib.ptr(w2), _lib.ptr(d), _lib.ptr(z), _lib.ptr(alpha2), N, K,
+                  ctx.bits, _lib.ptr(galpha), _lib.stream())
+        return None, None, None, galpha, None
+
+
+def adaround_soft(w: torch.Tensor, delta: torch.Tensor, zp: torch.Tensor, alpha: torch.Tensor, bits: int):
+    """δ·(clamp(floor(w/δ) + h(α) + z, 0, 2^bits−1) − z) with h the rectified sigmoid; differentiable in α (fp32)."""
+    _lib.require_gpu()
+    N = w.shape[0]
+    w2 = w.detach().reshape(N, -1).contiguous().float()
+    d = delta.detach().reshape(-1).contiguous().float()
+    z = torch.as_tensor(zp).detach().reshape(-1).float().to(w.device)
+    z = (z.expand(N) if z.numel() == 1 else z).contiguous()
+    assert d.numel() == N and z.numel() == N, "weight quantizer must be per output channel"
+    a2 = alpha.reshape(N, -1)
+    if a2.dtype != torch.float32 or not a2.is_contiguous():
+        a2 = a2.float().contiguous()
+    return _AdaRoundSoft.apply(w2, d, z, a2, bits).view(w.shape)
+
+
+class _AdaRoundReg(torch.autograd.Function):
+    """Σ (1 − |2h(α) − 1|^b) (reconstruction_util.py:68-70) — dgq_adaround_reg_fwd / _bwd."""
+
+    @staticmethod
+    def forward(ctx, alpha, b):
+        a = alpha.contiguous()
+        n = a.numel()
+        part = torch.empty((_lib.load().dgq_adaround_reg_blocks(n),), dtype=torch.float32, device=a.device)
+        _lib_call("dgq_adaround_reg_fwd", _lib.ptr(a), n, _c.c_float(b), _lib.ptr(part), _lib.stream())
+        ctx.save_for_backward(a)
+        ctx.b = b
+        return part.sum()
+
+    @staticmethod
+    def backward(ctx, g):
+        (a,) = ctx.saved_tensors
+        gs = g.reshape(1).float().contiguous()
+        galpha = torch.empty_like(a)
+        _lib_call("dgq_adaround_reg_bwd", _lib.ptr(a), a.numel(), _c.c_float(ctx.b), _lib.ptr(gs), _lib.ptr(galpha),
+                  _lib.stream())
+        return galpha.view_as(a), None
+
+
+def adaround_reg(alpha: torch.Tensor, b: float):
+    """The rounding regulariser Σ (1 − |2h(α) − 1|^b) as a 0-d tensor, differentiable in α."""
+    _lib.require_gpu()
+    assert alpha.dtype == torch.float32
+    return _AdaRoundReg.apply(alpha, float(b))
+
+
 def pack_weight(codes: torch.Tensor, kperm: Optional[torch.Tensor], Kp: int, bits: int):
     N, K = codes.shape
     kp = kperm.to(codes.device, torch.int32).contiguous() if kperm is not None else None

@@ -1,7 +1,8 @@
 """AdaRoundQuantizer — weight quantizer with learned rounding; at inference
 ``δ·(clamp(floor(w/δ) + (α≥0) + z, 0, 2^b−1) − z)`` (reference: quant/adaptive_rounding.py:12-90,
-hard mode :51,58-70).  Only the inference (hard) mode exists here; the codes are produced by
-dgq_quantize_weight with the α tensor."""
+hard mode :51,58-70).  Hard (inference) mode: the codes are produced by dgq_quantize_weight with the α tensor.
+Soft mode (``soft_tgt = True``, reconstruction time, adaptive_rounding.py:39-41,55-57): the differentiable
+``floor(w/δ) + h(α)`` through dgq_adaround_soft_fwd / _bwd (``ops.adaround_soft``)."""
 from enum import Enum
 
 import torch
@@ -44,11 +45,19 @@ class AdaRoundQuantizer(nn.Module):
     def init_from(self, x):
         pass
 
+    def get_soft_tgt(self) -> torch.Tensor:
+        """h(α) = clamp(sigmoid(α)·(ζ − γ) + γ, 0, 1) (adaptive_rounding.py:39-40) — inspection / logging; the loop's
+        regulariser evaluates it inside ops.adaround_reg."""
+        return torch.clamp(torch.sigmoid(self.alpha) * (self.zeta - self.gamma) + self.gamma, 0, 1)
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        if self.soft_tgt:
-            raise NotImplementedError("soft targets are reconstruction-time")
         if not x.is_cuda:
             raise RuntimeError("dgq_amd: AdaRoundQuantizer executes on the GPU only (no CPU fallback)")
+        if self.soft_tgt:
+            z = torch.as_tensor(self.zero_point).data.to(x.device)
+            if self.alpha.device != x.device:
+                self.alpha.data = self.alpha.data.to(x.device)
+            return ops.adaround_soft(x, self.delta.data.to(x.device), z, self.alpha, self.bits).to(x.dtype)
         d = self.delta.data.to(x.device)
         z = torch.as_tensor(self.zero_point).data.to(x.device)
         codes = ops.quantize_weight(x.float(), d, z, self.alpha.data.to(x.device), self.bits)

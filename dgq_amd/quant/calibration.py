@@ -1,7 +1,7 @@
 """``load_cali_model`` — the ``cali_ckpt`` reader (reference: quant/calibration.py:208-327; format SURVEY.md §5.4).
 
-Only the loader half of the reference file exists here; the calibration drivers (cali_model*, act_group_quant)
-are the producer side.  Differences in *how* (not what):
+plus ``cali_model`` — the weight-PTQ driver (reference: quant/calibration.py:100-206).  The activation
+producer is calibration_group_quantization.py.  Differences in *how* (not what):
   * weight quantizers are initialised by a vectorised per-channel min/max instead of a dummy forward with a
     python loop over channels (same values, calibration.py:224-225 -> quant_layer.py:253-264);
   * every ``act_<slot>`` table is planned and made device-resident once; the per-call reload of
@@ -164,3 +164,76 @@ def load_cali_model(qnn: QuantModel, init_data: Tuple[torch.Tensor], use_aq: boo
                     del m._placeholder
     qnn._drop_graphs()                               # anything captured before the (re)load is stale
     logger.info("Loading calibration model done.")
+
+
+def recon_targets(model: nn.Module, prev_name: str = "unet", tib_recon: bool = False):
+    """The reconstruction schedule of ``cali_model`` (calibration.py:113-141) as a list of (kind, dotted name, module,
+    keep_gpu): depth-first over ``named_children``; a QuantLayer that is not inside a quant block is reconstructed alone
+    (``'layer'``), a quant block as a unit (``'block'``); targets flagged ``ignore_recon`` are skipped.  ``keep_gpu`` follows
+    the reference's rule: cached tensors stay on the device only under ``down_blocks``."""
+    out = []
+    for name, module in model.named_children():
+        if name == "tib":
+            continue
+        if name == "time_embedding" and tib_recon:
+            raise NotImplementedError("tib_recon (TFMQ time-information block)")
+        keep_gpu = "down_blocks" in prev_name
+        if isinstance(module, QuantLayer):
+            if not module.ignore_recon:
+                out.append(("layer", "%s.%s" % (prev_name, name), module, keep_gpu))
+        elif isinstance(module, BaseQuantBlock):
+            if not module.ignore_recon:
+                out.append(("block", "%s.%s" % (prev_name, name), module, keep_gpu))
+        else:
+            out += recon_targets(module, "%s.%s" % (prev_name, name), tib_recon)
+    return out
+
+
+def cali_model(qnn: QuantModel, w_cali_data: Tuple[torch.Tensor], a_cali_data: Tuple[torch.Tensor] = None, use_aq: bool = False,
+               path: str = None, running_stat: bool = False, interval: int = 128, tib_recon: bool = False, **kwargs) -> dict:
+    """Weight PTQ driver (calibration.py:100-206): (1) weight-quantizer initialisation by one weight-only forward,
+    (2) BRECQ / AdaRound reconstruction of every target in network order — or a resume from ``resume_w`` — and (3) the
+    ``<path>_weight_only`` checkpoint ``{'weight': state_dict}`` that ``load_cali_model`` and the activation producer
+    (calibration_group_quantization.act_group_quant) consume.  Returns the saved dict.
+
+    kwargs as the reference passes them (src/quantize_weight.py:192-207): iters, batch_size, w, asym, warmup, opt_mode,
+    multi_gpu, no_recon, resume_w, plus anything layer_ / block_reconstruction accept.  ``use_aq`` with QDiff-style scalar
+    activation calibration (cali_model_aq of calibration.py:45-97) is not part of the DGQ recipe — activations are
+    calibrated by act_group_quant — and raises."""
+    from .reconstruction import block_reconstruction, layer_reconstruction
+    import os
+    if use_aq:
+        raise NotImplementedError("QDiff scalar activation calibration (calibration.py:45-97); DGQ calibrates activations with "
+                                  "calibration_group_quantization.act_group_quant")
+    if tib_recon:
+        raise NotImplementedError("tib_recon (TFMQ time-information block)")
+    kwargs = dict(kwargs)
+    resume_w = kwargs.pop("resume_w", None)
+    no_recon = kwargs.pop("no_recon", False)
+    logger.info("weight initialization...")
+    dev = qnn.device
+    qnn.set_quant_state(use_wq=True, use_aq=False)
+    with torch.no_grad():
+        qnn(*(x[:min(1, x.shape[0])].to(dev) for x in w_cali_data))      # every wqtizer initialises on its weight
+    qnn.disable_out_quantization()
+    if resume_w:
+        load_cali_model(qnn, init_data=None, use_aq=False, path=resume_w)
+        model_dict = {"weight": torch.load(resume_w, map_location="cpu")["weight"]}
+        return model_dict
+    if not no_recon:
+        for kind, name, module, keep_gpu in recon_targets(qnn, "unet"):
+            logger.info("Reconstruction for %s %s", kind, name)
+            fn = layer_reconstruction if kind == "layer" else block_reconstruction
+            fn(qnn, module, cali_data=w_cali_data, **dict(kwargs, keep_gpu=keep_gpu))
+    qnn.set_quant_state(use_wq=True, use_aq=False)
+    for name, module in qnn.model.named_modules():
+        if "wqtizer" in name and isinstance(module, (UniformAffineQuantizer, AdaRoundQuantizer)):
+            module.zero_point = _as_param(module.zero_point)
+            module.delta = _as_param(module.delta)
+    state = {k: v.detach().cpu().clone() for k, v in qnn.state_dict().items()}
+    model_dict = {"weight": state}
+    if path is not None:
+        os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+        torch.save(model_dict, "%s_weight_only" % path)
+        logger.info("calibrated model saved to %s_weight_only", path)
+    return model_dict

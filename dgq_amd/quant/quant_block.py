@@ -366,7 +366,10 @@ def quant_attention_forward(attn, hidden_states, encoder_hidden_states=None, res
         v = project(attn.to_v, "aqtizer_v", src, 0)
     b, t, c = q.shape
     s = k.shape[1]
-    if (D in ops.ATTN_HEAD_DIMS and q.is_cuda and q.dtype == k.dtype == v.dtype
+    # weight reconstruction (reconstruction.py) differentiates through the block: the fused kernels have no backward, so a
+    # forward that records a graph takes the materialised torch formulation below
+    needs_grad = torch.is_grad_enabled() and (q.requires_grad or k.requires_grad or v.requires_grad)
+    if (D in ops.ATTN_HEAD_DIMS and q.is_cuda and q.dtype == k.dtype == v.dtype and not needs_grad
             and (q.dtype == torch.float32
                  or (q.dtype in ops.FLOAT_DTYPES and use_aq and ops.attention_fuses_fakequant(D, mode_w)))):
         # fused two-pass attention (dgq_attention_f32): probabilities are never materialised

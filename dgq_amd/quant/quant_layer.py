@@ -447,7 +447,16 @@ class QuantLayer(nn.Module):
             raise RuntimeError("dgq_amd.QuantLayer: the quantized path runs only through the HIP kernels on the GPU "
                                "(no CPU fallback); got a %s tensor" % x.device)
         if not quant_act:
-            w = self.dequantized_weight(x.dtype)
+            if getattr(self.wqtizer, "soft_tgt", False):
+                # weight reconstruction in progress (reconstruction.py:37-41): the differentiable soft-rounded weight,
+                # re-evaluated every call like the reference's wqtizer(self.w) (quant_layer.py:642-643)
+                if not self.wqtizer.init:
+                    self.wqtizer.init_from(self.w.data)
+                w = self.wqtizer(self.w)
+                if self.is_conv:
+                    w = w.contiguous(memory_format=torch.channels_last)
+            else:
+                w = self.dequantized_weight(x.dtype)
             b = self.b.to(x.dtype) if self.b is not None else None
             if self.is_conv:
                 return F.conv2d(x, w, b, stride=self.fwd_kwargs["stride"], padding=self.fwd_kwargs["padding"])
@@ -488,7 +497,7 @@ class QuantLayer(nn.Module):
             elif pre_act == 2:
                 a, g = x.chunk(2, dim=-1)
                 x = a * F.gelu(g)
-            y = self.forward(x)
+            y = self(x)                                           # through __call__: forward hooks (data_utill.py) see it
             if fq is not None:
                 mode, dd, zz, T, D, skip, bits = fq
                 y = y.contiguous()
@@ -521,7 +530,7 @@ class QuantLayer(nn.Module):
             return _tap(self, ops.quant_conv2d(x, self._binding(), kh, kw, self.fwd_kwargs["stride"][0],
                                                self.fwd_kwargs["padding"][0], residual=residual),
                         x=x, prologue=False, residual=residual)
-        return self.forward(x) + residual
+        return self(x) + residual
 
     # -- state switches (quant_layer.py:663-686) -----------------------------------------------------------
     def set_quant_state(self, use_wq: bool = False, use_aq: bool = False) -> None:

@@ -253,6 +253,22 @@ int dgq_minmax_rows_cols(const void* x, int dtype, int rows, int C, int64_t ldx,
                          float* rowmin, float* rowmax, float* colmin, float* colmax,
                          float* partial_ws, int slices, void* stream);
 
+/* ---- weight PTQ: AdaRound soft quantiser + rounding regulariser -------------------------
+ * The elementwise device ops of the reconstruction loop (reference: quant/adaptive_rounding.py:39-70 with soft_tgt,
+ * quant/reconstruction_util.py:68-70), forward and backward; w, alpha, out, gout, galpha are [N][K] fp32 (K = the
+ * flattened C·kh·kw), delta / zp [N] per output channel.
+ *   soft_fwd : out = δ·(clamp(floor(w/δ) + h(α) + z, 0, 2^bits − 1) − z),  h(α) = clamp(sigmoid(α)·1.2 − 0.1, 0, 1)
+ *   soft_bwd : galpha = gout · ∂out/∂α  (the clamps pass the gradient on their closed intervals, as torch.clamp)
+ *   reg_fwd  : partial[blk] = Σ_blk (1 − |2h(α) − 1|^b); blk < dgq_adaround_reg_blocks(numel); the caller adds them up
+ *   reg_bwd  : galpha = g[0] · ∂/∂α Σ (1 − |2h(α) − 1|^b); g is a 1-element device tensor (no host sync) */
+int dgq_adaround_soft_fwd(const float* w, const float* delta, const float* zp, const float* alpha, int N, int K, int bits,
+                          float* out, void* stream);
+int dgq_adaround_soft_bwd(const float* gout, const float* w, const float* delta, const float* zp, const float* alpha, int N,
+                          int K, int bits, float* galpha, void* stream);
+int dgq_adaround_reg_blocks(int64_t numel);
+int dgq_adaround_reg_fwd(const float* alpha, int64_t numel, float b, float* partial, void* stream);
+int dgq_adaround_reg_bwd(const float* alpha, int64_t numel, float b, const float* g, float* galpha, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -73,6 +73,24 @@ def adaround_hard(w, delta, zero_point, alpha, bits):
     return delta * (q - zero_point)
 
 
+def adaround_soft_target(alpha, zeta=1.1, gamma=-0.1):
+    """h(α) = clamp(sigmoid(α)·(ζ − γ) + γ, 0, 1) — quant/adaptive_rounding.py:39-40 (get_soft_tgt)."""
+    return torch.clamp(torch.sigmoid(alpha) * (zeta - gamma) + gamma, 0, 1)
+
+
+def adaround_soft(w, delta, zero_point, alpha, bits):
+    """AdaRoundQuantizer.forward with soft_tgt = True — quant/adaptive_rounding.py:50-57,66-70; differentiable in alpha
+    through torch autograd (the checker of dgq_adaround_soft_fwd / _bwd)."""
+    x_int = torch.floor(w / delta) + adaround_soft_target(alpha)
+    x_q = torch.clamp(x_int + zero_point, 0, 2 ** bits - 1)
+    return delta * (x_q - zero_point)
+
+
+def adaround_round_loss(alpha, b):
+    """Σ (1 − |2h(α) − 1|^b) — quant/reconstruction_util.py:68-70 (the caller multiplies by the loss weight)."""
+    return (1 - ((adaround_soft_target(alpha) - .5).abs() * 2).pow(b)).sum()
+
+
 def log_quant(x, delta, bits):
     """T2ILogQuantizer.forward body (quant_layer_text.py:101-105):
     δ·2^(−clamp(rne(−log2(x/δ)), 0, 2^b−1)); log2(0) = −inf → code clamps to 2^b−1."""

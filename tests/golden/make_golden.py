@@ -3,6 +3,7 @@
 
     python tests/golden/make_golden.py small            # F2 quantizers, F3 layers, F4 blocks  (seconds)
     python tests/golden/make_golden.py schema           # F1 ckpt schema + F6 loader side effects
+    python tests/golden/make_golden.py calib | recon    # F8 DGQ activation calibration, F9 weight PTQ (mini model)
     python tests/golden/make_golden.py unet c1|c2|c3    # F5 full SD UNet, 64x64 latents (minutes each)
     python tests/golden/make_golden.py ddim [steps]     # F5 N-step DDIM final latent (tens of minutes)
     DIFFUSERS_REWRITE=sdxl python tests/golden/make_golden.py unet xl   # SDXL (separate process)
@@ -431,6 +432,116 @@ def make_calib(ref):
     save("f8_calibration_mini.pt", dict(meta=dict(c, sklearn=sklearn.__version__), act=act, ranges=ranges))
 
 
+# --------------------------------------------------------------------------------------- weight PTQ (f4)
+RECON = dict(wbits=4, n=8, res=16, ts=(901, 301), iters=8, batch_size=4, w=0.01, warmup=0.2, seed=1234,
+             full_alpha=("model.conv_in", "model.time_embedding.linear_1", "model.down_blocks.0.attentions.0.proj_in",
+                         "model.down_blocks.0.resnets.0.conv1",
+                         "model.down_blocks.0.attentions.0.transformer_blocks.0.attn1.to_q"))
+
+
+def recon_data():
+    c = RECON
+    xs = synth.named_randn("recon_x", (c["n"], 4, c["res"], c["res"]), 5)
+    ts = torch.tensor([c["ts"][i * len(c["ts"]) // c["n"]] for i in range(c["n"])], dtype=torch.int64)
+    ctx = synth.named_randn("recon_ctx", (c["n"], 77, 768), 6)
+    return xs, ts, ctx
+
+
+def make_recon(ref):
+    """F9: the reference's weight PTQ (quant/calibration.py:100-206 cali_model -> quant/reconstruction.py layer_ /
+    block_reconstruction, AdaRound soft targets, LossFunc) on the mini model: target order, per-target loss trajectories,
+    per-layer rounding decisions (packed signs of α) and α moments, full α of a few layers, the saved ckpt's schema; and
+    known-answer vectors of the soft quantiser / regulariser with their autograd gradients."""
+    import contextlib, io
+    import numpy as np
+    import quant.reconstruction as rec
+    import quant.reconstruction_util as ru
+    c = RECON
+    torch.set_grad_enabled(True)
+    # --- known-answer vectors: AdaRoundQuantizer soft forward + regulariser, values and gradients
+    kat = {}
+    for name, (N, K, bits) in dict(a=(6, 40, 4), b=(5, 33, 8)).items():
+        w = torch.randn(N, K, generator=g(91)) * 0.3
+        uq = ref.ql.UniformAffineQuantizer(bits=bits, channel_wise=True, scaler=ref.ql.Scaler.MINMAX)
+        uq(w)
+        q = ref.ar.AdaRoundQuantizer(uaqtizer=uq, rmode=ref.ar.RMODE.LEARNED_HARD_SIGMOID, w=w)
+        q.soft_tgt = True
+        with torch.no_grad():
+            q.alpha.add_(torch.randn(N, K, generator=g(92)) * 3.0)        # spread α over both clamp regions of h
+            q.alpha[0, :4] = torch.tensor([0.0, 30.0, -30.0, 1e-3])
+        gout = torch.randn(N, K, generator=g(93))
+        out = q(w)
+        (out * gout).sum().backward()
+        ga = q.alpha.grad.clone()
+        regs = {}
+        for b in (20.0, 7.3, 2.0):
+            q.alpha.grad = None
+            r = (1 - ((q.get_soft_tgt() - .5).abs() * 2).pow(b)).sum()
+            (0.01 * r).backward()
+            regs[b] = dict(value=r.detach().clone(), galpha=q.alpha.grad.clone())
+        kat[name] = dict(w=w, delta=q.delta.detach().clone(), zero_point=torch.as_tensor(q.zero_point).detach().clone(), bits=bits,
+                         alpha=q.alpha.detach().clone(), gout=gout, out=out.detach().clone(), galpha=ga,
+                         soft_tgt=q.get_soft_tgt().detach().clone(), reg=regs)
+    sched = {}
+    for iters, warm in ((8, 0.2), (20000, 0.2), (100, 0.0)):
+        lf = ru.LinearTempDecay(t_max=iters, rel_start_decay=warm, start_b=20, end_b=2)
+        pts = sorted(set([1, 2, max(1, int(iters * warm)), int(iters * warm) + 1, iters // 2, iters - 1, iters]))
+        sched[(iters, warm)] = [(t, float(lf(t))) for t in pts]
+    # --- the driver on the mini model
+    torch.set_grad_enabled(False)
+    unet = build_ref_mini(ref)
+    wq = {"bits": c["wbits"], "channel_wise": True, "scaler": ref.ql.Scaler.MINMAX, "leaf_param": False}
+    aq = {"bits": 8, "channel_wise": False, "scaler": ref.ql.Scaler.MINMAX, "leaf_param": False}
+    sm = {"softmax_a_bit": 8, "t2i_log_quant": True, "t2i_real_time": True, "t2i_start_peak": True, "log_max_1": False}
+    with contextlib.redirect_stdout(io.StringIO()):
+        qnn = ref.qm.QuantModel(model=unet, wq_params=wq, aq_params=aq, softmax_aq_params=sm,
+                                aq_mode=[ref.ql.QMODE.NORMAL.value, ref.ql.QMODE.QDIFF.value], tib_recon=False).eval()
+    names = {id(m): n for n, m in qnn.named_modules()}
+    order, traj = [], {}
+    orig_layer, orig_block, orig_call = rec.layer_reconstruction, rec.block_reconstruction, ru.LossFunc.__call__
+
+    def spy_call(self, pred, tgt, grad=None):
+        total = orig_call(self, pred, tgt, grad)
+        rec_l = float(ref.ql.lp_loss(pred, tgt, p=self.p))
+        traj.setdefault(names[id(self.o)], []).append((self.count, float(total), rec_l, float(total) - rec_l,
+                                                        float(self.temp_decay(self.count))))
+        return total
+    ru.LossFunc.__call__ = spy_call
+
+    def wrap(kind, fn):
+        def f(model, target, cali_data, **kw):
+            order.append((kind, names[id(target)], bool(kw.get("keep_gpu"))))
+            with torch.enable_grad():
+                return fn(model, target, cali_data=cali_data, **kw)
+        return f
+    ref.cal.layer_reconstruction = wrap("layer", orig_layer)
+    ref.cal.block_reconstruction = wrap("block", orig_block)
+    torch.manual_seed(c["seed"])
+    path = "/tmp/golden_recon/cali_ckpt.pth"
+    t0 = time.time()
+    with contextlib.redirect_stdout(io.StringIO()):
+        ref.cal.cali_model(qnn, w_cali_data=recon_data(), a_cali_data=None, use_aq=False, path=path, running_stat=False,
+                           interval=c["n"], tib_recon=False, iters=c["iters"], batch_size=c["batch_size"], w=c["w"], asym=True,
+                           warmup=c["warmup"], opt_mode=ru.RLOSS.MSE, multi_gpu=False, no_recon=False, resume_w=None)
+    ru.LossFunc.__call__ = orig_call
+    ref.cal.layer_reconstruction, ref.cal.block_reconstruction = orig_layer, orig_block
+    ck = torch.load(path + "_weight_only")["weight"]
+    layers = {}
+    for k, v in ck.items():
+        if k.endswith(".wqtizer.alpha"):
+            name = k[:-len(".wqtizer.alpha")]
+            a = v.float()
+            layers[name] = dict(shape=tuple(a.shape), up=torch.from_numpy(np.packbits((a >= 0).numpy().reshape(-1))),
+                                n_up=int((a >= 0).sum()), sum=float(a.double().sum()), abs_sum=float(a.double().abs().sum()),
+                                delta=ck[name + ".wqtizer.delta"].clone(), zero_point=ck[name + ".wqtizer.zero_point"].clone())
+            if name in c["full_alpha"]:
+                layers[name]["alpha"] = a.clone()
+    schema = {k: (tuple(v.shape), str(v.dtype)) for k, v in ck.items()}
+    print("targets: %d (%d blocks), alpha layers: %d, ckpt keys: %d, %.0f s" % (
+        len(order), sum(1 for o in order if o[0] == "block"), len(layers), len(schema), time.time() - t0))
+    save("f9_weight_ptq_mini.pt", dict(meta=c, kat=kat, sched=sched, order=order, traj=traj, layers=layers, schema=schema))
+
+
 # --------------------------------------------------------------------------------------- scheduler (f3)
 def load_vendored_pndm():
     """The reference's vendored diffusers 0.26.0 does not import as a package here; its
@@ -522,6 +633,8 @@ if __name__ == "__main__":
         make_unet(ref, arch, sys.argv[2], res=res)
     elif what == "calib":
         make_calib(ref)
+    elif what == "recon":
+        make_recon(ref)
     elif what == "ddim":
         make_ddim(ref, int(sys.argv[2]) if len(sys.argv) > 2 else 50,
                   int(sys.argv[3]) if len(sys.argv) > 3 else 64)
