@@ -41,6 +41,8 @@ SIGNATURES = {
     "dgq_adaround_reg_blocks": [_i64],
     "dgq_adaround_reg_fwd": [_vp, _i64, _f, _vp, _vp],
     "dgq_adaround_reg_bwd": [_vp, _i64, _f, _vp, _vp, _vp],
+    "dgq_linear_fused_batch": [_i, _vp, _vp],
+    "dgq_linear_fused_supported": [_i, _i, _i, _i, _i, _i],
 }
 
 
@@ -71,6 +73,16 @@ class GemmArgs(ctypes.Structure):
                 ("N", _i), ("per_m", _i), ("cdelta", _vp), ("cflush", _vp), ("mdelta", _vp), ("mzp", _vp), ("L", _i),
                 ("offset", _f), ("alpha", _vp), ("zw", _vp), ("gamma", _vp), ("vn", _vp), ("y", _vp), ("y_dtype", _i), ("ldy", _i),
                 ("extra", _vp)]
+
+
+class FusedLinearArgs(ctypes.Structure):
+    """dgq_fused_linear_args_t of include/dgq_hip.h"""
+    _fields_ = [("x", _vp), ("x_dtype", _i), ("M", _i), ("C", _i), ("hw", _i),
+                ("kdst", _vp), ("Kp", _i), ("per_m", _i), ("delta", _vp), ("zp", _vp), ("L", _i), ("a_bits", _i),
+                ("pre_scale", _vp), ("pre_shift", _vp), ("pre_act", _i), ("ln_gamma", _vp), ("ln_beta", _vp), ("ln_eps", _f),
+                ("wpacked", _vp), ("w_bits", _i), ("N", _i), ("cflush", _vp),
+                ("alpha", _vp), ("zw", _vp), ("gamma", _vp), ("vn", _vp),
+                ("y", _vp), ("y_dtype", _i), ("ldy", _i), ("extra", _vp)]
 
 
 class AttnFq(ctypes.Structure):

@@ -28,6 +28,7 @@
 #include <cstdlib>
 #include <type_traits>
 #include "dgq_common.h"
+#include "gemm_device.h"
 
 #define BK 128
 
@@ -63,41 +64,6 @@ struct GemmBatch {
     int n;                 // 1: p[0], blockIdx.z = K split;  > 1: blockIdx.z = problem, no split
 };
 
-typedef __attribute__((address_space(1))) const void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
-
-// LDS-DMA of 16 B per lane: LDS[lds_addr + lane*16] <- *gsrc.  Issued from inline asm on purpose: with the builtin
-// hipcc treats the DMA as an LDS store that every later ds_read may alias and drains it with s_waitcnt vmcnt(0)
-// before the first ds_read of each K step; here the ring is ordered by hand (counted vmcnt + barrier below).
-// M0 carries the wave-uniform LDS base: it is passed as an INPUT OPERAND bound to the physical register ("{m0}"), so
-// hipcc emits the s_mov_b32 m0 itself and tracks the register like any other (defined behaviour; the round-1 form wrote
-// M0 inside the asm and listed it as a clobber, which clang rejects as a reserved register and does not honour).  The
-// s_nop covers the M0-write -> LDS-DMA wait state, which the hazard recogniser does not see inside an asm statement.
-// Measured on 8192^3: each DMA piece costs ~4.5 % of the loop (skipping the two weight pieces of the six per wave per K
-// tile: 521 -> 474 us) — the largest non-MFMA cost, ~100 cycles per piece against 512 cycles of MFMA per wave per K tile.
-__device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_addr) {
-    asm volatile("s_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc), "{m0}"(lds_addr) : "memory");
-}
-
-// y -> [aqtizer_{q,k,v}(y)] -> [+ residual]; element (m, n) of the output
-__device__ __forceinline__ float dgq_extra(const dgq_gemm_extra_t& ex, float y, int m, int n) {
-    if (ex.fq_mode) {                                   // quant_layer.py:295-299 on the projection output (sd.py:174-182,199)
-        const int t = m % ex.fq_T;
-        if (t >= ex.fq_skip) {
-            const int idx = ex.fq_mode == 1 ? 0 : (ex.fq_mode == 2 ? t - ex.fq_skip : n % ex.fq_D);
-            const float d = ex.fq_delta[idx], z = ex.fq_zp[idx];
-            y = d * (dgq_affine_code(y, d, z, ex.fq_qmax) - z);
-        }
-    }
-    if (ex.residual) {
-        const int64_t i = (int64_t)(m / ex.res_div) * ex.ldr + n;
-        if (ex.res_dtype == DGQ_F16) y += __half2float(reinterpret_cast<const __half*>(ex.residual)[i]);
-        else if (ex.res_dtype == DGQ_BF16) y += __bfloat162float(reinterpret_cast<const __hip_bfloat16*>(ex.residual)[i]);
-        else y += reinterpret_cast<const float*>(ex.residual)[i];
-    }
-    return y;
-}
-
 template <bool PER_M>
 __device__ __forceinline__ float dgq_epilogue(const GemmParams& p, float acc, int m, int n, float al, float zw, float ga,
                                               float vn) {
@@ -117,11 +83,12 @@ __device__ __forceinline__ float dgq_epilogue(const GemmParams& p, float acc, in
 // the longer ring does.
 constexpr int gemm_stage_bytes(int wbits, int bm, int bn) { return bm * BK + bn * (wbits == 4 ? BK / 2 : BK); }
 constexpr int gemm_stages(int wbits, int bm, int bn) { return 3; }
-// blocks per CU the LDS ring of a tile shape allows (ring + tables), capped at 4: the register budget follows from it
+// blocks per CU the LDS ring of a tile shape allows (ring + tables), capped at 5 (32x64: 1280 slots = the whole
+// 8192 x 320 grid in one round): the register budget follows from it
 constexpr int gemm_occupancy(int wbits, int bm, int bn) {
     const int per_block = gemm_stages(wbits, bm, bn) * gemm_stage_bytes(wbits, bm, bn) + 6 * 1024;
     const int o = (160 * 1024) / per_block;
-    return o > 4 ? 4 : (o < 1 ? 1 : o);
+    return o > 5 ? 5 : (o < 1 ? 1 : o);
 }
 
 template <int WBITS, bool PER_M, typename TOut, int BM, int BN>
@@ -321,7 +288,7 @@ __global__ __launch_bounds__(256, gemm_occupancy(WBITS, BM, BN)) void gemm_wxa8_
 #pragma unroll
                     for (int j = 0; j < TN; ++j) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) accf[i][j][r] += sc * (float)acc[i][j][r];
+                        for (int r = 0; r < 4; ++r) accf[i][j][r] = __builtin_fmaf(sc, (float)acc[i][j][r], accf[i][j][r]);
                         acc[i][j] = (v4i){0, 0, 0, 0};
                     }
             }
@@ -597,7 +564,8 @@ static GemmPlan plan_gemm(int M, int N, int Kp, int w_bits, size_t ws_bytes, boo
         pl = {64, 128, 1, 0.0};
     } else if (nk > 60) {
         if (M <= 160) pl = {32, 64, 1, 0.0};
-        else if (N >= 1280) pl = {128, 64, 1, 0.0};
+        else if (N >= 1280) pl = (M >= 2048) ? GemmPlan{64, 64, 1, 0.0} : GemmPlan{128, 64, 1, 0.0};   // 2048x1280x11520: 57 -> 49 us
+        else if (M >= 4096 && N % 128 != 0) pl = {64, 64, 1, 0.0};        // N = 320: 128-wide tiles compute 384 columns
         else pl = {64, 128, 1, 0.0};
         const long grid = (long)((M + pl.bm - 1) / pl.bm) * ((N + pl.bn - 1) / pl.bn);
         if (grid < 256) {
@@ -608,9 +576,7 @@ static GemmPlan plan_gemm(int M, int N, int Kp, int w_bits, size_t ws_bytes, boo
             pl.splits = s < 1 ? 1 : s;
         }
     } else if (M >= 4096 && nk >= 24) {
-        pl = {32, 128, 1, 0.0};
-    } else if (per_m && nk >= 40) {
-        pl = {64, 64, 1, 0.0};
+        pl = (N % 128 != 0) ? GemmPlan{64, 64, 1, 0.0} : GemmPlan{32, 128, 1, 0.0};   // 8192x320x2880: 28 -> 25 us at 64x64
     }
     if (w_bits != 4) {                                   // W8 carries three tile shapes: nearest one
         if (pl.bm == 128 || pl.bn == 128) { pl.bm = 128; pl.bn = 128; }

@@ -3,6 +3,7 @@
 // kp (one packed dword) per lane per 256-wide step; rounding bit-identical to fp32 true division (see below).
 #include <algorithm>
 #include <atomic>
+#include <cstdlib>
 #include "dgq_common.h"
 
 struct QuantActParams {
@@ -445,6 +446,8 @@ __global__ __launch_bounds__(256) void quant_act_scatter_kernel(QuantActBatch bt
         const float* pre_sc = p.pre_scale ? p.pre_scale + (int64_t)b * p.C : nullptr;
         const float* pre_sh = p.pre_shift ? p.pre_shift + (int64_t)b * p.C : nullptr;
         const int taps = p.kh * p.kw;
+        float ln_mu = 0.0f, ln_rstd = 1.0f;                 // Linear inputs (taps == 1, one wave per row): LayerNorm over the row
+        if (p.ln_gamma) row_layernorm_stats<TIn>(img + (int64_t)(hbase * p.W + wbase) * p.ldc, p.C, p.ln_eps, lane, ln_mu, ln_rstd);
         for (int tap = wsub; tap < taps; tap += WPR) {
             const int dh = tap / p.kw, dw = tap - dh * p.kw;
             const int hi = hbase + dh, wi = wbase + dw;
@@ -460,9 +463,20 @@ __global__ __launch_bounds__(256) void quant_act_scatter_kernel(QuantActBatch bt
                         const float4 sh = *reinterpret_cast<const float4*>(pre_sh + c);
                         v[0] = v[0] * sc.x + sh.x; v[1] = v[1] * sc.y + sh.y; v[2] = v[2] * sc.z + sh.z; v[3] = v[3] * sc.w + sh.w;
                     }
+                    if (p.ln_gamma) {
+                        const float4 ga = *reinterpret_cast<const float4*>(p.ln_gamma + c);
+                        const float4 be = *reinterpret_cast<const float4*>(p.ln_beta + c);
+                        v[0] = (v[0] - ln_mu) * ln_rstd * ga.x + be.x; v[1] = (v[1] - ln_mu) * ln_rstd * ga.y + be.y;
+                        v[2] = (v[2] - ln_mu) * ln_rstd * ga.z + be.z; v[3] = (v[3] - ln_mu) * ln_rstd * ga.w + be.w;
+                    }
                     if (p.pre_act == 1) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) v[j] = dgq_silu(v[j]);
+                    } else if (p.pre_act == 2) {
+                        float g[4];
+                        load4<TIn>(src + p.C + c, g);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = v[j] * (0.5f * g[j] * (1.0f + erff(g[j] * 0.70710678118654752f)));
                     }
                 }
                 const int4 d4 = *reinterpret_cast<const int4*>(kd + c);
@@ -500,6 +514,17 @@ static int quant_act_variant(const QuantActParams& p, bool table) {
     // Linear inputs (one tap: the strip is the row itself, <= 16 KB) are always staged — the global gather pays one L1
     // access per code (8192 x 320 -> Kp 1024: 20 us) — together with their LayerNorm / GEGLU prologue.
     const int taps_ = p.kh * p.kw;
+    // per-K Linear inputs whose groups are short (K = 320 with 16 groups: Kp = 1024, 69 % padding): the staged gather
+    // evaluates the quantiser for every PACKED position, padding included; the scatter path evaluates it once per SOURCE
+    // element (K instead of Kp codes, 16-byte coalesced reads with the LayerNorm / GEGLU prologue applied on the way) and
+    // drops the byte into the row image in LDS.  One wave per row (RPB = 4).  DGQ_QA_LINEAR_SCATTER = 0 off, 2 always.
+    {
+        static const int mode = [] { const char* e = getenv("DGQ_QA_LINEAR_SCATTER"); return e && *e ? atoi(e) : 1; }();
+        const size_t tab_b = (((size_t)3 * (p.Kp >> 6) + 4) * 4 + 15) & ~(size_t)15;
+        if (mode && table && p.kdst && taps_ == 1 && p.C % 4 == 0 && ks == 1 && (!p.ln_gamma || p.C <= DGQ_LN_MAX_C) &&
+            tab_b + 4 * (size_t)p.Kp <= 150 * 1024 && (mode == 2 || 4 * p.Kp >= 5 * p.K))
+            return 3;
+    }
     const bool stage_conv = taps_ > 1 && p.pre_act != 2 && !p.ln_gamma && ks == 1;
     const bool stage_lin = taps_ == 1 && (!p.ln_gamma || p.C <= DGQ_LN_MAX_C);
     if (table && p.klds && p.C % 4 == 0 && strip_bytes <= 16 * 1024 && (stage_conv || stage_lin)) return 0;

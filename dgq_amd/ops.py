@@ -296,7 +296,7 @@ def quant_act(x_cl: torch.Tensor, B, H, W, C, kh, kw, stride, pad, ab: ActBindin
     a = _lib.QuantActArgs()
     a.x, a.x_dtype, a.B, a.H, a.W, a.C, a.kh, a.kw, a.stride, a.pad = x_cl.data_ptr(), _lib.DTYPE_CODE[x_cl.dtype], B, H, W, C, kh, kw, stride, pad
     a.ksrc, a.koff, a.klds = _dp(ab.ksrc), _dp(ab.koff(W, ldc)), _dp(ab.klds(kw, C))
-    a.kdst = _dp(ab.kdst(kw, C, kh * kw)) if (ab.ksrc is not None and kh * kw > 1) else None
+    a.kdst = _dp(ab.kdst(kw, C, kh * kw)) if ab.ksrc is not None else None
     a.Kp, a.per_m = ab.Kp, per_m
     a.delta, a.zp = (ab.cdelta.data_ptr(), ab.czp.data_ptr()) if not per_m else (ab.mdelta.data_ptr(), ab.mzp.data_ptr())
     a.L, a.bits = (1 if not per_m else ab.L), ab.abits
@@ -305,7 +305,8 @@ def quant_act(x_cl: torch.Tensor, B, H, W, C, kh, kw, stride, pad, ab: ActBindin
     a.pre_act = pre[2] if pre else 0
     lnp = (as_f32(ln[0]), as_f32(ln[1]), float(ln[2])) if ln else None
     a.ln_gamma, a.ln_beta, a.ln_eps = (lnp[0].data_ptr(), lnp[1].data_ptr(), lnp[2]) if lnp else (None, None, 0.0)
-    # the LDS-scatter path (per-K convs) takes the whole row in one wave / block: ask for it with one K split first
+    # the LDS-scatter path (per-K convs, per-K Linear inputs with short groups) takes the whole row in one wave / block:
+    # ask for it with one K split first
     parts = 1
     a.ksplits = 1
     a.codes = a.rowsum = 1                                   # placeholders: dgq_quant_act_variant only validates non-NULL
@@ -458,6 +459,71 @@ def gemm_wxa8(codes, rowsum, M, ab: ActBinding, out_dtype, out: Optional[torch.T
     return out
 
 
+#: Linear / 1x1-conv layers through dgq_linear_fused_batch (quantise-on-load inside the GEMM: one launch per layer, no int8
+#: operand in HBM).  OPT-IN (measured: no gain on the SD step).  DGQ_FUSED_LINEAR: 0 (default) = never, 1 = only the shape class where it measured faster than
+#: dgq_quant_act + dgq_gemm_wxa8 on MI355X (tools/bench_fused.py, profiles/r02_fused_linear_microbench.txt: per-M / scalar
+#: tables with C <= 320 and N <= 640 on >= 4096 rows: 15.8 vs 20.2 us; per-K 30.3 vs 27.2, wide N and C >= 640 2-4x SLOWER —
+#: a workgroup per 32-row panel leaves 4 waves per CU, so its two latency chains run unhidden), 2 = every supported shape.
+FUSED_LINEAR = int(os.environ.get("DGQ_FUSED_LINEAR", "0"))
+#: rows below which the two-kernel path is kept under mode 2 (few row panels: every column split re-quantises the panel)
+FUSED_MIN_M = int(os.environ.get("DGQ_FUSED_MIN_M", "1024"))
+
+
+def fused_linear_ok(M, C, ab: ActBinding):
+    if not FUSED_LINEAR or ab.pw.taps != 1 or ab.pw.K != C:
+        return False
+    if FUSED_LINEAR == 1 and not (ab.mode != "perK" and C <= 320 and ab.pw.N <= 640 and M >= 4096):
+        return False
+    return bool(M >= FUSED_MIN_M and
+                _lib.load().dgq_linear_fused_supported(M, C, ab.Kp, ab.pw.N, 0 if ab.mode == "perK" else 1, ab.pw.bits))
+
+
+def _fused_args(x2, M, C, hw, ab: ActBinding, out, pre, ln, extra):
+    """dgq_fused_linear_args_t for one layer; `pre` = (scale, shift, act) as quant_act, `ln` = (gamma, beta, eps) fp32"""
+    pw = ab.pw
+    per_m = 0 if ab.mode == "perK" else 1
+    a = _lib.FusedLinearArgs()
+    a.x, a.x_dtype, a.M, a.C, a.hw = x2.data_ptr(), _lib.DTYPE_CODE[x2.dtype], M, C, hw
+    a.kdst = _dp(ab.kdst(1, C, 1)) if not per_m else None
+    a.Kp, a.per_m = ab.Kp, per_m
+    a.delta, a.zp = (ab.cdelta.data_ptr(), ab.czp.data_ptr()) if not per_m else (ab.mdelta.data_ptr(), ab.mzp.data_ptr())
+    a.L, a.a_bits = (1 if not per_m else ab.L), ab.abits
+    a.pre_scale = _dp(pre[0]) if pre and pre[0] is not None else None
+    a.pre_shift = _dp(pre[1]) if pre and pre[1] is not None else None
+    a.pre_act = pre[2] if pre else 0
+    a.ln_gamma, a.ln_beta, a.ln_eps = (ln[0].data_ptr(), ln[1].data_ptr(), ln[2]) if ln else (None, None, 0.0)
+    a.wpacked, a.w_bits, a.N = ab.wpacked.data_ptr(), pw.bits, pw.N
+    a.cflush = ab.cflush.data_ptr() if not per_m else None
+    a.alpha, a.zw, a.gamma, a.vn = pw.alpha.data_ptr(), pw.zw.data_ptr(), ab.gamma.data_ptr(), (ab.vn.data_ptr() if per_m else None)
+    a.y, a.y_dtype, a.ldy = out.data_ptr(), _lib.DTYPE_CODE[out.dtype], out.stride(0)
+    a.extra = _c.cast(_c.pointer(extra), _c.c_void_p) if extra is not None else None
+    return a
+
+
+def linear_fused(x2: torch.Tensor, M, C, hw, bindings, pre=None, ln=None, extras=None):
+    """[y_i] = the layers `bindings` applied to the rows of x2 ([M][C], or [M][2C] with the GEGLU prologue) — up to 4 layers
+    that share x2 per launch (dgq_linear_fused_batch); per layer an optional dgq_gemm_extra_t (residual / fused quantizer)."""
+    lnp = (as_f32(ln[0]), as_f32(ln[1]), float(ln[2])) if ln else None
+    outs = [torch.empty((M, ab.pw.N), dtype=x2.dtype, device=x2.device) for ab in bindings]
+    extras = extras or [None] * len(bindings)
+    groups = {}
+    for i, ab in enumerate(bindings):
+        groups.setdefault((ab.mode == "perK", ab.Kp), []).append(i)
+    for idxs in groups.values():
+        for j0 in range(0, len(idxs), 4):
+            chunk = idxs[j0:j0 + 4]
+            arr = (_lib.FusedLinearArgs * len(chunk))(*[_fused_args(x2, M, C, hw, bindings[i], outs[i], pre, lnp, extras[i])
+                                                         for i in chunk])
+            n_chunk = len(chunk)
+
+            def issue(arr=arr, n_chunk=n_chunk):
+                _lib_call("dgq_linear_fused_batch", n_chunk, _c.cast(arr, _c.c_void_p), _lib.stream())
+            issue()
+            if GEMM_LAUNCH_HOOK is not None:
+                GEMM_LAUNCH_HOOK(issue, [(M, bindings[i], outs[i].element_size()) for i in chunk])
+    return outs
+
+
 def quant_linear(x: torch.Tensor, ab: ActBinding, pre_act=0, residual=None, fq=None, ln=None):
     """x [..., K] -> [..., N].  pre_act: 0 none, 1 SiLU(x), 2 GEGLU (x is [..., 2K]: x[:K]·gelu(x[K:])) folded into the
     quantise-on-load pass; residual [..., N] and fq (see make_extra) folded into the GEMM epilogue."""
@@ -468,12 +534,15 @@ def quant_linear(x: torch.Tensor, ab: ActBinding, pre_act=0, residual=None, fq=N
         x2 = x2.contiguous()
     rows = x2.shape[0]
     pre = (None, None, pre_act) if pre_act else None
-    codes, rowsum, M = quant_act(x2, rows, 1, 1, K, 1, 1, 1, 0, ab, pre, ln)
     res2 = None
     if residual is not None:
         res2 = residual.reshape(-1, ab.pw.N)
         if not res2.is_contiguous():
             res2 = res2.contiguous()
+    if fused_linear_ok(rows, K, ab):
+        y = linear_fused(x2, rows, K, 1, [ab], pre, ln, [make_extra(res2, fq)])[0]
+        return y.view(*x.shape[:-1], ab.pw.N)
+    codes, rowsum, M = quant_act(x2, rows, 1, 1, K, 1, 1, 1, 0, ab, pre, ln)
     y = gemm_wxa8(codes, rowsum, M, ab, x.dtype, extra=make_extra(res2, fq))
     return y.view(*x.shape[:-1], ab.pw.N)
 
@@ -490,24 +559,31 @@ def quant_linear_multi(x: torch.Tensor, bindings, ln=None):
     M = x2.shape[0]
     dev = x2.device
     lib = _lib.load()
+    if all(fused_linear_ok(M, Kin, ab) for ab in bindings):
+        return [o.view(*x.shape[:-1], o.shape[-1]) for o in linear_fused(x2, M, Kin, 1, bindings, None, ln)]
     lnp = (as_f32(ln[0]), as_f32(ln[1]), float(ln[2])) if ln else None
     qa, keep = [], []
     for ab in bindings:
         assert ab.pw.K == Kin and ab.pw.taps == 1
-        parts = act_ksplits(M, ab.Kp)
-        codes = torch.empty((M, ab.Kp), dtype=torch.int8, device=dev)
-        rowsum = torch.empty((parts, M), dtype=torch.float32, device=dev)
         per_m = 0 if ab.mode == "perK" else 1
         a = _lib.QuantActArgs()
         a.x, a.x_dtype, a.B, a.H, a.W, a.C, a.kh, a.kw, a.stride, a.pad = x2.data_ptr(), _lib.DTYPE_CODE[x2.dtype], M, 1, 1, Kin, 1, 1, 1, 0
-        a.ksrc, a.koff, a.klds, a.kdst = _dp(ab.ksrc), _dp(ab.koff(1, Kin)), _dp(ab.klds(1, Kin)), None
+        a.ksrc, a.koff, a.klds = _dp(ab.ksrc), _dp(ab.koff(1, Kin)), _dp(ab.klds(1, Kin))
+        a.kdst = _dp(ab.kdst(1, Kin, 1)) if ab.ksrc is not None else None
         a.Kp, a.per_m = ab.Kp, per_m
         a.delta, a.zp = (ab.cdelta.data_ptr(), ab.czp.data_ptr()) if not per_m else (ab.mdelta.data_ptr(), ab.mzp.data_ptr())
         a.L, a.bits = (1 if not per_m else ab.L), ab.abits
-        a.codes, a.rowsum, a.ksplits = codes.data_ptr(), rowsum.data_ptr(), parts
         a.pre_scale = a.pre_shift = None
         a.pre_act = 0
         a.ln_gamma, a.ln_beta, a.ln_eps = (lnp[0].data_ptr(), lnp[1].data_ptr(), lnp[2]) if lnp else (None, None, 0.0)
+        a.codes = a.rowsum = 1                               # placeholders: dgq_quant_act_variant only validates non-NULL
+        parts, a.ksplits = 1, 1                              # the scatter path takes whole rows: ask for it unsplit first
+        if a.kdst is None or lib.dgq_quant_act_variant(_c.byref(a)) not in (3, 4):
+            parts = act_ksplits(M, ab.Kp)
+            a.ksplits = parts
+        codes = torch.empty((M, ab.Kp), dtype=torch.int8, device=dev)
+        rowsum = torch.empty((parts, M), dtype=torch.float32, device=dev)
+        a.codes, a.rowsum = codes.data_ptr(), rowsum.data_ptr()
         variant = lib.dgq_quant_act_variant(_c.byref(a))
         qa.append((variant, per_m, a, codes, rowsum, parts))
     groups = {}
@@ -560,15 +636,20 @@ def quant_conv2d(x: torch.Tensor, ab: ActBinding, kh, kw, stride, pad, norm=None
         groups, eps, gamma, beta, act = norm
         sc, sh = groupnorm_scale_shift(x_store, B, H * W, C, groups, eps, gamma, beta)
         pre = (sc, sh, act)
-    codes, rowsum, M = quant_act(x_store, B, H, W, C, kh, kw, stride, pad, ab, pre)
+    Ho = (H + 2 * pad - kh) // stride + 1
+    Wo = (W + 2 * pad - kw) // stride + 1
+    M = B * Ho * Wo
     res2, res_div = None, 1
     if residual is not None:
         res2 = residual.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1).reshape(M, ab.pw.N)
     elif bias_rows is not None:                       # [B][N]: one row per image, broadcast over its Ho*Wo positions
         res2, res_div = bias_rows.contiguous(), M // B
+    if kh == 1 and kw == 1 and stride == 1 and pad == 0 and fused_linear_ok(M, C, ab):
+        # a 1x1 convolution on channels-last storage IS a Linear layer over the B·H·W pixel rows
+        y = linear_fused(x_store.reshape(M, C), M, C, H * W, [ab], pre, None, [make_extra(res2, res_div=res_div)])[0]
+        return y.view(B, Ho, Wo, ab.pw.N).permute(0, 3, 1, 2)
+    codes, rowsum, M = quant_act(x_store, B, H, W, C, kh, kw, stride, pad, ab, pre)
     y = gemm_wxa8(codes, rowsum, M, ab, x.dtype, extra=make_extra(res2, res_div=res_div))
-    Ho = (H + 2 * pad - kh) // stride + 1
-    Wo = (W + 2 * pad - kw) // stride + 1
     return y.view(B, Ho, Wo, ab.pw.N).permute(0, 3, 1, 2)
 
 

@@ -269,6 +269,28 @@ int dgq_adaround_reg_blocks(int64_t numel);
 int dgq_adaround_reg_fwd(const float* alpha, int64_t numel, float b, float* partial, void* stream);
 int dgq_adaround_reg_bwd(const float* alpha, int64_t numel, float b, const float* g, float* galpha, void* stream);
 
+/* ---- fused quantise-on-load + GEMM for Linear / 1x1-conv layers ------------------------------------------------
+ * dgq_linear_fused_batch: y = W·aqtizer(act(x)) + b for 1..4 layers that share one input x [M][C] (row stride C, or 2C
+ * with the GEGLU prologue) in ONE launch and without the int8 operand in HBM — the same arithmetic, term for term, as
+ * dgq_quant_act followed by dgq_gemm_wxa8 (QuantLayer.forward, quant/quant_layer.py:626-661).  A workgroup quantises a
+ * panel of 32 rows into LDS (prologues as dgq_quant_act: pre_scale/pre_shift [M/hw][C] of a folded GroupNorm, hw = rows per
+ * image; LayerNorm; pre_act 1 SiLU, 2 GEGLU) and multiplies it with its share of the weight columns.
+ *   per_m == 0: delta/zp [Kp/64] per 64-wide chunk, kdst [C] = packed position of channel c (the inverse of dgq_quant_act's
+ *               ksrc), cflush [Kp/64]; per_m == 1: delta/zp [L] indexed by m % L, natural K order, vn [N].
+ * Weights, epilogue vectors, extra: as dgq_gemm_wxa8 (w_bits == 4).  x and y share the dtype.
+ * dgq_linear_fused_supported: 1 when a shape runs on this path (C % 4 == 0, C <= 1280, Kp <= 2048, W4). */
+typedef struct dgq_fused_linear_args {
+    const void* x; int x_dtype; int M, C, hw;
+    const int32_t* kdst; int Kp; int per_m; const float* delta; const float* zp; int L; int a_bits;
+    const float* pre_scale; const float* pre_shift; int pre_act;
+    const float* ln_gamma; const float* ln_beta; float ln_eps;
+    const void* wpacked; int w_bits; int N; const uint8_t* cflush;
+    const float* alpha; const float* zw; const float* gamma; const float* vn;
+    void* y; int y_dtype; int ldy; const dgq_gemm_extra_t* extra;
+} dgq_fused_linear_args_t;
+int dgq_linear_fused_batch(int n, const dgq_fused_linear_args_t* args, void* stream);
+int dgq_linear_fused_supported(int M, int C, int Kp, int N, int per_m, int w_bits);
+
 #ifdef __cplusplus
 }
 #endif

@@ -107,11 +107,13 @@ def test_act_group_quant_producer_vs_reference_golden(tmp_path):
                 rel_rng.append(e)
                 worst_q = max(worst_q, e)
             in_order.append((name, worst_q))
-    print("first quantizers in graph order:", ["%s %.2g" % (n.split(".", 2)[-1], e) for n, e in in_order[:8]])
+    print("first quantizers in module order:", ["%s %.2g" % (n.split(".", 2)[-1], e) for n, e in in_order[:8]])
     # the calibration forwards are themselves quantized (scalar 8-bit activations): like every fake-quant graph they
     # amplify rounding differences with depth, so the statistics agree tightly where the graph starts and
     # at the few-percent level further down
-    assert max(e for _, e in in_order[:2]) < 1e-4, in_order[:2]
+    # the two quantizers the graph EXECUTES first (named_modules lists attentions before resnets, like the reference's classes)
+    first = [e for n, e in in_order if n.endswith("down_blocks.0.resnets.0.conv1.aqtizer") or n.endswith("down_blocks.0.resnets.0.conv2.aqtizer")]
+    assert len(first) == 2 and max(first) < 1e-4, first
     rel_rng.sort()
     print("range vectors vs reference: n=%d median rel-max %.3g, 90%% %.3g, worst %.3g"
           % (len(rel_rng), rel_rng[len(rel_rng) // 2], rel_rng[int(0.9 * len(rel_rng))], rel_rng[-1]))

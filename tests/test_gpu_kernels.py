@@ -586,3 +586,63 @@ def test_quant_linear_multi_equals_single_calls(M, K, with_ln, dev):
         ref = ops.quant_linear(x, ab, ln=ln)
         assert y.shape == ref.shape
         assert torch.equal(y, ref), (ab.pw.N, ab.mode, (y - ref).abs().max().item())
+
+
+@pytest.mark.parametrize("M,K,N,mode,prologue,dtype", [
+    (8192, 320, 320, "perK", "ln", torch.float32), (2048, 640, 640, "perM", "ln", torch.float32),
+    (1100, 320, 200, "perK", None, torch.float32), (1056, 1280, 320, "perK", "geglu", torch.float32),
+    (2048, 768, 640, "scalar", "silu", torch.float32), (1024, 1280, 1280, "perM", None, torch.float32),
+    (4096, 320, 2560, "perK", "ln", torch.float16), (1500, 640, 320, "perK", "ln", torch.bfloat16),
+    (4099, 64, 96, "perM", None, torch.float32)])
+def test_linear_fused_equals_quant_act_plus_gemm(M, K, N, mode, prologue, dtype, dev, monkeypatch):
+    """dgq_linear_fused_batch (quantise-on-load inside the GEMM) against dgq_quant_act + dgq_gemm_wxa8 on the same layer:
+    the codes are the same (same quantiser, the LayerNorm statistics use the same summation tree), the integer
+    contraction is exact, so the outputs differ only by the summation order of the fp32 row sums / group flushes
+    (a few 1e-7 relative); with a residual and an attention-side quantizer in the epilogue as well."""
+    from dgq_amd import ops, synth
+    from dgq_amd.plan import plan_act
+    g = torch.Generator().manual_seed(M + K + N)
+    x = (torch.randn(M, 2 * K if prologue == "geglu" else K, generator=g) * 1.3 - 0.2).to(dev, dtype)
+    w = torch.randn(N, K, generator=g) * 0.05
+    wd, wz = orc.minmax_channel(w, 4)
+    pw = ops.PackedWeight(w.to(dev), wd.to(dev), wz.to(dev), None, torch.randn(N, generator=g).to(dev), 4, K, 1)
+    if mode == "perK":
+        d, z = synth._group_params(K, 16, 8, "fused|%d" % N, 0)
+        lay = plan_act(d.view(1, 1, -1), z.view(1, 1, -1), "linear", K, 1, 8)
+    elif mode == "perM":
+        T = 64 if M % 64 == 0 else M
+        d, z = synth._group_params(T, 16, 8, "fused|%d" % N, 0)
+        lay = plan_act(d.view(1, -1, 1), z.view(1, -1, 1), "linear", K, 1, 8)
+    else:
+        lay = plan_act(torch.tensor(0.03), torch.tensor(120.0), "linear", K, 1, 8)
+    ab = ops.ActBinding(lay, pw, 8)
+    monkeypatch.setattr(ops, "FUSED_LINEAR", 2)                        # every supported shape, not only the default class
+    assert ops.fused_linear_ok(M, K, ab)
+    ln = ((1 + 0.1 * torch.randn(K, generator=g)).to(dev), (0.05 * torch.randn(K, generator=g)).to(dev), 1e-5) if prologue == "ln" else None
+    pre_act = {"silu": 1, "geglu": 2}.get(prologue, 0)
+    res = torch.randn(M, N, generator=g).to(dev, dtype)
+    fq = (3, (torch.rand(N, generator=g) * 0.02 + 0.02).to(dev), torch.randint(100, 156, (N,), generator=g).float().to(dev), M, N, 0, 8)
+    for residual, fqq in ((None, None), (res, None), (None, fq)):
+        y = ops.quant_linear(x, ab, pre_act=pre_act, residual=residual, fq=fqq, ln=ln)
+        monkeypatch.setattr(ops, "FUSED_LINEAR", 0)
+        ref = ops.quant_linear(x, ab, pre_act=pre_act, residual=residual, fq=fqq, ln=ln)
+        monkeypatch.setattr(ops, "FUSED_LINEAR", 2)
+        torch.cuda.synchronize()
+        assert y.shape == ref.shape == (M, N)
+        if fqq is None:
+            tol = 2e-6 if dtype == torch.float32 else 2e-3
+            assert rel_l2(y.float().cpu(), ref.float().cpu()) < tol, (residual is not None, rel_l2(y.float().cpu(), ref.float().cpu()))
+        else:                                           # a re-quantised output: isolated one-step flips where y sits on a boundary
+            diff = (y.float() - ref.float()).abs()
+            assert float((diff > 1e-4).float().mean()) < 2e-3
+    if prologue in (None, "ln") and mode != "scalar":   # three layers sharing the input: one launch
+        binds = [ab]
+        for i in range(2):
+            w2 = torch.randn(N, K, generator=g) * 0.05
+            wd2, wz2 = orc.minmax_channel(w2, 4)
+            pw2 = ops.PackedWeight(w2.to(dev), wd2.to(dev), wz2.to(dev), None, torch.randn(N, generator=g).to(dev), 4, K, 1)
+            binds.append(ops.ActBinding(lay, pw2, 8))
+        outs = ops.quant_linear_multi(x.view(1, M, K), binds, ln=ln)
+        for b2, o in zip(binds, outs):
+            one = ops.quant_linear(x.view(1, M, K), b2, ln=ln)
+            assert torch.equal(o, one)
