@@ -83,16 +83,18 @@ __device__ __forceinline__ float dgq_epilogue(const GemmParams& p, float acc, in
 // the longer ring does.
 constexpr int gemm_stage_bytes(int wbits, int bm, int bn) { return bm * BK + bn * (wbits == 4 ? BK / 2 : BK); }
 constexpr int gemm_stages(int wbits, int bm, int bn) { return 3; }
+// ... except for grids of at most ~2 workgroups per CU (M <= 512 layers: 320 tiles of 32x64), where occupancy is not LDS-bound
+// and the K loop waits on every tile: there 6 stages keep 5 tiles in flight per workgroup (template parameter NST).
 // blocks per CU the LDS ring of a tile shape allows (ring + tables), capped at 5 (32x64: 1280 slots = the whole
 // 8192 x 320 grid in one round): the register budget follows from it
-constexpr int gemm_occupancy(int wbits, int bm, int bn) {
-    const int per_block = gemm_stages(wbits, bm, bn) * gemm_stage_bytes(wbits, bm, bn) + 6 * 1024;
+constexpr int gemm_occupancy(int wbits, int bm, int bn, int nst) {
+    const int per_block = nst * gemm_stage_bytes(wbits, bm, bn) + 6 * 1024;
     const int o = (160 * 1024) / per_block;
     return o > 5 ? 5 : (o < 1 ? 1 : o);
 }
 
-template <int WBITS, bool PER_M, typename TOut, int BM, int BN>
-__global__ __launch_bounds__(256, gemm_occupancy(WBITS, BM, BN)) void gemm_wxa8_kernel(GemmBatch bt) {
+template <int WBITS, bool PER_M, typename TOut, int BM, int BN, int NST = 3>
+__global__ __launch_bounds__(256, gemm_occupancy(WBITS, BM, BN, NST)) void gemm_wxa8_kernel(GemmBatch bt) {
     const GemmParams& p = bt.p[bt.n > 1 ? blockIdx.z : 0];
     const int zsplit = bt.n > 1 ? 0 : blockIdx.z;
     // XCD-aware tile order.  Workgroups are dealt round-robin over the 8 XCDs (each with its own L2): in launch order the
@@ -111,7 +113,7 @@ __global__ __launch_bounds__(256, gemm_occupancy(WBITS, BM, BN)) void gemm_wxa8_
     }
     if (tile_n * BN >= p.N || tile_m * BM >= p.M) return;   // batch: a narrower problem than the grid (whole block)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    constexpr int STAGES = gemm_stages(WBITS, BM, BN);
+    constexpr int STAGES = NST;
     constexpr int WM = BM / 2, WN = BN / 2;                // per-wave output tile
     constexpr int TM = WM / 16, TN = WN / 16;              // MFMA tiles per wave
     static_assert(BM % 32 == 0 && BM <= 128 && BN % 64 == 0 && BN <= 128, "tile shape");
@@ -470,10 +472,10 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(GemmParams p) {
     }
 }
 
-template <int WBITS, bool PER_M, typename TOut, int BM, int BN>
+template <int WBITS, bool PER_M, typename TOut, int BM, int BN, int NST = 3>
 static void launch_tile(const GemmBatch& bt, hipStream_t st) {
     const GemmParams& p = bt.p[0];
-    constexpr int lds_stages = gemm_stages(WBITS, BM, BN) * gemm_stage_bytes(WBITS, BM, BN);
+    constexpr int lds_stages = NST * gemm_stage_bytes(WBITS, BM, BN);
     constexpr int lds_vec = (3 * BM + 4 * BN) * 4;
     constexpr int lds_max = lds_stages + lds_vec + 8192;        // + epilogue vectors + per-chunk scales (<= 2048 chunks)
     // the attribute is per device: one flag per device ordinal (set again by whichever thread gets there first — the
@@ -482,7 +484,7 @@ static void launch_tile(const GemmBatch& bt, hipStream_t st) {
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= 64 || !attr_set[dev].load(std::memory_order_acquire)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_wxa8_kernel<WBITS, PER_M, TOut, BM, BN>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_wxa8_kernel<WBITS, PER_M, TOut, BM, BN, NST>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
         if (dev >= 0 && dev < 64) attr_set[dev].store(true, std::memory_order_release);
     }
@@ -494,7 +496,7 @@ static void launch_tile(const GemmBatch& bt, hipStream_t st) {
     }
     const int lds = lds_stages + lds_vec + (PER_M ? 0 : ((2 * max_tps * 4 + 15) & ~15));
     dim3 grid((maxN + BN - 1) / BN, (maxM + BM - 1) / BM, bt.n > 1 ? bt.n : p.splits), block(256);
-    hipLaunchKernelGGL((gemm_wxa8_kernel<WBITS, PER_M, TOut, BM, BN>), grid, block, lds, st, bt);
+    hipLaunchKernelGGL((gemm_wxa8_kernel<WBITS, PER_M, TOut, BM, BN, NST>), grid, block, lds, st, bt);
 }
 
 // Tile shapes the host may pick (BM, BN): W4 {128x128, 128x64, 64x128, 64x64, 32x128, 32x64}; W8 (a secondary
@@ -507,7 +509,16 @@ static int launch_one(const GemmBatch& bt, int bm, int bn, hipStream_t st) {
     switch (key) {
         case 128128: launch_tile<WBITS, PER_M, TOut, 128, 128>(bt, st); break;
         case 64064: launch_tile<WBITS, PER_M, TOut, 64, 64>(bt, st); break;
-        case 32064: launch_tile<WBITS, PER_M, TOut, 32, 64>(bt, st); break;
+        case 32064: {
+            // small grids (<= 2 workgroups per CU) with enough K tiles: the 6-stage ring — measured 2 % SLOWER over the SD step's
+            // GEMMs (3.65 -> 3.73 ms: the longer prologue wait outweighs the extra tiles in flight); opt-in with DGQ_GEMM_DEEP=1
+            static const bool deep_ok = [] { const char* e = getenv("DGQ_GEMM_DEEP"); return e && *e == '1'; }();
+            long blocks = 0;
+            for (int i = 0; i < bt.n; ++i) blocks += (long)((bt.p[i].M + 31) / 32) * ((bt.p[i].N + 63) / 64) * (bt.n > 1 ? 1 : p.splits);
+            if (deep_ok && blocks <= 512 && p.tiles_per_split >= 8) launch_tile<WBITS, PER_M, TOut, 32, 64, 6>(bt, st);
+            else launch_tile<WBITS, PER_M, TOut, 32, 64>(bt, st);
+            break;
+        }
         default:
             if constexpr (WBITS == 4) {
                 switch (key) {

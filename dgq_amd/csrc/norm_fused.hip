@@ -116,17 +116,29 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x
     }
 }
 
-// grid (B*G): merges S partials, writes scale/shift for the group's channels
+// grid (B*G): merges S partials, writes scale/shift for the group's channels.  (A row-slice form of the partial pass —
+// one workgroup per slice of whole pixel rows, 16-byte coalesced reads, all channels — measured 0.7 % SLOWER on the SD step
+// than the per-(group, slice) kernel above, whose 40-byte runs are served from L2: dropped.)
 __global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ part, int S, int C, int G, float eps,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         float* __restrict__ scale, float* __restrict__ shift) {
     const int bg = blockIdx.x, b = bg / G, g = bg - b * G;
     const int Cg = C / G;
+    // lane t merges slices t, t + 64, ... in order, then a fixed xor-tree over the 64 lanes: deterministic for any S
     Moments m = {0.0f, 0.0f, 0.0f};
-    for (int s = 0; s < S; ++s) {                         // fixed order: deterministic
+    for (int s = threadIdx.x; s < S; s += 64) {
         const float* p = part + ((int64_t)bg * S + s) * 3;
         Moments o = {p[0], p[1], p[2]};
         m = merge(m, o);
+    }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        Moments other;
+        other.n = __shfl_xor(m.n, o, 64);
+        other.mean = __shfl_xor(m.mean, o, 64);
+        other.m2 = __shfl_xor(m.m2, o, 64);
+        // both partners must form the SAME value: merge in lane order (lower lane first)
+        m = (threadIdx.x & o) ? merge(other, m) : merge(m, other);
     }
     const float var = m.m2 / m.n;                         // biased variance, as F.group_norm
     const float rstd = rsqrtf(var + eps);
@@ -142,7 +154,7 @@ extern "C" int dgq_groupnorm_scale_shift(const void* x, int x_dtype, int B, int 
                                          const float* gamma, const float* beta, float* scale, float* shift,
                                          float* partial_ws, int slices, unsigned* counters, void* stream) {
     DGQ_CHECK_ARG(x && gamma && beta && scale && shift && partial_ws, "dgq_groupnorm_scale_shift: null pointer");
-    DGQ_CHECK_ARG(B > 0 && HW > 0 && C > 0 && G > 0 && C % G == 0 && slices >= 1 && slices <= 64,
+    DGQ_CHECK_ARG(B > 0 && HW > 0 && C > 0 && G > 0 && C % G == 0 && slices >= 1 && slices <= 256,
                   "dgq_groupnorm_scale_shift: bad shape");
     hipStream_t st = (hipStream_t)stream;
     const int rows_per = (HW + slices - 1) / slices;
