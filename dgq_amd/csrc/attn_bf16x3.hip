@@ -220,9 +220,9 @@ __global__ __launch_bounds__(256) void attn3_prep_kernel(const TIn* __restrict__
     constexpr bool QI8 = QM == 1;
     static_assert(D % 8 == 0, "head_dim must be a multiple of 8");
     const int bh = blockIdx.y, b = bh / H, hd = bh - b * H;
-    if (QM == 2 && (int)blockIdx.x >= NT) {
+    if (QM == 2 && (int)blockIdx.x >= 2 * NT) {
         // Q1K3: centred codes c'q = c − 2^(b−1) of aqtizer_q(q) as fp32 (exact), + (q scale, zero-point multiplier) per query
-        const int t0 = ((int)blockIdx.x - NT) * 32;
+        const int t0 = ((int)blockIdx.x - 2 * NT) * 32;
         constexpr int QC = D / 8;
         float* qtab = qfq + (size_t)B * T * H * D;
         const float off = 0.5f * (fqq.qmax + 1.0f);
@@ -251,10 +251,10 @@ __global__ __launch_bounds__(256) void attn3_prep_kernel(const TIn* __restrict__
         }
         return;
     }
-    if (QI8 && (int)blockIdx.x >= NT) {
+    if (QI8 && (int)blockIdx.x >= 2 * NT) {
         // QI8: int8 codes of aqtizer_q(q) for 32 query rows + (δq, z'q, Σc'q − D·z'q, start-peak score/δq) per query.
         // One thread per query row (D <= 160 elements); the row is read as 8-element vectors.
-        const int t = ((int)blockIdx.x - NT) * 32 + (threadIdx.x >> 3);
+        const int t = ((int)blockIdx.x - 2 * NT) * 32 + (threadIdx.x >> 3);
         const int part = threadIdx.x & 7;                       // 8 threads share a row: chunks part, part+8, ...
         int8_t* qc = reinterpret_cast<int8_t*>(qfq);             // [B][T][H][DP32] codes, then the float table
         float* qtab = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(qfq) + (size_t)B * T * H * G::DP32);
@@ -293,10 +293,10 @@ __global__ __launch_bounds__(256) void attn3_prep_kernel(const TIn* __restrict__
         }
         return;
     }
-    if ((int)blockIdx.x >= NT) {
+    if ((int)blockIdx.x >= 2 * NT) {
         // extra blocks (only when aqtizer_q is fused): fake-quantised copy of 32 query rows of this (batch, head), so
         // that the Q-fragment loads of the two main kernels stay plain loads
-        const int t0 = ((int)blockIdx.x - NT) * 32;
+        const int t0 = ((int)blockIdx.x - 2 * NT) * 32;
         constexpr int QC = D / 8;
         for (int i = threadIdx.x; i < 32 * QC; i += 256) {
             const int r = i / QC, c8 = i - r * QC;
@@ -311,14 +311,19 @@ __global__ __launch_bounds__(256) void attn3_prep_kernel(const TIn* __restrict__
         }
         return;
     }
-    const int s0 = blockIdx.x * KT;
+    // K and V images of a key tile are written by DIFFERENT workgroups (x < NT: K, NT <= x < 2·NT: V): each is a chain of
+    // a few dependent load rounds, and run back to back in one workgroup they set the duration of this launch (18-23 us
+    // for any token count; the data are a few hundred KB)
+    const bool do_k = (int)blockIdx.x < NT;
+    const int tile = do_k ? (int)blockIdx.x : (int)blockIdx.x - NT;
+    const int s0 = tile * KT;
     if (delta_reset && blockIdx.x == 0 && bh == 0 && threadIdx.x == 0) *delta_reset = 0.0f;   // real-time δ: max starts at 0
     const TIn* kbase = k + ((int64_t)(b * S) * H + hd) * D;
     const TIn* vbase = v + ((int64_t)(b * S) * H + hd) * D;
     const int64_t HD = (int64_t)H * D;
-    unsigned short* kimg = reinterpret_cast<unsigned short*>(planes + ((int64_t)bh * NT + blockIdx.x) * G::IMG_BYTES);
+    unsigned short* kimg = reinterpret_cast<unsigned short*>(planes + ((int64_t)bh * NT + tile) * G::IMG_BYTES);
     unsigned short* vimg = kimg + G::K_ELEMS;
-    if (QI8) {
+    if (QI8 && do_k) {
         // int8 K codes + per-key table; 8 threads per key row like the Q rows above
         int8_t* k8 = reinterpret_cast<int8_t*>(kimg);
         float* ktab = reinterpret_cast<float*>(k8 + G::K8_BYTES);
@@ -356,7 +361,7 @@ __global__ __launch_bounds__(256) void attn3_prep_kernel(const TIn* __restrict__
         }
     }
     constexpr int KC = G::KLD / 8;                       // 16-byte chunks per K row (padding chunks are zero)
-    if (QM == 2) {
+    if (QM == 2 && do_k) {
         // Q1K3: three planes of K̃[s][d] = aqtizer_k(k)[s][d]·(δq(d) for a per-head-dim aqtizer_q) and, per key,
         // Σ_d w(d)·K̃[s][d] with w = z'q(d) (per-head-dim) or 1; 8 threads per key row, deterministic shuffle reduction
         const int r = threadIdx.x >> 3, part = threadIdx.x & 7;
@@ -397,7 +402,7 @@ __global__ __launch_bounds__(256) void attn3_prep_kernel(const TIn* __restrict__
         for (int o = 4; o > 0; o >>= 1) corr += __shfl_xor(corr, o, 64);
         if (part == 0) reinterpret_cast<float*>(kimg + 3 * KT * G::KLD)[r] = corr;
     }
-    for (int i = threadIdx.x; QM == 0 && i < KT * KC; i += 256) {
+    for (int i = threadIdx.x; QM == 0 && do_k && i < KT * KC; i += 256) {
         const int r = i / KC, c8 = i - r * KC;
         const int sidx = s0 + r;
         unsigned wh[4], wm[4], wl[4];
@@ -424,7 +429,7 @@ __global__ __launch_bounds__(256) void attn3_prep_kernel(const TIn* __restrict__
         *reinterpret_cast<uint4*>(dst + 2 * KT * G::KLD) = make_uint4(wl[0], wl[1], wl[2], wl[3]);
     }
     constexpr int VC = G::VLD / 8;                       // 4 chunks of 8 key slots + 1 padding chunk per V^T row
-    for (int i = threadIdx.x; i < G::DV * VC; i += 256) {
+    for (int i = threadIdx.x; !do_k && i < G::DV * VC; i += 256) {
         const int c8 = i / G::DV, d = i - c8 * G::DV;    // lanes run over d: coalesced reads of every key row
         unsigned wh[4], wm[4], wl[4];
 #pragma unroll
@@ -878,7 +883,7 @@ static int launch_attn3(AttnParams p, const void* q_raw, unsigned char* planes, 
     // the main kernels read fp32 queries: the caller's tensor when it is fp32 and aqtizer_q is not fused, else a scratch
     // copy (converted / fake-quantised) written by extra blocks of the pre-pass; QI8: int8 codes + per-query table
     const bool q_copy = QM != 0 || ((p.fq[0].mode >= 0 || p.io_dtype != DGQ_F32) && qfq != nullptr);
-    const dim3 pgrid(p.NT + (q_copy ? (p.T + 31) / 32 : 0), p.B * p.H);
+    const dim3 pgrid(2 * p.NT + (q_copy ? (p.T + 31) / 32 : 0), p.B * p.H);   // K tiles, V tiles, Q row blocks
     float* dreset = p.mode == 1 ? p.delta : nullptr;
 #define DGQ_PREP(TT) hipLaunchKernelGGL((attn3_prep_kernel<D, TT, QM, VINT>), pgrid, dim3(256), 0, st, (const TT*)p.k, (const TT*)p.v, planes, \
                                         p.B, p.H, p.S, p.NT, p.fq[1], p.fq[2], dreset, (const TT*)q_raw, qfq, p.T, p.fq[0])
