@@ -93,7 +93,10 @@ constexpr int gemm_occupancy(int wbits, int bm, int bn, int nst) {
     return o > 5 ? 5 : (o < 1 ? 1 : o);
 }
 
-template <int WBITS, bool PER_M, typename TOut, int BM, int BN, int NST = 3>
+// WVN = waves along n (2: the four waves form a 2 x 2 grid; 4: a 1 x 4 row, each wave owning all BM rows of BN/4 columns).
+// With int4 weights every B fragment costs 6 VALU to widen and is reused by the TM row tiles of its wave: at BM = 32 the
+// 2 x 2 grid has TM = 1 (6 VALU per MFMA), the 1 x 4 row TM = 2 (3 per MFMA) at the same number of LDS reads.
+template <int WBITS, bool PER_M, typename TOut, int BM, int BN, int NST = 3, int WVN = 2>
 __global__ __launch_bounds__(256, gemm_occupancy(WBITS, BM, BN, NST)) void gemm_wxa8_kernel(GemmBatch bt) {
     const GemmParams& p = bt.p[bt.n > 1 ? blockIdx.z : 0];
     const int zsplit = bt.n > 1 ? 0 : blockIdx.z;
@@ -114,7 +117,9 @@ __global__ __launch_bounds__(256, gemm_occupancy(WBITS, BM, BN, NST)) void gemm_
     if (tile_n * BN >= p.N || tile_m * BM >= p.M) return;   // batch: a narrower problem than the grid (whole block)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr int STAGES = NST;
-    constexpr int WM = BM / 2, WN = BN / 2;                // per-wave output tile
+    constexpr int WVM = 4 / WVN;
+    constexpr int WM = BM / WVM, WN = BN / WVN;            // per-wave output tile
+    static_assert(WM % 16 == 0 && WN % 16 == 0, "wave tile");
     constexpr int TM = WM / 16, TN = WN / 16;              // MFMA tiles per wave
     static_assert(BM % 32 == 0 && BM <= 128 && BN % 64 == 0 && BN <= 128, "tile shape");
     constexpr int A_BYTES = BM * BK;                       // 16 KiB at BM = 128
@@ -129,7 +134,7 @@ __global__ __launch_bounds__(256, gemm_occupancy(WBITS, BM, BN, NST)) void gemm_
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wave_m = wid >> 1, wave_n = wid & 1;
+    const int wave_m = wid / WVN, wave_n = wid % WVN;
     const int n0 = tile_n * BN;
     const int m0 = tile_m * BM;
     const int nk_total = p.Kp / BK;
@@ -253,9 +258,7 @@ __global__ __launch_bounds__(256, gemm_occupancy(WBITS, BM, BN, NST)) void gemm_
     // The fragment loads are software-pipelined one K-half ahead of the MFMAs that consume them: while the 16 MFMAs of
     // half h run, the ds_reads of the next half (or of the next tile's first half, after the barrier) are in flight.
     // A/B on one box (8192^3): per-K g16 34.3 -> 35.3 % of peak, per-M 41.7 -> 41.9 %.  int4 stays packed in the fragment
-    // registers and is widened right before its MFMAs, so the load itself has no consumer until then.  (Tried and
-    // dropped: MFMAs with a constant-0 C operand after a flush instead of clearing the tile — a second copy of the
-    // 16 MFMAs behind a wave-uniform branch; no gain.)
+    // registers and is widened right before its MFMAs, so the load itself has no consumer until then.
     typedef typename std::conditional<WBITS == 4, uint2, v4i>::type wfrag_t;
     auto load_frags = [&](const uint8_t* sa, const uint8_t* sw, int h, v4i (&af)[TM], wfrag_t (&wf)[TN]) {
 #pragma unroll
@@ -281,7 +284,11 @@ __global__ __launch_bounds__(256, gemm_occupancy(WBITS, BM, BN, NST)) void gemm_
             for (int j = 0; j < TN; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[i], bf[j], acc[i][j], 0, 0, 0);
         if (!PER_M) {
-            // wave-uniform: > 0 on the last chunk of a DGQ group or of this K split
+            // wave-uniform: > 0 on the last chunk of a DGQ group or of this K split.  The flush costs 3 VALU per accumulator
+            // register (cvt, fma, clear): PMC on 8192 x 10240 x 1280 g16 (profiles/r02_gemm_pmc_instruction_mix.txt) counts
+            // 9.0 non-MFMA VALU per MFMA, 6.4 of them here.  Starting each group from the MFMA's constant-zero C operand
+            // instead of clearing (a second copy of the MFMA block behind a wave-uniform branch) was measured twice: no gain
+            // on the small tiles, and the 128x128 tile spills (8192 x 10240 x 1280: 287 -> 487 us).
             const float sc = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(
                 __builtin_bit_cast(int, ctab[chunk])));
             if (sc > 0.0f) {
@@ -472,7 +479,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(GemmParams p) {
     }
 }
 
-template <int WBITS, bool PER_M, typename TOut, int BM, int BN, int NST = 3>
+template <int WBITS, bool PER_M, typename TOut, int BM, int BN, int NST = 3, int WVN = 2>
 static void launch_tile(const GemmBatch& bt, hipStream_t st) {
     const GemmParams& p = bt.p[0];
     constexpr int lds_stages = NST * gemm_stage_bytes(WBITS, BM, BN);
@@ -484,7 +491,7 @@ static void launch_tile(const GemmBatch& bt, hipStream_t st) {
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= 64 || !attr_set[dev].load(std::memory_order_acquire)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_wxa8_kernel<WBITS, PER_M, TOut, BM, BN, NST>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_wxa8_kernel<WBITS, PER_M, TOut, BM, BN, NST, WVN>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
         if (dev >= 0 && dev < 64) attr_set[dev].store(true, std::memory_order_release);
     }
@@ -496,7 +503,7 @@ static void launch_tile(const GemmBatch& bt, hipStream_t st) {
     }
     const int lds = lds_stages + lds_vec + (PER_M ? 0 : ((2 * max_tps * 4 + 15) & ~15));
     dim3 grid((maxN + BN - 1) / BN, (maxM + BM - 1) / BM, bt.n > 1 ? bt.n : p.splits), block(256);
-    hipLaunchKernelGGL((gemm_wxa8_kernel<WBITS, PER_M, TOut, BM, BN, NST>), grid, block, lds, st, bt);
+    hipLaunchKernelGGL((gemm_wxa8_kernel<WBITS, PER_M, TOut, BM, BN, NST, WVN>), grid, block, lds, st, bt);
 }
 
 // Tile shapes the host may pick (BM, BN): W4 {128x128, 128x64, 64x128, 64x64, 32x128, 32x64}; W8 (a secondary
@@ -508,14 +515,16 @@ static int launch_one(const GemmBatch& bt, int bm, int bn, hipStream_t st) {
     const int key = bm * 1000 + bn;
     switch (key) {
         case 128128: launch_tile<WBITS, PER_M, TOut, 128, 128>(bt, st); break;
-        case 64064: launch_tile<WBITS, PER_M, TOut, 64, 64>(bt, st); break;
+        case 64064: launch_tile<WBITS, PER_M, TOut, 64, 64>(bt, st); break;   // (1 x 4 waves here: 3.567 -> 3.560 ms, not kept)
         case 32064: {
             // small grids (<= 2 workgroups per CU) with enough K tiles: the 6-stage ring — measured 2 % SLOWER over the SD step's
             // GEMMs (3.65 -> 3.73 ms: the longer prologue wait outweighs the extra tiles in flight); opt-in with DGQ_GEMM_DEEP=1
             static const bool deep_ok = [] { const char* e = getenv("DGQ_GEMM_DEEP"); return e && *e == '1'; }();
             long blocks = 0;
             for (int i = 0; i < bt.n; ++i) blocks += (long)((bt.p[i].M + 31) / 32) * ((bt.p[i].N + 63) / 64) * (bt.n > 1 ? 1 : p.splits);
+            static const bool row4 = [] { const char* e = getenv("DGQ_GEMM_WAVES"); return !(e && *e == '2'); }();   // A/B hook
             if (deep_ok && blocks <= 512 && p.tiles_per_split >= 8) launch_tile<WBITS, PER_M, TOut, 32, 64, 6>(bt, st);
+            else if (row4 && WBITS == 4) launch_tile<WBITS, PER_M, TOut, 32, 64, 3, 4>(bt, st);
             else launch_tile<WBITS, PER_M, TOut, 32, 64>(bt, st);
             break;
         }
@@ -524,7 +533,12 @@ static int launch_one(const GemmBatch& bt, int bm, int bn, hipStream_t st) {
                 switch (key) {
                     case 128064: launch_tile<WBITS, PER_M, TOut, 128, 64>(bt, st); break;
                     case 64128: launch_tile<WBITS, PER_M, TOut, 64, 128>(bt, st); break;
-                    case 32128: launch_tile<WBITS, PER_M, TOut, 32, 128>(bt, st); break;
+                    case 32128: {
+                        static const bool row4 = [] { const char* e = getenv("DGQ_GEMM_WAVES"); return !(e && *e == '2'); }();
+                        if (row4) launch_tile<WBITS, PER_M, TOut, 32, 128, 3, 4>(bt, st);
+                        else launch_tile<WBITS, PER_M, TOut, 32, 128>(bt, st);
+                        break;
+                    }
                     default: dgq_set_error("dgq_gemm_wxa8: no %dx%d tile", bm, bn); return DGQ_EINVAL;
                 }
             } else {
