@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256, gemm_occupancy(WBITS, BM, BN, NST)) void gemm_
     }
 
     // prologue: two tiles in flight first, then (while they fly) stage everything the epilogue needs into LDS with
-    // ordinary loads: per-chunk scales (+δ = flush after this chunk, −δ = keep accumulating), per-row and
+    // ordinary loads: per-chunk coefficients of the running totals (see below), per-row and
     // per-column dequantisation vectors.  A VMEM load inside the main loop would make hipcc drain the DMA ring with
     // vmcnt(0), and dependent global loads in the epilogue cost ~1 us each on a lone wave — both avoided this way.
 #pragma unroll
@@ -244,10 +244,16 @@ __global__ __launch_bounds__(256, gemm_occupancy(WBITS, BM, BN, NST)) void gemm_
             }
         }
         if (!PER_M) {
+            // Summation by parts: with T_c the RUNNING int32 total after chunk c (never cleared) and δ_c the scale of the
+            // chunk's group, Σ_groups δ_g·P_g = Σ_c (δ_c − δ_{c+1})·T_c, δ := 0 past this block's K range.  The coefficient
+            // is non-zero exactly at group ends, so a flush is cvt + fma per accumulator register and the clear (a third
+            // VALU per register per group: PMC, 9.0 non-MFMA VALU per MFMA on the g16 GEGLU shape) disappears.  |T| stays
+            // below 2^31 for every Kp the ABI admits with int4 weights, and below 2^24 (exact in fp32) up to Kp = 8800.
             for (int c = tid; c < 2 * nk; c += 256) {
                 const int chunk = kt_begin * 2 + c;
                 const float d = p.cdelta[chunk];
-                ctab[c] = (p.cflush[chunk] || c == 2 * nk - 1) ? d : -d;
+                const float dn = (c == 2 * nk - 1) ? 0.0f : p.cdelta[chunk + 1];
+                ctab[c] = d - dn;
             }
         }
     }
@@ -284,21 +290,16 @@ __global__ __launch_bounds__(256, gemm_occupancy(WBITS, BM, BN, NST)) void gemm_
             for (int j = 0; j < TN; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[i], bf[j], acc[i][j], 0, 0, 0);
         if (!PER_M) {
-            // wave-uniform: > 0 on the last chunk of a DGQ group or of this K split.  The flush costs 3 VALU per accumulator
-            // register (cvt, fma, clear): PMC on 8192 x 10240 x 1280 g16 (profiles/r02_gemm_pmc_instruction_mix.txt) counts
-            // 9.0 non-MFMA VALU per MFMA, 6.4 of them here.  Starting each group from the MFMA's constant-zero C operand
-            // instead of clearing (a second copy of the MFMA block behind a wave-uniform branch) was measured twice: no gain
-            // on the small tiles, and the 128x128 tile spills (8192 x 10240 x 1280: 287 -> 487 us).
+            // wave-uniform coefficient of this chunk's running total (0 inside a group: nothing to add)
             const float sc = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(
                 __builtin_bit_cast(int, ctab[chunk])));
-            if (sc > 0.0f) {
+            if (sc != 0.0f) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) accf[i][j][r] = __builtin_fmaf(sc, (float)acc[i][j][r], accf[i][j][r]);
-                        acc[i][j] = (v4i){0, 0, 0, 0};
                     }
             }
         }

@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void linear_fused_kernel(FusedBatch bt) {
         for (int i = tid; i < nch; i += 256) {
             const float d = p.qdelta[i];
             tdelta[i] = d; tinv[i] = dgq_rcp(d); tzp[i] = p.qzp[i];
-            ctab[i] = (p.cflush[i] || i == nch - 1) ? d : -d;
+            ctab[i] = d - (i == nch - 1 ? 0.0f : p.qdelta[i + 1]);        // summation by parts, as dgq_gemm_wxa8
         }
         for (int i = tid; i < p.C; i += 256) kd[i] = p.kdst[i];
     }
@@ -342,12 +342,11 @@ __global__ __launch_bounds__(256) void linear_fused_kernel(FusedBatch bt) {
             if (!PER_M) {
                 const float sc = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(
                     __builtin_bit_cast(int, ctab[2 * kt + h])));
-                if (sc > 0.0f) {
+                if (sc != 0.0f) {
 #pragma unroll
                     for (int jj = 0; jj < 2; ++jj) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) accf[jj][r] = __builtin_fmaf(sc, (float)acc[jj][r], accf[jj][r]);
-                        acc[jj] = (v4i){0, 0, 0, 0};
                     }
                 }
             }

@@ -127,7 +127,10 @@ int dgq_groupnorm_scale_shift(const void* x, int x_dtype, int B, int HW, int C, 
  * codes [M][Kp] int8; wpacked: w_bits==4 -> [N][Kp/2] (dgq_pack_w4), w_bits==8 -> [N][Kp] int8;
  * alpha = δw, zw = zero point in the stored code domain (zw − 8·0 for W4: unsigned nibbles; zw − 128 for W8);
  * gamma = bias (+ alpha·U for per_m==0, U[n] = Σ_k δx_k(offset − zx_k)(qw'[n,k] − zw[n]), precomputed per slot);
- * vn[n] = Σ_k qw'[n,k] − K·zw[n].  y [M][ldy] of y_dtype.  cflush[c] != 0 marks the last chunk of a group. */
+ * vn[n] = Σ_k qw'[n,k] − K·zw[n].  y [M][ldy] of y_dtype.  Every chunk of a DGQ group carries the group's δ in cdelta; the
+ * kernel sums by parts, Σ_c (cdelta[c] − cdelta[c+1])·T_c with T_c the running int32 total after chunk c, so a group boundary
+ * is wherever cdelta changes.  cflush[c] != 0 (last chunk of a group) is part of the ABI and must be non-NULL; the current
+ * kernels do not read it. */
 /* Optional epilogue extras (host struct, passed by pointer; NULL = none), applied in this order to the fp32 result:
  *   fq_mode != 0 : the attention-side quantizer of the projection output, aqtizer_{q,k,v} (sd.py:174-182,199):
  *                  y = δ·(clamp(rne(y/δ)+z, 0, fq_qmax) − z) with (δ,z) = table[0] (mode 1), table[(m % fq_T) − fq_skip]
