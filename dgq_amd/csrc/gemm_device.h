@@ -37,3 +37,18 @@ __device__ __forceinline__ float dgq_extra(const dgq_gemm_extra_t& ex, float y, 
     return y;
 }
 
+
+// Dequantising epilogue of one output element, shared by every GEMM-family kernel so that their results agree bit for bit:
+//   y = alpha·(R0·acc − zw·R1 + R2·vn) + gamma     per-K: R0 = 1, R1 = Σ_k δ_k s, R2 = 0;  per-M: R0 = δ_m, R1 = δ_m·Σ_k s,
+//   R2 = δ_m·(offset − z_m)
+// as explicit FMAs (the build uses -ffp-contract=off: written with * and + this was 7 VALU per output, and on short-K wide-N
+// layers the epilogue issues as many VALU as the K loop — PMC: 2.9 of the 4.4 non-MFMA VALU per MFMA of the per-M GEGLU GEMM).
+template <bool PER_M>
+__device__ __forceinline__ float dgq_dequant(float acc, float r0, float r1, float r2, float al, float zw, float ga, float vn) {
+    if (PER_M) {
+        float t = __builtin_fmaf(r0, acc, -(zw * r1));
+        t = __builtin_fmaf(r2, vn, t);
+        return __builtin_fmaf(al, t, ga);
+    }
+    return __builtin_fmaf(al, __builtin_fmaf(-zw, r1, acc), ga);
+}

@@ -72,9 +72,9 @@ __device__ __forceinline__ float dgq_epilogue(const GemmParams& p, float acc, in
     if (PER_M) {
         const int li = m % p.L;
         const float md = p.mdelta[li], mz = p.mzp[li];
-        return al * (md * acc - zw * (md * rs) + (md * (p.offset - mz)) * vn) + ga;
+        return dgq_dequant<true>(acc, md, md * rs, md * (p.offset - mz), al, zw, ga, vn);
     }
-    return al * (acc - zw * rs) + ga;
+    return dgq_dequant<false>(acc, 1.0f, rs, 0.0f, al, zw, ga, vn);
 }
 
 // LDS ring depth: 3 stages for every tile shape.  Deeper rings for the small tiles (6 stages at 32x64, 4 at 64x64 — more
@@ -423,10 +423,10 @@ __global__ __launch_bounds__(256, gemm_occupancy(WBITS, BM, BN, NST)) void gemm_
         const float r0 = vr[0], r1 = vr[BM], r2 = vr[2 * BM];
         // y = alpha·(R0·acc − zw·R1 + R2·vn) + gamma   (per-K: R0 = 1, R1 = rowsum, R2 = 0)
         float o[4];
-        o[0] = al.x * (r0 * v.x - zw.x * r1 + r2 * vn.x) + ga.x;
-        o[1] = al.y * (r0 * v.y - zw.y * r1 + r2 * vn.y) + ga.y;
-        o[2] = al.z * (r0 * v.z - zw.z * r1 + r2 * vn.z) + ga.z;
-        o[3] = al.w * (r0 * v.w - zw.w * r1 + r2 * vn.w) + ga.w;
+        o[0] = dgq_dequant<PER_M>(v.x, r0, r1, r2, al.x, zw.x, ga.x, vn.x);
+        o[1] = dgq_dequant<PER_M>(v.y, r0, r1, r2, al.y, zw.y, ga.y, vn.y);
+        o[2] = dgq_dequant<PER_M>(v.z, r0, r1, r2, al.z, zw.z, ga.z, vn.z);
+        o[3] = dgq_dequant<PER_M>(v.w, r0, r1, r2, al.w, zw.w, ga.w, vn.w);
         if (has_extra) {
 #pragma unroll
             for (int k = 0; k < 4; ++k)

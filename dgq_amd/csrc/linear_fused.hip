@@ -381,10 +381,10 @@ __global__ __launch_bounds__(256) void linear_fused_kernel(FusedBatch bt) {
                 const float* vr = vtab + wave_m * 16 + row;
                 const float r0 = vr[0], r1 = vr[FBM], r2 = vr[2 * FBM];
                 float o[4];
-                o[0] = al.x * (r0 * v.x - zw.x * r1 + r2 * vn.x) + ga.x;
-                o[1] = al.y * (r0 * v.y - zw.y * r1 + r2 * vn.y) + ga.y;
-                o[2] = al.z * (r0 * v.z - zw.z * r1 + r2 * vn.z) + ga.z;
-                o[3] = al.w * (r0 * v.w - zw.w * r1 + r2 * vn.w) + ga.w;
+                o[0] = dgq_dequant<PER_M>(v.x, r0, r1, r2, al.x, zw.x, ga.x, vn.x);
+                o[1] = dgq_dequant<PER_M>(v.y, r0, r1, r2, al.y, zw.y, ga.y, vn.y);
+                o[2] = dgq_dequant<PER_M>(v.z, r0, r1, r2, al.z, zw.z, ga.z, vn.z);
+                o[3] = dgq_dequant<PER_M>(v.w, r0, r1, r2, al.w, zw.w, ga.w, vn.w);
                 if (has_extra) {
 #pragma unroll
                     for (int k = 0; k < 4; ++k)

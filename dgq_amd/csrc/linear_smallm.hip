@@ -7,6 +7,7 @@
 // prologue and the exact-division rounding of dgq_quant_act), then each wave walks 16 weight rows with its lanes spread
 // over K (coalesced 16-byte loads of packed int4) and reduces across the wave.
 #include "dgq_common.h"
+#include "gemm_device.h"
 
 #define SMALLM_MAX_PROBLEMS 24
 #define SMALLM_MAX_M 16
@@ -118,7 +119,7 @@ __global__ __launch_bounds__(256) void linear_smallm_kernel(SmallMBatch b) {
             if (lane == 0) {
                 // the per_m epilogue of dgq_gemm_wxa8, term for term
                 const float rs = rsum[m];
-                const float out = al * (md * (float)a - zw * (md * rs) + (md * (off - mz)) * vn) + ga;
+                const float out = dgq_dequant<true>((float)a, md, md * rs, md * (off - mz), al, zw, ga, vn);
                 y[(int64_t)m * P.ldy + n] = dgq_from_float<TOut>(out);
             }
         }
