@@ -1,6 +1,6 @@
 """Debug aid (GPU box): per-layer comparison of the HIP path against the CPU oracle on a small UNet."""
 import sys, os, types
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from dgq_amd import synth
 from oracle import dgq_oracle as orc

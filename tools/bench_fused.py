@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from dgq_amd import ops, synth
 from dgq_amd.plan import plan_act
-from oracle import dgq_oracle as orc
+
 dev = torch.device("cuda:0")
 iters = 20
 
@@ -30,7 +30,7 @@ gen = torch.Generator().manual_seed(0)
 for M, K, N, mode, pro in shapes:
     x = torch.randn(M, 2 * K if pro == "geglu" else K, generator=gen).to(dev)
     w = torch.randn(N, K, generator=gen) * 0.05
-    wd, wz = orc.minmax_channel(w, 4)
+    wd, wz = synth.channel_minmax(w, 4)
     pw = ops.PackedWeight(w.to(dev), wd.to(dev), wz.to(dev), None, torch.zeros(N, device=dev), 4, K, 1)
     if mode == "perK":
         d, z = synth._group_params(K, 16, 8, "bf", 0)
