@@ -89,6 +89,7 @@ struct AttnParams {
     const float* qtab;             // QI8: [B][T][H][4] = δq, z'q, Σ_d c'q − D·z'q, start-peak score / δq
     int img_bytes;                 // bytes of one tile image in global memory (depends on the K / V plane formats)
     int kskip;                     // QI8: leading keys that bypass aqtizer_k (start-peak key 0: exact fp32 rank-1 score)
+    int xcd;                       // 1: workgroups of one (batch, head) share an XCD (its K/V tile images stay in one L2)
 };
 
 __device__ __forceinline__ unsigned short bf16_bits(float x) {
@@ -614,6 +615,22 @@ __device__ __forceinline__ v16f score_tile_q1(const unsigned short* kb, const bf
     return acc;
 }
 
+// Workgroup -> (query tile, batch·head).  Workgroups are dealt round-robin over the 8 XCDs, each with its own L2: in launch
+// order the query tiles of one (batch, head) — which all stream the same K / V tile images — sit on 8 different XCDs and
+// every L2 fetches every image.  Remapped (bijectively, any grid) so that XCD k owns a contiguous range of (batch·head)
+// major tiles, like the GEMM's tile order.
+__device__ __forceinline__ void attn_block_coords(int xcd_remap, int& bx, int& bh) {
+    bx = blockIdx.x; bh = blockIdx.y;
+    if (xcd_remap) {
+        const int gx = gridDim.x, T = gridDim.x * gridDim.y;
+        const int bid = blockIdx.x + gx * blockIdx.y;
+        const int q = T >> 3, r = T & 7, xcd = bid & 7;
+        const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        bh = logical / gx;
+        bx = logical - bh * gx;
+    }
+}
+
 // NW waves of 32 query rows per block.  NW = 8 (256 rows, one block per CU, two waves per SIMD) where the grid still
 // fills the chip (T >= 2048 at B*H = 16): the K/V tile images are then staged once per 256 rows instead of once per
 // 128 — half the LDS-DMA pieces per wave per tile, the largest non-MFMA cost of the loop.
@@ -624,8 +641,10 @@ __global__ __launch_bounds__(64 * NW) void attn3_stats_kernel(AttnParams p) {
     constexpr int ST = G::STATS_STAGES, NP = G::K_PIECES, SB = NP * 1024;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds8[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, h32 = lane >> 5;
-    const int bh = blockIdx.y, b = bh / p.H, hd = bh - b * p.H;
-    const int t = blockIdx.x * (32 * NW) + wid * 32 + (lane & 31);
+    int bx, bh;
+    attn_block_coords(p.xcd, bx, bh);
+    const int b = bh / p.H, hd = bh - b * p.H;
+    const int t = bx * (32 * NW) + wid * 32 + (lane & 31);
     const int tq = min(t, p.T - 1);
     const unsigned char* img_lane = p.planes + (int64_t)bh * p.NT * p.img_bytes + lane * 16;
     const uint32_t lds_base = (uint32_t)(uintptr_t)(lptr_t)lds8;
@@ -709,8 +728,10 @@ __global__ __launch_bounds__(64 * NW) void attn3_pv_kernel(AttnParams p) {
     constexpr int ST = G::PV_STAGES, NP = G::IMG_PIECES, SB = G::IMG_BYTES;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds8[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, h32 = lane >> 5;
-    const int bh = blockIdx.y, b = bh / p.H, hd = bh - b * p.H;
-    const int t = blockIdx.x * (32 * NW) + wid * 32 + (lane & 31);
+    int bx, bh;
+    attn_block_coords(p.xcd, bx, bh);
+    const int b = bh / p.H, hd = bh - b * p.H;
+    const int t = bx * (32 * NW) + wid * 32 + (lane & 31);
     const int tq = min(t, p.T - 1);
     const unsigned char* img_lane = p.planes + (int64_t)bh * p.NT * G::IMG_BYTES + lane * 16;
     const uint32_t lds_base = (uint32_t)(uintptr_t)(lptr_t)lds8;
@@ -971,6 +992,7 @@ int dgq_attention_bf16x3(const void* q, const void* k, const void* v, void* o, i
     p.mode = mode; p.skip = skip;
     p.qmax = qmax; p.stats = stats_ws; p.delta = delta_ws;
     p.NT = (S + KT - 1) / KT;
+    { static const int xcd = [] { const char* e = getenv("DGQ_ATTN_XCD"); return (e && *e == '0') ? 0 : 1; }(); p.xcd = xcd; }
     p.qcodes = nullptr; p.qtab = nullptr; p.kskip = 0;
     unsigned char* img = reinterpret_cast<unsigned char*>(planes);
     // int8 score path: aqtizer_q and aqtizer_k both fused and scalar / per-token (one scale per token outside the d sum);
