@@ -460,10 +460,10 @@ def gemm_wxa8(codes, rowsum, M, ab: ActBinding, out_dtype, out: Optional[torch.T
 
 
 #: Linear / 1x1-conv layers through dgq_linear_fused_batch (quantise-on-load inside the GEMM: one launch per layer, no int8
-#: operand in HBM).  OPT-IN (measured: no gain on the SD step).  DGQ_FUSED_LINEAR: 0 (default) = never, 1 = only the shape class where it measured faster than
-#: dgq_quant_act + dgq_gemm_wxa8 on MI355X (tools/bench_fused.py, profiles/r02_fused_linear_microbench.txt: per-M / scalar
-#: tables with C <= 320 and N <= 640 on >= 4096 rows: 15.8 vs 20.2 us; per-K 30.3 vs 27.2, wide N and C >= 640 2-4x SLOWER —
-#: a workgroup per 32-row panel leaves 4 waves per CU, so its two latency chains run unhidden), 2 = every supported shape.
+#: operand in HBM).  OPT-IN (measured: no gain on the SD step).  DGQ_FUSED_LINEAR: 0 (default) = never, 1 = only the shape class
+#: where it measured faster than dgq_quant_act + dgq_gemm_wxa8 on MI355X (tools/bench_fused.py,
+#: profiles/r02_fused_linear_microbench.txt: per-M / scalar tables with C <= 320 and N <= 640 on >= 4096 rows: 12.7 vs 20.2 us;
+#: per-K 30.6 vs 26.1 us, wide N 3x SLOWER — every 320 columns re-quantise the panel), 2 = every supported shape.
 FUSED_LINEAR = int(os.environ.get("DGQ_FUSED_LINEAR", "0"))
 #: rows below which the two-kernel path is kept under mode 2 (few row panels: every column split re-quantises the panel)
 FUSED_MIN_M = int(os.environ.get("DGQ_FUSED_MIN_M", "1024"))

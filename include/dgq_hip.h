@@ -276,7 +276,7 @@ int dgq_adaround_reg_bwd(const float* alpha, int64_t numel, float b, const float
  * dgq_linear_fused_batch: y = W·aqtizer(act(x)) + b for 1..4 layers that share one input x [M][C] (row stride C, or 2C
  * with the GEGLU prologue) in ONE launch and without the int8 operand in HBM — the same arithmetic, term for term, as
  * dgq_quant_act followed by dgq_gemm_wxa8 (QuantLayer.forward, quant/quant_layer.py:626-661).  A workgroup quantises a
- * panel of 32 rows into LDS (prologues as dgq_quant_act: pre_scale/pre_shift [M/hw][C] of a folded GroupNorm, hw = rows per
+ * panel of 16 rows into LDS (prologues as dgq_quant_act: pre_scale/pre_shift [M/hw][C] of a folded GroupNorm, hw = rows per
  * image; LayerNorm; pre_act 1 SiLU, 2 GEGLU) and multiplies it with its share of the weight columns.
  *   per_m == 0: delta/zp [Kp/64] per 64-wide chunk, kdst [C] = packed position of channel c (the inverse of dgq_quant_act's
  *               ksrc), cflush [Kp/64]; per_m == 1: delta/zp [L] indexed by m % L, natural K order, vn [N].

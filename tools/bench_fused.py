@@ -1,5 +1,5 @@
 """dgq_linear_fused_batch against dgq_quant_act + dgq_gemm_wxa8 per Linear shape of the SD1.4 step (hipGraph replay of 20
-calls -> us per call).  DGQ_FUSED_NSPLIT / DGQ_FUSED_DEBUG are read per call by the library."""
+calls -> us per call)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -44,13 +44,5 @@ for M, K, N, mode, pro in shapes:
     ops.FUSED_LINEAR = 0
     t_sep = timed(lambda: ops.quant_linear(x, ab, pre_act=pa, ln=ln))
     ops.FUSED_LINEAR, ops.FUSED_MIN_M = 2, 1
-    res = []
-    for ns in os.environ.get("NSPLITS", "0").split(","):
-        os.environ["DGQ_FUSED_NSPLIT"] = ns
-        row = []
-        for dbg in ("0", "1", "2"):
-            os.environ["DGQ_FUSED_DEBUG"] = dbg
-            row.append(timed(lambda: ops.quant_linear(x, ab, pre_act=pa, ln=ln)))
-        res.append("ns=%s: %.1f (p1 only %.1f, p2 only %.1f)" % (ns, row[0], row[1], row[2]))
-    os.environ["DGQ_FUSED_DEBUG"] = "0"
-    print("%5d x %4d -> %5d %s %-5s Kp=%4d | quant+gemm %6.1f us | fused %s" % (M, K, N, mode, pro or "", ab.Kp, t_sep, " | ".join(res)), flush=True)
+    t_fused = timed(lambda: ops.quant_linear(x, ab, pre_act=pa, ln=ln))
+    print("%5d x %4d -> %5d %s %-5s Kp=%4d | quant+gemm %6.1f us | fused %6.1f us" % (M, K, N, mode, pro or "", ab.Kp, t_sep, t_fused), flush=True)
