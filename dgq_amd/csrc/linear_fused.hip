@@ -60,6 +60,7 @@ struct FusedParams {
 
 struct FusedBatch {
     FusedParams p[DGQ_FUSED_BATCH];
+    int debug;                            // development (DGQ_FUSED_DEBUG, timing only): 1 = stop after phase 1, 2 = skip phase 1, 3 = skip the tile loop
 };
 
 template <typename TIn>
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(256) void linear_fused2_kernel(FusedBatch bt) {
     __syncthreads();
 
     // ---- phase 1: 4 rows per wave, 16 lanes per row ----------------------------------------------------------------------
-    {
+    if (bt.debug != 2) {
         const int r = wid * 4 + (lane >> 4), sub = lane & 15;
         const int m = min(m0 + r, p.M - 1);
         const T* xr = reinterpret_cast<const T*>(p.x) + (int64_t)m * p.ldc;
@@ -261,6 +262,7 @@ __global__ __launch_bounds__(256) void linear_fused2_kernel(FusedBatch bt) {
         }
     }
     __syncthreads();                                                     // the panel is complete; no barrier after this one
+    if (bt.debug == 1) return;
 
     // ---- phase 2: this wave's 80 columns x all K tiles, weights from L2 to registers ------------------------------------------
     const int fr = lane & 15, fq = lane >> 4;
@@ -283,7 +285,7 @@ __global__ __launch_bounds__(256) void linear_fused2_kernel(FusedBatch bt) {
         wc[j][0] = *reinterpret_cast<const uint2*>(wrow[j]);
         wc[j][1] = *reinterpret_cast<const uint2*>(wrow[j] + 32);
     }
-    for (int kt = 0; kt < nk; ++kt) {
+    for (int kt = 0; kt < (bt.debug == 3 ? 0 : nk); ++kt) {
         const int ktn = min(kt + 1, nk - 1);
 #pragma unroll
         for (int j = 0; j < F2_TN; ++j) {                                // next K tile's fragments fly during this tile's MFMAs
@@ -435,6 +437,7 @@ extern "C" int dgq_linear_fused_batch(int n, const dgq_fused_linear_args_t* args
         }
         maxN = a.N > maxN ? a.N : maxN;
     }
+    { const char* e = getenv("DGQ_FUSED_DEBUG"); bt.debug = e && *e ? atoi(e) : 0; }
     hipStream_t st = (hipStream_t)stream;
     const size_t lds = fused2_lds_bytes(a0.Kp, a0.C, a0.per_m != 0);
     DGQ_CHECK_ARG(lds <= 150 * 1024, "dgq_linear_fused_batch: %zu bytes of LDS", lds);

@@ -44,5 +44,10 @@ for M, K, N, mode, pro in shapes:
     ops.FUSED_LINEAR = 0
     t_sep = timed(lambda: ops.quant_linear(x, ab, pre_act=pa, ln=ln))
     ops.FUSED_LINEAR, ops.FUSED_MIN_M = 2, 1
-    t_fused = timed(lambda: ops.quant_linear(x, ab, pre_act=pa, ln=ln))
-    print("%5d x %4d -> %5d %s %-5s Kp=%4d | quant+gemm %6.1f us | fused %6.1f us" % (M, K, N, mode, pro or "", ab.Kp, t_sep, t_fused), flush=True)
+    ts = []
+    for dbg in ("0", "1", "2", "3"):
+        os.environ["DGQ_FUSED_DEBUG"] = dbg
+        ts.append(timed(lambda: ops.quant_linear(x, ab, pre_act=pa, ln=ln)))
+    os.environ["DGQ_FUSED_DEBUG"] = "0"
+    t_fused = ts[0]
+    print("%5d x %4d -> %5d %s %-5s Kp=%4d | quant+gemm %6.1f us | fused %6.1f us (quantise phase only %.1f, without it %.1f, without the tile loop %.1f)" % (M, K, N, mode, pro or "", ab.Kp, t_sep, t_fused, ts[1], ts[2], ts[3]), flush=True)
