@@ -559,8 +559,22 @@ def quant_linear_multi(x: torch.Tensor, bindings, ln=None):
     M = x2.shape[0]
     dev = x2.device
     lib = _lib.load()
-    if all(fused_linear_ok(M, Kin, ab) for ab in bindings):
-        return [o.view(*x.shape[:-1], o.shape[-1]) for o in linear_fused(x2, M, Kin, 1, bindings, None, ln)]
+    fused_idx = [i for i, ab in enumerate(bindings) if fused_linear_ok(M, Kin, ab)]
+    if fused_idx:
+        # the layers that qualify for the one-launch path share theirs; the others keep the shared two-kernel launches
+        outs = [None] * len(bindings)
+        for i, o in zip(fused_idx, linear_fused(x2, M, Kin, 1, [bindings[i] for i in fused_idx], None, ln)):
+            outs[i] = o.view(*x.shape[:-1], o.shape[-1])
+        rest = [i for i in range(len(bindings)) if i not in fused_idx]
+        if rest:
+            global FUSED_LINEAR
+            keep, FUSED_LINEAR = FUSED_LINEAR, 0
+            try:
+                for i, o in zip(rest, quant_linear_multi(x, [bindings[i] for i in rest], ln=ln)):
+                    outs[i] = o
+            finally:
+                FUSED_LINEAR = keep
+        return outs
     lnp = (as_f32(ln[0]), as_f32(ln[1]), float(ln[2])) if ln else None
     qa, keep = [], []
     for ab in bindings:
