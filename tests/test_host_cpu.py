@@ -242,3 +242,35 @@ def test_bench_launch_command_is_one_rank_per_gpu():
     assert cmd[-8:] == ["--gpus", "4", "--steps", "3", "--warmup", "1", "--config", "c5"]
     assert bench.CONFIGS["c5"]["prompts"] == 8 and bench.CONFIGS["c5"]["cfg"]["G"] == 1 and bench.CONFIGS["c5"]["cfg"]["abits"] == 6
     assert bench.CONFIGS["c4"]["arch"] == "sdxl" and bench.CONFIGS["c4"]["res"] == 128
+
+
+def test_summation_by_parts_matches_group_sums_on_planned_tables():
+    """The GEMM never clears its int32 tiles: a flush adds (δ_c − δ_{c+1})·T_c with T_c the running total after chunk c
+    (csrc/gemm_wxa8.hip).  On the chunk tables plan_act produces — every chunk of a group carries the group's δ, padding
+    chunks carry zero codes — that equals Σ_g δ_g·P_g exactly (integer partial sums, exact rational arithmetic), also for
+    any K-tile split where each split restarts its total at zero."""
+    from fractions import Fraction
+    g = torch.Generator().manual_seed(5)
+    for C, taps, G in ((320, 1, 16), (64, 9, 8), (1280, 1, 16)):
+        K = C * taps
+        d, z = synth._group_params(K, G, 8, "abel", 0)
+        shape = (1, 1, -1) if taps == 1 else (1, -1, 1)
+        lay = plan_act(d.view(*shape), z.view(*shape), "linear" if taps == 1 else "conv", C, taps, 8)
+        nch = lay.Kp // KCHUNK
+        valid = (lay.kperm.view(nch, KCHUNK) >= 0)
+        P = torch.randint(-50000, 50000, (nch,), generator=g)
+        P = torch.where(valid.any(dim=1), P, torch.zeros_like(P))          # all-padding chunks contribute nothing
+        cd = [Fraction(float(x)) for x in lay.cdelta]
+        ref = sum(cd[c] * int(P[c]) for c in range(nch))
+        for splits in (1, 2, 3):
+            tiles = nch // 2
+            per = -(-tiles // splits)
+            tot = Fraction(0)
+            for s0 in range(0, tiles, per):
+                c0, c1 = 2 * s0, min(nch, 2 * (s0 + per))
+                T = 0
+                for c in range(c0, c1):
+                    T += int(P[c])
+                    coef = cd[c] - (cd[c + 1] if c + 1 < c1 else 0)
+                    tot += coef * T
+            assert tot == ref, (C, taps, G, splits)
