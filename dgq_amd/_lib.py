@@ -14,8 +14,8 @@ _vp, _i, _f, _i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int6
 SIGNATURES = {
     "dgq_version": [],
     "dgq_quantize_weight": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp],
-    "dgq_pack_w4": [_vp, _i, _i, _vp, _i, _vp, _vp],
-    "dgq_unpack_w4": [_vp, _i, _i, _vp, _vp],
+    "dgq_pack_w4": [_vp, _i, _i, _vp, _i, _i, _vp, _vp],
+    "dgq_unpack_w4": [_vp, _i, _i, _i, _vp, _vp],
     "dgq_pack_w8": [_vp, _i, _i, _vp, _i, _vp, _vp],
     "dgq_quant_act": [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _i,
                       _vp, _vp, _i, _vp, _vp, _f, _vp],
@@ -41,8 +41,6 @@ SIGNATURES = {
     "dgq_adaround_reg_blocks": [_i64],
     "dgq_adaround_reg_fwd": [_vp, _i64, _f, _vp, _vp],
     "dgq_adaround_reg_bwd": [_vp, _i64, _f, _vp, _vp, _vp],
-    "dgq_linear_fused_batch": [_i, _vp, _vp],
-    "dgq_linear_fused_supported": [_i, _i, _i, _i, _i, _i],
 }
 
 
@@ -50,7 +48,7 @@ SIGNATURES = {
 class GemmExtra(ctypes.Structure):
     """dgq_gemm_extra_t of include/dgq_hip.h"""
     _fields_ = [("residual", _vp), ("ldr", _i), ("res_div", _i), ("res_dtype", _i), ("fq_mode", _i), ("fq_delta", _vp), ("fq_zp", _vp),
-                ("fq_T", _i), ("fq_D", _i), ("fq_skip", _i), ("fq_qmax", _f)]
+                ("fq_T", _i), ("fq_D", _i), ("fq_skip", _i), ("fq_qmax", _f), ("geglu", _i)]
 
 
 class SmallMProblem(ctypes.Structure):
@@ -73,16 +71,6 @@ class GemmArgs(ctypes.Structure):
                 ("N", _i), ("per_m", _i), ("cdelta", _vp), ("cflush", _vp), ("mdelta", _vp), ("mzp", _vp), ("L", _i),
                 ("offset", _f), ("alpha", _vp), ("zw", _vp), ("gamma", _vp), ("vn", _vp), ("y", _vp), ("y_dtype", _i), ("ldy", _i),
                 ("extra", _vp)]
-
-
-class FusedLinearArgs(ctypes.Structure):
-    """dgq_fused_linear_args_t of include/dgq_hip.h"""
-    _fields_ = [("x", _vp), ("x_dtype", _i), ("M", _i), ("C", _i), ("hw", _i),
-                ("kdst", _vp), ("Kp", _i), ("per_m", _i), ("delta", _vp), ("zp", _vp), ("L", _i), ("a_bits", _i),
-                ("pre_scale", _vp), ("pre_shift", _vp), ("pre_act", _i), ("ln_gamma", _vp), ("ln_beta", _vp), ("ln_eps", _f),
-                ("wpacked", _vp), ("w_bits", _i), ("N", _i), ("cflush", _vp),
-                ("alpha", _vp), ("zw", _vp), ("gamma", _vp), ("vn", _vp),
-                ("y", _vp), ("y_dtype", _i), ("ldy", _i), ("extra", _vp)]
 
 
 class AttnFq(ctypes.Structure):

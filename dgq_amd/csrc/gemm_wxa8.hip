@@ -1,28 +1,36 @@
-// W4A8 / W8A8 GEMM on V_MFMA_I32_16X16X64_I8 with DGQ per-group dequantisation fused in.
+// W4A8 / W8A8 GEMM on V_MFMA_I32_32X32X32_I8 with DGQ per-group dequantisation fused in.
 //
 //   A  = int8 activation codes [M][Kp]  (from dgq_quant_act; K already permuted so that each DGQ group is a run
-//        of 64-wide chunks)
-//   W  = int4 packed [N][Kp/2]  or int8 [N][Kp]
+//        of 32-wide chunks)
+//   W  = int4 packed [N][Kp/2] (layout 1 of dgq_pack_w4)  or int8 [N][Kp]
 //   Y  = fp [M][N]
 //
-// Tiling (wave64, gfx950): BM x BN block tile with BM in {32,64,128}, BN in {64,128} (template parameters; the host picks
-// the pair per shape so that the grid fills the 256 CUs without a K split wherever it can), BK = 128 (two MFMA K-slices),
-// 256 threads = 2x2 waves, each wave owns (BM/2)x(BN/2) = TM x TN MFMA tiles: 4·TM·TN int32 accumulators + (per-K mode)
-// as many fp32 accumulators (128x128: 64 + 64).
+// One 32-wide chunk = one MFMA K slice, scaled by a single δ.  Round 3 moved the kernel from MFMA_I32_16X16X64 (groups padded
+// to 64: K = 320 in 16 groups ran Kp = 1024) to the 32x32x32 shape: same operand bytes per MFMA cycle, half the group
+// padding, and a higher sustained rate on this chip (tools/mfma_rate.hip, profiles/r03_mfma_rate_int8_shapes.txt:
+// 4.04 against 3.13 Pop/s back to back; the 16x16x32 / 32x32x16 forms of gfx942 run at half rate).
+//
+// Tiling (wave64, gfx950): BM x BN block tile, BK = 128 (four chunks), WVM x WVN x WVK waves: each wave owns a
+// (BM/WVM) x (BN/WVN) output tile of TM x TN MFMA tiles and every WVK-th chunk of a K tile (WVK = 2 splits K INSIDE the
+// workgroup for the 32-row tiles, whose four waves would otherwise not find four 32x32 tiles; the two partial tiles meet in
+// LDS in the epilogue).  4·TM·TN·4 int32 accumulators + (per-K mode) as many fp32 accumulators per lane.
 //
 // Operand staging is LDS-DMA only (global_load_lds_dwordx4: no staging VGPRs, no ds_write — ds_write_b128 runs at
 // ~79 B/clk/CU and was the bottleneck of the register-staged version): a 3-stage LDS ring, tile t+2 is issued
 // before the MFMAs of tile t, a counted s_waitcnt vmcnt leaves it in flight across the (raw) barrier.
 // LDS images are lane-linear per DMA instruction, so the bank swizzle is applied to the per-lane SOURCE address
 // and to the ds_read address (cdna guide rule 21):
-//   A / int8-W tile: 128-byte rows, 16-byte chunk c stored at c ^ ((row>>1)&7)   -> conflict-free ds_read_b128
-//   int4-W tile    : 64-byte rows (packed), 8-byte slot s stored at s ^ (((row>>2)&3)<<1) -> conflict-free ds_read_b64
+//   A / int8-W tile: 128-byte rows, 16-byte piece p stored at p ^ ((row>>1)&7)       -> conflict-free ds_read_b128
+//   int4-W tile    : 64-byte rows (packed), 16-byte piece p (= one 32-chunk) stored at p ^ ((row>>2)&3); a lane reads the
+//                    8-byte half of its K half — the DMA cannot move 8-byte units, so rows with bit 4 set carry their two
+//                    halves exchanged in HBM already (dgq_pack_w4 layout 1): 32 lanes then cover all 64 banks  -> conflict-
+//                    free ds_read_b64
 // int4 weights stay packed in LDS (half the LDS bytes) and are widened to int8 in registers right after the
 // ds_read: (w & 0x0F0F0F0F), ((w>>4) & 0x0F0F0F0F) — the dgq_pack_w4 nibble order makes those 4 consecutive k each.
 //
-// Small grids (most SD1.4 layers give 10..192 tiles on 256 CUs) use deterministic split-K: grid.z slices of the
-// K-tile range write fp32 partial slabs [S][M][N] to a caller-provided workspace; splitk_epilogue_kernel sums
-// them in a fixed order and applies the dequantisation epilogue (no float atomics: results are bit-reproducible).
+// Small grids use deterministic split-K: grid.z slices of the K-tile range write fp32 partial slabs [S][M][N] to a
+// caller-provided workspace; splitk_epilogue_kernel sums them in a fixed order and applies the dequantisation epilogue
+// (no float atomics: results are bit-reproducible).
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
@@ -31,6 +39,10 @@
 #include "gemm_device.h"
 
 #define BK 128
+#define NCH 4                 // 32-wide chunks per K tile
+
+typedef int v16i __attribute__((ext_vector_type(16)));
+typedef float v16f __attribute__((ext_vector_type(16)));
 
 struct GemmParams {
     const int8_t* codes;
@@ -53,7 +65,7 @@ struct GemmParams {
     float* slab;          // split-K partials [S][M][N] (nullptr when S == 1)
     int splits;
     int tiles_per_split;  // K tiles (of BK) per split
-    dgq_gemm_extra_t ex;  // optional epilogue extras (residual add, fused attention-side quantizer)
+    dgq_gemm_extra_t ex;  // optional epilogue extras (residual add, fused attention-side quantizer, GEGLU pairs)
 };
 
 // Up to DGQ_GEMM_BATCH problems of one kernel instance (tile shape, weight bits, scale mode, output dtype; no K split) in
@@ -77,27 +89,54 @@ __device__ __forceinline__ float dgq_epilogue(const GemmParams& p, float acc, in
     return dgq_dequant<false>(acc, 1.0f, rs, 0.0f, al, zw, ga, vn);
 }
 
-// LDS ring depth: 3 stages for every tile shape.  Deeper rings for the small tiles (6 stages at 32x64, 4 at 64x64 — more
-// bytes in flight per block) measured 5-25 % SLOWER on the SD layer shapes (tools/tile_sweep.py: 2048x640x1408 per-K
-// 11.4 -> 12.4 us, 8192x320x1024 14.2 -> 17.9): the extra LDS costs a resident block per CU, which hides more latency than
-// the longer ring does.
+// x·gelu(g), gelu by erf as F.gelu's default (FeedForward's GEGLU, diffusers_rewrite/sd.py:210-222)
+__device__ __forceinline__ float dgq_geglu(float a, float g) { return a * (0.5f * g * (1.0f + erff(g * 0.70710678118654752f))); }
+
+// LDS ring: NST stages (template parameter; 3 is what ships — see launch_ring).
 constexpr int gemm_stage_bytes(int wbits, int bm, int bn) { return bm * BK + bn * (wbits == 4 ? BK / 2 : BK); }
-constexpr int gemm_stages(int wbits, int bm, int bn) { return 3; }
-// ... except for grids of at most ~2 workgroups per CU (M <= 512 layers: 320 tiles of 32x64), where occupancy is not LDS-bound
-// and the K loop waits on every tile: there 6 stages keep 5 tiles in flight per workgroup (template parameter NST).
-// blocks per CU the LDS ring of a tile shape allows (ring + tables), capped at 5 (32x64: 1280 slots = the whole
-// 8192 x 320 grid in one round): the register budget follows from it
-constexpr int gemm_occupancy(int wbits, int bm, int bn, int nst) {
+// waves per SIMD the LDS ring of a tile shape allows (ring + tables), capped at 5 blocks per CU: the register budget follows
+constexpr int gemm_waves_per_simd(int wbits, int bm, int bn, int nw, int nst) {
     const int per_block = nst * gemm_stage_bytes(wbits, bm, bn) + 6 * 1024;
-    const int o = (160 * 1024) / per_block;
-    return o > 5 ? 5 : (o < 1 ? 1 : o);
+    int o = (160 * 1024) / per_block;
+    o = o > 5 ? 5 : (o < 1 ? 1 : o);
+    const int w = o * nw / 4;
+    return w > 8 ? 8 : w;
 }
 
-// WVN = waves along n (2: the four waves form a 2 x 2 grid; 4: a 1 x 4 row, each wave owning all BM rows of BN/4 columns).
-// With int4 weights every B fragment costs 6 VALU to widen and is reused by the TM row tiles of its wave: at BM = 32 the
-// 2 x 2 grid has TM = 1 (6 VALU per MFMA), the 1 x 4 row TM = 2 (3 per MFMA) at the same number of LDS reads.
-template <int WBITS, bool PER_M, typename TOut, int BM, int BN, int NST = 3, int WVN = 2>
-__global__ __launch_bounds__(256, gemm_occupancy(WBITS, BM, BN, NST)) void gemm_wxa8_kernel(GemmBatch bt) {
+// prologue loads the compiler must not count: beside LDS-DMA in flight hipcc waits vmcnt(0) for any load of its own, which
+// would drain the ring it is supposed to leave in flight (cdna guide §5 trap (b)); the wait is the counted one below
+__device__ __forceinline__ float gload_f32(const float* q) {
+    float v;
+    asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(q) : "memory");
+    return v;
+}
+__device__ __forceinline__ uint32_t gload_u8(const uint8_t* q) {
+    uint32_t v;
+    asm volatile("global_load_ubyte %0, %1, off" : "=v"(v) : "v"(q) : "memory");
+    return v;
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt_lgkm0() {
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
+}
+// runtime count of DMA instructions that may stay in flight: `tiles` younger tiles of PER instructions each
+template <int PER, int MAXT>
+__device__ __forceinline__ void wait_ring(int tiles) {
+    static_assert(PER * MAXT <= 63, "vmcnt is a 6-bit counter");
+    if (tiles <= 0) wait_vmcnt_lgkm0<0>();
+    else if (MAXT >= 1 && tiles == 1) wait_vmcnt_lgkm0<PER>();
+    else if (MAXT >= 2 && tiles == 2) wait_vmcnt_lgkm0<PER * (MAXT >= 2 ? 2 : 0)>();
+    else if (MAXT >= 3 && tiles == 3) wait_vmcnt_lgkm0<PER * (MAXT >= 3 ? 3 : 0)>();
+    else wait_vmcnt_lgkm0<PER * (MAXT >= 4 ? 4 : 0)>();
+}
+
+// WVM x WVN x WVK waves; NST ring stages; ACCS int32 accumulator sets per wave (per-K mode only).  With ACCS = 2 consecutive
+// chunks of a wave alternate between two accumulator sets, each with its own running total, and a chunk's flush is issued
+// AFTER the MFMAs of the wave's next chunk: on the small tiles (one or two MFMAs per chunk) the MFMA latency and the flush
+// VALU of one chunk then overlap the next chunk's MFMAs instead of sitting between them.
+template <int WBITS, bool PER_M, typename TOut, int BM, int BN, int WVM, int WVN, int WVK, int NST, int ACCS>
+__global__ __launch_bounds__(64 * WVM * WVN * WVK, gemm_waves_per_simd(WBITS, BM, BN, WVM * WVN * WVK, NST))
+void gemm_wxa8_kernel(GemmBatch bt) {
     const GemmParams& p = bt.p[bt.n > 1 ? blockIdx.z : 0];
     const int zsplit = bt.n > 1 ? 0 : blockIdx.z;
     // XCD-aware tile order.  Workgroups are dealt round-robin over the 8 XCDs (each with its own L2): in launch order the
@@ -117,24 +156,27 @@ __global__ __launch_bounds__(256, gemm_occupancy(WBITS, BM, BN, NST)) void gemm_
     if (tile_n * BN >= p.N || tile_m * BM >= p.M) return;   // batch: a narrower problem than the grid (whole block)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr int STAGES = NST;
-    constexpr int WVM = 4 / WVN;
+    constexpr int NW = WVM * WVN * WVK, NT = 64 * NW;
     constexpr int WM = BM / WVM, WN = BN / WVN;            // per-wave output tile
-    static_assert(WM % 16 == 0 && WN % 16 == 0, "wave tile");
-    constexpr int TM = WM / 16, TN = WN / 16;              // MFMA tiles per wave
-    static_assert(BM % 32 == 0 && BM <= 128 && BN % 64 == 0 && BN <= 128, "tile shape");
-    constexpr int A_BYTES = BM * BK;                       // 16 KiB at BM = 128
+    static_assert(WM % 32 == 0 && WN % 32 == 0, "wave tile: multiples of the 32x32 MFMA tile");
+    constexpr int TM = WM / 32, TN = WN / 32;              // MFMA tiles per wave
+    constexpr int MYCH = NCH / WVK;                        // chunks per wave per K tile
+    static_assert(WVK == 1 || WVK == 2, "K split inside the workgroup: 1 or 2");
+    static_assert(ACCS == 1 || (ACCS == 2 && !PER_M), "two accumulator sets: per-K mode only");
+    static_assert(NST >= 3 && NST <= 6, "ring depth");
+    constexpr int A_BYTES = BM * BK;
     constexpr int W_ROW = (WBITS == 4) ? BK / 2 : BK;      // bytes per n-row per stage
     constexpr int W_BYTES = BN * W_ROW;
     constexpr int STAGE_BYTES = A_BYTES + W_BYTES;
-    constexpr int A_DMA = A_BYTES / 1024 / 4;              // DMA instructions per wave per tile (1 KiB each)
-    constexpr int W_DMA = W_BYTES / 1024 / 4;
-    static_assert(A_DMA >= 1 && W_DMA >= 1, "every wave stages at least one piece of each operand");
+    static_assert(A_BYTES % (1024 * NW) == 0 && W_BYTES % (1024 * NW) == 0, "every wave stages whole 1-KiB pieces of each operand");
+    constexpr int A_DMA = A_BYTES / 1024 / NW;             // DMA instructions per wave per tile (1 KiB each)
+    constexpr int W_DMA = W_BYTES / 1024 / NW;
     constexpr int DMA_PER_TILE = A_DMA + W_DMA;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wave_m = wid / WVN, wave_n = wid % WVN;
+    const int wave_k = wid / (WVM * WVN), wave_m = (wid / WVN) % WVM, wave_n = wid % WVN;
     const int n0 = tile_n * BN;
     const int m0 = tile_m * BM;
     const int nk_total = p.Kp / BK;
@@ -183,96 +225,141 @@ __global__ __launch_bounds__(256, gemm_occupancy(WBITS, BM, BN, NST)) void gemm_
             glds16(w_src[i] + kw, __builtin_amdgcn_readfirstlane(sw + (wid * W_DMA + i) * 1024));
     };
 
-    v4i acc[TM][TN];
-    v4f accf[TM][TN];
+    v16i acc[ACCS][TM][TN];
+    v16f accf[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            acc[i][j] = (v4i){0, 0, 0, 0};
-            accf[i][j] = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+#pragma unroll
+                for (int a = 0; a < ACCS; ++a) acc[a][i][j][r] = 0;
+                accf[i][j][r] = 0.0f;
+            }
         }
 
-    const int fr = lane & 15, fq = lane >> 4;
-    // ds_read byte offsets inside a stage (h = K half adds its chunk index below)
-    int a_off[TM][2], w_off[TN][2];
+    // MFMA_I32_32X32X32_I8 operands: lane l holds row (A) / column (B) l & 31 and the 16 k of half l >> 5 of the chunk
+    const int lr = lane & 31, hh = lane >> 5;
+    // ds_read byte offsets inside a stage, per chunk of this wave (chunk ci of the wave = chunk ci·WVK + wave_k of the tile)
+    int a_off[TM][MYCH], w_off[TN][MYCH];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int row = wave_m * WM + i * 16 + fr;
+    for (int ci = 0; ci < MYCH; ++ci) {
+        const int cg = ci * WVK + wave_k;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) a_off[i][h] = row * BK + (((4 * h + fq) ^ ((row >> 1) & 7)) << 4);
-    }
+        for (int i = 0; i < TM; ++i) {
+            const int row = wave_m * WM + i * 32 + lr;
+            a_off[i][ci] = row * BK + (((2 * cg + hh) ^ ((row >> 1) & 7)) << 4);
+        }
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int row = wave_n * WN + j * 16 + fr;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            if (WBITS == 4) w_off[j][h] = row * W_ROW + (((4 * h + fq) ^ (((row >> 2) & 3) << 1)) << 3);
-            else w_off[j][h] = row * BK + (((4 * h + fq) ^ ((row >> 1) & 7)) << 4);
+        for (int j = 0; j < TN; ++j) {
+            const int row = wave_n * WN + j * 32 + lr;
+            if (WBITS == 4) w_off[j][ci] = row * W_ROW + ((cg ^ ((row >> 2) & 3)) << 4) + ((hh ^ ((row >> 4) & 1)) << 3);
+            else w_off[j][ci] = row * BK + (((2 * cg + hh) ^ ((row >> 1) & 7)) << 4);
         }
     }
 
-    // prologue: two tiles in flight first, then (while they fly) stage everything the epilogue needs into LDS with
-    // ordinary loads: per-chunk coefficients of the running totals (see below), per-row and
-    // per-column dequantisation vectors.  A VMEM load inside the main loop would make hipcc drain the DMA ring with
-    // vmcnt(0), and dependent global loads in the epilogue cost ~1 us each on a lone wave — both avoided this way.
-#pragma unroll
-    for (int i = 0; i < STAGES - 1; ++i)
-        if (i < nk) issue_tile(kt_begin + i, i);
+    // ---- prologue.  Everything the epilogue and the flushes need is staged into LDS once: per-row and per-column
+    // dequantisation vectors, per-chunk flush coefficients.  The global loads for it are issued FIRST (asm loads the compiler
+    // does not count), then NST−1 tiles of LDS-DMA; one counted wait then retires the table loads and tile 0 only and leaves
+    // the younger tiles in flight.  All loads are unconditional at clamped indices: a load whose address or predicate depended
+    // on another load's result cost a full round trip each (four such chains made a per-K launch 3-4 us longer than its
+    // per-M twin).
     float* vtab = reinterpret_cast<float*>(smem + STAGES * STAGE_BYTES);   // [3][BM]: R0 R1 R2 | [4][BN]: alpha zw gamma vn
     float* vcol = vtab + 3 * BM;
-    float* ctab = vcol + 4 * BN;
+    float* ctab = vcol + 4 * BN;                                           // [WVK][nk·MYCH] flush coefficients | [nk] clear flags
+    static_assert(BM <= NT && BN <= NT, "one row / column of the epilogue vectors per thread");
+    // Summation by parts: with T the RUNNING int32 total of a chunk sequence and δ_c the scale of chunk c's group,
+    // Σ_groups δ_g·P_g = Σ_c (δ_c − δ_next(c))·T_c, δ := 0 past the sequence.  The coefficient is non-zero exactly at group
+    // ends, so a flush is cvt + fma per accumulator register.  A wave runs ACCS sequences (chunk ci of a tile belongs to
+    // sequence ci mod ACCS), the workgroup WVK·ACCS.  A clear mark (cflush == 2) on the LAST chunk of a K tile asks for the
+    // totals to be cleared behind that tile (|T| < 2^24: float(T) exact, dgq_amd/plan.py:mark_clears): the coefficient of each
+    // sequence's last chunk in the tile is then the full δ_c.  Marks on other chunks are not honoured (the planner places none).
+    // Table entries e < n_coef: coefficient of chunk i of wave kq;  e >= n_coef: clear flag of tile e − n_coef.
+    const int per_wave = nk * MYCH, n_coef = PER_M ? 0 : WVK * per_wave, n_tab = PER_M ? 0 : n_coef + nk;
+    struct CoefIdx { int g, gn, tl; bool is_coef, seq_last, tile_end, not_last_tile; };
+    auto coef_idx = [&](int e) {
+        CoefIdx x;
+        x.is_coef = e < n_coef;
+        const int ec = x.is_coef ? e : 0;
+        const int kq = ec / per_wave, i = ec - kq * per_wave;
+        const int tc = i / MYCH, ci = i - tc * MYCH;
+        const int t = x.is_coef ? tc : e - n_coef;
+        x.g = (kt_begin + tc) * NCH + ci * WVK + kq;
+        x.tile_end = (ci + ACCS >= MYCH);                                    // last chunk of its sequence in the tile
+        x.seq_last = x.tile_end && tc == nk - 1;
+        x.gn = min(x.tile_end ? (kt_begin + tc + 1) * NCH + (ci + ACCS - MYCH) * WVK + kq : x.g + ACCS * WVK, nk_total * NCH - 1);
+        x.tl = (kt_begin + t) * NCH + NCH - 1;
+        x.not_last_tile = t + 1 < nk;
+        return x;
+    };
+    auto coef_val = [&](const CoefIdx& x, float d, float dn, uint32_t cf) {
+        const bool clr = (cf & 0xFF) == 2;
+        const float coef = (x.seq_last || (x.tile_end && clr)) ? d : d - dn;
+        const float flag = (x.not_last_tile && clr) ? 1.0f : 0.0f;
+        return x.is_coef ? coef : flag;
+    };
     {
         const bool final_ep = (p.splits == 1);
-        if (final_ep) {
-            if (tid < BM) {
-                const int m = min(m0 + tid, p.M - 1);
-                float rs = 0.0f;
-                for (int j = 0; j < p.rowsum_parts; ++j) rs += p.rowsum[(int64_t)j * p.M + m];
-                float r0 = 1.0f, r1 = rs, r2 = 0.0f;
-                if (PER_M) {
-                    const int li = m % p.L;
-                    const float md = p.mdelta[li], mz = p.mzp[li];
-                    r0 = md; r1 = md * rs; r2 = md * (p.offset - mz);
-                }
-                vtab[tid] = r0; vtab[BM + tid] = r1; vtab[2 * BM + tid] = r2;
-            } else if (tid >= 128 && tid - 128 < BN) {
-                const int c = tid - 128;
-                const int n = min(n0 + c, p.N - 1);
-                vcol[c] = p.alpha[n]; vcol[BN + c] = p.zw[n]; vcol[2 * BN + c] = p.gamma[n];
-                vcol[3 * BN + c] = PER_M ? p.vn[n] : 0.0f;
-            }
+        const bool has_row = final_ep && tid < BM, has_col = final_ep && tid < BN;
+        const int m = min(m0 + tid, p.M - 1), n = min(n0 + tid, p.N - 1);
+        const int li = PER_M ? m % p.L : 0;
+        float md = 1.0f, mz = 0.0f, c_vn = 0.0f, c_d = 0.0f, c_dn = 0.0f;
+        uint32_t c_cf = 0;
+        float rs = gload_f32(p.rowsum + m);
+        if constexpr (PER_M) { md = gload_f32(p.mdelta + li); mz = gload_f32(p.mzp + li); }
+        float c_al = gload_f32(p.alpha + n), c_zw = gload_f32(p.zw + n), c_ga = gload_f32(p.gamma + n);
+        if constexpr (PER_M) c_vn = gload_f32(p.vn + n);
+        CoefIdx cx = {};
+        if constexpr (!PER_M) {
+            cx = coef_idx(min(tid, n_tab - 1));
+            c_d = gload_f32(p.cdelta + cx.g); c_dn = gload_f32(p.cdelta + cx.gn); c_cf = gload_u8(p.cflush + cx.tl);
         }
-        if (!PER_M) {
-            // Summation by parts: with T_c the RUNNING int32 total after chunk c (never cleared) and δ_c the scale of the
-            // chunk's group, Σ_groups δ_g·P_g = Σ_c (δ_c − δ_{c+1})·T_c, δ := 0 past this block's K range.  The coefficient
-            // is non-zero exactly at group ends, so a flush is cvt + fma per accumulator register and the clear (a third
-            // VALU per register per group: PMC, 9.0 non-MFMA VALU per MFMA on the g16 GEGLU shape) disappears.  |T| stays
-            // below 2^31 for every Kp the ABI admits with int4 weights, and below 2^24 (exact in fp32) up to Kp = 8800.
-            for (int c = tid; c < 2 * nk; c += 256) {
-                const int chunk = kt_begin * 2 + c;
-                const float d = p.cdelta[chunk];
-                const float dn = (c == 2 * nk - 1) ? 0.0f : p.cdelta[chunk + 1];
-                ctab[c] = d - dn;
+        int issued = 0;
+#pragma unroll
+        for (int i = 0; i < STAGES - 1; ++i)
+            if (i < nk) { issue_tile(kt_begin + i, i); ++issued; }
+        // table loads + tile 0 done; up to NST − 2 younger tiles stay in flight
+        wait_ring<DMA_PER_TILE, STAGES - 2>(issued - 1);
+        // the loaded registers become defined HERE for the compiler (volatile asm statements keep their order)
+        if (PER_M) asm volatile("" : "+v"(rs), "+v"(md), "+v"(mz), "+v"(c_al), "+v"(c_zw), "+v"(c_ga), "+v"(c_vn));
+        else asm volatile("" : "+v"(rs), "+v"(c_al), "+v"(c_zw), "+v"(c_ga), "+v"(c_d), "+v"(c_dn), "+v"(c_cf));
+        __builtin_amdgcn_sched_barrier(0);
+        if (has_row) {
+            for (int j = 1; j < p.rowsum_parts; ++j) rs += p.rowsum[(int64_t)j * p.M + m];     // K-split quantise passes only
+            float r0 = 1.0f, r1 = rs, r2 = 0.0f;
+            if (PER_M) { r0 = md; r1 = md * rs; r2 = md * (p.offset - mz); }
+            vtab[tid] = r0; vtab[BM + tid] = r1; vtab[2 * BM + tid] = r2;
+        }
+        if (has_col) {
+            vcol[tid] = c_al; vcol[BN + tid] = c_zw; vcol[2 * BN + tid] = c_ga; vcol[3 * BN + tid] = c_vn;
+        }
+        if constexpr (!PER_M) {
+            if (tid < n_tab) ctab[tid] = coef_val(cx, c_d, c_dn, c_cf);
+            for (int e = tid + NT; e < n_tab; e += NT) {    // long K only (ordinary loads: they drain the ring once)
+                const CoefIdx x = coef_idx(e);
+                ctab[e] = coef_val(x, p.cdelta[x.g], p.cdelta[x.gn], p.cflush[x.tl]);
             }
         }
     }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // DMA tiles 0,1 + the staging loads/stores
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the staging stores
     __builtin_amdgcn_s_barrier();
 
     // ring invariant at the top of iteration t: tiles t .. t+STAGES-2 are issued, tile t has landed.
-    // The fragment loads are software-pipelined one K-half ahead of the MFMAs that consume them: while the 16 MFMAs of
-    // half h run, the ds_reads of the next half (or of the next tile's first half, after the barrier) are in flight.
-    // A/B on one box (8192^3): per-K g16 34.3 -> 35.3 % of peak, per-M 41.7 -> 41.9 %.  int4 stays packed in the fragment
-    // registers and is widened right before its MFMAs, so the load itself has no consumer until then.
+    // The fragment loads are software-pipelined one chunk ahead of the MFMAs that consume them: while the MFMAs of a chunk
+    // run, the ds_reads of the next one (or of the next tile's first chunk, after the barrier) are in flight.  int4 stays
+    // packed in the fragment registers and is widened right before its MFMAs, so the load itself has no consumer until then.
     typedef typename std::conditional<WBITS == 4, uint2, v4i>::type wfrag_t;
-    auto load_frags = [&](const uint8_t* sa, const uint8_t* sw, int h, v4i (&af)[TM], wfrag_t (&wf)[TN]) {
+    auto load_frags = [&](const uint8_t* sa, const uint8_t* sw, int ci, v4i (&af)[TM], wfrag_t (&wf)[TN]) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const v4i*>(sa + a_off[i][h]);
+        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const v4i*>(sa + a_off[i][ci]);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) wf[j] = *reinterpret_cast<const wfrag_t*>(sw + w_off[j][h]);
+        for (int j = 0; j < TN; ++j) wf[j] = *reinterpret_cast<const wfrag_t*>(sw + w_off[j][ci]);
     };
-    auto mma_half = [&](const v4i (&af)[TM], const wfrag_t (&wf)[TN], int chunk) {
+    const float* ctw = ctab + wave_k * (nk * MYCH);
+    const float* tclr = ctab + WVK * (nk * MYCH);
+    typedef float cvec_t __attribute__((ext_vector_type(MYCH)));
+    auto mfma_chunk = [&](const v4i (&af)[TM], const wfrag_t (&wf)[TN], v16i (&ac)[TM][TN]) {
         v4i bf[TN];
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
@@ -288,20 +375,34 @@ __global__ __launch_bounds__(256, gemm_occupancy(WBITS, BM, BN, NST)) void gemm_
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[i], bf[j], acc[i][j], 0, 0, 0);
-        if (!PER_M) {
-            // wave-uniform coefficient of this chunk's running total (0 inside a group: nothing to add)
-            const float sc = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(
-                __builtin_bit_cast(int, ctab[chunk])));
-            if (sc != 0.0f) {
+                ac[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[i], bf[j], ac[i][j], 0, 0, 0);
+    };
+    // accf += coef · float(running total); coef is wave-uniform and 0 inside a group (nothing to add)
+    auto flush = [&](const v16i (&ac)[TM][TN], float coef) {
+        const float sc = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, coef)));
+        if (sc != 0.0f) {
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) {
+                for (int j = 0; j < TN; ++j) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) accf[i][j][r] = __builtin_fmaf(sc, (float)acc[i][j][r], accf[i][j][r]);
-                    }
-            }
+                    for (int r = 0; r < 16; ++r) accf[i][j][r] = __builtin_fmaf(sc, (float)ac[i][j][r], accf[i][j][r]);
+                }
+        }
+    };
+    // one chunk step: MFMAs of chunk ci into its accumulator set, then the flush that is due — the chunk's own (ACCS = 1) or,
+    // with two sets, the PREVIOUS chunk's (other set), whose MFMAs have had a whole step to finish
+    float pend = 0.0f;                                      // ACCS = 2: coefficient of the chunk whose flush is pending
+    auto step = [&](const v4i (&af)[TM], const wfrag_t (&wf)[TN], int ci, float coef) {
+        if constexpr (PER_M) {
+            mfma_chunk(af, wf, acc[0]);
+        } else if constexpr (ACCS == 1) {
+            mfma_chunk(af, wf, acc[0]);
+            flush(acc[0], coef);
+        } else {
+            if (ci & 1) { mfma_chunk(af, wf, acc[1]); flush(acc[0], pend); }
+            else { mfma_chunk(af, wf, acc[0]); flush(acc[1], pend); }
+            pend = coef;
         }
     };
     v4i af0[TM], af1[TM];
@@ -310,22 +411,30 @@ __global__ __launch_bounds__(256, gemm_occupancy(WBITS, BM, BN, NST)) void gemm_
     load_frags(smem, smem + A_BYTES, 0, af0, wf0);
     for (int t = 0; t < nk; ++t) {
         if (t + STAGES - 1 < nk) issue_tile(kt_begin + t + STAGES - 1, istage);
+        // this tile's flush coefficients and clear flag: two broadcast LDS reads issued FIRST, so that the flush decisions
+        // below never wait for the fragment reads queued behind them (LDS returns in order)
+        cvec_t cq;
+        float tc = 0.0f;
+        if (!PER_M) {
+            cq = *reinterpret_cast<const cvec_t*>(ctw + t * MYCH);
+            tc = tclr[t];
+            __builtin_amdgcn_sched_barrier(0);
+        }
         const uint8_t* sa = smem + stage * STAGE_BYTES;
-        load_frags(sa, sa + A_BYTES, 1, af1, wf1);
-        mma_half(af0, wf0, 2 * t);
+#pragma unroll
+        for (int ci = 0; ci + 1 < MYCH; ++ci) {
+            if ((ci & 1) == 0) {
+                load_frags(sa, sa + A_BYTES, ci + 1, af1, wf1);
+                step(af0, wf0, ci, PER_M ? 0.0f : cq[ci]);
+            } else {
+                load_frags(sa, sa + A_BYTES, ci + 1, af0, wf0);
+                step(af1, wf1, ci, PER_M ? 0.0f : cq[ci]);
+            }
+        }
         // tile t+1 must have landed (this wave's pieces) before anyone reads it; the STAGES-2 younger tiles may stay
         // in flight (vmcnt counts the wave's DMA instructions in issue order).  lgkmcnt(0): this wave's reads of tile t
         // are complete, so after the barrier its stage may be overwritten.
-        {
-            const int younger = min(STAGES - 2, max(0, nk - 2 - t));
-            switch (younger) {
-                case 0: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); break;
-                case 1: asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(1 * DMA_PER_TILE) : "memory"); break;
-                case 2: asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * DMA_PER_TILE) : "memory"); break;
-                case 3: asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(3 * DMA_PER_TILE) : "memory"); break;
-                default: asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(4 * DMA_PER_TILE) : "memory"); break;
-            }
-        }
+        wait_ring<DMA_PER_TILE, STAGES - 2>(min(STAGES - 2, nk - 2 - t));
         __builtin_amdgcn_s_barrier();
         stage = (stage + 1 == STAGES) ? 0 : stage + 1;
         istage = (istage + 1 == STAGES) ? 0 : istage + 1;
@@ -333,40 +442,70 @@ __global__ __launch_bounds__(256, gemm_occupancy(WBITS, BM, BN, NST)) void gemm_
             const uint8_t* sn = smem + stage * STAGE_BYTES;
             load_frags(sn, sn + A_BYTES, 0, af0, wf0);
         }
-        mma_half(af1, wf1, 2 * t + 1);
+        step(af1, wf1, MYCH - 1, PER_M ? 0.0f : cq[MYCH - 1]);   // MYCH is even: the last chunk of a tile sits in fragment set 1
+        if (!PER_M) {
+            if (__builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, tc)) != 0) {     // rare: a segment of running totals ends
+                if constexpr (ACCS == 2) { flush(acc[1], pend); pend = 0.0f; }
+#pragma unroll
+                for (int a = 0; a < ACCS; ++a)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) acc[a][i][j][r] = 0;
+            }
+        }
     }
+    if constexpr (!PER_M && ACCS == 2) flush(acc[1], pend);
 
-    // epilogue.  The MFMA C/D layout (col = lane&15, row = (lane>>4)*4 + reg) would give 4-byte stores in 64-byte
-    // runs; measured, that store pattern (not the MFMAs) bounded every small-K layer (~1 TB/s).  Each wave
-    // therefore transposes its WM x WN fp32 tile through the (now idle) LDS ring and writes 16 bytes per lane, WN·4
-    // contiguous bytes per row.  Row stride WN + 4 floats: conflict-free ds_write_b32, near conflict-free ds_read_b128.
+    // epilogue.  The MFMA C/D layout (col = lane&31, row = (reg&3) + 8·(reg>>2) + 4·(lane>>5)) gives 4-byte stores in 128-byte
+    // runs; 16 bytes per lane measured faster on every small-K layer (the stores, not the MFMAs, bound them).  Each wave
+    // therefore transposes its WM x WN fp32 tile through the (now idle) LDS ring and the workgroup writes 16 bytes per lane,
+    // WN·4 contiguous bytes per row.  Row stride WN + 4 floats: conflict-free ds_write_b32, near conflict-free ds_read_b128.
+    // With WVK = 2 the two K halves of a tile sit in two regions; after a barrier each of the two waves adds them (k = 0
+    // first: a fixed order) for half of the rows.
     constexpr int EP_LD = WN + 4;
     constexpr int LPR = WN / 4;                              // lanes per output row (4 consecutive n each)
     constexpr int RPP = 64 / LPR;                            // rows per pass of the wave
-    constexpr int PASSES = WM / RPP;
-    static_assert(4 * WM * EP_LD * 4 <= STAGES * STAGE_BYTES, "epilogue staging must fit the LDS ring");
-    float* ep = reinterpret_cast<float*>(smem) + wid * WM * EP_LD;
+    constexpr int PASSES = WM / RPP / WVK;                   // passes of this wave
+    constexpr int REGION = WM * EP_LD;                       // floats per wave tile
+    static_assert(NW * REGION * 4 <= STAGES * STAGE_BYTES, "epilogue staging must fit the LDS ring");
+    float* ep_all = reinterpret_cast<float*>(smem);
+    float* ep = ep_all + wid * REGION;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                ep[(i * 16 + fq * 4 + r) * EP_LD + j * 16 + fr] = PER_M ? (float)acc[i][j][r] : accf[i][j][r];
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // same-wave LDS round trip: no barrier needed
+            for (int r = 0; r < 16; ++r)
+                ep[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh) * EP_LD + j * 32 + lr] = PER_M ? (float)acc[0][i][j][r] : accf[i][j][r];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (WVK > 1) __builtin_amdgcn_s_barrier();              // WVK == 1: same-wave LDS round trip, no barrier needed
+    const float* ep0 = ep_all + (wave_m * WVN + wave_n) * REGION;                     // k = 0 half
+    const float* ep1 = ep0 + (WVM * WVN) * REGION;                                    // k = 1 half (WVK == 2)
     const int c4 = (lane % LPR) * 4;                         // 4 consecutive n per lane
     const int lrow = lane / LPR;
     const int nb = n0 + wave_n * WN + c4;
     const bool vec_ok = (nb + 3 < p.N);
+    auto tile_row = [&](int rr) { return (rr * WVK + wave_k) * RPP + lrow; };        // the wave's rr-th pass
+    auto tile_val = [&](int row) {
+        float4 v = *reinterpret_cast<const float4*>(ep0 + row * EP_LD + c4);
+        if (WVK > 1) {
+            const float4 u = *reinterpret_cast<const float4*>(ep1 + row * EP_LD + c4);
+            v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+        }
+        return v;
+    };
     if (p.splits > 1) {
         float* slab = p.slab + (int64_t)zsplit * p.M * p.N;
         const bool al16 = ((p.N & 3) == 0);
 #pragma unroll 4
         for (int rr = 0; rr < PASSES; ++rr) {
-            const int row = rr * RPP + lrow;
+            const int row = tile_row(rr);
             const int m = m0 + wave_m * WM + row;
             if (m >= p.M || nb >= p.N) continue;
-            const float4 v = *reinterpret_cast<const float4*>(ep + row * EP_LD + c4);
+            const float4 v = tile_val(row);
             float* dst = slab + (int64_t)m * p.N + nb;
             if (vec_ok && al16) {
                 *reinterpret_cast<float4*>(dst) = v;
@@ -383,6 +522,40 @@ __global__ __launch_bounds__(256, gemm_occupancy(WBITS, BM, BN, NST)) void gemm_
     const float4 zw = *reinterpret_cast<const float4*>(vc + BN);
     const float4 ga = *reinterpret_cast<const float4*>(vc + 2 * BN);
     const float4 vn = *reinterpret_cast<const float4*>(vc + 3 * BN);
+    if (p.ex.geglu) {
+        // FeedForward's GEGLU in the epilogue of ff.net.0 (sd.py:210-236): the weight rows were interleaved at pack time
+        // (row 2i = value half i, row 2i+1 = gate half i), so a lane's four columns are two (value, gate) pairs and it
+        // writes columns nb/2, nb/2 + 1 of the [M][N/2] output — half the stores, and no GEGLU pass in front of ff.net.2.
+        const int ob = nb >> 1;
+        const bool st2 = vec_ok && (p.ldy % 2 == 0) && ((reinterpret_cast<uintptr_t>(p.y) & 7) == 0);
+#pragma unroll
+        for (int rr = 0; rr < PASSES; ++rr) {
+            const int row = tile_row(rr);
+            const int m = m0 + wave_m * WM + row;
+            if (m >= p.M || nb >= p.N) continue;
+            const float4 v = tile_val(row);
+            const float* vr = vtab + wave_m * WM + row;
+            const float r0 = vr[0], r1 = vr[BM], r2 = vr[2 * BM];
+            const float a0 = dgq_dequant<PER_M>(v.x, r0, r1, r2, al.x, zw.x, ga.x, vn.x);
+            const float g0 = dgq_dequant<PER_M>(v.y, r0, r1, r2, al.y, zw.y, ga.y, vn.y);
+            const float a1 = dgq_dequant<PER_M>(v.z, r0, r1, r2, al.z, zw.z, ga.z, vn.z);
+            const float g1 = dgq_dequant<PER_M>(v.w, r0, r1, r2, al.w, zw.w, ga.w, vn.w);
+            const float o0 = dgq_geglu(a0, g0), o1 = dgq_geglu(a1, g1);
+            TOut* dst = y + (int64_t)m * p.ldy + ob;
+            if (st2) {
+                if (sizeof(TOut) == 4) {
+                    *reinterpret_cast<float2*>(dst) = make_float2(o0, o1);
+                } else {
+                    TOut t[2] = {dgq_from_float<TOut>(o0), dgq_from_float<TOut>(o1)};
+                    *reinterpret_cast<uint32_t*>(dst) = *reinterpret_cast<const uint32_t*>(t);
+                }
+            } else {
+                dst[0] = dgq_from_float<TOut>(o0);
+                if (nb + 3 < p.N) dst[1] = dgq_from_float<TOut>(o1);
+            }
+        }
+        return;
+    }
     const bool st_vec = vec_ok && ((p.ldy * (int)sizeof(TOut)) % 16 == 0) &&
                         ((reinterpret_cast<uintptr_t>(p.y) & 15) == 0) && (sizeof(TOut) == 4 || (p.ldy & 3) == 0);
     // residual tile: all rows of this lane fetched up front as 16-byte loads, so the epilogue pays one memory latency
@@ -394,7 +567,7 @@ __global__ __launch_bounds__(256, gemm_occupancy(WBITS, BM, BN, NST)) void gemm_
     if (res_vec) {
 #pragma unroll
         for (int rr = 0; rr < PASSES; ++rr) {
-            const int m = min(m0 + wave_m * WM + rr * RPP + lrow, p.M - 1);
+            const int m = min(m0 + wave_m * WM + tile_row(rr), p.M - 1);
             const int64_t i = (int64_t)(m / p.ex.res_div) * p.ex.ldr + nb;
             if (p.ex.res_dtype == DGQ_F32) {
                 res[rr] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.ex.residual) + i);
@@ -415,10 +588,10 @@ __global__ __launch_bounds__(256, gemm_occupancy(WBITS, BM, BN, NST)) void gemm_
     const bool has_extra = exl.fq_mode != 0 || exl.residual != nullptr;
 #pragma unroll
     for (int rr = 0; rr < PASSES; ++rr) {
-        const int row = rr * RPP + lrow;
+        const int row = tile_row(rr);
         const int m = m0 + wave_m * WM + row;
         if (m >= p.M || nb >= p.N) continue;
-        const float4 v = *reinterpret_cast<const float4*>(ep + row * EP_LD + c4);
+        const float4 v = tile_val(row);
         const float* vr = vtab + wave_m * WM + row;
         const float r0 = vr[0], r1 = vr[BM], r2 = vr[2 * BM];
         // y = alpha·(R0·acc − zw·R1 + R2·vn) + gamma   (per-K: R0 = 1, R1 = rowsum, R2 = 0)
@@ -480,19 +653,22 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(GemmParams p) {
     }
 }
 
-template <int WBITS, bool PER_M, typename TOut, int BM, int BN, int NST = 3, int WVN = 2>
+template <int WBITS, bool PER_M, typename TOut, int BM, int BN, int WVM, int WVN, int WVK, int NST>
 static void launch_tile(const GemmBatch& bt, hipStream_t st) {
     const GemmParams& p = bt.p[0];
+    constexpr int NW = WVM * WVN * WVK;
+    // two accumulator sets (flush behind the next chunk's MFMAs) wherever a wave has at most two MFMA tiles
+    constexpr int ACCS = (!PER_M && (BM / WVM / 32) * (BN / WVN / 32) <= 2) ? 2 : 1;
     constexpr int lds_stages = NST * gemm_stage_bytes(WBITS, BM, BN);
     constexpr int lds_vec = (3 * BM + 4 * BN) * 4;
-    constexpr int lds_max = lds_stages + lds_vec + 8192;        // + epilogue vectors + per-chunk scales (<= 2048 chunks)
+    constexpr int lds_max = lds_stages + lds_vec + 32768;       // + epilogue vectors + per-chunk coefficients (<= 4096 chunks)
     // the attribute is per device: one flag per device ordinal (set again by whichever thread gets there first — the
     // call is idempotent, so a benign race at worst repeats it)
     static std::atomic<bool> attr_set[64];
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= 64 || !attr_set[dev].load(std::memory_order_acquire)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_wxa8_kernel<WBITS, PER_M, TOut, BM, BN, NST, WVN>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_wxa8_kernel<WBITS, PER_M, TOut, BM, BN, WVM, WVN, WVK, NST, ACCS>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
         if (dev >= 0 && dev < 64) attr_set[dev].store(true, std::memory_order_release);
     }
@@ -502,44 +678,37 @@ static void launch_tile(const GemmBatch& bt, hipStream_t st) {
         maxM = bt.p[i].M > maxM ? bt.p[i].M : maxM;
         max_tps = bt.p[i].tiles_per_split > max_tps ? bt.p[i].tiles_per_split : max_tps;
     }
-    const int lds = lds_stages + lds_vec + (PER_M ? 0 : ((2 * max_tps * 4 + 15) & ~15));
-    dim3 grid((maxN + BN - 1) / BN, (maxM + BM - 1) / BM, bt.n > 1 ? bt.n : p.splits), block(256);
-    hipLaunchKernelGGL((gemm_wxa8_kernel<WBITS, PER_M, TOut, BM, BN, NST, WVN>), grid, block, lds, st, bt);
+    const int lds = lds_stages + lds_vec + (PER_M ? 0 : (((NCH + 1) * max_tps * 4 + 15) & ~15));
+    dim3 grid((maxN + BN - 1) / BN, (maxM + BM - 1) / BM, bt.n > 1 ? bt.n : p.splits), block(64 * NW);
+    hipLaunchKernelGGL((gemm_wxa8_kernel<WBITS, PER_M, TOut, BM, BN, WVM, WVN, WVK, NST, ACCS>), grid, block, lds, st, bt);
 }
 
-// Tile shapes the host may pick (BM, BN): W4 {128x128, 128x64, 64x128, 64x64, 32x128, 32x64}; W8 (a secondary
-// configuration) carries {128x128, 64x64, 32x64}.
+// Ring depth: 3 stages for every tile shape.  A 6-stage ring (five tiles in flight, counted prologue wait so that only tile 0
+// is waited for) measured SLOWER on every SD layer shape in round 3 as in round 2 (tools/gemm_gap.py: 512x1280x1280 per-M
+// 6.5 -> 7.2 us, 8192x320x320 7.5 -> 9.1): the K loop of these launches is not paced by the DMA latency.
+template <int WBITS, bool PER_M, typename TOut, int BM, int BN, int WVM, int WVN, int WVK>
+static void launch_ring(const GemmBatch& bt, hipStream_t st) {
+    launch_tile<WBITS, PER_M, TOut, BM, BN, WVM, WVN, WVK, 3>(bt, st);
+}
 
+// Tile shapes the host may pick (BM x BN, waves m x n x k):
+//   W4: 32x64 (1x2x2), 32x128 (1x4x1), 64x64 (2x2x1), 64x128 (1x4x1: a widened int4 fragment feeds two row tiles),
+//       128x64 (2x2x1), 128x128 (2x2x1)
+//   W8 (a secondary configuration): 32x64, 64x64, 128x128
 template <int WBITS, bool PER_M, typename TOut>
 static int launch_one(const GemmBatch& bt, int bm, int bn, hipStream_t st) {
     const GemmParams& p = bt.p[0];
     const int key = bm * 1000 + bn;
     switch (key) {
-        case 128128: launch_tile<WBITS, PER_M, TOut, 128, 128>(bt, st); break;
-        case 64064: launch_tile<WBITS, PER_M, TOut, 64, 64>(bt, st); break;   // (1 x 4 waves here: 3.567 -> 3.560 ms, not kept)
-        case 32064: {
-            // small grids (<= 2 workgroups per CU) with enough K tiles: the 6-stage ring — measured 2 % SLOWER over the SD step's
-            // GEMMs (3.65 -> 3.73 ms: the longer prologue wait outweighs the extra tiles in flight); opt-in with DGQ_GEMM_DEEP=1
-            static const bool deep_ok = [] { const char* e = getenv("DGQ_GEMM_DEEP"); return e && *e == '1'; }();
-            long blocks = 0;
-            for (int i = 0; i < bt.n; ++i) blocks += (long)((bt.p[i].M + 31) / 32) * ((bt.p[i].N + 63) / 64) * (bt.n > 1 ? 1 : p.splits);
-            static const bool row4 = [] { const char* e = getenv("DGQ_GEMM_WAVES"); return !(e && *e == '2'); }();   // A/B hook
-            if (deep_ok && blocks <= 512 && p.tiles_per_split >= 8) launch_tile<WBITS, PER_M, TOut, 32, 64, 6>(bt, st);
-            else if (row4 && WBITS == 4) launch_tile<WBITS, PER_M, TOut, 32, 64, 3, 4>(bt, st);
-            else launch_tile<WBITS, PER_M, TOut, 32, 64>(bt, st);
-            break;
-        }
+        case 128128: launch_ring<WBITS, PER_M, TOut, 128, 128, 2, 2, 1>(bt, st); break;
+        case 64064: launch_ring<WBITS, PER_M, TOut, 64, 64, 2, 2, 1>(bt, st); break;
+        case 32064: launch_ring<WBITS, PER_M, TOut, 32, 64, 1, 2, 2>(bt, st); break;
         default:
             if constexpr (WBITS == 4) {
                 switch (key) {
-                    case 128064: launch_tile<WBITS, PER_M, TOut, 128, 64>(bt, st); break;
-                    case 64128: launch_tile<WBITS, PER_M, TOut, 64, 128>(bt, st); break;
-                    case 32128: {
-                        static const bool row4 = [] { const char* e = getenv("DGQ_GEMM_WAVES"); return !(e && *e == '2'); }();
-                        if (row4) launch_tile<WBITS, PER_M, TOut, 32, 128, 3, 4>(bt, st);
-                        else launch_tile<WBITS, PER_M, TOut, 32, 128>(bt, st);
-                        break;
-                    }
+                    case 128064: launch_ring<WBITS, PER_M, TOut, 128, 64, 2, 2, 1>(bt, st); break;
+                    case 64128: launch_ring<WBITS, PER_M, TOut, 64, 128, 1, 4, 1>(bt, st); break;
+                    case 32128: launch_ring<WBITS, PER_M, TOut, 32, 128, 1, 4, 1>(bt, st); break;
                     default: dgq_set_error("dgq_gemm_wxa8: no %dx%d tile", bm, bn); return DGQ_EINVAL;
                 }
             } else {
@@ -570,8 +739,7 @@ static int launch_gemm(const GemmBatch& p, int bm, int bn, int y_dtype, hipStrea
 }
 
 // Launch plan (tile shape + K split).  Rules distilled from the measured sweep of every (tile, split) candidate over the
-// SD1.4 / SDXL layer shapes (tools/tile_sweep.py, profiles/r02_gemm_tile_sweep_*.txt; within 2 % of the per-shape optimum
-// on the SD step, 14 % better than the analytic model they replace).  What the measurements say:
+// SD1.4 / SDXL layer shapes (tools/tile_sweep.py, profiles/r0*_gemm_tile_sweep_*.txt).  What the measurements say:
 //   * these GEMMs are latency-bound per K tile, not MFMA-bound: the smallest tile (32x64: 1280 blocks at 8192x320, 640 at
 //     2048x640) wins whenever the output is small (M·N <= 3M), because many resident blocks hide each other's DMA latency;
 //   * once K is long (>= 24 K tiles) and M large, operand re-reads through L2 dominate (blocks · tiles · (BM·128 + BN·64)
@@ -633,8 +801,11 @@ static int fill_gemm(const dgq_gemm_args_t& a, GemmParams& p) {
     DGQ_CHECK_ARG(a.M > 0 && a.N > 0 && a.Kp > 0 && a.Kp % DGQ_KTILE == 0, "dgq_gemm_wxa8: bad shape M=%d N=%d Kp=%d", a.M, a.N, a.Kp);
     DGQ_CHECK_ARG(a.w_bits == 4 || a.w_bits == 8, "dgq_gemm_wxa8: w_bits=%d unsupported", a.w_bits);
     DGQ_CHECK_ARG(a.rowsum_parts >= 1 && a.rowsum_parts <= 64, "dgq_gemm_wxa8: rowsum_parts=%d", a.rowsum_parts);
-    DGQ_CHECK_ARG(a.ldy >= a.N, "dgq_gemm_wxa8: ldy < N");
-    DGQ_CHECK_ARG(a.Kp / DGQ_KCHUNK <= 2048, "dgq_gemm_wxa8: Kp=%d too large (max %d)", a.Kp, 2048 * DGQ_KCHUNK);
+    DGQ_CHECK_ARG(a.ldy >= (a.extra && a.extra->geglu ? a.N / 2 : a.N), "dgq_gemm_wxa8: ldy < output columns");
+    // per-M keeps ONE running int32 total over the whole K range: |T| <= Kp·128·wmax must stay below 2^31
+    // (per-K totals are cleared by the cflush == 2 marks of the planner and never pass 2^24)
+    DGQ_CHECK_ARG(a.Kp / DGQ_KCHUNK <= 4096 && (!a.per_m || a.Kp <= (a.w_bits == 4 ? 1 << 20 : 1 << 17)),
+                  "dgq_gemm_wxa8: Kp=%d too large for W%d", a.Kp, a.w_bits);
     DGQ_CHECK_ARG((reinterpret_cast<uintptr_t>(a.codes) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.wpacked) & 15) == 0,
                   "dgq_gemm_wxa8: codes/wpacked must be 16-byte aligned");
     if (a.per_m) {
@@ -652,9 +823,11 @@ static int fill_gemm(const dgq_gemm_args_t& a, GemmParams& p) {
         DGQ_CHECK_ARG(p.ex.fq_mode == 0 || (p.ex.fq_delta && p.ex.fq_zp && p.ex.fq_T > 0 && p.ex.fq_D > 0), "dgq_gemm_wxa8: fused quantizer needs tables");
         DGQ_CHECK_ARG(!p.ex.residual || (p.ex.ldr >= a.N && p.ex.res_div >= 1 && p.ex.res_dtype >= DGQ_F32 && p.ex.res_dtype <= DGQ_BF16),
                       "dgq_gemm_wxa8: bad residual descriptor (ldr < N, res_div < 1 or unknown dtype)");
+        DGQ_CHECK_ARG(!p.ex.geglu || (a.N % 4 == 0 && !p.ex.residual && p.ex.fq_mode == 0),
+                      "dgq_gemm_wxa8: the GEGLU epilogue needs N %% 4 == 0 and no other extra");
     } else {
         p.ex.residual = nullptr; p.ex.ldr = 0; p.ex.res_div = 1; p.ex.res_dtype = DGQ_F32; p.ex.fq_mode = 0; p.ex.fq_delta = nullptr; p.ex.fq_zp = nullptr;
-        p.ex.fq_T = 1; p.ex.fq_D = 1; p.ex.fq_skip = 0; p.ex.fq_qmax = 255.0f;
+        p.ex.fq_T = 1; p.ex.fq_D = 1; p.ex.fq_skip = 0; p.ex.fq_qmax = 255.0f; p.ex.geglu = 0;
     }
     p.splits = 1; p.slab = nullptr;
     p.tiles_per_split = a.Kp / BK;
@@ -708,6 +881,7 @@ extern "C" int dgq_gemm_wxa8(const int8_t* codes, const float* rowsum, int rowsu
         DGQ_CHECK_ARG(pl.splits == 1 || (workspace && (size_t)pl.splits * M * N * 4 <= workspace_bytes),
                       "dgq_gemm_wxa8: DGQ_GEMM_FORCE split does not fit the workspace");
     }
+    if (p.ex.geglu) pl.splits = 1;                       // the pair epilogue lives in the GEMM kernel, not in the combine
     p.splits = pl.splits;
     p.slab = p.splits > 1 ? reinterpret_cast<float*>(workspace) : nullptr;
     const int nk = Kp / BK;

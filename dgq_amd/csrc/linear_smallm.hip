@@ -14,7 +14,7 @@
 #define SMALLM_MAX_K 2048
 
 struct SmallMProblem {
-    const uint8_t* wpacked;    // W4: [N][Kp/2] (dgq_pack_w4, natural K order); W8: [N][Kp] int8
+    const uint8_t* wpacked;    // W4: [N][Kp/2] (dgq_pack_w4 layout 1, natural K order); W8: [N][Kp] int8
     const float* alpha;        // δw [N]
     const float* zw;           // zero point in the stored code domain [N]
     const float* gamma;        // bias [N]
@@ -77,7 +77,9 @@ __global__ __launch_bounds__(256) void linear_smallm_kernel(SmallMBatch b) {
         if (P.w_bits == 4) {
             for (int k0 = lane * 32; k0 < Kq; k0 += 64 * 32) {           // 16 bytes = 32 k per lane
                 const uint4 w = *reinterpret_cast<const uint4*>(wrow + k0 / 2);
-                const unsigned ww[4] = {w.x, w.y, w.z, w.w};
+                // layout 1: rows with bit 4 set store the two 8-byte halves of a 32-chunk exchanged (wave-uniform)
+                const bool sw = (n & 16) != 0;
+                const unsigned ww[4] = {sw ? w.z : w.x, sw ? w.w : w.y, sw ? w.x : w.z, sw ? w.y : w.w};
 #pragma unroll
                 for (int m = 0; m < SMALLM_MAX_M; ++m) {
                     if (m >= b.M) break;

@@ -14,7 +14,7 @@ struct QuantActParams {
     const int32_t* klds;      // optional [Kp]: (dh*kw + dw)*C + c, -1 for padding (LDS-staged conv path)
     const int32_t* kdst;      // optional [taps*C]: packed position kp of element (tap, c) — the inverse of ksrc (scatter path)
     int Kp, K;
-    const float* delta;       // per_m: [L]; else [Kp/64]
+    const float* delta;       // per_m: [L]; else [Kp/32]
     const float* zp;
     int L;
     float qmax, offset;
@@ -111,7 +111,7 @@ __device__ __forceinline__ uint32_t dgq_pack4(const float (&biased)[4], float& f
 
 // One wave per output row; each lane owns 4 consecutive kp per 256-wide step (one packed dword), so that the
 // table read (int4), the gathered loads (lane stride 16 B within a (group, tap) run) and the code store (256 B per
-// wave instruction) are all coalesced.  The 4 kp of a lane share one 64-wide chunk, hence one (δ, z).
+// wave instruction) are all coalesced.  The 4 kp of a lane share one 32-wide chunk, hence one (δ, z).
 template <typename TIn, bool HAS_TABLE, bool PER_M>
 __global__ __launch_bounds__(256) void quant_act_kernel(QuantActBatch bt) {
     const QuantActParams& p = bt.p[blockIdx.z];
@@ -217,8 +217,8 @@ __global__ __launch_bounds__(256) void quant_act_kernel(QuantActBatch bt) {
                 if (kp0 < k_end) {
                     float d = md, z = mz, inv = minv;
                     if (!PER_M) {
-                        d = p.delta[kp0 >> 6];
-                        z = p.zp[kp0 >> 6];
+                        d = p.delta[kp0 >> 5];
+                        z = p.zp[kp0 >> 5];
                         inv = dgq_rcp(d);
                     }
                     float biased[4], fsum = 0.0f;
@@ -238,8 +238,8 @@ __global__ __launch_bounds__(256) void quant_act_kernel(QuantActBatch bt) {
     for (int kp0 = k_begin + lane * 4; kp0 < k_end; kp0 += 256) {
         float d = md, z = mz, inv = minv;
         if (!PER_M) {
-            d = p.delta[kp0 >> 6];
-            z = p.zp[kp0 >> 6];
+            d = p.delta[kp0 >> 5];
+            z = p.zp[kp0 >> 5];
             inv = dgq_rcp(d);
         }
         float v[4];
@@ -386,8 +386,8 @@ __global__ __launch_bounds__(256) void quant_act_staged_kernel(QuantActBatch bt)
             if (kp0 < k_end) {
                 float d = md, z = mz, inv = minv;
                 if (!PER_M) {
-                    d = p.delta[kp0 >> 6];
-                    z = p.zp[kp0 >> 6];
+                    d = p.delta[kp0 >> 5];
+                    z = p.zp[kp0 >> 5];
                     inv = dgq_rcp(d);
                 }
                 float biased[4], fsum = 0.0f;
@@ -420,7 +420,7 @@ __global__ __launch_bounds__(256) void quant_act_scatter_kernel(QuantActBatch bt
     extern __shared__ __attribute__((aligned(16))) uint8_t sc_smem[];
     constexpr int WPR = 4 / RPB;                             // waves per row
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int nch = p.Kp >> 6;
+    const int nch = p.Kp >> 5;
     float* tdelta = reinterpret_cast<float*>(sc_smem);
     float* tinv = tdelta + nch;
     float* tzp = tinv + nch;
@@ -483,7 +483,7 @@ __global__ __launch_bounds__(256) void quant_act_scatter_kernel(QuantActBatch bt
                 const int dst[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const int ch = dst[j] >> 6;
+                    const int ch = dst[j] >> 5;
                     const float d = tdelta[ch];
                     const float sc = dgq_affine_code_fast(v[j], d, tinv[ch], tzp[ch], p.qmax) - p.offset;
                     image[dst[j]] = (uint8_t)(int)sc;
@@ -514,13 +514,13 @@ static int quant_act_variant(const QuantActParams& p, bool table) {
     // Linear inputs (one tap: the strip is the row itself, <= 16 KB) are always staged — the global gather pays one L1
     // access per code (8192 x 320 -> Kp 1024: 20 us) — together with their LayerNorm / GEGLU prologue.
     const int taps_ = p.kh * p.kw;
-    // per-K Linear inputs whose groups are short (K = 320 with 16 groups: Kp = 1024, 69 % padding): the staged gather
+    // per-K Linear inputs whose groups are short (K = 320 with 16 groups: Kp = 512, 38 % padding): the staged gather
     // evaluates the quantiser for every PACKED position, padding included; the scatter path evaluates it once per SOURCE
     // element (K instead of Kp codes, 16-byte coalesced reads with the LayerNorm / GEGLU prologue applied on the way) and
     // drops the byte into the row image in LDS.  One wave per row (RPB = 4).  DGQ_QA_LINEAR_SCATTER = 0 off, 2 always.
     {
         static const int mode = [] { const char* e = getenv("DGQ_QA_LINEAR_SCATTER"); return e && *e ? atoi(e) : 1; }();
-        const size_t tab_b = (((size_t)3 * (p.Kp >> 6) + 4) * 4 + 15) & ~(size_t)15;
+        const size_t tab_b = (((size_t)3 * (p.Kp >> 5) + 4) * 4 + 15) & ~(size_t)15;
         if (mode && table && p.kdst && taps_ == 1 && p.C % 4 == 0 && ks == 1 && (!p.ln_gamma || p.C <= DGQ_LN_MAX_C) &&
             tab_b + 4 * (size_t)p.Kp <= 150 * 1024 && (mode == 2 || 4 * p.Kp >= 5 * p.K))
             return 3;
@@ -532,7 +532,7 @@ static int quant_act_variant(const QuantActParams& p, bool table) {
     const bool prefer_scatter = conv_scatter && stage_conv && p.kdst != nullptr;
     if (!prefer_scatter && table && p.klds && p.C % 4 == 0 && strip_bytes <= 16 * 1024 && (stage_conv || stage_lin)) return 0;
     // scatter path: per-K table, more than one tap, the whole row in one wave/block (no K split), no LN / GEGLU prologue
-    const size_t sc_tab = (((size_t)3 * (p.Kp >> 6) + 4) * 4 + 15) & ~(size_t)15;
+    const size_t sc_tab = (((size_t)3 * (p.Kp >> 5) + 4) * 4 + 15) & ~(size_t)15;
     if (table && p.kdst && taps_ > 1 && p.C % 4 == 0 && ks == 1 && p.pre_act != 2 && !p.ln_gamma && sc_tab + (size_t)p.Kp <= 150 * 1024)
         return (p.M >= 2048 && sc_tab + 4 * (size_t)p.Kp <= 150 * 1024) ? 3 : 4;
     return table ? 1 : 2;
@@ -552,7 +552,7 @@ static void launch_quant_act(const QuantActBatch& bt, int n, int variant, bool p
     if (variant == 3 || variant == 4) {
         size_t lds = 0;
         for (int i = 0; i < n; ++i) {
-            const size_t tab = (((size_t)3 * (bt.p[i].Kp >> 6) + 4) * 4 + 15) & ~(size_t)15;
+            const size_t tab = (((size_t)3 * (bt.p[i].Kp >> 5) + 4) * 4 + 15) & ~(size_t)15;
             lds = std::max(lds, tab + (variant == 3 ? 4 : 1) * (size_t)bt.p[i].Kp);
         }
         static std::atomic<bool> attr_set[64];

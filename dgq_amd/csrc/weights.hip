@@ -18,9 +18,16 @@ __global__ void quantize_weight_kernel(const float* __restrict__ w, const float*
     }
 }
 
+// layout 1 (dgq_gemm_wxa8): rows with (n & 16) keep the two 8-byte halves of every 16 packed bytes exchanged — word w of a
+// row sits at w ^ 2 (see include/dgq_hip.h)
+__device__ __forceinline__ int64_t w4_word_index(int64_t i, int wpr, int layout) {
+    if (layout == 1 && (((i / wpr) >> 4) & 1)) return i ^ 2;
+    return i;
+}
+
 // one thread per packed 32-bit word = 8 consecutive kp
 __global__ void pack_w4_kernel(const uint8_t* __restrict__ codes, int N, int K, const int32_t* __restrict__ kperm,
-                               int Kp, uint32_t* __restrict__ packed) {
+                               int Kp, int layout, uint32_t* __restrict__ packed) {
     int wpr = Kp / 8;
     int64_t total = (int64_t)N * wpr;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
@@ -36,16 +43,16 @@ __global__ void pack_w4_kernel(const uint8_t* __restrict__ codes, int N, int K, 
             int byte = j & 3, hi = j >> 2;
             word |= c << (8 * byte + 4 * hi);
         }
-        packed[i] = word;
+        packed[w4_word_index(i, wpr, layout)] = word;
     }
 }
 
-__global__ void unpack_w4_kernel(const uint32_t* __restrict__ packed, int N, int Kp, uint8_t* __restrict__ out) {
+__global__ void unpack_w4_kernel(const uint32_t* __restrict__ packed, int N, int Kp, int layout, uint8_t* __restrict__ out) {
     int wpr = Kp / 8;
     int64_t total = (int64_t)N * wpr;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (int64_t)gridDim.x * blockDim.x) {
-        uint32_t word = packed[i];
+        uint32_t word = packed[w4_word_index(i, wpr, layout)];
         uint32_t lo = word & 0x0F0F0F0Fu, hi = (word >> 4) & 0x0F0F0F0Fu;   // the GEMM's unpack
         uint2 o = make_uint2(lo, hi);
         *reinterpret_cast<uint2*>(out + i * 8) = o;
@@ -81,21 +88,22 @@ extern "C" int dgq_quantize_weight(const float* w, const float* delta, const flo
     return dgq_launch_status("dgq_quantize_weight");
 }
 
-extern "C" int dgq_pack_w4(const uint8_t* codes, int N, int K, const int32_t* kperm, int Kp, uint8_t* packed,
+extern "C" int dgq_pack_w4(const uint8_t* codes, int N, int K, const int32_t* kperm, int Kp, int layout, uint8_t* packed,
                            void* stream) {
     DGQ_CHECK_ARG(codes && packed, "dgq_pack_w4: null pointer");
+    DGQ_CHECK_ARG(layout == 0 || layout == 1, "dgq_pack_w4: layout=%d", layout);
     DGQ_CHECK_ARG(N > 0 && K > 0 && Kp > 0 && Kp % DGQ_KTILE == 0, "dgq_pack_w4: Kp=%d must be a multiple of %d", Kp, DGQ_KTILE);
     DGQ_CHECK_ARG(kperm || Kp >= K, "dgq_pack_w4: identity order needs Kp >= K");
     hipLaunchKernelGGL(pack_w4_kernel, dim3(grid_for((int64_t)N * Kp / 8, 256)), dim3(256), 0, (hipStream_t)stream,
-                       codes, N, K, kperm, Kp, reinterpret_cast<uint32_t*>(packed));
+                       codes, N, K, kperm, Kp, layout, reinterpret_cast<uint32_t*>(packed));
     return dgq_launch_status("dgq_pack_w4");
 }
 
-extern "C" int dgq_unpack_w4(const uint8_t* packed, int N, int Kp, uint8_t* out, void* stream) {
+extern "C" int dgq_unpack_w4(const uint8_t* packed, int N, int Kp, int layout, uint8_t* out, void* stream) {
     DGQ_CHECK_ARG(packed && out, "dgq_unpack_w4: null pointer");
-    DGQ_CHECK_ARG(N > 0 && Kp > 0 && Kp % 8 == 0, "dgq_unpack_w4: bad shape");
+    DGQ_CHECK_ARG(N > 0 && Kp > 0 && Kp % 8 == 0 && (layout == 0 || (layout == 1 && Kp % 32 == 0)), "dgq_unpack_w4: bad shape / layout");
     hipLaunchKernelGGL(unpack_w4_kernel, dim3(grid_for((int64_t)N * Kp / 8, 256)), dim3(256), 0, (hipStream_t)stream,
-                       reinterpret_cast<const uint32_t*>(packed), N, Kp, out);
+                       reinterpret_cast<const uint32_t*>(packed), N, Kp, layout, out);
     return dgq_launch_status("dgq_unpack_w4");
 }
 

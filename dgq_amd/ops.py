@@ -8,7 +8,7 @@ from typing import Optional
 import torch
 
 from . import _lib
-from .plan import ActLayout, natural_kperm, round_up, KTILE, act_offset
+from .plan import ActLayout, natural_kperm, round_up, KTILE, act_offset, mark_clears
 
 _c = ctypes
 
@@ -104,12 +104,16 @@ def adaround_reg(alpha: torch.Tensor, b: float):
     return _AdaRoundReg.apply(alpha, float(b))
 
 
+#: dgq_pack_w4 layout every kernel of this package reads (rows with bit 4 set: 8-byte halves of a 32-chunk exchanged)
+W4_LAYOUT = 1
+
+
 def pack_weight(codes: torch.Tensor, kperm: Optional[torch.Tensor], Kp: int, bits: int):
     N, K = codes.shape
     kp = kperm.to(codes.device, torch.int32).contiguous() if kperm is not None else None
     if bits == 4:
         out = torch.empty((N, Kp // 2), dtype=torch.uint8, device=codes.device)
-        _lib_call("dgq_pack_w4", _lib.ptr(codes), N, K, _lib.ptr(kp), Kp, _lib.ptr(out), _lib.stream())
+        _lib_call("dgq_pack_w4", _lib.ptr(codes), N, K, _lib.ptr(kp), Kp, W4_LAYOUT, _lib.ptr(out), _lib.stream())
     elif bits == 8:
         out = torch.empty((N, Kp), dtype=torch.int8, device=codes.device)
         _lib_call("dgq_pack_w8", _lib.ptr(codes), N, K, _lib.ptr(kp), Kp, _lib.ptr(out), _lib.stream())
@@ -118,10 +122,10 @@ def pack_weight(codes: torch.Tensor, kperm: Optional[torch.Tensor], Kp: int, bit
     return out
 
 
-def unpack_w4(packed: torch.Tensor, Kp: int):
+def unpack_w4(packed: torch.Tensor, Kp: int, layout: int = W4_LAYOUT):
     N = packed.shape[0]
     out = torch.empty((N, Kp), dtype=torch.uint8, device=packed.device)
-    _lib_call("dgq_unpack_w4", _lib.ptr(packed), N, Kp, _lib.ptr(out), _lib.stream())
+    _lib_call("dgq_unpack_w4", _lib.ptr(packed), N, Kp, layout, _lib.ptr(out), _lib.stream())
     return out
 
 
@@ -210,7 +214,7 @@ class ActBinding:
             self._koff = {}
             self.cdelta = layout.cdelta.to(dev)
             self.czp = layout.czp.to(dev)
-            self.cflush = layout.cflush.to(dev)
+            self.cflush = mark_clears(layout.cflush, abits, pw.bits).to(dev)     # + where the GEMM clears its running total
             self.wpacked = pack_weight(pw.codes, layout.kperm, layout.Kp, pw.bits)
             U = (pw.centered() @ layout.kcoef.to(dev)).float()             # Σ_k δ_k(o − z_k)(qw − zw)
             self.gamma = (pw.bias + pw.alpha * U).contiguous()
@@ -406,14 +410,15 @@ class Fork:
         self.used = []
 
 
-def make_extra(residual=None, fq=None, res_div=1):
+def make_extra(residual=None, fq=None, res_div=1, geglu=False):
     """dgq_gemm_extra_t: residual [M / res_div][N] fp32 (row stride = its stride(0); res_div > 1 broadcasts each row
     over res_div consecutive output rows); fq = (mode, delta, zp, T, D, skip, bits) with mode 1 scalar / 2 per token /
-    3 per head-dim.  Keeps the tensors alive on the returned object."""
-    if residual is None and fq is None:
+    3 per head-dim; geglu = the pair epilogue of a row-interleaved ff.net.0.  Keeps the tensors alive on the returned object."""
+    if residual is None and fq is None and not geglu:
         return None
     ex = _lib.GemmExtra()
     ex.res_div = 1
+    ex.geglu = 1 if geglu else 0
     keep = []
     if residual is not None:
         assert residual.dtype in _lib.DTYPE_CODE and residual.stride(-1) == 1
@@ -441,7 +446,7 @@ def gemm_wxa8(codes, rowsum, M, ab: ActBinding, out_dtype, out: Optional[torch.T
     pw = ab.pw
     ws = workspace(codes.device)
     if out is None:
-        out = torch.empty((M, pw.N), dtype=out_dtype, device=codes.device)
+        out = torch.empty((M, pw.N // 2 if (extra is not None and extra.geglu) else pw.N), dtype=out_dtype, device=codes.device)
     per_m = 0 if ab.mode == "perK" else 1
     parts = rowsum.shape[0] if rowsum.dim() == 2 else 1
     def issue():
@@ -459,74 +464,10 @@ def gemm_wxa8(codes, rowsum, M, ab: ActBinding, out_dtype, out: Optional[torch.T
     return out
 
 
-#: Linear / 1x1-conv layers through dgq_linear_fused_batch (quantise-on-load inside the GEMM: one launch per layer, no int8
-#: operand in HBM).  OPT-IN (measured: no gain on the SD step).  DGQ_FUSED_LINEAR: 0 (default) = never, 1 = only the shape class
-#: where it measured faster than dgq_quant_act + dgq_gemm_wxa8 on MI355X (tools/bench_fused.py,
-#: profiles/r02_fused_linear_microbench.txt: per-M / scalar tables with C <= 320 and N <= 640 on >= 4096 rows: 12.7 vs 20.2 us;
-#: per-K 30.6 vs 26.1 us, wide N 3x SLOWER — every 320 columns re-quantise the panel), 2 = every supported shape.
-FUSED_LINEAR = int(os.environ.get("DGQ_FUSED_LINEAR", "0"))
-#: rows below which the two-kernel path is kept under mode 2 (few row panels: every column split re-quantises the panel)
-FUSED_MIN_M = int(os.environ.get("DGQ_FUSED_MIN_M", "1024"))
-
-
-def fused_linear_ok(M, C, ab: ActBinding):
-    if not FUSED_LINEAR or ab.pw.taps != 1 or ab.pw.K != C:
-        return False
-    if FUSED_LINEAR == 1 and not (ab.mode != "perK" and C <= 320 and ab.pw.N <= 640 and M >= 4096):
-        return False
-    return bool(M >= FUSED_MIN_M and
-                _lib.load().dgq_linear_fused_supported(M, C, ab.Kp, ab.pw.N, 0 if ab.mode == "perK" else 1, ab.pw.bits))
-
-
-def _fused_args(x2, M, C, hw, ab: ActBinding, out, pre, ln, extra):
-    """dgq_fused_linear_args_t for one layer; `pre` = (scale, shift, act) as quant_act, `ln` = (gamma, beta, eps) fp32"""
-    pw = ab.pw
-    per_m = 0 if ab.mode == "perK" else 1
-    a = _lib.FusedLinearArgs()
-    a.x, a.x_dtype, a.M, a.C, a.hw = x2.data_ptr(), _lib.DTYPE_CODE[x2.dtype], M, C, hw
-    a.kdst = _dp(ab.kdst(1, C, 1)) if not per_m else None
-    a.Kp, a.per_m = ab.Kp, per_m
-    a.delta, a.zp = (ab.cdelta.data_ptr(), ab.czp.data_ptr()) if not per_m else (ab.mdelta.data_ptr(), ab.mzp.data_ptr())
-    a.L, a.a_bits = (1 if not per_m else ab.L), ab.abits
-    a.pre_scale = _dp(pre[0]) if pre and pre[0] is not None else None
-    a.pre_shift = _dp(pre[1]) if pre and pre[1] is not None else None
-    a.pre_act = pre[2] if pre else 0
-    a.ln_gamma, a.ln_beta, a.ln_eps = (ln[0].data_ptr(), ln[1].data_ptr(), ln[2]) if ln else (None, None, 0.0)
-    a.wpacked, a.w_bits, a.N = ab.wpacked.data_ptr(), pw.bits, pw.N
-    a.cflush = ab.cflush.data_ptr() if not per_m else None
-    a.alpha, a.zw, a.gamma, a.vn = pw.alpha.data_ptr(), pw.zw.data_ptr(), ab.gamma.data_ptr(), (ab.vn.data_ptr() if per_m else None)
-    a.y, a.y_dtype, a.ldy = out.data_ptr(), _lib.DTYPE_CODE[out.dtype], out.stride(0)
-    a.extra = _c.cast(_c.pointer(extra), _c.c_void_p) if extra is not None else None
-    return a
-
-
-def linear_fused(x2: torch.Tensor, M, C, hw, bindings, pre=None, ln=None, extras=None):
-    """[y_i] = the layers `bindings` applied to the rows of x2 ([M][C], or [M][2C] with the GEGLU prologue) — up to 4 layers
-    that share x2 per launch (dgq_linear_fused_batch); per layer an optional dgq_gemm_extra_t (residual / fused quantizer)."""
-    lnp = (as_f32(ln[0]), as_f32(ln[1]), float(ln[2])) if ln else None
-    outs = [torch.empty((M, ab.pw.N), dtype=x2.dtype, device=x2.device) for ab in bindings]
-    extras = extras or [None] * len(bindings)
-    groups = {}
-    for i, ab in enumerate(bindings):
-        groups.setdefault((ab.mode == "perK", ab.Kp), []).append(i)
-    for idxs in groups.values():
-        for j0 in range(0, len(idxs), 4):
-            chunk = idxs[j0:j0 + 4]
-            arr = (_lib.FusedLinearArgs * len(chunk))(*[_fused_args(x2, M, C, hw, bindings[i], outs[i], pre, lnp, extras[i])
-                                                         for i in chunk])
-            n_chunk = len(chunk)
-
-            def issue(arr=arr, n_chunk=n_chunk):
-                _lib_call("dgq_linear_fused_batch", n_chunk, _c.cast(arr, _c.c_void_p), _lib.stream())
-            issue()
-            if GEMM_LAUNCH_HOOK is not None:
-                GEMM_LAUNCH_HOOK(issue, [(M, bindings[i], outs[i].element_size()) for i in chunk])
-    return outs
-
-
-def quant_linear(x: torch.Tensor, ab: ActBinding, pre_act=0, residual=None, fq=None, ln=None):
+def quant_linear(x: torch.Tensor, ab: ActBinding, pre_act=0, residual=None, fq=None, ln=None, geglu=False):
     """x [..., K] -> [..., N].  pre_act: 0 none, 1 SiLU(x), 2 GEGLU (x is [..., 2K]: x[:K]·gelu(x[K:])) folded into the
-    quantise-on-load pass; residual [..., N] and fq (see make_extra) folded into the GEMM epilogue."""
+    quantise-on-load pass; residual [..., N] and fq (see make_extra) folded into the GEMM epilogue.  geglu: the weight rows
+    are (value, gate) interleaved and the epilogue writes value·gelu(gate), [..., N/2]."""
     Kin = x.shape[-1]
     K = Kin // 2 if pre_act == 2 else Kin
     x2 = x.reshape(-1, Kin)
@@ -539,12 +480,9 @@ def quant_linear(x: torch.Tensor, ab: ActBinding, pre_act=0, residual=None, fq=N
         res2 = residual.reshape(-1, ab.pw.N)
         if not res2.is_contiguous():
             res2 = res2.contiguous()
-    if fused_linear_ok(rows, K, ab):
-        y = linear_fused(x2, rows, K, 1, [ab], pre, ln, [make_extra(res2, fq)])[0]
-        return y.view(*x.shape[:-1], ab.pw.N)
     codes, rowsum, M = quant_act(x2, rows, 1, 1, K, 1, 1, 1, 0, ab, pre, ln)
-    y = gemm_wxa8(codes, rowsum, M, ab, x.dtype, extra=make_extra(res2, fq))
-    return y.view(*x.shape[:-1], ab.pw.N)
+    y = gemm_wxa8(codes, rowsum, M, ab, x.dtype, extra=make_extra(res2, fq, geglu=geglu))
+    return y.view(*x.shape[:-1], y.shape[-1])
 
 
 def quant_linear_multi(x: torch.Tensor, bindings, ln=None):
@@ -559,22 +497,6 @@ def quant_linear_multi(x: torch.Tensor, bindings, ln=None):
     M = x2.shape[0]
     dev = x2.device
     lib = _lib.load()
-    fused_idx = [i for i, ab in enumerate(bindings) if fused_linear_ok(M, Kin, ab)]
-    if fused_idx:
-        # the layers that qualify for the one-launch path share theirs; the others keep the shared two-kernel launches
-        outs = [None] * len(bindings)
-        for i, o in zip(fused_idx, linear_fused(x2, M, Kin, 1, [bindings[i] for i in fused_idx], None, ln)):
-            outs[i] = o.view(*x.shape[:-1], o.shape[-1])
-        rest = [i for i in range(len(bindings)) if i not in fused_idx]
-        if rest:
-            global FUSED_LINEAR
-            keep, FUSED_LINEAR = FUSED_LINEAR, 0
-            try:
-                for i, o in zip(rest, quant_linear_multi(x, [bindings[i] for i in rest], ln=ln)):
-                    outs[i] = o
-            finally:
-                FUSED_LINEAR = keep
-        return outs
     lnp = (as_f32(ln[0]), as_f32(ln[1]), float(ln[2])) if ln else None
     qa, keep = [], []
     for ab in bindings:
@@ -658,10 +580,6 @@ def quant_conv2d(x: torch.Tensor, ab: ActBinding, kh, kw, stride, pad, norm=None
         res2 = residual.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1).reshape(M, ab.pw.N)
     elif bias_rows is not None:                       # [B][N]: one row per image, broadcast over its Ho*Wo positions
         res2, res_div = bias_rows.contiguous(), M // B
-    if kh == 1 and kw == 1 and stride == 1 and pad == 0 and fused_linear_ok(M, C, ab):
-        # a 1x1 convolution on channels-last storage IS a Linear layer over the B·H·W pixel rows
-        y = linear_fused(x_store.reshape(M, C), M, C, H * W, [ab], pre, None, [make_extra(res2, res_div=res_div)])[0]
-        return y.view(B, Ho, Wo, ab.pw.N).permute(0, 3, 1, 2)
     codes, rowsum, M = quant_act(x_store, B, H, W, C, kh, kw, stride, pad, ab, pre)
     y = gemm_wxa8(codes, rowsum, M, ab, x.dtype, extra=make_extra(res2, res_div=res_div))
     return y.view(B, Ho, Wo, ab.pw.N).permute(0, 3, 1, 2)

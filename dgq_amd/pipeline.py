@@ -13,7 +13,7 @@ What the loop relies on from the UNet object — and what QuantModel therefore p
     activation tables alias onto one slot (quant/calibration.py:301-304)."""
 import torch
 
-from .scheduler import DDIMScheduler, PNDMScheduler
+from .scheduler import DDIMScheduler, EulerAncestralDiscreteScheduler, PNDMScheduler
 
 
 @torch.no_grad()
@@ -42,24 +42,22 @@ def stable_diffusion_denoise(unet, latents, prompt_embeds, num_inference_steps=2
 
 
 @torch.no_grad()
-def sdxl_turbo_denoise(unet, latents, prompt_embeds, text_embeds, time_ids, timesteps=(999, 749, 499, 249), on_call=None):
+def sdxl_turbo_denoise(unet, latents, prompt_embeds, text_embeds, time_ids, num_inference_steps=4, generator=None, on_call=None):
     """pipeline_stable_diffusion_xl.py:1170-1200 with guidance_scale = 0 (src/inference_qmodel.py:49): no CFG batch;
-    ``added_cond_kwargs = {"text_embeds", "time_ids"}``.  SDXL-turbo's scheduler is EulerAncestralDiscrete ("trailing"
-    spacing: t = 999, 749, 499, 249 for 4 steps); its update draws noise and is not on the quantized path, so a plain
-    Euler step on the same sigmas stands in for it here."""
+    ``added_cond_kwargs = {"text_embeds", "time_ids"}``; SDXL-turbo's EulerAncestralDiscrete scheduler ("trailing" spacing:
+    t = 999, 749, 499, 249 for 4 steps) with its ancestral noise drawn from ``generator`` (a CPU torch.Generator, as the
+    pipeline's ``generator=`` argument; None = the global RNG).  ``latents``: unit-variance noise, scaled by
+    ``init_noise_sigma`` here as ``prepare_latents`` does."""
     assert unet.config.addition_time_embed_dim is not None
-    betas = torch.linspace(0.00085 ** 0.5, 0.012 ** 0.5, 1000, dtype=torch.float32) ** 2
-    ac = torch.cumprod(1.0 - betas, dim=0)
-    sig = ((1 - ac) / ac) ** 0.5
-    sigmas = [float(sig[t]) for t in timesteps] + [0.0]
-    x = latents * (sigmas[0] ** 2 + 1) ** 0.5
+    sch = EulerAncestralDiscreteScheduler(num_inference_steps)
+    x = latents * sch.init_noise_sigma
     added = {"text_embeds": text_embeds, "time_ids": time_ids}
-    for i, t in enumerate(timesteps):
-        tt = torch.tensor(t, dtype=torch.int64, device=latents.device)
-        inp = x / ((sigmas[i] ** 2 + 1) ** 0.5)                  # scheduler.scale_model_input
+    for i, t in enumerate(sch.timesteps):
+        tt = torch.tensor(t, device=latents.device)              # the scheduler's timesteps are float32 (999., 749., ...)
+        inp = sch.scale_model_input(x, t)
         if on_call is not None:
             on_call(i, t)
         eps = unet(inp, tt, encoder_hidden_states=prompt_embeds, timestep_cond=None, cross_attention_kwargs=None,
                    added_cond_kwargs=added, return_dict=False)[0]
-        x = x + eps * (sigmas[i + 1] - sigmas[i])
+        x = sch.step(eps, t, x, generator=generator)
     return x

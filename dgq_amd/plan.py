@@ -8,15 +8,21 @@ K orders:
   * reference order  k_ref = c·(kh·kw) + tap     (``w.view(N,-1)`` / ``F.unfold`` row order, quant_layer.py:557,634)
   * natural physical kp = tap·C + c               (channels-last friendly; used for per-M / scalar scales)
   * grouped physical: DGQ groups (= distinct (δ,z) pairs, arbitrary channel sets, quant_layer.py:405-418)
-    made contiguous, each padded with zero codes to a multiple of 64 (one MFMA_I32_16x16x64_I8 slice can
-    then be scaled by a single δ), whole K padded to a multiple of 128 (the GEMM's K tile).
+    made contiguous, each padded with zero codes to a multiple of 32 (one MFMA_I32_32x32x32_I8 slice is
+    then scaled by a single δ; rounds 1-2 padded to 64 for MFMA_I32_16x16x64_I8: K = 320 in 16 groups
+    gave Kp = 1024, now 512), whole K padded to a multiple of 128 (the GEMM's K tile).
+
+The GEMM sums by parts over running int32 totals T_c (Σ_g δ_g·P_g = Σ_c (δ_c − δ_{c+1})·T_c); ``cflush`` marks where
+a group ends (1); ``mark_clears`` adds, per weight width, the chunks after which the running total is cleared (2) so
+that |T| never exceeds 2^24 and its fp32 conversion in the flush stays exact (a clear may fall inside a group: the
+coefficient of the chunk in front of it is then the full δ_c).
 """
 from dataclasses import dataclass
 from typing import Optional
 
 import torch
 
-KCHUNK = 64
+KCHUNK = 32
 KTILE = 128
 
 
@@ -45,9 +51,9 @@ class ActLayout:
     # perK
     kperm: Optional[torch.Tensor] = None      # [Kp] int32: k_ref or -1   (weight packing)
     ksrc: Optional[torch.Tensor] = None       # [Kp] int32: (dh<<24)|(dw<<16)|c or -1 (activation gather)
-    cdelta: Optional[torch.Tensor] = None     # [Kp/64] f32
+    cdelta: Optional[torch.Tensor] = None     # [Kp/32] f32
     czp: Optional[torch.Tensor] = None
-    cflush: Optional[torch.Tensor] = None     # [Kp/64] u8
+    cflush: Optional[torch.Tensor] = None     # [Kp/32] u8: 0 inside a group, 1 group end (2 after mark_clears: clear the running total)
     kcoef: Optional[torch.Tensor] = None      # [K] f64 in k_ref order: δ_k·(offset − z_k), for U[n]
     Kp: int = 0
     n_groups: int = 0
@@ -72,6 +78,22 @@ def classify_act_params(delta: torch.Tensor, kind: str):
         if delta.shape[1] == 1:
             return "perM"
     raise ValueError("unsupported activation-quantizer shape %s for %s" % (tuple(delta.shape), kind))
+
+
+def seg_limit(abits: int, wbits: int) -> int:
+    """Codes (a multiple of KTILE: clears sit behind whole K tiles) a running int32 total may span before it is cleared:
+    |s| <= 2^(abits−1) and |qw'| <= 15 (W4, unsigned nibbles) or 128 (W8, centred), so |T| <= 2^24 and float(T) is exact."""
+    wmax = 15 if wbits == 4 else 128
+    return max(KTILE, (1 << 24) // ((1 << (abits - 1)) * wmax) // KTILE * KTILE)
+
+
+def mark_clears(cflush: torch.Tensor, abits: int, wbits: int) -> torch.Tensor:
+    """cflush with value 2 on the last chunk of every seg_limit-long segment (uniform segments from chunk 0; always the
+    last chunk of a K tile, the only place where dgq_gemm_wxa8 honours the mark)."""
+    out = cflush.clone()
+    step = seg_limit(abits, wbits) // KCHUNK
+    out[step - 1::step] = 2
+    return out
 
 
 def plan_act(delta: torch.Tensor, zp: torch.Tensor, kind: str, C: int, taps: int, abits: int, kw: int = 0) -> ActLayout:

@@ -34,6 +34,8 @@ FUSE_NORM = True
 _F_RES = _os.environ.get("DGQ_FUSE_RESIDUAL", "1") == "1"
 _F_FQ = _os.environ.get("DGQ_FUSE_FQ", "0") == "1"
 _F_GEGLU = _os.environ.get("DGQ_FUSE_GEGLU", "1") == "1"
+# ... or (round 3) in ff.net.0's GEMM epilogue: half the stores of the widest layer, no GEGLU pass in front of ff.net.2
+_F_GEGLU_EPI = _os.environ.get("DGQ_FUSE_GEGLU_EPILOGUE", "1") == "1"
 _F_SILU = _os.environ.get("DGQ_FUSE_SILU", "1") == "1"
 # norm1/2/3 of the transformer block folded into the quantise-on-load pass of the layers that consume them
 _F_LN = _os.environ.get("DGQ_FUSE_LN", "1") == "1"
@@ -228,6 +230,10 @@ class QuantBasicTransformerBlock(BaseQuantBlock):
         self.attn2 = tran.attn2
         self.norm3 = tran.norm3
         self.ff = tran.ff
+        net = self.ff.net
+        if (_F_GEGLU_EPI and len(net) == 3 and hasattr(net[0], "proj") and isinstance(net[0].proj, QuantLayer)
+                and net[0].proj.w.shape[0] % 4 == 0):
+            net[0].proj.geglu_rows = True                      # packed rows (value, gate) interleaved: see QuantLayer
         for attn in (self.attn1, self.attn2):
             attn.aqtizer_q = UniformAffineQuantizer(**aq_params)
             attn.aqtizer_k = UniformAffineQuantizer(**aq_params)
@@ -262,6 +268,9 @@ class QuantBasicTransformerBlock(BaseQuantBlock):
         x = quant_attention_forward(self.attn2, _prenorm(x, self.norm2), encoder_hidden_states, residual=x)
         net = self.ff.net
         if len(net) == 3 and hasattr(net[0], "proj") and isinstance(net[1], nn.Dropout):
+            if isinstance(net[0].proj, QuantLayer) and net[0].proj.geglu_rows and isinstance(net[2], QuantLayer):
+                h2 = _apply(net[0].proj, _prenorm(x, self.norm3), geglu=True)   # value·gelu(gate) in ff.net.0's epilogue
+                return net[2].forward_fused(h2, residual=x)
             h = _apply(net[0].proj, _prenorm(x, self.norm3))  # GEGLU projection (sd.py:210-236)
             if _F_GEGLU and isinstance(net[2], QuantLayer):
                 return net[2].forward_fused(h, pre_act=2, residual=x)   # a·gelu(g) happens in ff.net.2's load

@@ -358,6 +358,9 @@ class QuantLayer(nn.Module):
         self._bindings = {}
         self._act_tables = {}            # slot -> (δ, z) CPU tensors from the cali_ckpt
         self._slot_ref: Optional[SlotRef] = None
+        #: ff.net.0 of a GEGLU feed-forward (set by QuantBasicTransformerBlock): the packed weight keeps its rows interleaved
+        #: (2i = value column i, 2i+1 = gate column i) so that dgq_gemm_wxa8's pair epilogue can form value·gelu(gate)
+        self.geglu_rows = False
 
     # -- geometry ---------------------------------------------------------------------------------
     @property
@@ -387,19 +390,35 @@ class QuantLayer(nn.Module):
         key = self._weight_key()
         if self._pw is None or key != self._pw_key:
             dev = self.w.device
-            self._pw = ops.PackedWeight(self.w.data.float(), q.delta.data.to(dev), torch.as_tensor(q.zero_point).data.to(dev),
-                                        getattr(q, "alpha", None), self.b.data if self.b is not None else None,
-                                        q.bits, self.in_channels, self.taps)
+            w, d, z = self.w.data.float(), q.delta.data.to(dev), torch.as_tensor(q.zero_point).data.to(dev)
+            alpha, b = getattr(q, "alpha", None), (self.b.data if self.b is not None else None)
+            if self.geglu_rows:
+                rp = self._row_perm(dev)
+                w, d, z = w[rp], d.reshape(w.shape[0], -1)[rp], z.reshape(w.shape[0], -1)[rp]
+                alpha = alpha.data[rp] if alpha is not None else None
+                b = b[rp] if b is not None else None
+            self._pw = ops.PackedWeight(w, d, z, alpha, b, q.bits, self.in_channels, self.taps)
             self._pw_key = key
             self._bindings = {}
             self._wdq = None
         return self._pw
 
+    def _row_perm(self, dev):
+        """packed row 2i = reference row i (value half), 2i+1 = reference row i + N/2 (gate half)"""
+        N = self.w.shape[0]
+        return torch.stack([torch.arange(N // 2, device=dev), torch.arange(N // 2, device=dev) + N // 2], 1).flatten()
+
+    def _row_unperm(self, dev):
+        return torch.argsort(self._row_perm(dev))
+
     def dequantized_weight(self, dtype):
         """δ·(q − z) as a tensor: weight-only mode feeds it to the library GEMM/conv."""
         pw = self.packed_weight()
         if self._wdq is None or self._wdq.dtype != dtype:
-            w = (pw.alpha[:, None] * (pw.codes.float() - pw.zp_true[:, None])).view(self.w.shape)
+            w = pw.alpha[:, None] * (pw.codes.float() - pw.zp_true[:, None])
+            if self.geglu_rows:
+                w = w[self._row_unperm(w.device)]
+            w = w.view(self.w.shape)
             self._wdq = w.to(dtype)
             if self.is_conv:
                 self._wdq = self._wdq.contiguous(memory_format=torch.channels_last)
@@ -474,19 +493,24 @@ class QuantLayer(nn.Module):
             kh, kw = self.w.shape[2], self.w.shape[3]
             return _tap(self, ops.quant_conv2d(x, ab, kh, kw, self.fwd_kwargs["stride"][0], self.fwd_kwargs["padding"][0]),
                         x=x, prologue=False)
-        return _tap(self, ops.quant_linear(x, ab), x=x, prologue=False)
+        y = ops.quant_linear(x, ab)
+        if self.geglu_rows:                     # the plain path returns the reference's column order
+            y = y.index_select(-1, self._row_unperm(y.device))
+        return _tap(self, y, x=x, prologue=False)
 
     def on_integer_path(self, x: torch.Tensor) -> bool:
         """True when forward(x) would run dgq_quant_act + dgq_gemm_wxa8 (weights and activations quantised, GPU)."""
         return (self.use_wq and self.use_aq and not self.disable_aq and x.is_cuda
                 and (self.aqtizer.init or (self._slot_ref is not None and self._slot_ref.slot in self._act_tables)))
 
-    def forward_fused(self, x: torch.Tensor, pre_act: int = 0, residual=None, fq=None, ln=None) -> torch.Tensor:
+    def forward_fused(self, x: torch.Tensor, pre_act: int = 0, residual=None, fq=None, ln=None, geglu: bool = False) -> torch.Tensor:
         """``fq(self(act(x))) + residual`` with the elementwise pieces folded into the two kernels of the layer:
         pre_act 1 = SiLU(x), 2 = GEGLU (x[..., :K]·gelu(x[..., K:])) inside the quantise-on-load pass; ``fq`` (an
         attention-side quantizer, see ops.make_extra) and ``residual`` inside the GEMM epilogue.  Linear layers on the
         integer path only; anything else falls back to the unfused sequence of the same kernels/ops.  ``ln`` = an
-        nn.LayerNorm module applied to x first, folded into the same load pass (per-row statistics in the kernel)."""
+        nn.LayerNorm module applied to x first, folded into the same load pass (per-row statistics in the kernel).
+        ``geglu``: the layer is the GEGLU projection ff.net.0 and the result is value·gelu(gate), [..., N/2] — formed in the
+        GEMM epilogue when the packed rows are interleaved (``geglu_rows``)."""
         if ln is not None and (self.is_conv or not self.on_integer_path(x) or x.dtype not in ops.FLOAT_DTYPES or pre_act
                                or x.shape[-1] % 4 or x.shape[-1] > 2048):
             x = ln(x)                                           # nn.LayerNorm module: unfused
@@ -498,14 +522,21 @@ class QuantLayer(nn.Module):
                 a, g = x.chunk(2, dim=-1)
                 x = a * F.gelu(g)
             y = self(x)                                           # through __call__: forward hooks (data_utill.py) see it
+            if geglu:
+                a, g = y.chunk(2, dim=-1)
+                y = a * F.gelu(g)
             if fq is not None:
                 mode, dd, zz, T, D, skip, bits = fq
                 y = y.contiguous()
                 ops.fakequant_rows(y.view(-1, y.shape[-1]), T, D, mode - 1, dd, zz, skip, bits)
             return y if residual is None else y + residual
         lnp = (ln.weight, ln.bias, float(ln.eps)) if ln is not None else None
-        return _tap(self, ops.quant_linear(x, self._binding(), pre_act=pre_act, residual=residual, fq=fq, ln=lnp),
-                    x=x, prologue=bool(pre_act or lnp is not None), residual=residual, fq=fq)
+        if geglu and not self.geglu_rows:                         # rows not interleaved: GEGLU as its own step
+            y = self.forward_fused(x, pre_act=pre_act, ln=ln)
+            a, g = y.chunk(2, dim=-1)
+            return a * F.gelu(g)
+        return _tap(self, ops.quant_linear(x, self._binding(), pre_act=pre_act, residual=residual, fq=fq, ln=lnp, geglu=geglu),
+                    x=x, prologue=bool(pre_act or lnp is not None), residual=residual, fq=fq, geglu=geglu)
 
     def can_fuse_prenorm(self, x: torch.Tensor) -> bool:
         """True when this layer runs on the integer path, so a preceding GroupNorm(+SiLU) can be folded into its

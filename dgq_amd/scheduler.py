@@ -90,3 +90,47 @@ class PNDMScheduler:
         out = self._prev_sample(sample, t, prev_t, model_output)
         self.counter += 1
         return out
+
+
+class EulerAncestralDiscreteScheduler:
+    """SDXL-turbo's scheduler (``src/inference_qmodel.py`` runs sdxl-turbo with its repo's scheduler_config: Euler ancestral,
+    scaled_linear β 0.00085→0.012, "trailing" timestep spacing, ε-prediction).  Restates diffusers
+    scheduling_euler_ancestral_discrete.py: ``set_timesteps`` (:262-303: t = round(arange(T, 0, −T/N)) − 1, σ interpolated
+    from ((1−ᾱ)/ᾱ)^½ in float64 and stored as float32, a trailing 0), ``init_noise_sigma`` (:219-225), ``scale_model_input``
+    (:234-260) and ``step`` (:322-420) with the ancestral noise drawn from an explicit generator on the CPU and moved to the
+    sample's device, as diffusers' ``randn_tensor`` does for a CPU generator.  4 steps: t = 999, 749, 499, 249."""
+
+    def __init__(self, num_inference_steps, num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012):
+        import numpy as np
+        betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
+        alphas_cumprod = torch.cumprod(1.0 - betas, dim=0)
+        step_ratio = num_train_timesteps / num_inference_steps
+        timesteps = np.arange(num_train_timesteps, 0, -step_ratio).round().copy().astype(np.float32) - 1
+        sig = np.array(((1 - alphas_cumprod) / alphas_cumprod) ** 0.5)
+        sig = np.interp(timesteps, np.arange(0, len(sig)), sig)
+        self.sigmas = torch.from_numpy(np.concatenate([sig, [0.0]]).astype(np.float32))
+        self.timesteps = [float(t) for t in timesteps]
+        self.num_inference_steps = num_inference_steps
+        self.step_index = 0
+
+    @property
+    def init_noise_sigma(self):
+        return self.sigmas.max()
+
+    def scale_model_input(self, sample, t=None):
+        sigma = self.sigmas[self.step_index]
+        return sample / ((sigma ** 2 + 1) ** 0.5)
+
+    def step(self, model_output, t, sample, generator=None):
+        sigma = self.sigmas[self.step_index]
+        sample = sample.to(torch.float32)
+        pred_original_sample = sample - sigma * model_output
+        sigma_from, sigma_to = self.sigmas[self.step_index], self.sigmas[self.step_index + 1]
+        sigma_up = (sigma_to ** 2 * (sigma_from ** 2 - sigma_to ** 2) / sigma_from ** 2) ** 0.5
+        sigma_down = (sigma_to ** 2 - sigma_up ** 2) ** 0.5
+        derivative = (sample - pred_original_sample) / sigma
+        prev_sample = sample + derivative * (sigma_down - sigma)
+        noise = torch.randn(model_output.shape, generator=generator, dtype=model_output.dtype).to(model_output.device)
+        prev_sample = prev_sample + noise * sigma_up
+        self.step_index += 1
+        return prev_sample.to(model_output.dtype)

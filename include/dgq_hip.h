@@ -29,7 +29,7 @@ extern "C" {
 #define DGQ_F16 1
 #define DGQ_BF16 2
 
-#define DGQ_KCHUNK 64     /* K granularity of one MFMA_I32_16x16x64_I8 slice = DGQ group padding */
+#define DGQ_KCHUNK 32     /* K granularity of one MFMA_I32_32x32x32_I8 slice = DGQ group padding */
 #define DGQ_KTILE 128     /* Kp (padded, permuted K) must be a multiple of this */
 
 int dgq_version(void);
@@ -47,10 +47,13 @@ int dgq_quantize_weight(const float* w, const float* delta, const float* zp, con
 /* dgq_pack_w4: codes u8 [N][K] (values 0..15) -> packed [N][Kp/2] bytes.  kperm [Kp] gives for each
  * packed position the source k (or -1 = zero padding); NULL = identity (Kp == K).  Layout per 8
  * consecutive kp: one 32-bit word, byte j holds kp+j in its low nibble and kp+4+j in its high nibble,
- * so that (word & 0x0F0F0F0F) and ((word >> 4) & 0x0F0F0F0F) are 4 consecutive int8 each. */
-int dgq_pack_w4(const uint8_t* codes, int N, int K, const int32_t* kperm, int Kp, uint8_t* packed, void* stream);
+ * so that (word & 0x0F0F0F0F) and ((word >> 4) & 0x0F0F0F0F) are 4 consecutive int8 each.
+ * layout 0: rows as described.  layout 1 (what dgq_gemm_wxa8 and dgq_linear_smallm_batch read): in rows n with (n & 16) != 0 the two
+ * 8-byte halves of every 16 packed bytes (= one 32-wide chunk) are exchanged — the GEMM stages 16-byte pieces into LDS by
+ * DMA and a lane reads the 8 bytes of its K half; with the exchange the 32 lanes of a read cover all 64 LDS banks. */
+int dgq_pack_w4(const uint8_t* codes, int N, int K, const int32_t* kperm, int Kp, int layout, uint8_t* packed, void* stream);
 /* exact inverse (test hook for the "bit-exact int4 unpack" requirement): out [N][Kp] u8 */
-int dgq_unpack_w4(const uint8_t* packed, int N, int Kp, uint8_t* out, void* stream);
+int dgq_unpack_w4(const uint8_t* packed, int N, int Kp, int layout, uint8_t* out, void* stream);
 /* W8: out[n][kp] = (int8)(codes[n][kperm[kp]] - 128), 0 for padding */
 int dgq_pack_w8(const uint8_t* codes, int N, int K, const int32_t* kperm, int Kp, int8_t* packed, void* stream);
 
@@ -68,7 +71,7 @@ int dgq_pack_w8(const uint8_t* codes, int N, int K, const int32_t* kperm, int Kp
  *                  taps all lie inside the image (no bounds checks); klds (optional) = (dh·kw + dw)·C + c or -1: the
  *                  index into the [tap][C] strip a wave stages in LDS (kh·kw > 1 and kh·kw·C·4 <= 64 KB).
  * Quantiser parameters:
- *   per_m == 0 : cdelta/czp [Kp/64] — one (δ,z) per 64-wide chunk (DGQ groups are chunk aligned);
+ *   per_m == 0 : cdelta/czp [Kp/32] — one (δ,z) per 32-wide chunk (DGQ groups are chunk aligned);
  *                rowsum[m] = Σ_kp δ(kp)·s[m,kp]
  *   per_m == 1 : mdelta/mzp [L] indexed by (m % L) (L=1: scalar quantiser);
  *                rowsum[m] = Σ_kp s[m,kp]  (exact integer in f32)
@@ -127,10 +130,13 @@ int dgq_groupnorm_scale_shift(const void* x, int x_dtype, int B, int HW, int C, 
  * codes [M][Kp] int8; wpacked: w_bits==4 -> [N][Kp/2] (dgq_pack_w4), w_bits==8 -> [N][Kp] int8;
  * alpha = δw, zw = zero point in the stored code domain (zw − 8·0 for W4: unsigned nibbles; zw − 128 for W8);
  * gamma = bias (+ alpha·U for per_m==0, U[n] = Σ_k δx_k(offset − zx_k)(qw'[n,k] − zw[n]), precomputed per slot);
- * vn[n] = Σ_k qw'[n,k] − K·zw[n].  y [M][ldy] of y_dtype.  Every chunk of a DGQ group carries the group's δ in cdelta; the
- * kernel sums by parts, Σ_c (cdelta[c] − cdelta[c+1])·T_c with T_c the running int32 total after chunk c, so a group boundary
- * is wherever cdelta changes.  cflush[c] != 0 (last chunk of a group) is part of the ABI and must be non-NULL; the current
- * kernels do not read it. */
+ * vn[n] = Σ_k qw'[n,k] − K·zw[n].  y [M][ldy] of y_dtype.  cdelta / cflush have Kp/32 entries (one per 32-wide chunk).
+ * Every chunk of a DGQ group carries the group's δ in cdelta; the kernel sums by parts, Σ_c (cdelta[c] − cdelta[c+1])·T_c
+ * with T_c the running int32 total after chunk c, so a group boundary is wherever cdelta changes.  cflush[c] == 2 on the
+ * LAST chunk of a K tile (c % 4 == 3) asks for the running totals to be cleared behind that tile (the coefficient in front
+ * of the clear is then the full cdelta): the caller places such marks so that |T| stays below 2^24 and its fp32
+ * conversion is exact (dgq_amd/plan.py: every 8704 codes for W4A8, 1024 for W8A8); marks on other chunks are ignored,
+ * other values (0 inside a group, 1 at a group end) are informative. */
 /* Optional epilogue extras (host struct, passed by pointer; NULL = none), applied in this order to the fp32 result:
  *   fq_mode != 0 : the attention-side quantizer of the projection output, aqtizer_{q,k,v} (sd.py:174-182,199):
  *                  y = δ·(clamp(rne(y/δ)+z, 0, fq_qmax) − z) with (δ,z) = table[0] (mode 1), table[(m % fq_T) − fq_skip]
@@ -138,7 +144,11 @@ int dgq_groupnorm_scale_shift(const void* x, int x_dtype, int B, int HW, int C, 
  *   residual     : y += residual[(m / res_div)·ldr + n]  (x + attn(x), x + ff(x), shortcut + conv2(...) of the Quant
  *                  blocks, quant_block.py:98-119,165-186; res_div = Ho·Wo broadcasts one row per image: conv1(...) +
  *                  time_emb_proj(...)[:, :, None, None]) — dtype res_dtype (DGQ_F32/F16/BF16; ldr in elements), may alias
- *                  nothing written by this call; res_div >= 1. */
+ *                  nothing written by this call; res_div >= 1;
+ *   geglu != 0   : FeedForward's GEGLU (diffusers_rewrite/sd.py:210-222) for a ff.net.0 whose weight rows were
+ *                  interleaved at pack time (row 2i = value column i, row 2i+1 = gate column i; alpha / zw / gamma / vn
+ *                  likewise): y has N/2 columns, y[m, i] = h[m, 2i]·gelu(h[m, 2i+1]) (erf form).  No other extra, no K
+ *                  split, N % 4 == 0. */
 typedef struct dgq_gemm_extra {
     const void* residual;
     int ldr;
@@ -149,6 +159,7 @@ typedef struct dgq_gemm_extra {
     const float* fq_zp;
     int fq_T, fq_D, fq_skip;
     float fq_qmax;
+    int geglu;
 } dgq_gemm_extra_t;
 
 int dgq_gemm_wxa8(const int8_t* codes, const float* rowsum, int rowsum_parts, int M, int Kp,
@@ -231,7 +242,7 @@ size_t dgq_attention_workspace_bytes(int B, int H, int T, int S, int D);
  * x [M][K] of M <= 16 rows — the time_emb_proj(SiLU(temb)) projections of every resnet block of a forward
  * (quant_block.py:98-119), which do not depend on the latents — in ONE launch: quantise-on-load (scalar activation
  * quantizer of each layer, SiLU prologue when pre_act == 1) + integer dot products + the per_m epilogue of dgq_gemm_wxa8
- * (same arithmetic, term for term).  Weights in the natural K order (dgq_pack_w4 / dgq_pack_w8 with kperm == NULL... Kp
+ * (same arithmetic, term for term).  Weights in the natural K order (dgq_pack_w4 layout 1 / dgq_pack_w8 with kperm == NULL... Kp
  * padded to DGQ_KTILE); K <= 2048.  probs: host array, copied into the kernel arguments. */
 typedef struct dgq_smallm_problem {
     const void* wpacked;
@@ -271,28 +282,6 @@ int dgq_adaround_soft_bwd(const float* gout, const float* w, const float* delta,
 int dgq_adaround_reg_blocks(int64_t numel);
 int dgq_adaround_reg_fwd(const float* alpha, int64_t numel, float b, float* partial, void* stream);
 int dgq_adaround_reg_bwd(const float* alpha, int64_t numel, float b, const float* g, float* galpha, void* stream);
-
-/* ---- fused quantise-on-load + GEMM for Linear / 1x1-conv layers ------------------------------------------------
- * dgq_linear_fused_batch: y = W·aqtizer(act(x)) + b for 1..4 layers that share one input x [M][C] (row stride C, or 2C
- * with the GEGLU prologue) in ONE launch and without the int8 operand in HBM — the same arithmetic, term for term, as
- * dgq_quant_act followed by dgq_gemm_wxa8 (QuantLayer.forward, quant/quant_layer.py:626-661).  A workgroup quantises a
- * panel of 16 rows into LDS (prologues as dgq_quant_act: pre_scale/pre_shift [M/hw][C] of a folded GroupNorm, hw = rows per
- * image; LayerNorm; pre_act 1 SiLU, 2 GEGLU) and multiplies it with its share of the weight columns.
- *   per_m == 0: delta/zp [Kp/64] per 64-wide chunk, kdst [C] = packed position of channel c (the inverse of dgq_quant_act's
- *               ksrc), cflush [Kp/64]; per_m == 1: delta/zp [L] indexed by m % L, natural K order, vn [N].
- * Weights, epilogue vectors, extra: as dgq_gemm_wxa8 (w_bits == 4).  x and y share the dtype.
- * dgq_linear_fused_supported: 1 when a shape runs on this path (C % 4 == 0, C <= 1280, Kp <= 2048, W4). */
-typedef struct dgq_fused_linear_args {
-    const void* x; int x_dtype; int M, C, hw;
-    const int32_t* kdst; int Kp; int per_m; const float* delta; const float* zp; int L; int a_bits;
-    const float* pre_scale; const float* pre_shift; int pre_act;
-    const float* ln_gamma; const float* ln_beta; float ln_eps;
-    const void* wpacked; int w_bits; int N; const uint8_t* cflush;
-    const float* alpha; const float* zw; const float* gamma; const float* vn;
-    void* y; int y_dtype; int ldy; const dgq_gemm_extra_t* extra;
-} dgq_fused_linear_args_t;
-int dgq_linear_fused_batch(int n, const dgq_fused_linear_args_t* args, void* stream);
-int dgq_linear_fused_supported(int M, int C, int Kp, int N, int per_m, int w_bits);
 
 #ifdef __cplusplus
 }

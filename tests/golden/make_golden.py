@@ -6,6 +6,8 @@
     python tests/golden/make_golden.py calib | recon    # F8 DGQ activation calibration, F9 weight PTQ (mini model)
     python tests/golden/make_golden.py unet c1|c2|c3    # F5 full SD UNet, 64x64 latents (minutes each)
     python tests/golden/make_golden.py ddim [steps]     # F5 N-step DDIM final latent (tens of minutes)
+    python tests/golden/make_golden.py pndm | euler     # F7 vendored PNDM / EulerAncestral schedulers on a closed-form ε model
+    python tests/golden/make_golden.py pndm_unet [steps] [res]   # F10 the reference QuantModel under the pipeline's PNDM loop
     DIFFUSERS_REWRITE=sdxl python tests/golden/make_golden.py unet xl   # SDXL (separate process)
 
 Fixtures are DATA: seeded inputs and the reference's outputs (``.pt`` files of plain tensors +
@@ -543,9 +545,10 @@ def make_recon(ref):
 
 
 # --------------------------------------------------------------------------------------- scheduler (f3)
-def load_vendored_pndm():
+def load_vendored_pndm(which="pndm"):
     """The reference's vendored diffusers 0.26.0 does not import as a package here; its
-    schedulers/scheduling_pndm.py is loaded on its own with minimal stand-ins for the three modules it imports from."""
+    schedulers/scheduling_pndm.py (or scheduling_euler_ancestral_discrete.py) is loaded on its own with minimal stand-ins
+    for the three modules it imports from."""
     import dataclasses, enum, importlib.util, types
     import numpy  # noqa: F401
     root = "/root/reference/diffusers/src/diffusers"
@@ -568,7 +571,18 @@ def load_vendored_pndm():
         return inner
     cu.ConfigMixin, cu.register_to_config = ConfigMixin, register_to_config
     ut = types.ModuleType("vdiff.utils"); ut.__path__ = []
-    tu = types.ModuleType("vdiff.utils.torch_utils"); tu.randn_tensor = lambda *a, **k: None
+    import logging as _logging
+
+    class BaseOutput(dict):
+        pass
+    ut.BaseOutput = BaseOutput
+    ut.logging = types.SimpleNamespace(get_logger=_logging.getLogger)
+    tu = types.ModuleType("vdiff.utils.torch_utils")
+
+    def randn_tensor(shape, generator=None, device=None, dtype=None, layout=None):
+        # what diffusers' randn_tensor does for a CPU generator: draw on the CPU, then move
+        return torch.randn(shape, generator=generator, dtype=dtype).to(device)
+    tu.randn_tensor = randn_tensor
     sc = types.ModuleType("vdiff.schedulers"); sc.__path__ = [root + "/schedulers"]
     su = types.ModuleType("vdiff.schedulers.scheduling_utils")
 
@@ -584,11 +598,12 @@ def load_vendored_pndm():
     su.KarrasDiffusionSchedulers, su.SchedulerMixin, su.SchedulerOutput = KarrasDiffusionSchedulers, SchedulerMixin, SchedulerOutput
     sys.modules.update({"vdiff": pk, "vdiff.configuration_utils": cu, "vdiff.utils": ut, "vdiff.utils.torch_utils": tu,
                         "vdiff.schedulers": sc, "vdiff.schedulers.scheduling_utils": su})
-    spec = importlib.util.spec_from_file_location("vdiff.schedulers.scheduling_pndm", root + "/schedulers/scheduling_pndm.py")
+    fname = "scheduling_pndm" if which == "pndm" else "scheduling_euler_ancestral_discrete"
+    spec = importlib.util.spec_from_file_location("vdiff.schedulers." + fname, root + "/schedulers/%s.py" % fname)
     mod = importlib.util.module_from_spec(spec)
     sys.modules[spec.name] = mod
     spec.loader.exec_module(mod)
-    return mod.PNDMScheduler
+    return mod.PNDMScheduler if which == "pndm" else mod.EulerAncestralDiscreteScheduler
 
 
 def fake_eps(x, t):
@@ -615,10 +630,90 @@ def make_pndm():
     save("f7_pndm_schedule.pt", out)
 
 
+def make_euler():
+    """F7b: the vendored EulerAncestralDiscreteScheduler in SDXL-turbo's configuration (scaled_linear 0.00085-0.012,
+    "trailing" spacing, ε-prediction) driven like pipeline_stable_diffusion_xl.py:1170-1200 (init_noise_sigma, scale_model_input,
+    step with a seeded CPU generator) with a closed-form ε model: timesteps, sigmas, every scaled model input and latent."""
+    E = load_vendored_pndm("euler")
+    out = {}
+    for n in (4, 1, 8):
+        sch = E(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
+                timestep_spacing="trailing", steps_offset=1)
+        sch.set_timesteps(n)
+        gen = g(1234 + n)
+        x = torch.randn(2, 4, 8, 8, generator=g(78)) * sch.init_noise_sigma
+        xs, ins = [x.clone()], []
+        for t in sch.timesteps:
+            xi = sch.scale_model_input(x, t)
+            ins.append(xi.clone())
+            x = sch.step(fake_eps(xi, float(t)), t, x, generator=gen, return_dict=False)[0]
+            xs.append(x.clone())
+        out[n] = dict(timesteps=[float(t) for t in sch.timesteps], sigmas=sch.sigmas.clone(), init_noise_sigma=float(sch.init_noise_sigma),
+                      samples=torch.stack(xs), inputs=torch.stack(ins), noise_seed=1234 + n)
+        print("euler-ancestral n=%d: timesteps %s sigmas %s" % (n, out[n]["timesteps"], [round(float(v), 4) for v in sch.sigmas]))
+    save("f7_euler_ancestral_schedule.pt", out)
+
+
+def make_pndm_unet(steps=8, res=64, name="c2"):
+    """F10: the REFERENCE QuantModel under the pipeline's PNDM loop — the vendored PNDMScheduler,
+    CFG 7.5, the time-aware slot formula with num_inference_steps = steps (N + 1 UNet calls, the 2nd and 3rd at the same
+    timestep = the same slot) exactly as pipeline_stable_diffusion.py:1013-1044 drives ``pipe.unet``.  Stored: the timesteps,
+    for the first three calls the UNet input and output (and the output of the same call with one BLAS thread: the
+    reference's own sensitivity to summation order), the final latent of the 8-thread and of a 1-thread trajectory."""
+    ref = rh.import_reference("sd")
+    P = load_vendored_pndm("pndm")
+    c = dict(UNET_CFG[name])
+    c["steps"] = steps
+    qnn, path = build_ref_unet_qnn(ref, "sd", c, res, 2, steps, path="/tmp/golden_sd_pndm%d_%s_r%d.pth" % (steps, name, res))
+    lat0 = synth.named_randn("latent", (1, 4, res, res), 1)
+    ctx = synth.named_randn("ctx", (2, 77, 768), 2)
+
+    def trajectory(record):
+        sch = P(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
+                skip_prk_steps=True, set_alpha_to_one=False, steps_offset=1)
+        sch.set_timesteps(steps)
+        x = lat0.clone() * sch.init_noise_sigma
+        for i, t in enumerate(sch.timesteps):
+            t0 = time.time()
+            inp = sch.scale_model_input(torch.cat([x] * 2), t)
+            y = qnn(inp, t, encoder_hidden_states=ctx, timestep_cond=None, cross_attention_kwargs=None,
+                    added_cond_kwargs=None, return_dict=False)[0]
+            if record is not None and i < 3:
+                record.append((int(t), inp.clone(), y.clone()))
+            u, v = y.chunk(2)
+            x = sch.step(u + 7.5 * (v - u), t, x, return_dict=False)[0]
+            print("  call %d t=%d %.1fs" % (i, int(t), time.time() - t0), flush=True)
+        return x, [int(t) for t in sch.timesteps]
+    rec = []
+    final, ts = trajectory(rec)
+    nt = torch.get_num_threads()
+    torch.set_num_threads(1)
+    outs1 = []
+    for (t, inp, y) in rec:                                   # the same three calls, one BLAS thread
+        t0 = time.time()
+        y1 = qnn(inp, torch.tensor(t), encoder_hidden_states=ctx, return_dict=False)[0]
+        print("  1-thread call t=%d %.1fs rel-L2 vs %d threads %.4g" % (t, time.time() - t0, nt, ((y1 - y).norm() / y.norm()).item()), flush=True)
+        outs1.append(y1.clone())
+    final1, _ = trajectory(None)
+    torch.set_num_threads(nt)
+    print("final latent: 1-thread vs %d-thread rel-L2 %.4g" % (nt, ((final1 - final).norm() / final.norm()).item()))
+    meta = dict(c)
+    meta.update(arch="sd", res=res, guidance=7.5, scheduler="pndm", threads=nt)
+    save("f10_pndm%d_sd_%s_r%d.pt" % (steps, name, res),
+         dict(meta=meta, timesteps=ts, calls=[dict(t=t, inp=inp, out=y, out_1thread=y1) for (t, inp, y), y1 in zip(rec, outs1)],
+              final_latent=final, final_latent_1thread=final1))
+
+
 if __name__ == "__main__":
     what = sys.argv[1]
     if what == "pndm":
         make_pndm()
+        sys.exit(0)
+    if what == "euler":
+        make_euler()
+        sys.exit(0)
+    if what == "pndm_unet":
+        make_pndm_unet(int(sys.argv[2]) if len(sys.argv) > 2 else 8, int(sys.argv[3]) if len(sys.argv) > 3 else 64)
         sys.exit(0)
     arch = os.environ.get("DIFFUSERS_REWRITE", "sd")
     ref = rh.import_reference(arch)

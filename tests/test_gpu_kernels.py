@@ -51,6 +51,14 @@ def test_int4_pack_unpack_bit_exact(dev):
     packed = ops.pack_weight(codes.to(dev), None, 256, 4)
     un = ops.unpack_w4(packed, 256).cpu()
     assert torch.equal(un[:, :K], codes) and int(un[:, K:].sum()) == 0
+    # layout 1 (what the kernels read) = layout 0 with the 8-byte halves of every 16 bytes exchanged in rows with bit 4 set
+    from dgq_amd import _lib
+    p0 = torch.empty_like(packed)
+    _lib.check(_lib.load().dgq_pack_w4(_lib.ptr(codes.to(dev)), N, K, None, 256, 0, _lib.ptr(p0), _lib.stream()), "dgq_pack_w4")
+    a, b = p0.view(N, -1, 2, 8).cpu(), packed.view(N, -1, 2, 8).cpu()
+    swap = ((torch.arange(N) >> 4) & 1).bool()
+    assert torch.equal(b[~swap], a[~swap]) and torch.equal(b[swap], a[swap].flip(2))
+    assert torch.equal(ops.unpack_w4(p0, 256, layout=0).cpu(), un)
 
 
 def test_weight_codes_match_oracle(dev):
@@ -70,75 +78,91 @@ def test_weight_codes_match_oracle(dev):
 
 
 # ------------------------------------------------------------------------------------------ MFMA layout
-def test_gemm_exact_integer(dev):
-    """int8 x int4 -> exact integers through V_MFMA_I32_16X16X64_I8 (asymmetric data; catches any
-    row/col or k-order mistake). All scales are powers of two, so the fp epilogue is exact too."""
+def _gemm_exact_case(dev, M, N, Kp, wbits, seed=1):
     from dgq_amd import _lib, ops
-    from dgq_amd.plan import ActLayout
-    g = torch.Generator().manual_seed(1)
+    import ctypes
+    g = torch.Generator().manual_seed(seed)
     ws = ops.workspace(dev)
+    s = torch.randint(-16, 16, (M, Kp), generator=g, dtype=torch.int32)
+    s[::7, ::13] = -128            # int8 extremes, sparsely (keeps every fp32 step exact)
+    s[3::11, 5::17] = 127
+    hi = 16 if wbits == 4 else 256
+    q = torch.randint(0, hi, (N, Kp), generator=g, dtype=torch.int32)
+    nch = Kp // 32
+    cd = torch.tensor([2.0 ** ((i % 5) - 2) for i in range(nch)])
+    gend = torch.tensor([(i % 3 == 1 or i == nch - 1) for i in range(nch)])
+    fl = gend.to(torch.uint8)
+    fl[3::12] = 2                  # clears of the running totals behind every third K tile: at group ends and inside groups alike
+    fl[6::16] = 2                  # (marks elsewhere are ignored)
+    # groups = runs of chunks ending at a group end; scale of a group = scale of its last chunk
+    gscale = cd.clone()
+    for i in range(nch - 2, -1, -1):
+        if not gend[i]:
+            gscale[i] = gscale[i + 1]
+    woff = 0 if wbits == 4 else 128
+    qs = (q - woff)
+    acc = torch.zeros(M, N, dtype=torch.float64)
+    for c in range(nch):
+        acc += gscale[c].double() * (s[:, 32 * c:32 * c + 32].double() @ qs[:, 32 * c:32 * c + 32].double().T)
+    alpha = torch.tensor([2.0 ** ((n % 3) - 1) for n in range(N)])
+    zw = torch.tensor([float((n * 7) % 16) for n in range(N)]) - woff
+    gamma = torch.tensor([float(n % 11) - 5 for n in range(N)])
+    rowsum = torch.tensor([float((m * 3) % 17) - 8 for m in range(M)])
+    expect = alpha[None, :].double() * (acc - zw[None, :].double() * rowsum[:, None].double()) + gamma[None, :].double()
+
+    codes = s.to(torch.int8).to(dev)
+    if wbits == 4:
+        wp = ops.pack_weight(q.to(torch.uint8).to(dev), None, Kp, 4)
+    else:
+        wp = qs.to(torch.int8).to(dev)
+    y = torch.empty(M, N, dtype=torch.float32, device=dev)
+    lib = _lib.load()
+    t = lambda x: x.to(dev).contiguous()
+    cdg, flg, al, zwg, ga, rs = t(gscale), t(fl), t(alpha), t(zw), t(gamma), t(rowsum)
+    rc = lib.dgq_gemm_wxa8(_lib.ptr(codes), _lib.ptr(rs), 1, M, Kp, _lib.ptr(wp), wbits, N, 0,
+                           _lib.ptr(cdg), _lib.ptr(flg), None, None, 1, ctypes.c_float(128.0),
+                           _lib.ptr(al), _lib.ptr(zwg), _lib.ptr(ga), None,
+                           _lib.ptr(y), 0, N, _lib.ptr(ws), ws.numel(), None, _lib.stream())
+    _lib.check(rc, "dgq_gemm_wxa8")
+    torch.cuda.synchronize()
+    assert torch.equal(y.cpu().double(), expect), (M, N, Kp, wbits, (y.cpu().double() - expect).abs().max())
+    # per-M epilogue, L=5
+    L = 5
+    md = torch.tensor([2.0 ** (i - 2) for i in range(L)])
+    mz = torch.tensor([float(100 + 9 * i) for i in range(L)])
+    vn = torch.tensor([float((n * 5) % 23) - 11 for n in range(N)])
+    acc1 = s.double() @ qs.double().T
+    mi = torch.arange(M) % L
+    expect = alpha[None, :].double() * md[mi][:, None].double() * (
+        acc1 - zw[None, :].double() * rowsum[:, None].double()
+        + (128.0 - mz[mi][:, None].double()) * vn[None, :].double()) + gamma[None, :].double()
+    mdg, mzg, vng = t(md), t(mz), t(vn)
+    rc = lib.dgq_gemm_wxa8(_lib.ptr(codes), _lib.ptr(rs), 1, M, Kp, _lib.ptr(wp), wbits, N, 1,
+                           None, None, _lib.ptr(mdg), _lib.ptr(mzg), L, ctypes.c_float(128.0),
+                           _lib.ptr(al), _lib.ptr(zwg), _lib.ptr(ga), _lib.ptr(vng),
+                           _lib.ptr(y), 0, N, _lib.ptr(ws), ws.numel(), None, _lib.stream())
+    _lib.check(rc, "dgq_gemm_wxa8")
+    torch.cuda.synchronize()
+    got = y.cpu().double()
+    assert rel_l2(got, expect) < 1e-6, (M, N, Kp, wbits, rel_l2(got, expect))
+
+
+def test_gemm_exact_integer(dev):
+    """int8 x int4 -> exact integers through V_MFMA_I32_32X32X32_I8 (asymmetric data; catches any row/col or k-order
+    mistake), incl. clears of the running totals inside and between groups. All scales are powers of two, so the fp
+    epilogue is exact too."""
     for (M, N, Kp, wbits) in ((200, 136, 384, 4), (64, 320, 128, 4), (130, 72, 256, 8), (100, 200, 2048, 4),
                               (300, 136, 1024, 8), (2, 320, 1280, 4)):      # the last three take the split-K path
-        s = torch.randint(-16, 16, (M, Kp), generator=g, dtype=torch.int32)
-        s[::7, ::13] = -128            # int8 extremes, sparsely (keeps every fp32 step exact)
-        s[3::11, 5::17] = 127
-        hi = 16 if wbits == 4 else 256
-        q = torch.randint(0, hi, (N, Kp), generator=g, dtype=torch.int32)
-        nch = Kp // 64
-        cd = torch.tensor([2.0 ** ((i % 5) - 2) for i in range(nch)])
-        fl = torch.tensor([1 if (i % 2 == 1 or i == nch - 1) else 0 for i in range(nch)], dtype=torch.uint8)
-        # groups = runs of chunks ending at a flush; scale of a group = scale of its last chunk
-        gscale = cd.clone()
-        for i in range(nch - 2, -1, -1):
-            if not fl[i]:
-                gscale[i] = gscale[i + 1]
-        woff = 0 if wbits == 4 else 128
-        qs = (q - woff)
-        acc = torch.zeros(M, N, dtype=torch.float64)
-        for c in range(nch):
-            acc += gscale[c].double() * (s[:, 64 * c:64 * c + 64].double() @ qs[:, 64 * c:64 * c + 64].double().T)
-        alpha = torch.tensor([2.0 ** ((n % 3) - 1) for n in range(N)])
-        zw = torch.tensor([float((n * 7) % 16) for n in range(N)]) - woff
-        gamma = torch.tensor([float(n % 11) - 5 for n in range(N)])
-        rowsum = torch.tensor([float((m * 3) % 17) - 8 for m in range(M)])
-        expect = alpha[None, :].double() * (acc - zw[None, :].double() * rowsum[:, None].double()) + gamma[None, :].double()
+        _gemm_exact_case(dev, M, N, Kp, wbits)
 
-        codes = s.to(torch.int8).to(dev)
-        if wbits == 4:
-            wp = ops.pack_weight(q.to(torch.uint8).to(dev), None, Kp, 4)
-        else:
-            wp = qs.to(torch.int8).to(dev)
-        y = torch.empty(M, N, dtype=torch.float32, device=dev)
-        lib = _lib.load()
-        import ctypes
-        t = lambda x: x.to(dev).contiguous()
-        cdg, flg, al, zwg, ga, rs = t(gscale), t(fl), t(alpha), t(zw), t(gamma), t(rowsum)
-        rc = lib.dgq_gemm_wxa8(_lib.ptr(codes), _lib.ptr(rs), 1, M, Kp, _lib.ptr(wp), wbits, N, 0,
-                               _lib.ptr(cdg), _lib.ptr(flg), None, None, 1, ctypes.c_float(128.0),
-                               _lib.ptr(al), _lib.ptr(zwg), _lib.ptr(ga), None,
-                               _lib.ptr(y), 0, N, _lib.ptr(ws), ws.numel(), None, _lib.stream())
-        _lib.check(rc, "dgq_gemm_wxa8")
-        torch.cuda.synchronize()
-        assert torch.equal(y.cpu().double(), expect), (M, N, Kp, wbits, (y.cpu().double() - expect).abs().max())
-        # per-M epilogue, L=5
-        L = 5
-        md = torch.tensor([2.0 ** (i - 2) for i in range(L)])
-        mz = torch.tensor([float(100 + 9 * i) for i in range(L)])
-        vn = torch.tensor([float((n * 5) % 23) - 11 for n in range(N)])
-        acc1 = s.double() @ qs.double().T
-        mi = torch.arange(M) % L
-        expect = alpha[None, :].double() * md[mi][:, None].double() * (
-            acc1 - zw[None, :].double() * rowsum[:, None].double()
-            + (128.0 - mz[mi][:, None].double()) * vn[None, :].double()) + gamma[None, :].double()
-        mdg, mzg, vng = t(md), t(mz), t(vn)
-        rc = lib.dgq_gemm_wxa8(_lib.ptr(codes), _lib.ptr(rs), 1, M, Kp, _lib.ptr(wp), wbits, N, 1,
-                               None, None, _lib.ptr(mdg), _lib.ptr(mzg), L, ctypes.c_float(128.0),
-                               _lib.ptr(al), _lib.ptr(zwg), _lib.ptr(ga), _lib.ptr(vng),
-                               _lib.ptr(y), 0, N, _lib.ptr(ws), ws.numel(), None, _lib.stream())
-        _lib.check(rc, "dgq_gemm_wxa8")
-        torch.cuda.synchronize()
-        got = y.cpu().double()
-        assert rel_l2(got, expect) < 1e-6, (M, N, Kp, wbits, rel_l2(got, expect))
+
+@pytest.mark.parametrize("tile", ["32,64,1", "32,128,1", "64,64,1", "64,128,1", "128,64,1", "128,128,1", "32,64,3", "64,128,2"])
+def test_gemm_exact_integer_every_tile(tile, dev, monkeypatch):
+    """the same on every tile shape of the family (DGQ_GEMM_FORCE = BM,BN,splits), ragged M / N edges included"""
+    monkeypatch.setenv("DGQ_GEMM_FORCE", tile)
+    _gemm_exact_case(dev, 203, 332, 640, 4, seed=3)
+    if tile in ("32,64,1", "64,64,1", "128,128,1", "32,64,3"):
+        _gemm_exact_case(dev, 170, 200, 384, 8, seed=4)
 
 
 # ------------------------------------------------------------------------------------------ activation codes
@@ -588,61 +612,34 @@ def test_quant_linear_multi_equals_single_calls(M, K, with_ln, dev):
         assert torch.equal(y, ref), (ab.pw.N, ab.mode, (y - ref).abs().max().item())
 
 
-@pytest.mark.parametrize("M,K,N,mode,prologue,dtype", [
-    (8192, 320, 320, "perK", "ln", torch.float32), (2048, 640, 640, "perM", "ln", torch.float32),
-    (1100, 320, 200, "perK", None, torch.float32), (1056, 1280, 320, "perK", "geglu", torch.float32),
-    (2048, 768, 640, "scalar", "silu", torch.float32), (1024, 1280, 1280, "perM", None, torch.float32),
-    (4096, 320, 2560, "perK", "ln", torch.float16), (1500, 640, 320, "perK", "ln", torch.bfloat16),
-    (4099, 64, 96, "perM", None, torch.float32)])
-def test_linear_fused_equals_quant_act_plus_gemm(M, K, N, mode, prologue, dtype, dev, monkeypatch):
-    """dgq_linear_fused_batch (quantise-on-load inside the GEMM) against dgq_quant_act + dgq_gemm_wxa8 on the same layer:
-    the codes are the same (same quantiser, the LayerNorm statistics use the same summation tree), the integer
-    contraction is exact, so the outputs differ only by the summation order of the fp32 row sums / group flushes
-    (a few 1e-7 relative); with a residual and an attention-side quantizer in the epilogue as well."""
+@pytest.mark.parametrize("M,K,N,mode,dtype", [(512, 320, 2560, "perK", torch.float32), (300, 640, 5120, "perM", torch.float32),
+                                              (1024, 1280, 10240, "perK", torch.bfloat16), (96, 64, 200, "perK", torch.float16)])
+def test_gemm_geglu_epilogue_equals_projection_then_geglu(M, K, N, mode, dtype, dev):
+    """ff.net.0 with the GEGLU in the GEMM epilogue (weight rows (value, gate) interleaved at pack time, dgq_gemm_extra_t.geglu)
+    against the same layer's plain output followed by value·gelu(gate) (diffusers_rewrite/sd.py:210-222): the projection
+    values are the same bit for bit (same tiles, same accumulation order per column), so only the final product differs
+    by the rounding of one multiply-chain — and by the output dtype's rounding for half types."""
     from dgq_amd import ops, synth
     from dgq_amd.plan import plan_act
-    g = torch.Generator().manual_seed(M + K + N)
-    x = (torch.randn(M, 2 * K if prologue == "geglu" else K, generator=g) * 1.3 - 0.2).to(dev, dtype)
+    g = torch.Generator().manual_seed(M + N)
+    x = (torch.randn(M, K, generator=g) * 1.2).to(dev, dtype)
     w = torch.randn(N, K, generator=g) * 0.05
+    b = torch.randn(N, generator=g) * 0.1
     wd, wz = orc.minmax_channel(w, 4)
-    pw = ops.PackedWeight(w.to(dev), wd.to(dev), wz.to(dev), None, torch.randn(N, generator=g).to(dev), 4, K, 1)
     if mode == "perK":
-        d, z = synth._group_params(K, 16, 8, "fused|%d" % N, 0)
+        d, z = synth._group_params(K, 16, 8, "geglu|%d" % N, 0)
         lay = plan_act(d.view(1, 1, -1), z.view(1, 1, -1), "linear", K, 1, 8)
-    elif mode == "perM":
-        T = 64 if M % 64 == 0 else M
-        d, z = synth._group_params(T, 16, 8, "fused|%d" % N, 0)
-        lay = plan_act(d.view(1, -1, 1), z.view(1, -1, 1), "linear", K, 1, 8)
     else:
-        lay = plan_act(torch.tensor(0.03), torch.tensor(120.0), "linear", K, 1, 8)
-    ab = ops.ActBinding(lay, pw, 8)
-    monkeypatch.setattr(ops, "FUSED_LINEAR", 2)                        # every supported shape, not only the default class
-    assert ops.fused_linear_ok(M, K, ab)
-    ln = ((1 + 0.1 * torch.randn(K, generator=g)).to(dev), (0.05 * torch.randn(K, generator=g)).to(dev), 1e-5) if prologue == "ln" else None
-    pre_act = {"silu": 1, "geglu": 2}.get(prologue, 0)
-    res = torch.randn(M, N, generator=g).to(dev, dtype)
-    fq = (3, (torch.rand(N, generator=g) * 0.02 + 0.02).to(dev), torch.randint(100, 156, (N,), generator=g).float().to(dev), M, N, 0, 8)
-    for residual, fqq in ((None, None), (res, None), (None, fq)):
-        y = ops.quant_linear(x, ab, pre_act=pre_act, residual=residual, fq=fqq, ln=ln)
-        monkeypatch.setattr(ops, "FUSED_LINEAR", 0)
-        ref = ops.quant_linear(x, ab, pre_act=pre_act, residual=residual, fq=fqq, ln=ln)
-        monkeypatch.setattr(ops, "FUSED_LINEAR", 2)
-        torch.cuda.synchronize()
-        assert y.shape == ref.shape == (M, N)
-        if fqq is None:
-            tol = 2e-6 if dtype == torch.float32 else 2e-3
-            assert rel_l2(y.float().cpu(), ref.float().cpu()) < tol, (residual is not None, rel_l2(y.float().cpu(), ref.float().cpu()))
-        else:                                           # a re-quantised output: isolated one-step flips where y sits on a boundary
-            diff = (y.float() - ref.float()).abs()
-            assert float((diff > 1e-4).float().mean()) < 2e-3
-    if prologue in (None, "ln") and mode != "scalar":   # three layers sharing the input: one launch
-        binds = [ab]
-        for i in range(2):
-            w2 = torch.randn(N, K, generator=g) * 0.05
-            wd2, wz2 = orc.minmax_channel(w2, 4)
-            pw2 = ops.PackedWeight(w2.to(dev), wd2.to(dev), wz2.to(dev), None, torch.randn(N, generator=g).to(dev), 4, K, 1)
-            binds.append(ops.ActBinding(lay, pw2, 8))
-        outs = ops.quant_linear_multi(x.view(1, M, K), binds, ln=ln)
-        for b2, o in zip(binds, outs):
-            one = ops.quant_linear(x.view(1, M, K), b2, ln=ln)
-            assert torch.equal(o, one)
+        d, z = synth._group_params(M, 16, 8, "geglu|%d" % N, 0)
+        lay = plan_act(d.view(1, -1, 1), z.view(1, -1, 1), "linear", K, 1, 8)
+    pw = ops.PackedWeight(w.to(dev), wd.to(dev), wz.to(dev), None, b.to(dev), 4, K, 1)
+    y = ops.quant_linear(x, ops.ActBinding(lay, pw, 8)).float()
+    a, gt = y.chunk(2, dim=-1)
+    ref = a * torch.nn.functional.gelu(gt)
+    rp = torch.stack([torch.arange(N // 2), torch.arange(N // 2) + N // 2], 1).flatten()
+    pwi = ops.PackedWeight(w[rp].to(dev), wd[rp].to(dev), wz[rp].to(dev), None, b[rp].to(dev), 4, K, 1)
+    out = ops.quant_linear(x, ops.ActBinding(lay, pwi, 8), geglu=True)
+    torch.cuda.synchronize()
+    assert out.shape == (M, N // 2) and out.dtype == dtype
+    tol = 1e-6 if dtype == torch.float32 else (2e-3 if dtype == torch.float16 else 8e-3)
+    assert rel_l2(out.float().cpu(), ref.cpu()) < tol, rel_l2(out.float().cpu(), ref.cpu())

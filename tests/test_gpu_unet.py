@@ -174,13 +174,18 @@ def fused_teacher_forced_check(qnn, io, run):
     stats = {"out": [], "pro": [], "in": [], "attn": [], "aout": []}
     seen = []
 
-    def tap(layer, y, x=None, prologue=False, residual=None, bias_rows=None, fq=None):
+    def tap(layer, y, x=None, prologue=False, residual=None, bias_rows=None, fq=None, geglu=False):
         name = names[id(layer)]
         if name not in io or fq is not None:
             return y
         seen.append(name)
         x_ref, y_ref = io[name]
-        exp = y_ref.to(y.device, torch.float32).reshape(y.shape)
+        exp = y_ref.to(y.device, torch.float32)
+        if geglu:
+            # ff.net.0 with the GEGLU in its epilogue: the expected tensor is the oracle's own value·gelu(gate) — recorded as
+            # the INPUT of ff.net.2 — so that ff.net.2 is teacher-forced with bit-identical operands
+            exp = io[name.replace("net.0.proj", "net.2")][0].to(y.device, torch.float32)
+        exp = exp.reshape(y.shape)
         if residual is not None:
             exp = exp + residual.float().reshape(y.shape)
         if bias_rows is not None:

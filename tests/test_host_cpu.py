@@ -27,7 +27,7 @@ def test_abi_library_loads_and_exports_every_declared_symbol():
     assert lib.dgq_version() >= 100
     assert isinstance(_lib.last_error(), str)
     # argument validation happens before any launch: bad arguments -> DGQ_EINVAL and a message
-    rc = lib.dgq_pack_w4(None, 0, 0, None, 0, None, None)
+    rc = lib.dgq_pack_w4(None, 0, 0, None, 0, 0, None, None)
     assert rc == -1 and "dgq_pack_w4" in _lib.last_error()
 
 
@@ -56,7 +56,7 @@ def test_plan_perK_groups_are_chunk_aligned_permutation():
     assert lay.mode == "perK" and lay.Kp % KTILE == 0 and lay.n_groups <= G
     real = lay.kperm[lay.kperm >= 0]
     assert sorted(real.tolist()) == list(range(K))                     # a permutation of the reference K order
-    for c in range(lay.Kp // KCHUNK):                                  # one (δ,z) per 64-wide chunk
+    for c in range(lay.Kp // KCHUNK):                                  # one (δ,z) per 32-wide chunk
         ks = lay.kperm[c * KCHUNK:(c + 1) * KCHUNK]
         ks = ks[ks >= 0].long()
         assert torch.all(d[ks] == lay.cdelta[c]) and torch.all(z[ks] == lay.czp[c])
@@ -244,33 +244,65 @@ def test_bench_launch_command_is_one_rank_per_gpu():
     assert bench.CONFIGS["c4"]["arch"] == "sdxl" and bench.CONFIGS["c4"]["res"] == 128
 
 
-def test_summation_by_parts_matches_group_sums_on_planned_tables():
-    """The GEMM never clears its int32 tiles: a flush adds (δ_c − δ_{c+1})·T_c with T_c the running total after chunk c
-    (csrc/gemm_wxa8.hip).  On the chunk tables plan_act produces — every chunk of a group carries the group's δ, padding
-    chunks carry zero codes — that equals Σ_g δ_g·P_g exactly (integer partial sums, exact rational arithmetic), also for
-    any K-tile split where each split restarts its total at zero."""
+def _abel_total(cd, cf, P, c0, c1, wvk):
+    """What one workgroup of csrc/gemm_wxa8.hip adds up over the chunks [c0, c1) of its K range: WVK wave sequences (every
+    WVK-th chunk of each 4-chunk K tile), each with a running total T that a flush multiplies by δ_c − δ_next and a
+    cflush == 2 mark on the last chunk of a K tile clears behind that tile (coefficient of the wave's last chunk: δ_c)."""
     from fractions import Fraction
+    tot = Fraction(0)
+    mych = 4 // wvk
+    nk = (c1 - c0) // 4
+    for kq in range(wvk):
+        seq = [c0 + (i // mych) * 4 + (i % mych) * wvk + kq for i in range(nk * mych)]
+        T = 0
+        for i, g in enumerate(seq):
+            T += int(P[g])
+            last = i == len(seq) - 1
+            clr = (not last) and (i % mych == mych - 1) and int(cf[g // 4 * 4 + 3]) == 2
+            coef = cd[g] - (0 if (last or clr) else cd[seq[i + 1]])
+            tot += coef * T
+            if clr:
+                T = 0
+    return tot
+
+
+def test_summation_by_parts_matches_group_sums_on_planned_tables():
+    """The GEMM keeps running int32 totals: a flush adds (δ_c − δ_next)·T_c (csrc/gemm_wxa8.hip).  On the 32-wide chunk tables
+    plan_act produces — every chunk of a group carries the group's δ, padding chunks carry zero codes — that equals
+    Σ_g δ_g·P_g exactly (integer partial sums, exact rational arithmetic): for any K-tile split where each split restarts
+    its total at zero, for one or two wave sequences per workgroup (WVK), and with the clear marks of mark_clears."""
+    from fractions import Fraction
+    from dgq_amd.plan import mark_clears, seg_limit
     g = torch.Generator().manual_seed(5)
     for C, taps, G in ((320, 1, 16), (64, 9, 8), (1280, 1, 16)):
         K = C * taps
         d, z = synth._group_params(K, G, 8, "abel", 0)
         shape = (1, 1, -1) if taps == 1 else (1, -1, 1)
         lay = plan_act(d.view(*shape), z.view(*shape), "linear" if taps == 1 else "conv", C, taps, 8)
+        assert KCHUNK == 32 and lay.Kp % KTILE == 0
+        assert lay.Kp <= K + lay.n_groups * (KCHUNK - 1) + KTILE - 1       # at most 31 padding codes per group + the K tile
         nch = lay.Kp // KCHUNK
         valid = (lay.kperm.view(nch, KCHUNK) >= 0)
         P = torch.randint(-50000, 50000, (nch,), generator=g)
         P = torch.where(valid.any(dim=1), P, torch.zeros_like(P))          # all-padding chunks contribute nothing
         cd = [Fraction(float(x)) for x in lay.cdelta]
         ref = sum(cd[c] * int(P[c]) for c in range(nch))
-        for splits in (1, 2, 3):
-            tiles = nch // 2
-            per = -(-tiles // splits)
-            tot = Fraction(0)
-            for s0 in range(0, tiles, per):
-                c0, c1 = 2 * s0, min(nch, 2 * (s0 + per))
-                T = 0
-                for c in range(c0, c1):
-                    T += int(P[c])
-                    coef = cd[c] - (cd[c + 1] if c + 1 < c1 else 0)
-                    tot += coef * T
-            assert tot == ref, (C, taps, G, splits)
+        marks = [lay.cflush, mark_clears(lay.cflush, 8, 4), mark_clears(lay.cflush, 8, 8)]
+        forced = lay.cflush.clone()
+        forced[3::8] = 2                                                   # a clear behind every other K tile, inside groups too
+        marks.append(forced)
+        tiles = nch // 4
+        for cf in marks:
+            for wvk in (1, 2):
+                for splits in (1, 2, 3):
+                    per = -(-tiles // splits)
+                    tot = Fraction(0)
+                    for s0 in range(0, tiles, per):
+                        tot += _abel_total(cd, cf, P, 4 * s0, min(nch, 4 * (s0 + per)), wvk)
+                    assert tot == ref, (C, taps, G, splits, wvk)
+    # clear marks: uniform segments of whole K tiles, W4A8 8704 codes, W8A8 1024, never longer than what keeps |T| <= 2^24
+    assert seg_limit(8, 4) == 8704 and seg_limit(8, 8) == 1024 and seg_limit(6, 4) == 34944
+    for ab, wb in ((8, 4), (8, 8), (6, 4)):
+        assert seg_limit(ab, wb) * (1 << (ab - 1)) * (15 if wb == 4 else 128) <= 1 << 24
+    cf = mark_clears(torch.zeros(100, dtype=torch.uint8), 8, 8)
+    assert cf.tolist().count(2) == 3 and int(cf[31]) == 2 and int(cf[63]) == 2 and int(cf[95]) == 2

@@ -33,6 +33,27 @@ def test_pndm_restatement_matches_vendored_scheduler(n):
         assert torch.equal(x, g["samples"][i + 1]), (n, i, (x - g["samples"][i + 1]).abs().max())
 
 
+@pytest.mark.parametrize("n", [4, 1, 8])
+def test_euler_ancestral_restatement_matches_vendored_scheduler(n):
+    """tests/golden/f7_euler_ancestral_schedule.pt = the reference's vendored diffusers EulerAncestralDiscreteScheduler in
+    SDXL-turbo's configuration (make_golden.py `euler`): timesteps, sigmas, init_noise_sigma, every scaled model input and
+    every latent of a run with a seeded CPU generator — bit for bit."""
+    from dgq_amd.scheduler import EulerAncestralDiscreteScheduler
+    g = torch.load(os.path.join(GOLD, "f7_euler_ancestral_schedule.pt"))[n]
+    sch = EulerAncestralDiscreteScheduler(n)
+    assert sch.timesteps == g["timesteps"] and torch.equal(sch.sigmas, g["sigmas"])
+    assert float(sch.init_noise_sigma) == g["init_noise_sigma"]
+    if n == 4:
+        assert sch.timesteps == [999.0, 749.0, 499.0, 249.0]
+    gen = torch.Generator().manual_seed(g["noise_seed"])
+    x = g["samples"][0].clone()
+    for i, t in enumerate(sch.timesteps):
+        xi = sch.scale_model_input(x, t)
+        assert torch.equal(xi, g["inputs"][i]), (n, i)
+        x = sch.step(_fake_eps(xi, t), t, x, generator=gen)
+        assert torch.equal(x, g["samples"][i + 1]), (n, i, (x - g["samples"][i + 1]).abs().max())
+
+
 def test_pipeline_loop_calls_the_unet_like_diffusers_does():
     """Keyword set, 0-d int64 timestep tensor, CFG batch, return_dict=False + [0] (pipeline_stable_diffusion.py:1027-1035)."""
     from dgq_amd.pipeline import stable_diffusion_denoise, sdxl_turbo_denoise
