@@ -156,7 +156,10 @@ def main(argv=None):
     elif args.dtype == "bf16":
         qnn.to(torch.bfloat16)
     adt = {"fp32": torch.float32, "fp16": torch.float16, "bf16": torch.bfloat16}[args.dtype]
+    t_prep = time.perf_counter()
     qnn.prepare_slots(slots)
+    torch.cuda.synchronize()
+    t_prep = time.perf_counter() - t_prep
     if not args.no_graph:
         qnn.enable_graphs(True)
 
@@ -253,10 +256,26 @@ def main(argv=None):
 
     if rank == 0:
         n = max(world, 1)
+        # kernel-class shares of the step: a STATIC record from the rocprofv3 kernel trace of this command
+        # (tools/profile_step.sh + tools/kernel_classes.py), attached only to the configuration it was profiled on and
+        # stamped with the commit it was measured at
         glue = None
-        gj = os.path.join(ROOT, "profiles", "r02_step_kernel_classes.json")    # from the rocprofv3 kernel trace of this command
-        if args.config == "c2" and os.path.exists(gj):
-            glue = json.load(open(gj))
+        import glob
+        for gj in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_step_kernel_classes.json")), reverse=True):
+            gd = json.load(open(gj))
+            if (gd.get("config") == args.config and gd.get("dtype") == args.dtype and gd.get("graph", True) == (not args.no_graph)
+                    and (args.prompts_per_gpu or C["prompts"]) == C["prompts"]):
+                glue = gd
+                break
+        import resource
+        load = dict(getattr(qnn, "_build_laps", {}))
+        load.update({"prepare_slots (plan + pack %d slots)" % len(slots): round(t_prep, 2),
+                     "model_ready_s": round(sum(v for k, v in load.items() if k != "write cali_ckpt") + t_prep, 1),
+                     "note": "model_ready_s = FP UNet + weights + get_qmodel (wrap, load_cali_model) + prepare_slots; the "
+                             "synthetic ckpt's generation ('write cali_ckpt') is test-data synthesis, not a load cost; the reference's "
+                             "load_cali_model alone is 91-107 s on CPU (SURVEY.md §6)",
+                     "host_max_rss_gb": round(resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1e6, 1),
+                     "device_mem_gb": round(torch.cuda.max_memory_allocated() / 1e9, 1)})
         out = {
             "metric": C["metric"], "value": round(K * n * P / elapsed, 4),
             "unit": "steps/s", "n_gpus": n, "steps": K, "warmup": W, "ms_per_step": round(1e3 * elapsed / (K * P), 3),
@@ -268,7 +287,7 @@ def main(argv=None):
             "windows": {"n": len(windows), "steps_each": K, "value_from": "median",
                         "ms_per_step_min": round(1e3 * min(windows) / (K * P), 3),
                         "ms_per_step_all": [round(1e3 * w / (K * P), 3) for w in windows]},
-            "roofline": roofline, "cpu_baseline": cpu_baseline,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "load": load,
             "non_hip_kernels": glue,
         }
         print(json.dumps(out))
@@ -314,12 +333,14 @@ def measure_gemm_roofline(torch, ops, qnn, run_step, args):
     # HBM-side bytes per launch come from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/pmc_traffic.py);
     # a STATIC figure, valid only for the configuration it was profiled on — otherwise null
     traffic, traffic_src = None, None
-    tj = os.path.join(ROOT, "profiles", "r02_gemm_hbm_traffic.json")
-    if os.path.exists(tj):
+    import glob
+    for tj in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_gemm_hbm_traffic.json")), reverse=True):
         tjd = json.load(open(tj))
         if tjd.get("config") == args.config and tjd.get("dtype") == args.dtype and tjd.get("prompts_per_gpu", 1) == (args.prompts_per_gpu or CONFIGS[args.config]["prompts"]):
             traffic = round(tjd["traffic_bytes_per_launch"] / 1e6, 3)
-            traffic_src = "static: profiles/r02_gemm_hbm_traffic.json (rocprofv3 --pmc passes of this command, not this run)"
+            traffic_src = "static: profiles/%s (rocprofv3 --pmc passes of this command at commit %s, not this run)" % (
+                os.path.basename(tj), tjd.get("measured_at_commit", "of round %s" % os.path.basename(tj)[1:3]))
+            break
     return {"kernel": "dgq_gemm_wxa8 / dgq_gemm_wxa8_batch (gemm_wxa8_kernel<...> tile family + split-K combine where used); the "
                       "23 time_emb_proj layers (2 rows each, 0.1 Gop) run in dgq_linear_smallm_batch and are not counted",
             "layers_covered": layers[0], "bound": "mfma",

@@ -69,7 +69,10 @@ def load_cali_model(qnn: QuantModel, init_data: Tuple[torch.Tensor], use_aq: boo
     self-initialisation forward of calibration.py:256-257 is skipped (quantizers not covered by the ckpt
     then initialise on their first real input) — used by CPU-side tests of the loader logic."""
     logger.info("Loading calibration model...")
-    full = torch.load(path, map_location="cpu")
+    try:                                          # zip-format files are memory-mapped: pages are read as tensors are used
+        full = torch.load(path, map_location="cpu", mmap=True)
+    except (RuntimeError, ValueError):            # legacy (non-zip) serialisation
+        full = torch.load(path, map_location="cpu")
     ckpt = full["weight"] if "weight" in full else full
     ckpt = dict(ckpt)
 

@@ -57,12 +57,14 @@ def build_synthetic_qnn(arch, cfg, res, batch, slots, ckpt_dir="/tmp", seed=0, d
     from .quant import get_qmodel, Scaler
     verbose = os.environ.get("DGQ_BUILD_TIMING") == "1"
     t_last = [time.time()]
+    laps = {}
 
     def lap(what):
+        now = time.time()
+        laps[what] = round(now - t_last[0], 2)
         if verbose:
-            now = time.time()
             print("[build %s] %-28s %.1f s" % (arch, what, now - t_last[0]), flush=True)
-            t_last[0] = now
+        t_last[0] = now
     path = os.path.join(ckpt_dir, "dgq_synth_%s_w%da%dg%d_r%d_b%d_s%s_%s.pth" % (
         arch, cfg["wbits"], cfg["abits"], cfg["G"], res, batch,
         ("%d" % slots) if isinstance(slots, int) else "x".join(str(s) for s in synth.slot_list(slots)),
@@ -78,8 +80,10 @@ def build_synthetic_qnn(arch, cfg, res, batch, slots, ckpt_dir="/tmp", seed=0, d
         barrier()
     unet = UNet2DConditionModel(arch)
     lap("construct FP UNet")
-    synth.load_synth_weights(unet, arch, seed)
-    lap("synthetic FP weights")
+    # FP weights (conv_in / conv_out keep their constructor-time copies): read back from the ckpt file
+    # (memory-mapped) — the same name-keyed tensors rank 0 generated for it, without regenerating them on every rank
+    unet.load_state_dict(synth.state_dict_from_ckpt(path))
+    lap("FP weights from the ckpt (mmap)")
     pipe = types.SimpleNamespace(unet=unet)
     wq, aq, sm = quant_params(Scaler, cfg["wbits"], cfg["abits"], cfg["use_aq"], cfg["log"], cfg["rt"], cfg["sp"])
     qnn = get_qmodel(arch, pipe, path, wq, cfg["use_aq"], aq, sm, cfg["G"] > 1, cfg["steps"],
@@ -88,4 +92,5 @@ def build_synthetic_qnn(arch, cfg, res, batch, slots, ckpt_dir="/tmp", seed=0, d
     qnn.float()
     qnn = qnn.to(device)
     qnn.disable_out_quantization()
+    qnn._build_laps = laps                   # seconds per build phase (bench.py reports them as "load")
     return qnn, path

@@ -90,6 +90,24 @@ def load_synth_weights(unet: nn.Module, arch="sd", seed=0):
     return unet
 
 
+def state_dict_from_ckpt(path):
+    """The FP state-dict (HF key names) read back from a cali_ckpt's 'weight' dict (``model.<path>.w`` / ``.b`` of wrapped
+    layers), memory-mapped: the ranks of a multi-GPU launch load the file rank 0 wrote instead of
+    regenerating 3.4 GB (SD) / 10 GB (SDXL) of normal variates each."""
+    full = torch.load(path, map_location="cpu", mmap=True)
+    out = OrderedDict()
+    for k, v in full["weight"].items():
+        if "wqtizer" in k:
+            continue
+        k = k[len("model."):] if k.startswith("model.") else k
+        if k.endswith(".w"):
+            k = k[:-2] + ".weight"
+        elif k.endswith(".b"):
+            k = k[:-2] + ".bias"
+        out[k] = v
+    return out
+
+
 def synth_inputs(arch="sd", batch=2, seed=1, res=None):
     """(sample, t-independent) inputs of SURVEY.md §8(d): latents/ctx ~ N(0,1)."""
     a = ARCH[arch]
@@ -300,14 +318,28 @@ def slot_list(num_slots):
     return sorted(set(int(s) for s in num_slots) | {0})
 
 
+class _one_thread:
+    """The quantizer-table generators issue ~100 k torch ops on tensors of a few hundred elements: with the intra-op pool of
+    a 64-thread host each costs milliseconds (50 slots of SD tables: 118 s, 42 of them in torch.bucketize alone); on one
+    thread the same values (bit for bit) take a third of the time."""
+
+    def __enter__(self):
+        self.n = torch.get_num_threads()
+        torch.set_num_threads(1)
+
+    def __exit__(self, *a):
+        torch.set_num_threads(self.n)
+
+
 def build_cali_ckpt(arch="sd", wbits=4, abits=8, G=16, num_slots=1, seed=0, batch=2, res=None,
                     start_peak=False, uniform_softmax=False, adaround=False, with_act=True):
     """The merged checkpoint as a dict (what write_cali_ckpt saves)."""
     ck = OrderedDict()
     if with_act:
         recs = enumerate_act_quantizers(arch, batch, res)
-        for s in slot_list(num_slots):
-            ck["act_%d" % s] = synth_act_slot(arch, abits, G, s, seed, batch, res, start_peak, uniform_softmax, recs)
+        with _one_thread():
+            for s in slot_list(num_slots):
+                ck["act_%d" % s] = synth_act_slot(arch, abits, G, s, seed, batch, res, start_peak, uniform_softmax, recs)
     ck["weight"] = synth_weight_ckpt(arch, wbits, seed, adaround)
     return ck
 

@@ -168,7 +168,7 @@ def fused_teacher_forced_check(qnn, io, run):
     and replaced by it.  Layers WITHOUT a folded prologue see the same operand as the oracle (compared: "in" / "attn").
     Layers WITH a folded GroupNorm / LayerNorm / SiLU / GEGLU quantise values that are rounded differently from the
     reference's separately materialised norm (x·(rstd·γ) + (β − μ·rstd·γ) vs ((x − μ)·rstd)·γ + β): a few codes per
-    thousand move by one step ("pro": measured median 4e-7 .. 2e-6, worst 4e-4 over SD / SDXL; asserted 2e-5 / 2e-3)."""
+    thousand move by one step ("pro": measured median 4e-7 .. 2e-6, worst 4e-4 over SD / SDXL; asserted 2e-5 / 5e-4)."""
     from dgq_amd.quant import QuantLayer, quant_layer
     names = {id(m): n for n, m in qnn.model.named_modules() if isinstance(m, QuantLayer)}
     stats = {"out": [], "pro": [], "in": [], "attn": [], "aout": []}
@@ -285,7 +285,7 @@ def test_fused_unet_teacher_forced_vs_oracle(arch, res, cname, batch, ts, ckdir)
     assert sorted(seen) == sorted(rec.io.keys()), (len(seen), len(rec.io))     # every quantized layer, exactly once
     assert len(stats["pro"]) > 0.3 * len(seen)                                   # the folded prologues really are in use
     fails = _report("fused %s/%s res=%d t=%d" % (arch, cname, res, t), stats,
-                    (("out", 1e-4, None), ("pro", 2e-3, 2e-5), ("in", 2e-5, None), ("attn", 2e-2, 1e-5), ("aout", 2e-2, 1e-5)))
+                    (("out", 1e-4, None), ("pro", 5e-4, 2e-5), ("in", 2e-5, None), ("attn", 2e-2, 1e-5), ("aout", 2e-2, 1e-5)))
     assert not fails, fails
     e = rel_l2(out["y"].float().cpu(), ref)
     print("fused %s/%s res=%d t=%d final (teacher-forced, folded conv_norm_out) rel-L2 %.3g" % (arch, cname, res, t, e))
@@ -371,6 +371,62 @@ def test_ddim8_free_running_vs_reference_golden(ckdir):
     assert e < 0.5, e
 
 
+def test_ddim50_literal_c2_vs_reference_golden(ckdir):
+    """BASELINE config 2 LITERALLY: SD v1.4 W4A8 g=16, 50-step DDIM, 512x512 (64x64 latents), CFG 7.5, one hipGraph per
+    time-aware slot (50 slots), against the REAL reference's final latent of the same 50-step run
+    (tests/golden/f5_ddim50_sd_c2_r64.pt).  50 chaotic UNet calls apart, the two trajectories are only loosely correlated
+    (8 steps: 0.18, test above): asserted are sanity bounds — finite, same scale, well below the ~1.41 of unrelated
+    outputs — and the value is printed for the record."""
+    from dgq_amd.runtime import denoise_loop
+    g = torch.load(os.path.join(GOLD, "f5_ddim50_sd_c2_r64.pt"))
+    c = dict(C2, steps=50)
+    qnn, _ = get_qnn("sd", c, 64, 2, 50, ckdir)
+    qnn.prepare_slots()
+    qnn.enable_graphs(True)
+    try:
+        lat = synth.named_randn("latent", (1, 4, 64, 64), 1).cuda()
+        ctx = synth.named_randn("ctx", (2, 77, 768), 2).cuda()
+        out = denoise_loop(lambda x, t, cc: qnn(x, t, cc)[0], lat, ctx, 50, guidance=7.5).float().cpu()
+    finally:
+        qnn.enable_graphs(False)
+        _QNN.pop(("sd", tuple(sorted(c.items())), 64, 2, tuple(synth.slot_list(50))), None)    # 50 slots of tables: free them
+    ref = g["final_latent"]
+    e = rel_l2(out, ref)
+    print("DDIM-50 final latent: rel-L2 vs reference %.3g, |out| %.3g |ref| %.3g" % (e, out.norm().item(), ref.norm().item()))
+    assert torch.isfinite(out).all()
+    assert 0.5 < out.norm().item() / ref.norm().item() < 2.0
+    assert e < 1.0, e
+
+
+def test_sdxl_full_size_c4_vs_reference_golden(ckdir):
+    """BASELINE config 4 at its literal size: SDXL-turbo W4A8 g=16, 1024x1024 (128x128 latents), batch 1, first and last of
+    the 4 steps, against the REAL reference's outputs (tests/golden/f5_unet_sdxl_xl_r128.pt, with its 1-thread twin):
+    finite, every quantized layer on the HIP path, within 2.5x the reference's own thread-count deviation."""
+    from dgq_amd.quant import QuantLayer, quant_layer
+    g = torch.load(os.path.join(GOLD, "f5_unet_sdxl_xl_r128.pt"))
+    c = dict(C2, steps=4)
+    qnn, _ = get_qnn("sdxl", c, 128, 1, [0, 3], ckdir)
+    inp = synth.synth_inputs("sdxl", 1, 1, 128)
+    ack = {"text_embeds": inp["text_embeds"].cuda(), "time_ids": inp["time_ids"].cuda()}
+    seen = set()
+    quant_layer.LAYER_TAP = lambda layer, y, **kw: (seen.add(id(layer)), y)[1]
+    try:
+        for t in sorted(g["outputs"].keys(), reverse=True):
+            with torch.no_grad():
+                y = qnn(inp["sample"].cuda(), torch.tensor(t), inp["encoder_hidden_states"].cuda(), added_cond_kwargs=ack)[0]
+            y = y.float().cpu()
+            ref = g["outputs"][t]
+            e = rel_l2(y, ref)
+            self_dev = rel_l2(g["outputs_1thread"][t], ref)
+            print("xl 128x128 t=%d rel_l2=%.3g  (reference 1-thread vs 8-thread: %.3g)" % (t, e, self_dev))
+            assert torch.isfinite(y).all() and e < 2.5 * self_dev, (t, e, self_dev)
+    finally:
+        quant_layer.LAYER_TAP = None
+        _QNN.pop(("sdxl", tuple(sorted(c.items())), 128, 1, tuple(synth.slot_list([0, 3]))), None)
+    n_q = sum(1 for m in qnn.model.modules() if isinstance(m, QuantLayer) and m.use_wq and m.use_aq and not m.disable_aq)
+    assert len(seen) == n_q == N_QUANT_LAYERS["sdxl"], (len(seen), n_q)
+
+
 def test_pndm8_pipeline_vs_reference_golden(ckdir):
     """f3 on the GPU: tests/golden/f10_pndm8_sd_c2_r64.pt = the REFERENCE QuantModel (C2: W4A8 g16, log2
     real-time softmax quantiser, start-peak, time-aware tables for 8 steps) driven by its vendored diffusers PNDMScheduler
@@ -421,71 +477,87 @@ def test_pndm8_pipeline_vs_reference_golden(ckdir):
     assert e < 2.5 * self_dev and e < 0.7, (e, self_dev)
 
 
+def _deviation_row(arch, res, batch, cname, ckdir, seed, t, with_r1):
+    """One (seed, t) sample of the distribution-level criterion: distances of the HIP path (fused and unfused graph) and of the
+    reference's fp32 evaluation(s) from the exact-contraction oracle E, and the per-layer activation-code flip rates vs E."""
+    from dgq_amd.quant import QuantLayer, quant_block
+    c, slots, qnn, _ = _tf_setup(arch, res, cname, batch, ckdir)
+    inp = synth.synth_inputs(arch, batch, seed, res)
+    pkw = product_kwargs(arch, inp)
+    E, recE, omE = oracle_run(arch, c, res, batch, slots, inp, t, exact=True)
+    R, recR, _ = oracle_run(arch, c, res, batch, slots, inp, t)
+    dR1 = None
+    if with_r1:
+        R1, _, _ = oracle_run(arch, c, res, batch, slots, inp, t, threads=1)
+        dR1 = rel_l2(R1, E)
+    xs = {}
+    handles = [m.register_forward_pre_hook(lambda mod, args, _n=n: xs.__setitem__(_n, args[0].detach().float().cpu()))
+               for n, m in qnn.model.named_modules() if isinstance(m, QuantLayer) and n in recE.io]
+    quant_block.FUSION = False
+    try:
+        with torch.no_grad():
+            Hu = qnn(inp["sample"].cuda(), torch.tensor(t), inp["encoder_hidden_states"].cuda(), **pkw)[0].float().cpu()
+    finally:
+        quant_block.FUSION = True
+        for h in handles:
+            h.remove()
+    with torch.no_grad():
+        Hf = qnn(inp["sample"].cuda(), torch.tensor(t), inp["encoder_hidden_states"].cuda(), **pkw)[0].float().cpu()
+    fH, fR = [], []
+    for name, (xE, _) in recE.io.items():
+        if name not in xs:
+            continue
+        cE = omE.act_codes(name, xE, *recE.geom[name])
+        cH = omE.act_codes(name, xs[name].reshape(xE.shape), *recE.geom[name])
+        cR = omE.act_codes(name, recR.io[name][0], *recE.geom[name])
+        fH.append((cH != cE).float().mean().item())
+        fR.append((cR != cE).float().mean().item())
+    fH.sort(), fR.sort()
+    row = dict(seed=seed, t=t, dHf=rel_l2(Hf, E), dHu=rel_l2(Hu, E), dR=rel_l2(R, E), dR1=dR1,
+               flipH_med=fH[len(fH) // 2], flipR_med=fR[len(fR) // 2], flipH_max=fH[-1], flipR_max=fR[-1])
+    print("%s seed %d t=%d: |H_fused−E| %.3g  |H_unfused−E| %.3g  |R−E| %.3g  |R1−E| %s ; code flips vs E per layer: "
+          "HIP median %.3g max %.3g, reference-fp32 median %.3g max %.3g"
+          % (arch, seed, t, row["dHf"], row["dHu"], row["dR"], "%.3g" % dR1 if dR1 is not None else "-",
+             row["flipH_med"], row["flipH_max"], row["flipR_med"], row["flipR_max"]))
+    return row, fH, fR
+
+
+def _med(v):
+    v = sorted(v)
+    return v[len(v) // 2]
+
+
 def test_free_running_deviation_vs_exact_oracle(ckdir):
     """The principled end-to-end criterion: take the reference's arithmetic with every contraction
     evaluated EXACTLY (float64 GEMMs rounded once, oracle exact_gemm) as the target E.  Two fp32 runs of the reference
     (R: all host threads, R1: one thread) each deviate from E through nothing but the rounding of their GEMMs; the HIP
     path H (integer-exact GEMMs + an fp32 epilogue) is acceptable if it is not farther from E than the reference's own
-    fp32 runs are — in distribution over seeds x timesteps, for the final output AND for the rate at which activation
-    codes flip layer by layer in free-running mode (the mechanism of the divergence)."""
-    from dgq_amd.quant import QuantLayer, quant_block
-    arch, res, batch = "sd", 16, 2
-    c, slots, qnn, _ = _tf_setup(arch, res, "C2", batch, ckdir)
+    fp32 runs are — in distribution over 8 (seed, timestep) samples (was 3), for the final output AND for the
+    rate at which activation codes flip layer by layer in free-running mode (the mechanism of the divergence)."""
     rows, flipH_all, flipR_all = [], [], []
-    for seed, t in ((1, 999), (1, 499), (7, 999)):
-        inp = synth.synth_inputs(arch, batch, seed, res)
-        if True:
-            E, recE, omE = oracle_run(arch, c, res, batch, slots, inp, t, exact=True)
-            R, recR, _ = oracle_run(arch, c, res, batch, slots, inp, t)
-            dR1 = None
-            if (seed, t) == (1, 999):
-                R1, _, _ = oracle_run(arch, c, res, batch, slots, inp, t, threads=1)
-                dR1 = rel_l2(R1, E)
-            xs = {}
-            handles = [m.register_forward_pre_hook(lambda mod, args, _n=n: xs.__setitem__(_n, args[0].detach().float().cpu()))
-                       for n, m in qnn.model.named_modules() if isinstance(m, QuantLayer) and n in recE.io]
-            quant_block.FUSION = False
-            try:
-                with torch.no_grad():
-                    Hu = qnn(inp["sample"].cuda(), torch.tensor(t), inp["encoder_hidden_states"].cuda())[0].float().cpu()
-            finally:
-                quant_block.FUSION = True
-                for h in handles:
-                    h.remove()
-            with torch.no_grad():
-                Hf = qnn(inp["sample"].cuda(), torch.tensor(t), inp["encoder_hidden_states"].cuda())[0].float().cpu()
-            fH, fR = [], []
-            for name, (xE, _) in recE.io.items():
-                if name not in xs:
-                    continue
-                cE = omE.act_codes(name, xE, *recE.geom[name])
-                cH = omE.act_codes(name, xs[name].reshape(xE.shape), *recE.geom[name])
-                cR = omE.act_codes(name, recR.io[name][0], *recE.geom[name])
-                fH.append((cH != cE).float().mean().item())
-                fR.append((cR != cE).float().mean().item())
-            fH.sort(), fR.sort()
-            flipH_all += fH
-            flipR_all += fR
-            row = dict(seed=seed, t=t, dHf=rel_l2(Hf, E), dHu=rel_l2(Hu, E), dR=rel_l2(R, E), dR1=dR1,
-                       flipH_med=fH[len(fH) // 2], flipR_med=fR[len(fR) // 2], flipH_max=fH[-1], flipR_max=fR[-1])
-            rows.append(row)
-            print("seed %d t=%d: |H_fused−E| %.3g  |H_unfused−E| %.3g  |R−E| %.3g  |R1−E| %s ; code flips vs E per layer: "
-                  "HIP median %.3g max %.3g, reference-fp32 median %.3g max %.3g"
-                  % (seed, t, row["dHf"], row["dHu"], row["dR"], "%.3g" % dR1 if dR1 is not None else "-",
-                     row["flipH_med"], row["flipH_max"], row["flipR_med"], row["flipR_max"]))
-
-    def med(v):
-        v = sorted(v)
-        return v[len(v) // 2]
+    for seed, t in ((1, 999), (1, 499), (7, 999), (7, 499), (11, 999), (11, 499), (23, 999), (23, 499)):
+        row, fH, fR = _deviation_row("sd", 16, 2, "C2", ckdir, seed, t, with_r1=(seed == 1 and t == 999))
+        rows.append(row)
+        flipH_all += fH
+        flipR_all += fR
     dH = [max(r["dHf"], r["dHu"]) for r in rows]
     dRef = [max(r["dR"], r["dR1"] or 0.0) for r in rows]
-    print("medians: |H−E| %.3g  |R−E| %.3g ; per-layer flip rate HIP %.3g reference %.3g"
-          % (med(dH), med(dRef), med(flipH_all), med(flipR_all)))
-    # HIP is no farther from the exact target than the reference's own fp32 evaluations (25 % slack on 3 samples; every
+    print("medians over %d samples: |H−E| %.3g  |R−E| %.3g ; per-layer flip rate HIP %.3g reference %.3g"
+          % (len(rows), _med(dH), _med(dRef), _med(flipH_all), _med(flipR_all)))
+    # HIP is no farther from the exact target than the reference's own fp32 evaluations (25 % slack on the medians; every
     # single sample within 2x of the largest reference deviation)
-    assert med(dH) <= 1.25 * med(dRef) + 1e-3, (med(dH), med(dRef))
+    assert _med(dH) <= 1.25 * _med(dRef) + 1e-3, (_med(dH), _med(dRef))
     assert max(dH) <= 2.0 * max(dRef), (max(dH), max(dRef))
-    assert med(flipH_all) <= 1.25 * med(flipR_all) + 1e-4, (med(flipH_all), med(flipR_all))
+    assert _med(flipH_all) <= 1.25 * _med(flipR_all) + 1e-4, (_med(flipH_all), _med(flipR_all))
+
+
+def test_free_running_deviation_vs_exact_oracle_sdxl(ckdir):
+    """The same criterion on the SDXL graph (792 quantized layers, 32x32 latents, C4's switches): one sample — the exact
+    oracle of this graph costs minutes — with the reference's fp32 run as the yardstick."""
+    row, fH, fR = _deviation_row("sdxl", 32, 1, "C2", ckdir, 1, 999, with_r1=False)
+    dH, dRef = max(row["dHf"], row["dHu"]), row["dR"]
+    assert dH <= 2.0 * dRef, (dH, dRef)
+    assert _med(fH) <= 1.5 * _med(fR) + 1e-4, (_med(fH), _med(fR))
 
 
 # ----------------------------------------------------------------------------------------------- fusion / dtype / CLI
