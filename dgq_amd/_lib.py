@@ -24,6 +24,8 @@ SIGNATURES = {
     "dgq_gemm_wxa8": [_vp, _vp, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _vp, _i, _i,
                       _vp, ctypes.c_size_t, _vp, _vp],
     "dgq_gemm_workspace_bytes": [_i, _i, _i],
+    "dgq_gemm_plan_splits": [_i, _i, _i, _i, _i, ctypes.c_size_t],
+    "dgq_groupnorm_from_partials": [_vp, _i, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp],
     "dgq_fakequant_rows": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp],
     "dgq_max_f32": [_vp, _i64, _i, _i, _vp, _vp],
     "dgq_logquant_f32": [_vp, _vp, _i64, _i, _i, _vp, _i, _vp],
@@ -48,7 +50,7 @@ SIGNATURES = {
 class GemmExtra(ctypes.Structure):
     """dgq_gemm_extra_t of include/dgq_hip.h"""
     _fields_ = [("residual", _vp), ("ldr", _i), ("res_div", _i), ("res_dtype", _i), ("fq_mode", _i), ("fq_delta", _vp), ("fq_zp", _vp),
-                ("fq_T", _i), ("fq_D", _i), ("fq_skip", _i), ("fq_qmax", _f), ("geglu", _i)]
+                ("fq_T", _i), ("fq_D", _i), ("fq_skip", _i), ("fq_qmax", _f), ("geglu", _i), ("gn_partial", _vp)]
 
 
 class SmallMProblem(ctypes.Structure):

@@ -488,7 +488,9 @@ void gemm_wxa8_kernel(GemmBatch bt) {
     const int lrow = lane / LPR;
     const int nb = n0 + wave_n * WN + c4;
     const bool vec_ok = (nb + 3 < p.N);
-    auto tile_row = [&](int rr) { return (rr * WVK + wave_k) * RPP + lrow; };        // the wave's rr-th pass
+    // the wave's rr-th pass: the two K halves of a WVK = 2 tile take the upper / lower half of the rows (contiguous row sets per
+    // wave: the GroupNorm partials below are per 16-row block)
+    auto tile_row = [&](int rr) { return wave_k * (WM / WVK) + rr * RPP + lrow; };
     auto tile_val = [&](int row) {
         float4 v = *reinterpret_cast<const float4*>(ep0 + row * EP_LD + c4);
         if (WVK > 1) {
@@ -586,6 +588,16 @@ void gemm_wxa8_kernel(GemmBatch bt) {
     dgq_gemm_extra_t exl = p.ex;
     if (res_vec) exl.residual = nullptr;                 // added below from the prefetched tile
     const bool has_extra = exl.fq_mode != 0 || exl.residual != nullptr;
+    // GroupNorm partial statistics of the OUTPUT tensor (ex.gn_partial, M % 16 == 0 and N % 4 == 0 checked on the host): per
+    // 16-row block and column the mean and the sum of squared deviations of the values this launch stores, so that the
+    // GroupNorm in front of the next layer (QuantResnetBlock2D norm2 / the next block's norm1, quant_block.py:98-119) needs
+    // no pass over the tensor: dgq_groupnorm_from_partials merges them.  A wave's rows are contiguous; a lane sums its
+    // PPB passes of a block with the block's first value as the shift (no cancellation), the RPP lanes that share the
+    // columns merge pairwise (equal counts: Chan's formula), lane row 0 writes.
+    constexpr int PPB = (16 / RPP) < 1 ? 1 : (16 / RPP);  // passes per 16-row block
+    static_assert(RPP <= 16 && (WM / WVK) % 16 == 0, "GroupNorm partials: 16-row blocks per wave");
+    const bool gn = p.ex.gn_partial != nullptr;
+    float gK[4] = {0.f, 0.f, 0.f, 0.f}, g1[4] = {0.f, 0.f, 0.f, 0.f}, g2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int rr = 0; rr < PASSES; ++rr) {
         const int row = tile_row(rr);
@@ -619,6 +631,40 @@ void gemm_wxa8_kernel(GemmBatch bt) {
             }
         } else {
             for (int k = 0; k < 4 && nb + k < p.N; ++k) dst[k] = dgq_from_float<TOut>(o[k]);
+        }
+        if (gn) {                                        // wave-uniform; rows of a 16-row block are all valid or all past M
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float val = dgq_to_float(dgq_from_float<TOut>(o[k]));      // the value as stored
+                if (rr % PPB == 0) { gK[k] = val; g1[k] = 0.0f; g2[k] = 0.0f; }
+                else { const float dv = val - gK[k]; g1[k] += dv; g2[k] += dv * dv; }
+            }
+            if (rr % PPB == PPB - 1) {
+                float mean[4], m2[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float md = g1[k] * (1.0f / PPB);
+                    mean[k] = gK[k] + md;
+                    m2[k] = fmaxf(g2[k] - g1[k] * md, 0.0f);
+                }
+                float cnt = (float)PPB;
+#pragma unroll
+                for (int off = LPR; off < 64; off <<= 1) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float om = __shfl_xor(mean[k], off, 64), o2 = __shfl_xor(m2[k], off, 64);
+                        const float dd = om - mean[k];
+                        m2[k] = m2[k] + o2 + dd * dd * (0.5f * cnt);
+                        mean[k] = 0.5f * (mean[k] + om);
+                    }
+                    cnt *= 2.0f;
+                }
+                if (lrow == 0) {
+                    float* q = p.ex.gn_partial + ((int64_t)(m >> 4) * p.N + nb) * 2;
+                    *reinterpret_cast<float4*>(q) = make_float4(mean[0], m2[0], mean[1], m2[1]);
+                    *reinterpret_cast<float4*>(q + 4) = make_float4(mean[2], m2[2], mean[3], m2[3]);
+                }
+            }
         }
     }
 }
@@ -790,6 +836,17 @@ static bool forced_plan(GemmPlan& pl) {
     return true;
 }
 
+// K splits the library would use for a shape (1: the whole epilogue runs in the GEMM kernel; callers ask before they request
+// GroupNorm partials for a layer that is better off split — the request forces splits = 1)
+extern "C" int dgq_gemm_plan_splits(int M, int N, int Kp, int w_bits, int per_m, size_t workspace_bytes) {
+    GemmPlan pl = plan_gemm(M, N, Kp, w_bits, workspace_bytes, per_m != 0);
+    forced_plan(pl);
+    const int nk = Kp / BK;
+    if (pl.splits < 1) pl.splits = 1;
+    const int tps = (nk + pl.splits - 1) / pl.splits;
+    return (nk + tps - 1) / tps;
+}
+
 extern "C" size_t dgq_gemm_workspace_bytes(int M, int N, int Kp) {
     const GemmPlan a = plan_gemm(M, N, Kp, 4, (size_t)-1, false), b = plan_gemm(M, N, Kp, 4, (size_t)-1, true);
     const int s = a.splits > b.splits ? a.splits : b.splits;
@@ -825,9 +882,12 @@ static int fill_gemm(const dgq_gemm_args_t& a, GemmParams& p) {
                       "dgq_gemm_wxa8: bad residual descriptor (ldr < N, res_div < 1 or unknown dtype)");
         DGQ_CHECK_ARG(!p.ex.geglu || (a.N % 4 == 0 && !p.ex.residual && p.ex.fq_mode == 0),
                       "dgq_gemm_wxa8: the GEGLU epilogue needs N %% 4 == 0 and no other extra");
+        DGQ_CHECK_ARG(!p.ex.gn_partial || (a.M % 16 == 0 && a.N % 4 == 0 && !p.ex.geglu && p.ex.fq_mode == 0 &&
+                                           (reinterpret_cast<uintptr_t>(p.ex.gn_partial) & 15) == 0),
+                      "dgq_gemm_wxa8: GroupNorm partials need M %% 16 == 0, N %% 4 == 0, a 16-byte aligned buffer and no GEGLU / fused quantizer");
     } else {
         p.ex.residual = nullptr; p.ex.ldr = 0; p.ex.res_div = 1; p.ex.res_dtype = DGQ_F32; p.ex.fq_mode = 0; p.ex.fq_delta = nullptr; p.ex.fq_zp = nullptr;
-        p.ex.fq_T = 1; p.ex.fq_D = 1; p.ex.fq_skip = 0; p.ex.fq_qmax = 255.0f; p.ex.geglu = 0;
+        p.ex.fq_T = 1; p.ex.fq_D = 1; p.ex.fq_skip = 0; p.ex.fq_qmax = 255.0f; p.ex.geglu = 0; p.ex.gn_partial = nullptr;
     }
     p.splits = 1; p.slab = nullptr;
     p.tiles_per_split = a.Kp / BK;
@@ -881,7 +941,7 @@ extern "C" int dgq_gemm_wxa8(const int8_t* codes, const float* rowsum, int rowsu
         DGQ_CHECK_ARG(pl.splits == 1 || (workspace && (size_t)pl.splits * M * N * 4 <= workspace_bytes),
                       "dgq_gemm_wxa8: DGQ_GEMM_FORCE split does not fit the workspace");
     }
-    if (p.ex.geglu) pl.splits = 1;                       // the pair epilogue lives in the GEMM kernel, not in the combine
+    if (p.ex.geglu || p.ex.gn_partial) pl.splits = 1;    // these epilogues live in the GEMM kernel, not in the combine
     p.splits = pl.splits;
     p.slab = p.splits > 1 ? reinterpret_cast<float*>(workspace) : nullptr;
     const int nk = Kp / BK;

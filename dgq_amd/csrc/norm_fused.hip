@@ -150,6 +150,70 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict
     }
 }
 
+// grid (B*G), 256 threads: the (batch, group)'s statistic from the per-(16-row block, channel) partials written by
+// dgq_gemm_wxa8's epilogue.  Every partial stands for 16 values, so the merge is plain sums: with K the group's first partial mean,
+// mean = K + Σ(m_i − K)/E and M2 = Σ M2_i + 16·(Σ(m_i − K)² − (Σ(m_i − K))²/E) — independent loads, no division in the loop
+// (a lane-serial Chan merge of the same entries took ~10 us per statistic: 40 dependent iterations with two divisions each).
+// Fixed summation order (thread-strided, then a fixed shuffle / LDS tree): deterministic.  Channels [0, C1) come from `part`,
+// [C1, C1 + C2) from `part2` (a channel concat).
+__global__ __launch_bounds__(256) void gn_from_partials_kernel(const float* __restrict__ part, int C1, const float* __restrict__ part2,
+                                                              int C2, int HW, int G, float eps, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, float* __restrict__ scale,
+                                                              float* __restrict__ shift) {
+    const int bg = blockIdx.x, b = bg / G, g = bg - b * G;
+    const int C = C1 + C2, Cg = C / G, RB = HW / 16;
+    const int total = RB * Cg;
+    auto entry = [&](int e) {
+        const int rb = e / Cg, c = g * Cg + (e - rb * Cg);
+        return (c < C1) ? part + ((int64_t)(b * RB + rb) * C1 + c) * 2 : part2 + ((int64_t)(b * RB + rb) * C2 + (c - C1)) * 2;
+    };
+    const float K = entry(0)[0];
+    float s1 = 0.0f, s2 = 0.0f, sm = 0.0f;
+#pragma unroll 4
+    for (int e = threadIdx.x; e < total; e += 256) {
+        const float2 v = *reinterpret_cast<const float2*>(entry(e));
+        const float d = v.x - K;
+        s1 += d; s2 += d * d; sm += v.y;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s1 += __shfl_down(s1, o, 64); s2 += __shfl_down(s2, o, 64); sm += __shfl_down(sm, o, 64);
+    }
+    __shared__ float red[4][3];
+    __shared__ float fin[2];
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = s1; red[threadIdx.x >> 6][1] = s2; red[threadIdx.x >> 6][2] = sm; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float t1 = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+        const float t2 = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
+        const float tm = (red[0][2] + red[1][2]) + (red[2][2] + red[3][2]);
+        const float E = (float)total;
+        const float md = t1 / E;
+        const float m2 = tm + 16.0f * fmaxf(t2 - t1 * md, 0.0f);
+        fin[0] = K + md;
+        fin[1] = rsqrtf(m2 / (16.0f * E) + eps);                      // biased variance, as F.group_norm
+    }
+    __syncthreads();
+    const float mean = fin[0], rstd = fin[1];
+    for (int c = threadIdx.x; c < Cg; c += 256) {
+        const int ch = g * Cg + c;
+        const float sc = rstd * gamma[ch];
+        scale[(int64_t)b * C + ch] = sc;
+        shift[(int64_t)b * C + ch] = beta[ch] - mean * sc;
+    }
+}
+
+extern "C" int dgq_groupnorm_from_partials(const float* partial, int C1, const float* partial2, int C2, int B, int HW, int G,
+                                           float eps, const float* gamma, const float* beta, float* scale, float* shift,
+                                           void* stream) {
+    DGQ_CHECK_ARG(partial && gamma && beta && scale && shift && (C2 == 0 || partial2), "dgq_groupnorm_from_partials: null pointer");
+    DGQ_CHECK_ARG(B > 0 && HW > 0 && HW % 16 == 0 && C1 > 0 && C2 >= 0 && G > 0 && (C1 + C2) % G == 0,
+                  "dgq_groupnorm_from_partials: bad shape (HW %% 16 == 0, (C1 + C2) %% G == 0)");
+    hipLaunchKernelGGL(gn_from_partials_kernel, dim3(B * G), dim3(256), 0, (hipStream_t)stream, partial, C1, partial2, C2, HW, G,
+                       eps, gamma, beta, scale, shift);
+    return dgq_launch_status("dgq_groupnorm_from_partials");
+}
+
 extern "C" int dgq_groupnorm_scale_shift(const void* x, int x_dtype, int B, int HW, int C, int G, float eps,
                                          const float* gamma, const float* beta, float* scale, float* shift,
                                          float* partial_ws, int slices, unsigned* counters, void* stream) {

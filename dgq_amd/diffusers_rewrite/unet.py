@@ -24,6 +24,14 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+def _cat_channels(a, b):
+    """skip concatenation; tensors that carry GroupNorm partials from the GEMM that produced them (dgq_amd.ops) keep them"""
+    if getattr(a, "_dgq_gn", None) is not None and getattr(b, "_dgq_gn", None) is not None:
+        from .. import ops
+        return ops.cat_channels(a, b)
+    return torch.cat([a, b], dim=1)
+
+
 ARCH = {
     # name: dict(block_out, down=(kind, n_tf_layers, has_down), up=(kind, n_tf_layers, has_up), ...)
     "sd": dict(
@@ -288,7 +296,7 @@ class _Stage(nn.Module):
 
     def run_up(self, h, temb, ctx, skips):
         for j, r in enumerate(self.resnets):
-            h = self._att(j, r(torch.cat([h, skips.pop()], dim=1), temb), ctx)
+            h = self._att(j, r(_cat_channels(h, skips.pop()), temb), ctx)
         if hasattr(self, "upsamplers"):
             h = self.upsamplers[0](h)
         return h

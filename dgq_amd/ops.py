@@ -288,6 +288,36 @@ def groupnorm_scale_shift(x_cl: torch.Tensor, B, HW, C, groups, eps, gamma, beta
     return scale, shift
 
 
+#: GroupNorm statistics out of the producing GEMM's epilogue (dgq_gemm_extra_t.gn_partial + dgq_groupnorm_from_partials) instead
+#: of a pass over the tensor.  A conv output carries its partials as a tensor attribute (``_dgq_gn``); a GroupNorm folded
+#: into the next layer's load uses them when the very same tensor object (or a channel concat of two such tensors,
+#: ``cat_channels``) reaches it.  DGQ_GN_FROM_GEMM=0 restores the standalone statistics kernels.
+GN_FROM_GEMM = os.environ.get("DGQ_GN_FROM_GEMM", "1") == "1"
+
+
+def cat_channels(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """torch.cat([a, b], dim=1) of two NCHW tensors that keeps the GroupNorm partials of both sources (the skip concatenation in
+    front of an up block's norm1): dgq_groupnorm_from_partials takes the two partial buffers as one channel range."""
+    y = torch.cat([a, b], dim=1)
+    ga, gb = getattr(a, "_dgq_gn", None), getattr(b, "_dgq_gn", None)
+    if ga is not None and gb is not None and len(ga["parts"]) == 1 and len(gb["parts"]) == 1 and ga["B"] == gb["B"] and ga["HW"] == gb["HW"]:
+        y._dgq_gn = dict(parts=ga["parts"] + gb["parts"], B=ga["B"], HW=ga["HW"], C=ga["C"] + gb["C"])
+    return y
+
+
+def groupnorm_from_partials(gn, groups, eps, gamma, beta):
+    """scale / shift [B][C] of GN(x) from the partial statistics the producer(s) of x wrote (see dgq_groupnorm_from_partials)"""
+    parts = gn["parts"]
+    B, HW, C = gn["B"], gn["HW"], gn["C"]
+    dev = parts[0][0].device
+    scale = torch.empty((B, C), dtype=torch.float32, device=dev)
+    shift = torch.empty((B, C), dtype=torch.float32, device=dev)
+    p2, c2 = (parts[1][0], parts[1][1]) if len(parts) > 1 else (None, 0)
+    _lib_call("dgq_groupnorm_from_partials", _lib.ptr(parts[0][0]), parts[0][1], _lib.ptr(p2), c2, B, HW, groups, _c.c_float(eps),
+              _lib.ptr(as_f32(gamma)), _lib.ptr(as_f32(beta)), _lib.ptr(scale), _lib.ptr(shift), _lib.stream())
+    return scale, shift
+
+
 def quant_act(x_cl: torch.Tensor, B, H, W, C, kh, kw, stride, pad, ab: ActBinding, pre=None, ln=None):
     """x_cl: contiguous channels-last storage [B][H][W][C] (any fp dtype). Returns (codes, rowsum[parts][M], M).
     pre = (scale [B][C], shift [B][C], act) folds a GroupNorm (+SiLU when act == 1) into the load;
@@ -410,21 +440,24 @@ class Fork:
         self.used = []
 
 
-def make_extra(residual=None, fq=None, res_div=1, geglu=False):
+def make_extra(residual=None, fq=None, res_div=1, geglu=False, gn_partial=None):
     """dgq_gemm_extra_t: residual [M / res_div][N] fp32 (row stride = its stride(0); res_div > 1 broadcasts each row
     over res_div consecutive output rows); fq = (mode, delta, zp, T, D, skip, bits) with mode 1 scalar / 2 per token /
     3 per head-dim; geglu = the pair epilogue of a row-interleaved ff.net.0.  Keeps the tensors alive on the returned object."""
-    if residual is None and fq is None and not geglu:
+    if residual is None and fq is None and not geglu and gn_partial is None:
         return None
     ex = _lib.GemmExtra()
     ex.res_div = 1
     ex.geglu = 1 if geglu else 0
+    ex.gn_partial = gn_partial.data_ptr() if gn_partial is not None else None
     keep = []
     if residual is not None:
         assert residual.dtype in _lib.DTYPE_CODE and residual.stride(-1) == 1
         ex.residual, ex.ldr, ex.res_div = residual.data_ptr(), residual.stride(0), res_div
         ex.res_dtype = _lib.DTYPE_CODE[residual.dtype]
         keep.append(residual)
+    if gn_partial is not None:
+        keep.append(gn_partial)
     if fq is not None:
         mode, delta, zp, T, D, skip, bits = fq
         ex.fq_mode, ex.fq_delta, ex.fq_zp = mode, delta.data_ptr(), zp.data_ptr()
@@ -559,7 +592,7 @@ def quant_linear_multi(x: torch.Tensor, bindings, ln=None):
     return [o.view(*x.shape[:-1], o.shape[-1]) for o in outs]
 
 
-def quant_conv2d(x: torch.Tensor, ab: ActBinding, kh, kw, stride, pad, norm=None, residual=None, bias_rows=None):
+def quant_conv2d(x: torch.Tensor, ab: ActBinding, kh, kw, stride, pad, norm=None, residual=None, bias_rows=None, gn_out=True):
     """x logical NCHW (any strides; made channels-last) -> logical NCHW output in channels-last storage.
     norm = (groups, eps, gamma, beta, act): GroupNorm (+SiLU) of x folded into the quantise-on-load pass;
     residual (logical NCHW, same shape as the output) is added in the GEMM epilogue; bias_rows [B][N] likewise, one row
@@ -570,7 +603,11 @@ def quant_conv2d(x: torch.Tensor, ab: ActBinding, kh, kw, stride, pad, norm=None
     pre = None
     if norm is not None:
         groups, eps, gamma, beta, act = norm
-        sc, sh = groupnorm_scale_shift(x_store, B, H * W, C, groups, eps, gamma, beta)
+        gn = getattr(x, "_dgq_gn", None) if GN_FROM_GEMM else None
+        if gn is not None and gn["B"] == B and gn["HW"] == H * W and gn["C"] == C and C % groups == 0:
+            sc, sh = groupnorm_from_partials(gn, groups, eps, gamma, beta)      # statistics left by the producing GEMM(s)
+        else:
+            sc, sh = groupnorm_scale_shift(x_store, B, H * W, C, groups, eps, gamma, beta)
         pre = (sc, sh, act)
     Ho = (H + 2 * pad - kh) // stride + 1
     Wo = (W + 2 * pad - kw) // stride + 1
@@ -581,8 +618,17 @@ def quant_conv2d(x: torch.Tensor, ab: ActBinding, kh, kw, stride, pad, norm=None
     elif bias_rows is not None:                       # [B][N]: one row per image, broadcast over its Ho*Wo positions
         res2, res_div = bias_rows.contiguous(), M // B
     codes, rowsum, M = quant_act(x_store, B, H, W, C, kh, kw, stride, pad, ab, pre)
-    y = gemm_wxa8(codes, rowsum, M, ab, x.dtype, extra=make_extra(res2, res_div=res_div))
-    return y.view(B, Ho, Wo, ab.pw.N).permute(0, 3, 1, 2)
+    # GroupNorm partials of the output for whoever normalises it next — where the launch would not be K-split anyway
+    N = ab.pw.N
+    part = None
+    if (GN_FROM_GEMM and gn_out and (Ho * Wo) % 16 == 0 and N % 4 == 0 and
+            _lib.load().dgq_gemm_plan_splits(M, N, ab.Kp, ab.pw.bits, 0 if ab.mode == "perK" else 1, WORKSPACE_BYTES) == 1):
+        part = torch.empty((M // 16, N, 2), dtype=torch.float32, device=x.device)
+    y = gemm_wxa8(codes, rowsum, M, ab, x.dtype, extra=make_extra(res2, res_div=res_div, gn_partial=part))
+    out = y.view(B, Ho, Wo, N).permute(0, 3, 1, 2)
+    if part is not None:
+        out._dgq_gn = dict(parts=[(part, N)], B=B, HW=Ho * Wo, C=N)
+    return out
 
 
 # ------------------------------------------------------------------------------------------ attention side

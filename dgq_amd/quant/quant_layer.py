@@ -302,7 +302,13 @@ LAYER_TAP = None
 
 
 def _tap(layer, y, **info):
-    return y if LAYER_TAP is None else LAYER_TAP(layer, y, **info)
+    if LAYER_TAP is None:
+        return y
+    out = LAYER_TAP(layer, y, **info)
+    gn = getattr(y, "_dgq_gn", None)
+    if gn is not None and out is not y and out.shape == y.shape:
+        out._dgq_gn = gn                     # a teacher-forced tensor keeps the statistics the GEMM epilogue produced
+    return out
 
 
 class SlotRef:

@@ -121,6 +121,13 @@ int dgq_quant_act_variant(const dgq_quant_act_args_t* args);
 int dgq_groupnorm_scale_shift(const void* x, int x_dtype, int B, int HW, int C, int G, float eps,
                               const float* gamma, const float* beta, float* scale, float* shift,
                               float* partial_ws, int slices, unsigned* counters, void* stream);
+/* The same scale / shift from the partial statistics a producing dgq_gemm_wxa8 left behind (dgq_gemm_extra_t.gn_partial):
+ * partial [B·HW/16][C][2] = (mean, Σ(x − mean)²) per 16-row block and channel; HW % 16 == 0.  One small launch, no pass
+ * over the tensor; the blocks and channels of a (batch, group) are merged in a fixed order (Chan), biased variance.
+ * partial2 / C2 (optional, NULL / 0): a second source whose channels FOLLOW the first's — the statistics of
+ * torch.cat([a, b], dim=1) from those of a and b (the skip concatenations in front of the up blocks' norm1). */
+int dgq_groupnorm_from_partials(const float* partial, int C1, const float* partial2, int C2, int B, int HW, int G, float eps,
+                                const float* gamma, const float* beta, float* scale, float* shift, void* stream);
 
 /* ---- the hot kernel: W4A8 / W8A8 MFMA GEMM with fused dequantisation ------------------------------
  * Replaces F.linear / `w.view(N,-1) @ unfolded` / F.conv2d on fake-quantised operands
@@ -148,7 +155,11 @@ int dgq_groupnorm_scale_shift(const void* x, int x_dtype, int B, int HW, int C, 
  *   geglu != 0   : FeedForward's GEGLU (diffusers_rewrite/sd.py:210-222) for a ff.net.0 whose weight rows were
  *                  interleaved at pack time (row 2i = value column i, row 2i+1 = gate column i; alpha / zw / gamma / vn
  *                  likewise): y has N/2 columns, y[m, i] = h[m, 2i]·gelu(h[m, 2i+1]) (erf form).  No other extra, no K
- *                  split, N % 4 == 0. */
+ *                  split, N % 4 == 0;
+ *   gn_partial   : (or NULL) [M/16][N][2] floats: per 16-row block and column the mean and the sum of squared deviations of
+ *                  the values this call stores (after residual; as rounded to y_dtype) — GroupNorm statistics of the output
+ *                  for dgq_groupnorm_from_partials, instead of a pass over the tensor.  M % 16 == 0, N % 4 == 0, 16-byte
+ *                  aligned; forces an unsplit launch (dgq_gemm_plan_splits tells what the shape would otherwise get). */
 typedef struct dgq_gemm_extra {
     const void* residual;
     int ldr;
@@ -160,6 +171,7 @@ typedef struct dgq_gemm_extra {
     int fq_T, fq_D, fq_skip;
     float fq_qmax;
     int geglu;
+    float* gn_partial;
 } dgq_gemm_extra_t;
 
 int dgq_gemm_wxa8(const int8_t* codes, const float* rowsum, int rowsum_parts, int M, int Kp,
@@ -186,6 +198,7 @@ int dgq_gemm_wxa8_batch(int n, const dgq_gemm_args_t* args, void* stream);
  * shape needs; with workspace == NULL (or too small) fewer / no splits are used — results do not depend on it
  * beyond fp32 summation order. */
 size_t dgq_gemm_workspace_bytes(int M, int N, int Kp);
+int dgq_gemm_plan_splits(int M, int N, int Kp, int w_bits, int per_m, size_t workspace_bytes);
 
 /* ---- attention-side quantizers --------------------------------------------------------------------
  * dgq_fakequant_rows: aqtizer_q/k/v (sd.py:174-182,199 -> quant_layer.py:295-299) applied on the

@@ -643,3 +643,49 @@ def test_gemm_geglu_epilogue_equals_projection_then_geglu(M, K, N, mode, dtype, 
     assert out.shape == (M, N // 2) and out.dtype == dtype
     tol = 1e-6 if dtype == torch.float32 else (2e-3 if dtype == torch.float16 else 8e-3)
     assert rel_l2(out.float().cpu(), ref.cpu()) < tol, rel_l2(out.float().cpu(), ref.cpu())
+
+
+@pytest.mark.parametrize("B,C,H,N,k,mode,dtype", [(2, 64, 16, 64, 3, "perK", torch.float32), (2, 320, 32, 320, 3, "perM", torch.float32),
+                                                   (1, 128, 8, 96, 1, "perK", torch.float32), (2, 96, 16, 640, 3, "perK", torch.bfloat16),
+                                                   (2, 64, 64, 160, 3, "perK", torch.float32)])
+def test_groupnorm_from_gemm_epilogue_partials(B, C, H, N, k, mode, dtype, dev):
+    """GroupNorm statistics out of the producing GEMM's epilogue (dgq_gemm_extra_t.gn_partial + dgq_groupnorm_from_partials)
+    against the standalone statistics kernels on the stored tensor: the per-(batch, channel) scale / shift agree to
+    rounding (1e-5 relative), for one source and for a channel concat of two; with a residual in the epilogue; the conv
+    output itself is bit-identical with and without the partials."""
+    from dgq_amd import ops, synth
+    from dgq_amd.plan import plan_act
+    g = torch.Generator().manual_seed(B + C + N)
+    taps = k * k
+    x = torch.randn(B, C, H, H, generator=g).to(dev, dtype)
+    w = torch.randn(N, C, k, k, generator=g) * 0.05
+    wd, wz = orc.minmax_channel(w, 4)
+    pw = ops.PackedWeight(w.to(dev), wd.to(dev), wz.to(dev), None, torch.randn(N, generator=g).to(dev), 4, C, taps)
+    if mode == "perK":
+        d, z = synth._group_params(C * taps, 16, 8, "gnp|%d" % N, 0)
+        lay = plan_act(d.view(1, -1, 1), z.view(1, -1, 1), "conv", C, taps, 8, kw=k)
+    else:
+        d, z = synth._group_params(H * H, 16, 8, "gnp|%d" % N, 0)
+        lay = plan_act(d.view(1, 1, -1), z.view(1, 1, -1), "conv", C, taps, 8, kw=k)
+    ab = ops.ActBinding(lay, pw, 8)
+    res = torch.randn(B, N, H, H, generator=g).to(dev, dtype)
+    gamma = (1 + 0.1 * torch.randn(N, generator=g)).to(dev)
+    beta = (0.1 * torch.randn(N, generator=g)).to(dev)
+    for residual in (None, res):
+        y = ops.quant_conv2d(x, ab, k, k, 1, k // 2, residual=residual, gn_out=True)
+        y0 = ops.quant_conv2d(x, ab, k, k, 1, k // 2, residual=residual, gn_out=False)
+        assert torch.equal(y, y0) and getattr(y, "_dgq_gn", None) is not None and getattr(y0, "_dgq_gn", None) is None
+        sc, sh = ops.groupnorm_from_partials(y._dgq_gn, 32, 1e-5, gamma, beta)
+        ys = y.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)
+        sc0, sh0 = ops.groupnorm_scale_shift(ys, B, H * H, N, 32, 1e-5, gamma, beta)
+        torch.cuda.synchronize()
+        assert rel_l2(sc.cpu(), sc0.cpu()) < 1e-5 and rel_l2(sh.cpu(), sh0.cpu()) < 1e-5, (rel_l2(sc.cpu(), sc0.cpu()), rel_l2(sh.cpu(), sh0.cpu()))
+    # channel concat of two producers: statistics of torch.cat([y, y2], 1) from the two partial buffers
+    y2 = ops.quant_conv2d(x.flip(0), ab, k, k, 1, k // 2)
+    cat = ops.cat_channels(y, y2)
+    g2 = torch.cat([gamma, gamma.flip(0)]); b2 = torch.cat([beta, beta.flip(0)])
+    sc, sh = ops.groupnorm_from_partials(cat._dgq_gn, 32, 1e-6, g2, b2)
+    cs = cat.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)
+    sc0, sh0 = ops.groupnorm_scale_shift(cs, B, H * H, 2 * N, 32, 1e-6, g2, b2)
+    torch.cuda.synchronize()
+    assert rel_l2(sc.cpu(), sc0.cpu()) < 1e-5 and rel_l2(sh.cpu(), sh0.cpu()) < 1e-5

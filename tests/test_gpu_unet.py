@@ -622,6 +622,52 @@ def test_half_mode_runs_on_the_fused_kernels(dtype, tmp_path_factory, monkeypatc
     assert e < 0.5, e
 
 
+HALF_TF_TOL = {
+    # worst / median rel-L2 per class, stated per dtype.  The kernels compute in fp32 whatever the tensor dtype
+    # (integer contraction, fp32 epilogue, ONE rounding at the store), so a teacher-forced layer differs from the fp32 oracle by
+    #   (1) the rounding of its output: 2^-9 (bf16) / 2^-12 (fp16) relative per element, and
+    #   (2) the codes that flip because its INPUT was rounded to the half type before quantisation (a rounding error of
+    #       2^-9·|x| against an 8-bit quantiser step of range/255: ~10 % of the codes move by one step in bf16, ~1.5 % in fp16)
+    #       — (2) dominates: it is what "bf16 / fp16 between the layers" costs this W4A8 network, on any implementation.
+    # Measured on SD 16x16 C2 (median / worst rel-L2 per layer): bf16 inputs 1.7e-3 / 3.3e-3, outputs 2.5e-2 / 3.0e-2, folded-
+    # prologue layers 2.6e-2 / 3.9e-2, attention cores 5.2e-2 / 9.9e-2; fp16 inputs 2.1e-4 / 4.2e-4, outputs 8.7e-3 / 1.1e-2,
+    # prologue layers 9.3e-3 / 1.4e-2, attention cores 2.7e-2 / 7.9e-2.  Tolerances = ~1.5x the measurement.
+    torch.bfloat16: dict(out=(5e-2, 3.5e-2), pro=(6e-2, 4e-2), inp=(6e-3, 3e-3), attn=(0.15, 8e-2), aout=(8e-2, 2.5e-2), final=8e-2),
+    torch.float16: dict(out=(2e-2, 1.4e-2), pro=(2.5e-2, 1.5e-2), inp=(8e-4, 4e-4), attn=(0.15, 5e-2), aout=(8e-2, 1.5e-2), final=2e-2),
+}
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_fused_unet_teacher_forced_half_modes(dtype, tmp_path_factory):
+    """BASELINE config 2's "bf16 accumulate" store mode and the reference's --fp16 mode (quant_model.py:183-201,
+    src/inference_qmodel.py:93) as first-class configurations: the FUSED SD graph (280 layers, 16x16) with bf16 / fp16 tensors
+    between the layers, every quantized layer teacher-forced against the fp32 oracle (tolerances per dtype in HALF_TF_TOL —
+    the half types' own rounding, not a looser arithmetic: the contraction stays integer-exact, the epilogue fp32)."""
+    from dgq_amd.runtime import build_synthetic_qnn
+    arch, res, batch, t = "sd", 16, 2, 999
+    c = dict(CFGS["C2"], steps=2)
+    tmp = str(tmp_path_factory.mktemp("ckhalf"))
+    qnn, _ = build_synthetic_qnn(arch, c, res, batch, 2, ckpt_dir=tmp)               # not cached: the model is recast
+    qnn = qnn.half() if dtype == torch.float16 else qnn.to(torch.bfloat16)
+    inp = synth.synth_inputs(arch, batch, 1, res)
+    ref, rec, _ = oracle_run(arch, c, res, batch, 2, inp, t, cache_key="tf")
+    out = {}
+
+    def run():
+        with torch.no_grad():
+            out["y"] = qnn(inp["sample"].cuda().to(dtype), torch.tensor(t), inp["encoder_hidden_states"].cuda().to(dtype))[0]
+    stats, seen = fused_teacher_forced_check(qnn, rec.io, run)
+    assert sorted(seen) == sorted(rec.io.keys()), (len(seen), len(rec.io))
+    assert out["y"].dtype == dtype
+    tol = HALF_TF_TOL[dtype]
+    fails = _report("fused-%s %s/C2 res=%d t=%d" % (str(dtype).split(".")[-1], arch, res, t), stats,
+                    (("out",) + tol["out"], ("pro",) + tol["pro"], ("in",) + tol["inp"], ("attn",) + tol["attn"], ("aout",) + tol["aout"]))
+    assert not fails, fails
+    e = rel_l2(out["y"].float().cpu(), ref)
+    print("fused %s final (teacher-forced) rel-L2 %.3g" % (dtype, e))
+    assert e < tol["final"], e
+
+
 def test_graph_cache_is_invalidated_by_state_changes(ckdir):
     """a captured hipGraph bakes in the quantisation state; set_quant_state / dtype casts must drop it."""
     from dgq_amd.runtime import build_synthetic_qnn
