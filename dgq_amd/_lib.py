@@ -37,6 +37,7 @@ SIGNATURES = {
     "dgq_linear_smallm_batch": [_vp, _i, _i, _i, _i64, _i, _i, _vp, _i, _vp],
     "dgq_quant_act_batch": [_i, _vp, _vp],
     "dgq_quant_act_variant": [_vp],
+    "dgq_quant_act_conv_tile": [_i, _i, _i, _i, _i, _vp],
     "dgq_gemm_wxa8_batch": [_i, _vp, _vp],
     "dgq_adaround_soft_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp],
     "dgq_adaround_soft_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp],
@@ -64,7 +65,7 @@ class QuantActArgs(ctypes.Structure):
     _fields_ = [("x", _vp), ("x_dtype", _i), ("B", _i), ("H", _i), ("W", _i), ("C", _i), ("kh", _i), ("kw", _i), ("stride", _i),
                 ("pad", _i), ("ksrc", _vp), ("koff", _vp), ("klds", _vp), ("kdst", _vp), ("Kp", _i), ("per_m", _i), ("delta", _vp), ("zp", _vp),
                 ("L", _i), ("bits", _i), ("codes", _vp), ("rowsum", _vp), ("ksplits", _i), ("pre_scale", _vp), ("pre_shift", _vp),
-                ("pre_act", _i), ("ln_gamma", _vp), ("ln_beta", _vp), ("ln_eps", _f)]
+                ("pre_act", _i), ("ln_gamma", _vp), ("ln_beta", _vp), ("ln_eps", _f), ("kpat", _vp)]
 
 
 class GemmArgs(ctypes.Structure):

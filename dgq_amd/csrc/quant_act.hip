@@ -13,6 +13,7 @@ struct QuantActParams {
     const int32_t* koff;      // optional [Kp]: (dh*W + dw)*ldc + c for THIS geometry, -1 for padding (interior rows)
     const int32_t* klds;      // optional [Kp]: (dh*kw + dw)*C + c, -1 for padding (LDS-staged conv path)
     const int32_t* kdst;      // optional [taps*C]: packed position kp of element (tap, c) — the inverse of ksrc (scatter path)
+    const int32_t* kpat;      // optional [Kp]: (dh*PW + dw)*C + c inside the input patch of a conv tile (PW of dgq_quant_act_conv_tile), -1 padding
     int Kp, K;
     const float* delta;       // per_m: [L]; else [Kp/32]
     const float* zp;
@@ -504,6 +505,161 @@ __global__ __launch_bounds__(256) void quant_act_scatter_kernel(QuantActBatch bt
     }
 }
 
+// Convolutions (kh·kw > 1), block-staged.  The quantizer sees the UNFOLDED operand, so every input element is quantised once
+// per tap that reads it — but the GroupNorm scale/shift and the SiLU in front of it depend on the element alone.  The per-row
+// kernels above applied them once per (row, tap) (9x per element for a 3x3; the 64x64-level convs were VALU-bound: 55 us for
+// 8192 x 2880 codes).  Here a workgroup owns a TH x TW tile of output positions: it stages the tile's input patch
+// ((TH−1)·stride + kh) x ((TW−1)·stride + kw) pixels x C channels ONCE in LDS as fp32, prologue applied (zeros for pixels
+// outside the image: F.unfold pads before the quantizer), 16-byte coalesced reads; then every wave takes output rows and
+// gathers its codes from the patch through the kpat table (lane = 4 consecutive kp, one packed dword, 256-byte row
+// segments per store), with the same exact-division quantiser.  Per-K (kpat in the weight's group-sorted K order, one (δ, z)
+// per 32-chunk) and per-M / scalar (natural order, one (δ, z) per row) alike.
+template <typename TIn, bool PER_M, int TH, int TW, int NW>
+__global__ __launch_bounds__(64 * NW) void quant_act_conv_kernel(QuantActBatch bt) {
+    const QuantActParams& p = bt.p[blockIdx.z];
+    extern __shared__ __attribute__((aligned(16))) float patch[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_w = (p.Wo + TW - 1) / TW, tiles_h = (p.Ho + TH - 1) / TH;
+    int t = blockIdx.x;
+    const int b = t / (tiles_h * tiles_w);
+    t -= b * tiles_h * tiles_w;
+    const int th = t / tiles_w, tw = t - th * tiles_w;
+    if (b >= p.B) return;
+    const int ho0 = th * TH, wo0 = tw * TW;
+    const int PH = (TH - 1) * p.stride + p.kh, PW = (TW - 1) * p.stride + p.kw;
+    const int hi0 = ho0 * p.stride - p.pad, wi0 = wo0 * p.stride - p.pad;
+    const TIn* img = reinterpret_cast<const TIn*>(p.x) + (int64_t)b * p.H * p.W * p.C;
+    const float* pre_sc = p.pre_scale ? p.pre_scale + (int64_t)b * p.C : nullptr;
+    const float* pre_sh = p.pre_shift ? p.pre_shift + (int64_t)b * p.C : nullptr;
+    // ---- stage the patch: wave w takes pixels w, w + NW, ...
+    for (int pp = wv; pp < PH * PW; pp += NW) {
+        const int ph = pp / PW, pw_ = pp - ph * PW;
+        const int hi = hi0 + ph, wi = wi0 + pw_;
+        const bool inb = hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;       // wave-uniform
+        const TIn* src = img + ((int64_t)hi * p.W + wi) * p.C;
+        float* dst = patch + pp * p.C;
+        for (int c = lane * 4; c < p.C; c += 256) {
+            float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (inb) {
+                load4<TIn>(src + c, v);
+                if (pre_sc) {
+                    const float4 sc = *reinterpret_cast<const float4*>(pre_sc + c);
+                    const float4 sh = *reinterpret_cast<const float4*>(pre_sh + c);
+                    v[0] = v[0] * sc.x + sh.x; v[1] = v[1] * sc.y + sh.y; v[2] = v[2] * sc.z + sh.z; v[3] = v[3] * sc.w + sh.w;
+                }
+                if (p.pre_act == 1) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = dgq_silu(v[j]);
+                }
+            }
+            *reinterpret_cast<float4*>(dst + c) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+    // the gather table (and the per-chunk quantiser tables) behind the patch: read once per workgroup, every row of the tile
+    // then finds them at LDS latency (read from L1 per row, their ~1 us round trips were exposed at two waves per SIMD)
+    // (16-bit entries: a patch holds < 2^16 floats; 0xFFFF = padding)
+    uint16_t* tab = reinterpret_cast<uint16_t*>(patch + PH * PW * p.C);
+    float* tdl = reinterpret_cast<float*>(tab + p.Kp);
+    float* tzp = tdl + (p.Kp >> 5);
+    for (int k = tid * 4; k < p.Kp; k += 4 * 64 * NW) {
+        const int4 e = *reinterpret_cast<const int4*>(p.kpat + k);
+        *reinterpret_cast<uint2*>(tab + k) = make_uint2(((uint32_t)e.x & 0xFFFFu) | ((uint32_t)e.y << 16), ((uint32_t)e.z & 0xFFFFu) | ((uint32_t)e.w << 16));
+    }
+    if (!PER_M)
+        for (int c = tid; c < (p.Kp >> 5); c += 64 * NW) { tdl[c] = p.delta[c]; tzp[c] = p.zp[c]; }
+    __syncthreads();
+    // ---- gather + quantise: wave w takes output positions w, w + NW, ... of the tile
+    const float bias = 128.0f - p.offset;
+    for (int r = wv; r < TH * TW; r += NW) {
+        const int i = r / TW, j = r - i * TW;
+        const int ho = ho0 + i, wo = wo0 + j;
+        if (ho >= p.Ho || wo >= p.Wo) continue;                               // wave-uniform
+        const int row = (b * p.Ho + ho) * p.Wo + wo;
+        const float* pr = patch + ((i * p.stride) * PW + j * p.stride) * p.C;
+        float md = 1.0f, mz = 0.0f, minv = 1.0f;
+        if (PER_M) {
+            const int li = row % p.L;
+            md = p.delta[li];
+            mz = p.zp[li];
+            minv = dgq_rcp(md);
+        }
+        float partial = 0.0f;
+        uint32_t* out = reinterpret_cast<uint32_t*>(p.codes + (int64_t)row * p.Kp);
+        for (int kb = lane * 4; kb < p.Kp; kb += 1024) {
+            int idx[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int kp0 = kb + 256 * u;
+                uint2 tt = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+                if (kp0 < p.Kp) tt = *reinterpret_cast<const uint2*>(tab + kp0);
+                idx[u][0] = tt.x & 0xFFFF; idx[u][1] = tt.x >> 16; idx[u][2] = tt.y & 0xFFFF; idx[u][3] = tt.y >> 16;
+            }
+            float v[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[u][q] = pr[idx[u][q] == 0xFFFF ? 0 : idx[u][q]];   // padding reads element 0: value unused
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int kp0 = kb + 256 * u;
+                if (kp0 < p.Kp) {
+                    float d = md, z = mz, inv = minv;
+                    if (!PER_M) {
+                        d = tdl[kp0 >> 5];
+                        z = tzp[kp0 >> 5];
+                        inv = dgq_rcp(d);
+                    }
+                    float biased[4], fsum = 0.0f;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float qq = dgq_affine_code_fast(v[u][q], d, inv, z, p.qmax);
+                        biased[q] = idx[u][q] != 0xFFFF ? qq + bias : 128.0f;
+                    }
+                    out[kp0 >> 2] = dgq_pack4(biased, fsum);
+                    fsum -= 512.0f;
+                    partial += PER_M ? fsum : d * fsum;
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) partial += __shfl_down(partial, o, 64);
+        if (lane == 0) p.rowsum[row] = partial;
+    }
+}
+
+// tile of the block-staged conv path for a geometry: the largest of 4x8 / 4x4 / 2x4 output positions whose input patch fits
+// the LDS (two workgroups per CU for the first, one for the others); 0 = none (the per-row paths take the layer)
+struct ConvTile { int id, th, tw, pw; size_t lds; };
+static ConvTile conv_tile(int C, int kh, int kw, int stride, int Kp) {
+    const int cand[3][2] = {{4, 8}, {4, 4}, {2, 4}};
+    const size_t tables = (size_t)Kp * 2 + (size_t)(Kp >> 5) * 8 + 64;
+    ConvTile fit = {0, 0, 0, 0, 0};
+    for (int i = 0; i < 3; ++i) {
+        const int th = cand[i][0], tw = cand[i][1];
+        const int ph = (th - 1) * stride + kh, pw = (tw - 1) * stride + kw;
+        const size_t lds = (size_t)ph * pw * C * sizeof(float) + tables;
+        if (lds <= 78u * 1024) return {i + 1, th, tw, pw, lds};           // two workgroups per CU: staging of one overlaps the other's gather
+        if (fit.id == 0 && lds <= 150u * 1024) fit = {i + 1, th, tw, pw, lds};
+    }
+    return fit;
+}
+// Where the path pays (tools/bench_qact_conv.py, profiles/r03_quant_act_conv_block.txt): the tile grid must cover the chip
+// (>= 256 workgroups), i.e. the 64x64-level convolutions and the wide 32x32 ones; on smaller grids the per-row paths, whose
+// workgroups hold four rows, keep more of the chip busy.
+static bool conv_block_pays(const QuantActParams& p, const ConvTile& t) {
+    if (t.id == 0) return false;
+    const long tiles = (long)p.B * ((p.Ho + t.th - 1) / t.th) * ((p.Wo + t.tw - 1) / t.tw);
+    return tiles >= 256 && p.M >= 2048;
+}
+
+extern "C" int dgq_quant_act_conv_tile(int C, int kh, int kw, int stride, int Kp, int* patch_w) {
+    if (C <= 0 || kh <= 0 || kw <= 0 || stride <= 0 || kh * kw <= 1 || C % 4 != 0 || Kp <= 0) return 0;
+    const ConvTile t = conv_tile(C, kh, kw, stride, Kp);
+    if (patch_w) *patch_w = t.pw;
+    return t.id;
+}
+
 // kernel variant of one problem: 0 = LDS-staged strips, 1 = table gather from global, 2 = natural order, 3 / 4 = scatter
 // through an LDS row image with 4 rows / 1 row per block
 static int quant_act_variant(const QuantActParams& p, bool table) {
@@ -524,6 +680,13 @@ static int quant_act_variant(const QuantActParams& p, bool table) {
         if (mode && table && p.kdst && taps_ == 1 && p.C % 4 == 0 && ks == 1 && (!p.ln_gamma || p.C <= DGQ_LN_MAX_C) &&
             tab_b + 4 * (size_t)p.Kp <= 150 * 1024 && (mode == 2 || 4 * p.Kp >= 5 * p.K))
             return 3;
+    }
+    // convolutions whose input patch fits the LDS: the block-staged path (DGQ_QA_CONV_BLOCK=0: A/B hook)
+    {
+        static const bool conv_block = [] { const char* e = getenv("DGQ_QA_CONV_BLOCK"); return !(e && *e == '0'); }();
+        if (conv_block && p.kpat && taps_ > 1 && p.C % 4 == 0 && ks == 1 && p.pre_act != 2 && !p.ln_gamma &&
+            conv_block_pays(p, conv_tile(p.C, p.kh, p.kw, p.stride, p.Kp)))
+            return 5;
     }
     const bool stage_conv = taps_ > 1 && p.pre_act != 2 && !p.ln_gamma && ks == 1;
     const bool stage_lin = taps_ == 1 && (!p.ln_gamma || p.C <= DGQ_LN_MAX_C);
@@ -548,6 +711,27 @@ static void launch_quant_act(const QuantActBatch& bt, int n, int variant, bool p
         const QuantActParams& p = bt.p[i];
         ks = std::max(ks, (p.Kp + p.kp_per_split - 1) / p.kp_per_split);
         strip_bytes = std::max(strip_bytes, (size_t)p.kh * p.kw * p.C * sizeof(float));
+    }
+    if (variant == 5) {
+        const ConvTile t = conv_tile(p0.C, p0.kh, p0.kw, p0.stride, p0.Kp);
+        const int tiles = p0.B * ((p0.Ho + t.th - 1) / t.th) * ((p0.Wo + t.tw - 1) / t.tw);
+        static std::atomic<bool> attr5[64];
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (dev < 0 || dev >= 64 || !attr5[dev].load(std::memory_order_acquire)) {          // all six instantiations of this dtype, once
+#define DGQ_QA_ATTR(PM, TH_, TW_) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&quant_act_conv_kernel<TIn, PM, TH_, TW_, 8>), \
+                                                            hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024)
+            DGQ_QA_ATTR(true, 4, 8); DGQ_QA_ATTR(false, 4, 8); DGQ_QA_ATTR(true, 4, 4); DGQ_QA_ATTR(false, 4, 4);
+            DGQ_QA_ATTR(true, 2, 4); DGQ_QA_ATTR(false, 2, 4);
+#undef DGQ_QA_ATTR
+            if (dev >= 0 && dev < 64) attr5[dev].store(true, std::memory_order_release);
+        }
+#define DGQ_QA_CONV(PM, TH_, TW_) hipLaunchKernelGGL((quant_act_conv_kernel<TIn, PM, TH_, TW_, 8>), dim3(tiles, 1, n), dim3(512), t.lds, st, bt)
+        if (t.id == 1) { if (per_m) DGQ_QA_CONV(true, 4, 8); else DGQ_QA_CONV(false, 4, 8); }
+        else if (t.id == 2) { if (per_m) DGQ_QA_CONV(true, 4, 4); else DGQ_QA_CONV(false, 4, 4); }
+        else { if (per_m) DGQ_QA_CONV(true, 2, 4); else DGQ_QA_CONV(false, 2, 4); }
+#undef DGQ_QA_CONV
+        return;
     }
     if (variant == 3 || variant == 4) {
         size_t lds = 0;
@@ -614,6 +798,7 @@ static int fill_quant_act(const dgq_quant_act_args_t& a, QuantActParams& p) {
     p.x = a.x; p.B = a.B; p.H = a.H; p.W = a.W; p.C = a.C; p.kh = a.kh; p.kw = a.kw; p.stride = a.stride; p.pad = a.pad;
     p.Ho = Ho; p.Wo = Wo; p.ksrc = a.ksrc; p.koff = a.ksrc ? a.koff : nullptr; p.klds = a.ksrc ? a.klds : nullptr;
     p.kdst = a.ksrc ? a.kdst : nullptr;
+    p.kpat = a.kpat;
     p.Kp = a.Kp; p.K = K; p.delta = a.delta; p.zp = a.zp; p.L = a.per_m ? a.L : 1;
     p.qmax = (float)((1 << a.bits) - 1);
     p.offset = (float)(1 << (a.bits - 1));
@@ -649,7 +834,8 @@ extern "C" int dgq_quant_act_batch(int n, const dgq_quant_act_args_t* args, void
     return dgq_launch_status("dgq_quant_act");
 }
 
-// which problems may share a launch: the kernel variant the library would pick for this problem (0 staged, 1 gather, 2 natural)
+// which problems may share a launch: the kernel variant the library would pick for this problem (0 staged, 1 gather, 2 natural,
+// 3 / 4 LDS scatter, 5 block-staged conv)
 extern "C" int dgq_quant_act_variant(const dgq_quant_act_args_t* a) {
     QuantActParams p;
     if (!a || fill_quant_act(*a, p) != DGQ_OK) return -1;
@@ -665,7 +851,7 @@ extern "C" int dgq_quant_act(const void* x, int x_dtype, int B, int H, int W, in
                              const float* ln_gamma, const float* ln_beta, float ln_eps, void* stream) {
     dgq_quant_act_args_t a;
     a.x = x; a.x_dtype = x_dtype; a.B = B; a.H = H; a.W = W; a.C = C; a.kh = kh; a.kw = kw; a.stride = stride; a.pad = pad;
-    a.ksrc = ksrc; a.koff = koff; a.klds = klds; a.kdst = nullptr; a.Kp = Kp; a.per_m = per_m; a.delta = delta; a.zp = zp; a.L = L; a.bits = bits;
+    a.ksrc = ksrc; a.koff = koff; a.klds = klds; a.kdst = nullptr; a.kpat = nullptr; a.Kp = Kp; a.per_m = per_m; a.delta = delta; a.zp = zp; a.L = L; a.bits = bits;
     a.codes = codes; a.rowsum = rowsum; a.ksplits = ksplits; a.pre_scale = pre_scale; a.pre_shift = pre_shift; a.pre_act = pre_act;
     a.ln_gamma = ln_gamma; a.ln_beta = ln_beta; a.ln_eps = ln_eps;
     return dgq_quant_act_batch(1, &a, stream);

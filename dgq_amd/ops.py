@@ -204,6 +204,26 @@ class ActBinding:
             self._koff[key] = out.contiguous()
         return self._koff[key]
 
+    def kpat(self, kh, kw, C, stride):
+        """(dh·PW + dw)·C + c of every packed position inside the input patch of a conv tile (dgq_quant_act's block-staged
+        path; PW from dgq_quant_act_conv_tile), -1 for padding; None when the geometry has no such path.  Cached."""
+        key = ("pat", kh, kw, C, stride)
+        if key not in self._koff:
+            pw_ = _c.c_int(0)
+            tile = _lib.load().dgq_quant_act_conv_tile(C, kh, kw, stride, self.Kp, _c.byref(pw_))
+            if tile == 0:
+                self._koff[key] = None
+            elif self.ksrc is not None:
+                e = self.ksrc
+                idx = (((e >> 24) & 0x7F) * pw_.value + ((e >> 16) & 0xFF)) * C + (e & 0xFFFF)
+                self._koff[key] = torch.where(e >= 0, idx, torch.full_like(idx, -1)).to(torch.int32).contiguous()
+            else:                                                   # natural order kp = tap·C + c, padded to Kp
+                kp = torch.arange(self.Kp, device=self.pw.codes.device)
+                tap, c = kp // C, kp % C
+                idx = ((tap // kw) * pw_.value + (tap % kw)) * C + c
+                self._koff[key] = torch.where(kp < kh * kw * C, idx, torch.full_like(idx, -1)).to(torch.int32).contiguous()
+        return self._koff[key]
+
     def __init__(self, layout: ActLayout, pw: PackedWeight, abits: int):
         dev = pw.codes.device
         self.mode, self.abits, self.offset = layout.mode, abits, act_offset(abits)
@@ -222,6 +242,7 @@ class ActBinding:
         else:
             self.wpacked, self.Kp = pw.natural()
             self.ksrc = None
+            self._koff = {}
             self.mdelta = layout.mdelta.to(dev).contiguous()
             self.mzp = layout.mzp.to(dev).contiguous()
             self.L = layout.L
@@ -331,6 +352,7 @@ def quant_act(x_cl: torch.Tensor, B, H, W, C, kh, kw, stride, pad, ab: ActBindin
     a.x, a.x_dtype, a.B, a.H, a.W, a.C, a.kh, a.kw, a.stride, a.pad = x_cl.data_ptr(), _lib.DTYPE_CODE[x_cl.dtype], B, H, W, C, kh, kw, stride, pad
     a.ksrc, a.koff, a.klds = _dp(ab.ksrc), _dp(ab.koff(W, ldc)), _dp(ab.klds(kw, C))
     a.kdst = _dp(ab.kdst(kw, C, kh * kw)) if ab.ksrc is not None else None
+    a.kpat = _dp(ab.kpat(kh, kw, C, stride)) if (kh * kw > 1 and C % 4 == 0) else None
     a.Kp, a.per_m = ab.Kp, per_m
     a.delta, a.zp = (ab.cdelta.data_ptr(), ab.czp.data_ptr()) if not per_m else (ab.mdelta.data_ptr(), ab.mzp.data_ptr())
     a.L, a.bits = (1 if not per_m else ab.L), ab.abits
@@ -344,7 +366,7 @@ def quant_act(x_cl: torch.Tensor, B, H, W, C, kh, kw, stride, pad, ab: ActBindin
     parts = 1
     a.ksplits = 1
     a.codes = a.rowsum = 1                                   # placeholders: dgq_quant_act_variant only validates non-NULL
-    if a.kdst is None or _lib.load().dgq_quant_act_variant(_c.byref(a)) not in (3, 4):
+    if (a.kdst is None and a.kpat is None) or _lib.load().dgq_quant_act_variant(_c.byref(a)) not in (3, 4, 5):
         parts = act_ksplits(M, ab.Kp)
         a.ksplits = parts
     codes = torch.empty((M, ab.Kp), dtype=torch.int8, device=x_cl.device)

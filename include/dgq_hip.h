@@ -97,7 +97,8 @@ int dgq_quant_act_parts(int Kp, int ksplits);
 /* The same with the arguments in a struct, for 1..8 problems in ONE launch (dgq_quant_act_batch): the q / k / v
  * projections of an attention quantise one input with three tables, the to_k / to_v of every cross-attention quantise
  * the one text context.  All problems of a batch must have the same row count M, dtype, scale mode (per_m) and kernel
- * variant (dgq_quant_act_variant: 0 LDS-staged, 1 table gather, 2 natural order, 3 / 4 LDS scatter) — DGQ_EINVAL otherwise. */
+ * variant (dgq_quant_act_variant: 0 LDS-staged, 1 table gather, 2 natural order, 3 / 4 LDS scatter, 5 block-staged conv) —
+ * DGQ_EINVAL otherwise. */
 typedef struct dgq_quant_act_args {
     const void* x; int x_dtype; int B, H, W, C, kh, kw, stride, pad;
     const int32_t* ksrc; const int32_t* koff; const int32_t* klds;
@@ -108,9 +109,17 @@ typedef struct dgq_quant_act_args {
     int8_t* codes; float* rowsum; int ksplits;
     const float* pre_scale; const float* pre_shift; int pre_act;
     const float* ln_gamma; const float* ln_beta; float ln_eps;
+    const int32_t* kpat;      /* optional [Kp] (convolutions): (dh·PW + dw)·C + c of packed position kp inside the input patch of
+                                 a tile, PW from dgq_quant_act_conv_tile; -1 = padding.  Natural order (ksrc == NULL) too.
+                                 Enables the block-staged conv path (variant 5): a workgroup stages the input patch of a tile
+                                 of output positions once in LDS with the GroupNorm / SiLU prologue applied once per element
+                                 (the per-row paths apply it once per tap), then gathers every row's codes from it. */
 } dgq_quant_act_args_t;
 int dgq_quant_act_batch(int n, const dgq_quant_act_args_t* args, void* stream);
 int dgq_quant_act_variant(const dgq_quant_act_args_t* args);
+/* tile id (1: 4x8, 2: 4x4, 3: 2x4 output positions; 0: the patch does not fit, no block-staged path) and patch width PW
+ * = (TW − 1)·stride + kw of the block-staged conv path for a geometry: what the caller needs to build `kpat` */
+int dgq_quant_act_conv_tile(int C, int kh, int kw, int stride, int Kp, int* patch_w);
 
 /* GroupNorm of a channels-last tensor x [B][HW][C] as per-(b,c) scale/shift (biased variance, eps as F.group_norm):
  * GN(x) = x·scale + shift.  Replaces norm1/norm2 of QuantResnetBlock2D.forward (quant_block.py:98-119) together with
