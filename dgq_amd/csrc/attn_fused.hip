@@ -73,7 +73,6 @@ __device__ __forceinline__ v16f score_tile(const float* ks, const float (&qreg)[
 template <int D>
 __global__ __launch_bounds__(256) void attn_stats_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int LD = D + 1;
     float* ks = lds;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, h32 = lane >> 5;
     const int bh = blockIdx.y, b = bh / p.H, hd = bh - b * p.H;

@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void linear_smallm_kernel(SmallMBatch b) {
                 const unsigned ww[4] = {sw ? w.z : w.x, sw ? w.w : w.y, sw ? w.x : w.z, sw ? w.y : w.w};
 #pragma unroll
                 for (int m = 0; m < SMALLM_MAX_M; ++m) {
-                    if (m >= b.M) break;
+                    if (m >= b.M) continue;                 // (no break: the loop stays unrollable and acc[] in registers)
                     const int4 c0 = *reinterpret_cast<const int4*>(codes + m * Kq + k0);
                     const int4 c1 = (k0 + 16 < Kq) ? *reinterpret_cast<const int4*>(codes + m * Kq + k0 + 16) : make_int4(0, 0, 0, 0);
                     const int cc[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void linear_smallm_kernel(SmallMBatch b) {
                 const int4 w = *reinterpret_cast<const int4*>(wrow + k0);
 #pragma unroll
                 for (int m = 0; m < SMALLM_MAX_M; ++m) {
-                    if (m >= b.M) break;
+                    if (m >= b.M) continue;
                     const int4 c = *reinterpret_cast<const int4*>(codes + m * Kq + k0);
                     int a = acc[m];
                     a = __builtin_amdgcn_sdot4(c.x, w.x, a, false);
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void linear_smallm_kernel(SmallMBatch b) {
         const float al = P.alpha[n], zw = P.zw[n], ga = P.gamma[n], vn = P.vn[n];
 #pragma unroll
         for (int m = 0; m < SMALLM_MAX_M; ++m) {
-            if (m >= b.M) break;
+            if (m >= b.M) continue;
             int a = acc[m];
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);

@@ -383,6 +383,9 @@ def _dp(t):
 _WORKSPACE = {}
 _SIDE_STREAMS = {}
 WORKSPACE_BYTES = 128 << 20
+#: slabs kept for user streams (other than the default / capture stream and the registered side streams): least recently
+#: used first out, so a program that keeps creating streams does not leak 128 MB per handle
+_STREAM_SLABS_MAX = 4
 
 
 def workspace(device):
@@ -404,7 +407,13 @@ def workspace(device):
         if torch.cuda.is_current_stream_capturing():
             raise RuntimeError("dgq_amd: split-K workspace of a forked stream must exist before graph capture "
                                "(ops.prepare_side_streams)")
+        if isinstance(branch, tuple):                       # a user stream: bounded, least recently used first out
+            old = [k for k in _WORKSPACE if k[0] == str(device) and isinstance(k[1], tuple)]
+            while len(old) >= _STREAM_SLABS_MAX:
+                _WORKSPACE.pop(old.pop(0))
         _WORKSPACE[key] = torch.empty(WORKSPACE_BYTES, dtype=torch.uint8, device=device)
+    elif isinstance(branch, tuple):
+        _WORKSPACE[key] = _WORKSPACE.pop(key)               # most recently used last
     return _WORKSPACE[key]
 
 
@@ -732,6 +741,21 @@ def minmax_rows_cols(x2d: torch.Tensor, rows=True, cols=True):
 
 
 ATTN_HEAD_DIMS = (8, 16, 40, 64, 80, 160)
+_ATTN_WS = {}
+
+
+def _attn_workspace(device, nbytes):
+    """The attention kernels' scratch (δ scalar, row statistics, K / V tile images): one grow-only buffer per device and
+    stream chain instead of an allocation per call — attentions of one forward run back to back on one stream, each fully
+    overwrites what it reads.  Under graph capture a buffer allocated here belongs to the graph's pool like any other."""
+    cap = torch.cuda.is_current_stream_capturing()
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream if not cap else "capture")
+    buf = _ATTN_WS.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty((max(nbytes, 1 << 20),), dtype=torch.uint8, device=device)      # caching allocator: 512-byte aligned
+        if not cap:
+            _ATTN_WS[key] = buf
+    return buf
 
 
 def attention_fuses_fakequant(D, mode):
@@ -749,7 +773,7 @@ def attention(q, k, v, H, D, scale, mode, skip, delta, bits, fq=None):
     S = k.shape[1]
     o = torch.empty_like(q)
     nbytes = _lib.load().dgq_attention_workspace_bytes(B, H, T, S, D)
-    ws = torch.empty((nbytes,), dtype=torch.uint8, device=q.device)      # caching allocator: 512-byte aligned
+    ws = _attn_workspace(q.device, nbytes)
     desc = None
     if fq is not None and any(f is not None for f in fq):
         desc = (_lib.AttnFq * 3)()

@@ -61,8 +61,12 @@ def cali_model_aq(model_type, qnn: QuantModel, a_cali_data, model_dict, group_nu
         inds = np.arange(t_cali_data[0].shape[0])
         np.random.shuffle(inds)
         qnn.set_group_num(group_num)
-        for i in range(0, t_cali_data[0].shape[0], batch_size):
-            _ = qnn(*(x[inds[i: i + batch_size]].to(dev) for x in t_cali_data))
+        try:
+            for i in range(0, t_cali_data[0].shape[0], batch_size):
+                _ = qnn(*(x[inds[i: i + batch_size]].to(dev) for x in t_cali_data))
+        except BaseException:
+            qnn.restore_fusion()                              # a failed calibration forward must not leave the process unfused
+            raise
         qnn.done_group_num(group_num, mode=group_mode)
         for name, module in qnn.model.named_modules():      # zero points become parameters like δ (:92-98)
             if "aqtizer" in name and isinstance(module, UniformAffineQuantizer) and module.delta is not None:

@@ -58,6 +58,9 @@ class QuantModel(nn.Module):
             grp = TembGroup(temb_layers, self._epoch)
             for l in temb_layers:
                 l.__dict__["_temb_group"] = grp          # plain attribute: not a submodule, not in the state dict
+        # the epoch also ticks when the wrapped UNet is run directly (qnn.model(...), a hook or test that re-enters it): a
+        # forward pre-hook on the UNet itself, so the shared-launch caches can never serve a previous run's projections
+        self.model.register_forward_pre_hook(lambda mod, args: self._tick())
         self.time_aware = None          # set by load_cali_model(time_aware_aqtizer=True)
         self._graphs = None
         self._graph_pool = None
@@ -122,9 +125,21 @@ class QuantModel(nn.Module):
             return self._graph_forward(slot, sample, timesteps, encoder_hidden_states, kwargs)
         return self._run_model(sample, timesteps, encoder_hidden_states, *args, **kwargs)
 
-    def _run_model(self, *args, **kwargs):
+    def _tick(self):
         self._epoch[0] += 1
-        return self.model(*args, **kwargs)
+
+    def _run_model(self, *args, **kwargs):
+        try:
+            return self.model(*args, **kwargs)           # the pre-hook ticks the epoch
+        finally:
+            self._release_shared()
+
+    def _release_shared(self):
+        """drop what the shared-launch caches pinned for this run (the context / temb tensors and every projection output)"""
+        for m in self.model.modules():
+            for g in (m.__dict__.get("_ctx_group"), m.__dict__.get("_temb_group")):
+                if g is not None:
+                    g._src, g._out = None, {}
 
     # -- hipGraph replay of a whole denoise step -------------------------------------------------------------------
     def enable_graphs(self, enabled: bool = True):
@@ -226,7 +241,9 @@ class QuantModel(nn.Module):
         quantizer (QuantLayer inputs, unfolded for convs; attention q / k / v).  The blocks run unfused meanwhile."""
         from . import quant_block
         self._drop_graphs()
-        self._fusion_was = quant_block.FUSION
+        if not getattr(self, "_calibrating", False):      # a second set_group_num before done_group_num keeps the saved flag
+            self._fusion_was = quant_block.FUSION
+            self._calibrating = True
         quant_block.FUSION = False
         for m in self.model.modules():
             if isinstance(m, QuantLayer):
@@ -242,8 +259,15 @@ class QuantModel(nn.Module):
                 m.done_group_num(group_num, mode=mode)
         for q in self._attn_quantizers():
             q.done_group_num(group_num, mode=mode)
-        quant_block.FUSION = getattr(self, "_fusion_was", True)
+        self.restore_fusion()
         self._drop_graphs()
+
+    def restore_fusion(self):
+        """undo set_group_num's switch to the unfused graph (also called by cali_model_aq when a calibration forward raises)"""
+        from . import quant_block
+        if getattr(self, "_calibrating", False):
+            quant_block.FUSION = getattr(self, "_fusion_was", True)
+            self._calibrating = False
 
     def set_running_stat(self, running_stat: bool = False) -> None:
         self._drop_graphs()

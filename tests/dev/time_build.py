@@ -1,4 +1,4 @@
-"""Where the synthetic-model build time goes (GPU box): python tools/time_build.py sdxl 32"""
+"""Where the synthetic-model build time goes (GPU box): python tests/dev/time_build.py sdxl 32"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 os.environ["DGQ_BUILD_TIMING"] = "1"
