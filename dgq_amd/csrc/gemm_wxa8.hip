@@ -704,7 +704,11 @@ static void launch_tile(const GemmBatch& bt, hipStream_t st) {
     const GemmParams& p = bt.p[0];
     constexpr int NW = WVM * WVN * WVK;
     // two accumulator sets (flush behind the next chunk's MFMAs) wherever a wave has at most two MFMA tiles
+#ifdef DGQ_ACCS1
+    constexpr int ACCS = 1;
+#else
     constexpr int ACCS = (!PER_M && (BM / WVM / 32) * (BN / WVN / 32) <= 2) ? 2 : 1;
+#endif
     constexpr int lds_stages = NST * gemm_stage_bytes(WBITS, BM, BN);
     constexpr int lds_vec = (3 * BM + 4 * BN) * 4;
     constexpr int lds_max = lds_stages + lds_vec + 32768;       // + epilogue vectors + per-chunk coefficients (<= 4096 chunks)

@@ -304,11 +304,9 @@ LAYER_TAP = None
 def _tap(layer, y, **info):
     if LAYER_TAP is None:
         return y
-    out = LAYER_TAP(layer, y, **info)
-    gn = getattr(y, "_dgq_gn", None)
-    if gn is not None and out is not y and out.shape == y.shape:
-        out._dgq_gn = gn                     # a teacher-forced tensor keeps the statistics the GEMM epilogue produced
-    return out
+    # (a tensor the tap REPLACES carries no GroupNorm partials: they describe the tensor the GEMM wrote, and the next
+    # GroupNorm then takes its statistics from the replacement itself — tests/test_gpu_kernels.py pins the partials path)
+    return LAYER_TAP(layer, y, **info)
 
 
 class SlotRef:

@@ -4,6 +4,7 @@
     python tests/golden/make_golden.py small            # F2 quantizers, F3 layers, F4 blocks  (seconds)
     python tests/golden/make_golden.py schema           # F1 ckpt schema + F6 loader side effects
     python tests/golden/make_golden.py calib | recon    # F8 DGQ activation calibration, F9 weight PTQ (mini model)
+    python tests/golden/make_golden.py qstats           # F8b statistics of the calibration, quantizer by quantizer
     python tests/golden/make_golden.py unet c1|c2|c3    # F5 full SD UNet, 64x64 latents (minutes each)
     python tests/golden/make_golden.py ddim [steps]     # F5 N-step DDIM final latent (tens of minutes)
     python tests/golden/make_golden.py pndm | euler     # F7 vendored PNDM / EulerAncestral schedulers on a closed-form ε model
@@ -434,6 +435,46 @@ def make_calib(ref):
     save("f8_calibration_mini.pt", dict(meta=dict(c, sklearn=sklearn.__version__), act=act, ranges=ranges))
 
 
+def make_qstats(ref):
+    """F8b: the statistics half of DGQ's calibration, quantizer by quantizer: the REFERENCE's
+    UniformAffineQuantizer in the state cali_model_aq puts it in (scalar self-initialisation by the first batch, then
+    group_num = G) over three batches of 3-D (Linear / unfolded conv), 4-D (attention q / k) and 2-D inputs:
+    the per-batch (min, max) vectors it records (quant_layer.py:301-313), the folded ranges, the (δ, z) of done_group_num
+    (:315-429), and — second quantizer per case — the scalar EMA range of act_momentum_update (:431-446, group_num = 1)."""
+    G = 8
+    out = {}
+    for name, shape in recipes.QSTAT_CASES:
+        xs = recipes.qstat_batches(name, shape)
+        q = ref.ql.UniformAffineQuantizer(bits=8, channel_wise=False, scaler=ref.ql.Scaler.MINMAX, leaf_param=True)
+        q(xs[0])                                              # scalar self-init (calibration_group_quantization.py:83-85)
+        d0, z0 = q.delta.data.clone(), torch.as_tensor(q.zero_point).clone()
+        q.group_num = G
+        per_batch = []
+        for x in xs:
+            q(x)
+            if q.min_max_per_in_channel:
+                per_batch.append(tuple(t.clone() for t in q.min_max_per_in_channel[-1] + q.min_max_per_out_channel[-1]))
+        rec = dict(shape=shape, init_delta=d0, init_zp=z0, per_batch=per_batch)
+        if q.min_max_per_in_channel:
+            im = torch.stack([m[0] for m in q.min_max_per_in_channel]).min(dim=0)[0]
+            ix = torch.stack([m[1] for m in q.min_max_per_in_channel]).max(dim=0)[0]
+            om = torch.stack([m[0] for m in q.min_max_per_out_channel]).min(dim=0)[0]
+            ox = torch.stack([m[1] for m in q.min_max_per_out_channel]).max(dim=0)[0]
+            rec["ranges"] = (im, ix, om, ox)
+        q.done_group_num(G, "minmax")
+        rec["delta"], rec["zero_point"] = q.delta.data.clone(), torch.as_tensor(q.zero_point).clone()
+        q2 = ref.ql.UniformAffineQuantizer(bits=8, channel_wise=False, scaler=ref.ql.Scaler.MINMAX, leaf_param=True)
+        q2(xs[0])
+        q2.group_num = 1                                      # "elif self.group_num != -1": the scalar EMA branch
+        for x in xs[1:]:
+            q2(x)
+        rec["ema"] = (q2.x_min.clone(), q2.x_max.clone(), q2.delta.data.clone(), torch.as_tensor(q2.zero_point).clone())
+        out[name] = rec
+        print(name, shape, "delta", tuple(rec["delta"].shape), "distinct", int(torch.unique(rec["delta"]).numel()))
+    import sklearn
+    save("f8b_quantizer_statistics.pt", dict(meta=dict(G=G, sklearn=sklearn.__version__), cases=out))
+
+
 # --------------------------------------------------------------------------------------- weight PTQ (f4)
 RECON = dict(wbits=4, n=8, res=16, ts=(901, 301), iters=8, batch_size=4, w=0.01, warmup=0.2, seed=1234,
              full_alpha=("model.conv_in", "model.time_embedding.linear_1", "model.down_blocks.0.attentions.0.proj_in",
@@ -704,7 +745,7 @@ def make_pndm_unet(steps=8, res=64, name="c2"):
               final_latent=final, final_latent_1thread=final1))
 
 
-if __name__ == "__main__":
+if __name__ == "__main__":  # noqa: C901
     what = sys.argv[1]
     if what == "pndm":
         make_pndm()
@@ -728,6 +769,8 @@ if __name__ == "__main__":
         make_unet(ref, arch, sys.argv[2], res=res)
     elif what == "calib":
         make_calib(ref)
+    elif what == "qstats":
+        make_qstats(ref)
     elif what == "recon":
         make_recon(ref)
     elif what == "ddim":

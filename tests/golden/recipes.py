@@ -161,3 +161,26 @@ def f4_resnet_inputs():
         ov[name] = (d.view(shape), z.view(shape))
     out["act_override"] = ov
     return out
+
+
+# --------------------------------------------------------------------------------------- F8b (quantizer statistics)
+QSTAT_CASES = (("linear3d", (4, 37, 96)), ("unfolded_conv", (4, 576, 49)), ("attn_q", (4, 8, 33, 40)), ("attn_k", (4, 8, 76, 40)),
+               ("wide_tokens", (2, 256, 64)), ("linear2d", (4, 128)))
+
+
+def qstat_batches(name, shape, n=3):
+    """name-keyed inputs of the statistics fixture: per-channel and per-token structure, a different scale per batch"""
+    out = []
+    for i in range(n):
+        x = _synth().named_randn("qstat|%s|%d" % (name, i), shape, 11)
+        if len(shape) > 2:
+            x = x * (0.5 + _synth().named_rand("qstat|%s|c" % name, (shape[-1],), 11)) + _synth().named_randn("qstat|%s|t" % name, shape[-2:-1] + (1,), 11)
+        out.append(x * (1.0 + 0.3 * i))
+    return out
+
+
+
+
+def _synth():
+    from dgq_amd import synth
+    return synth

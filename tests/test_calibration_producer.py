@@ -150,3 +150,46 @@ def test_act_group_quant_producer_vs_reference_golden(tmp_path):
     with torch.no_grad():
         y = qnn(xs[:2].cuda(), torch.tensor(901), ctx[:2].cuda())[0]
     assert torch.isfinite(y).all()
+
+
+@pytest.mark.gpu
+def test_quantizer_statistics_vs_reference_golden():
+    """VERDICT r2 item 6b — the statistics half of the producer pinned quantizer by quantizer, for every tensor rank the graph
+    feeds a quantizer (3-D Linear, unfolded conv, 4-D attention q / k, 2-D): tests/golden/f8b_quantizer_statistics.pt = the
+    REFERENCE's UniformAffineQuantizer driven as cali_model_aq drives it (scalar self-init, group_num = G, three batches,
+    done_group_num) on name-keyed inputs.  On the GPU (dgq_minmax_rows_cols + the folds of observe / done_group_num):
+    the per-batch (min, max) vectors, the folded ranges, δ and z are BIT-IDENTICAL (minima / maxima have no rounding); the
+    scalar EMA branch (group_num = 1) agrees to an fp32 ulp.  Together with test_grouping_from_reference_ranges_is_exact and
+    the statistics-kernel test this pins every link between a quantizer's input and its table."""
+    from dgq_amd.quant import Scaler
+    from dgq_amd.quant.quant_layer import UniformAffineQuantizer
+    from tests.golden.recipes import qstat_batches
+    g = torch.load(os.path.join(os.path.dirname(GOLD), "f8b_quantizer_statistics.pt"))
+    G = g["meta"]["G"]
+    for name, rec in g["cases"].items():
+        xs = [x.cuda() for x in qstat_batches(name, tuple(rec["shape"]))]
+        q = UniformAffineQuantizer(bits=8, channel_wise=False, scaler=Scaler.MINMAX, leaf_param=True)
+        q.observe(xs[0])                                     # scalar self-initialisation
+        assert torch.equal(q.delta.data.cpu().reshape(()), rec["init_delta"].reshape(())), name
+        assert torch.equal(torch.as_tensor(q.zero_point).cpu().reshape(()), rec["init_zp"].reshape(())), name
+        q.group_num = G
+        for i, x in enumerate(xs):
+            q.observe(x)
+            if rec["per_batch"]:
+                mine = q.min_max_per_in_channel[-1] + q.min_max_per_out_channel[-1]
+                for a, b in zip(mine, rec["per_batch"][i]):
+                    assert torch.equal(a.cpu(), b), (name, i)
+        q.done_group_num(G, "minmax")
+        if "ranges" in rec:
+            for a, b in zip(q.last_ranges, rec["ranges"]):
+                assert torch.equal(a, b), name
+        assert q.delta.data.shape == rec["delta"].shape, (name, q.delta.data.shape, rec["delta"].shape)
+        assert torch.equal(q.delta.data.cpu(), rec["delta"]) and torch.equal(torch.as_tensor(q.zero_point).cpu(), rec["zero_point"]), name
+        q2 = UniformAffineQuantizer(bits=8, channel_wise=False, scaler=Scaler.MINMAX, leaf_param=True)
+        q2.observe(xs[0])
+        q2.group_num = 1
+        for x in xs[1:]:
+            q2.observe(x)
+        xmin, xmax, d, z = rec["ema"]
+        assert abs(float(q2.x_min) - float(xmin)) <= 1e-6 * abs(float(xmin)) and abs(float(q2.x_max) - float(xmax)) <= 1e-6 * abs(float(xmax)), name
+        assert abs(float(q2.delta) - float(d)) <= 1e-6 * float(d) and float(torch.as_tensor(q2.zero_point)) == float(z), name
