@@ -703,12 +703,9 @@ template <int WBITS, bool PER_M, typename TOut, int BM, int BN, int WVM, int WVN
 static void launch_tile(const GemmBatch& bt, hipStream_t st) {
     const GemmParams& p = bt.p[0];
     constexpr int NW = WVM * WVN * WVK;
-    // two accumulator sets (flush behind the next chunk's MFMAs) wherever a wave has at most two MFMA tiles
-#ifdef DGQ_ACCS1
-    constexpr int ACCS = 1;
-#else
+    // two accumulator sets (flush behind the next chunk's MFMAs) wherever a wave has at most two MFMA tiles; with one set
+    // the same per-K launches take 0.4-1.9 µs longer (profiles/r03_gemm_perk_gap.txt)
     constexpr int ACCS = (!PER_M && (BM / WVM / 32) * (BN / WVN / 32) <= 2) ? 2 : 1;
-#endif
     constexpr int lds_stages = NST * gemm_stage_bytes(WBITS, BM, BN);
     constexpr int lds_vec = (3 * BM + 4 * BN) * 4;
     constexpr int lds_max = lds_stages + lds_vec + 32768;       // + epilogue vectors + per-chunk coefficients (<= 4096 chunks)
