@@ -158,6 +158,13 @@ template <int D, int QM = 0, bool VINT = false> struct Geo {
     // VINT (scalar / per-head-dim aqtizer_v): ONE plane of centred integer codes c'v (exact bf16) instead of three planes
     // of the dequantised values — P̂·V is then a single bf16 product, δv(d) and the zero point move to the epilogue
     static constexpr int V_PLANES = VINT ? 1 : 3;
+    // Q1K3 with >= 3 zero-padded depth slots (D = 8, 40): the per-key zero-point correction −zmul(t)·tv[s] rides in the
+    // padding of the score product itself — K slots D..D+2 each hold the three-way split of tv[s], the query's slots hold
+    // the three bf16 terms of −zmul(t) — instead of one fma per score behind it
+    static constexpr bool FOLDZ = QM == 2 && (DP - D) >= 3;
+    // VINT with a spare row in the last d tile (D = 8, 16, 40, 80): V^T row D is all ones, so Σ_s p̂/δ (the zero-point term
+    // of V) comes out of the P̂·V product as O^T[D] instead of one add per score
+    static constexpr bool VONES = VINT && (NDT * 32 > D);
     static constexpr int V_ELEMS = V_PLANES * DV * VLD;
     // One 32-key tile of a (batch, head) is ONE contiguous image in global memory, laid out exactly as it sits in LDS
     // (K planes [3][KT][KLD] then V^T planes [3][DV][VLD], padding included), so staging is a flat LDS-DMA copy in
@@ -402,6 +409,14 @@ __global__ __launch_bounds__(256) void attn3_prep_kernel(const TIn* __restrict__
 #pragma unroll
         for (int o = 4; o > 0; o >>= 1) corr += __shfl_xor(corr, o, 64);
         if (part == 0) reinterpret_cast<float*>(kimg + 3 * KT * G::KLD)[r] = corr;
+        if (G::FOLDZ && part == (D / 8) % 8) {               // (this thread wrote the zero chunk D/8 above: same-thread order)
+            unsigned short th, tm, tl;
+            split3(corr, th, tm, tl);
+            unsigned short* dst = kimg + r * G::KLD + D;     // slots D, D+1, D+2 all hold tv[s] = th + tm + tl
+            *reinterpret_cast<uint2*>(dst) = make_uint2((unsigned)th | ((unsigned)th << 16), (unsigned)th);
+            *reinterpret_cast<uint2*>(dst + KT * G::KLD) = make_uint2((unsigned)tm | ((unsigned)tm << 16), (unsigned)tm);
+            *reinterpret_cast<uint2*>(dst + 2 * KT * G::KLD) = make_uint2((unsigned)tl | ((unsigned)tl << 16), (unsigned)tl);
+        }
     }
     for (int i = threadIdx.x; QM == 0 && do_k && i < KT * KC; i += 256) {
         const int r = i / KC, c8 = i - r * KC;
@@ -441,6 +456,7 @@ __global__ __launch_bounds__(256) void attn3_prep_kernel(const TIn* __restrict__
                 const int slot8 = 2 * j + e;                               // slot within the chunk = 4a + b
                 const int key = 16 * (c8 >> 1) + 8 * (slot8 >> 2) + 4 * (c8 & 1) + (slot8 & 3);
                 const int sidx = s0 + key;
+                if (G::VONES && c8 < 4 && d == D) hh[e] = 0x3F80;          // the ones row (every slot: padding keys carry p̂ = 0)
                 if (c8 < 4 && sidx < S && d < D) {
                     const float xv = dgq_to_float(vbase[sidx * HD + d]);
                     if (VINT) {                                            // centred code (|c'| <= 128: exact in bf16)
@@ -585,6 +601,15 @@ __device__ __forceinline__ v16f score_tile_i8(const unsigned char* kimg, const v
 
 // Q1K3 S^T tile in units of the query scale: acc[r] = Σ_d c'q[t][d]·K̃[s][d] − zmul·tv[s] (three bf16 products per 16-deep
 // step: the Q plane is exact, K̃ is split three ways)
+// the query's −zmul(t) = zh + zm + zl in depth slots D, D+1, D+2 of its (single) code plane (Geo::FOLDZ)
+template <int D>
+__device__ __forceinline__ void fold_zmul(bf16x8 (&qf)[3][Geo<D>::NKK], float zmul, int h32) {
+    unsigned short zh, zm, zl;
+    split3(-zmul, zh, zm, zl);
+    if (h32 == (D / 8) % 2)
+        qf[0][D / 16] = __builtin_bit_cast(bf16x8, make_uint4((unsigned)zh | ((unsigned)zm << 16), (unsigned)zl, 0u, 0u));
+}
+
 template <int D>
 __device__ __forceinline__ v16f score_tile_q1(const unsigned short* kb, const bf16x8 (&qf)[3][Geo<D>::NKK], float zmul, int lane) {
     using G = Geo<D, 2, false>;
@@ -602,15 +627,17 @@ __device__ __forceinline__ v16f score_tile_q1(const unsigned short* kb, const bf
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(km, qf[0][kk], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qf[0][kk], acc, 0, 0, 0);
     }
-    const float* tv = reinterpret_cast<const float*>(kb + 3 * PL);
-    const int h32 = lane >> 5;
+    if constexpr (!G::FOLDZ) {
+        const float* tv = reinterpret_cast<const float*>(kb + 3 * PL);
+        const int h32 = lane >> 5;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const float4 t4 = *reinterpret_cast<const float4*>(tv + 8 * g + 4 * h32);
-        acc[4 * g + 0] = fmaf(-zmul, t4.x, acc[4 * g + 0]);
-        acc[4 * g + 1] = fmaf(-zmul, t4.y, acc[4 * g + 1]);
-        acc[4 * g + 2] = fmaf(-zmul, t4.z, acc[4 * g + 2]);
-        acc[4 * g + 3] = fmaf(-zmul, t4.w, acc[4 * g + 3]);
+        for (int g = 0; g < 4; ++g) {
+            const float4 t4 = *reinterpret_cast<const float4*>(tv + 8 * g + 4 * h32);
+            acc[4 * g + 0] = fmaf(-zmul, t4.x, acc[4 * g + 0]);
+            acc[4 * g + 1] = fmaf(-zmul, t4.y, acc[4 * g + 1]);
+            acc[4 * g + 2] = fmaf(-zmul, t4.z, acc[4 * g + 2]);
+            acc[4 * g + 3] = fmaf(-zmul, t4.w, acc[4 * g + 3]);
+        }
     }
     return acc;
 }
@@ -662,6 +689,7 @@ __global__ __launch_bounds__(64 * NW) void attn3_stats_kernel(AttnParams p) {
         const float2 t2 = *reinterpret_cast<const float2*>(p.qtab + ((int64_t)(b * p.T + tq) * p.H + hd) * 2);
         qt.x = t2.x;
         qt.y = t2.y;
+        if constexpr (G::FOLDZ) fold_zmul<D>(qf, qt.y, h32);
     }
     const float sl2 = p.scale * LOG2E * qt.x;            // scores in log2 units: p = 2^(s2 − m)/l  (QI8: δq folded in, > 0)
     float mraw = -INFINITY, l = 0.0f, m2raw = -INFINITY; // running maxima of the UNSCALED scores (scale > 0)
@@ -690,14 +718,13 @@ __global__ __launch_bounds__(64 * NW) void attn3_stats_kernel(AttnParams p) {
             for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, acc[r]);
             tmax2 = tmax;
         }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        tmax2 = fmaxf(tmax2, __shfl_xor(tmax2, 32, 64));
+        // the two half-waves of a query keep their own (max, sum) over their own keys — no cross-lane traffic inside the
+        // loop; merged once behind it.  A half-wave that has seen no key yet (S < 8) holds max = −inf: offset 0 then.
         const float mn = fmaxf(mraw, tmax);
-        const float nb = -(mn * sl2);
+        const float nb = (mn == -INFINITY) ? 0.0f : -(mn * sl2);
         float part = 0.0f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) part += __builtin_amdgcn_exp2f(fmaf(acc[r], sl2, nb));   // args <= 0: no range fix-up needed
-        part += __shfl_xor(part, 32, 64);
         l = l * __builtin_amdgcn_exp2f(fmaf(mraw, sl2, nb)) + part;
         mraw = mn;
         m2raw = fmaxf(m2raw, tmax2);
@@ -707,6 +734,13 @@ __global__ __launch_bounds__(64 * NW) void attn3_stats_kernel(AttnParams p) {
         istage = (istage + 1 == ST) ? 0 : istage + 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // no DMA may outlive the block's LDS allocation
+    {
+        const float mo = __shfl_xor(mraw, 32, 64), lo = __shfl_xor(l, 32, 64);
+        const float mm = fmaxf(mraw, mo), nb = -(mm * sl2);                   // finite: key 0 exists for every query
+        l = l * __builtin_amdgcn_exp2f(fmaf(mraw, sl2, nb)) + lo * __builtin_amdgcn_exp2f(fmaf(mo, sl2, nb));
+        mraw = mm;
+        m2raw = fmaxf(m2raw, __shfl_xor(m2raw, 32, 64));
+    }
     const float m = mraw * sl2;
     if (t < p.T && h32 == 0) {
         float* st = p.stats + ((int64_t)bh * p.T + t) * 2;
@@ -747,6 +781,7 @@ __global__ __launch_bounds__(64 * NW) void attn3_pv_kernel(AttnParams p) {
         const float2 t2 = *reinterpret_cast<const float2*>(p.qtab + ((int64_t)(b * p.T + tq) * p.H + hd) * 2);
         qt.x = t2.x;
         qt.y = t2.y;
+        if constexpr (G::FOLDZ) fold_zmul<D>(qf, qt.y, h32);
     }
     const float m = p.stats[((int64_t)bh * p.T + tq) * 2], l = p.stats[((int64_t)bh * p.T + tq) * 2 + 1];
     const float delta = p.delta[0];
@@ -804,18 +839,41 @@ __global__ __launch_bounds__(64 * NW) void attn3_pv_kernel(AttnParams p) {
                     }
                 }
                 acc[r] = ph;
-                if (VINT) psum += ph;
+                if constexpr (VINT && !G::VONES) psum += ph;
             }
         };
-        if (edge) quantise(std::true_type{});
-        else quantise(std::false_type{});
-        // B fragments of the two 16-key steps: exact bf16 = upper halves of the fp32 words
-        bf16x8 pf[2];
+        bf16x8 pf[2];                                    // B fragments of the two 16-key steps
+        if (!UNIFORM && !edge) {
+            // interior tiles of the log2 quantiser never form p̂ as a float: the clamped magic-number integers of a key
+            // pair are merged (their low halves = the two codes), and 2^-code as a bf16 is 0x3F80 − (code << 7), so the
+            // packed pair is 0x3F803F80 − 128·(c0 | c1 << 16) — one 24-bit multiply-add (codes <= 127: no borrow)
+            int ci[16];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+            for (int r = 0; r < 16; ++r) {
+                const float x = fmaf(acc[r], nsl2, a0);
+                ci[r] = min(max(__float_as_int(x + MAGIC), MAGIC_I), cmax_i);
+                if constexpr (VINT && !G::VONES) psum += __int_as_float(0x3F800000 - (ci[r] << 23));
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                unsigned w[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const unsigned pair = __builtin_amdgcn_perm((unsigned)ci[8 * ks + 2 * i + 1], (unsigned)ci[8 * ks + 2 * i], 0x05040100u);
+                    w[i] = (unsigned)(__mul24((int)pair, -128) + 0x3F803F80);
+                }
+                pf[ks] = __builtin_bit_cast(bf16x8, make_uint4(w[0], w[1], w[2], w[3]));
+            }
+        } else {
+            if (edge) quantise(std::true_type{});
+            else quantise(std::false_type{});
+            // exact bf16 = upper halves of the fp32 words
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
 #define PK(i) ((__float_as_uint(acc[8 * ks + 2 * (i)]) >> 16) | (__float_as_uint(acc[8 * ks + 2 * (i) + 1]) & 0xFFFF0000u))
-            pf[ks] = __builtin_bit_cast(bf16x8, make_uint4(PK(0), PK(1), PK(2), PK(3)));
+                pf[ks] = __builtin_bit_cast(bf16x8, make_uint4(PK(0), PK(1), PK(2), PK(3)));
 #undef PK
+            }
         }
 #pragma unroll
         for (int j = 0; j < G::NDT; ++j) {
@@ -839,7 +897,12 @@ __global__ __launch_bounds__(64 * NW) void attn3_pv_kernel(AttnParams p) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // no DMA may outlive the block's LDS allocation
     if (p.skip > 0) p_bypass = __shfl(p_bypass, lane & 31, 64);   // key 0 lives in the lower half-wave
-    if (VINT) psum += __shfl_xor(psum, 32, 64);          // both half-waves hold keys of the same query
+    if constexpr (G::VONES) {                            // Σ p̂/δ over ALL keys = O^T[D] (the ones row): d = D sits in one half-wave
+        constexpr int kd = D % 32, rr = (kd & 3) + 4 * (kd >> 3), hh = (kd >> 2) & 1;
+        psum = __shfl(oacc[D / 32][rr], (lane & 31) + 32 * hh, 64);
+    } else if (VINT) {
+        psum += __shfl_xor(psum, 32, 64);                // both half-waves hold keys of the same query
+    }
     // VINT: (δv, z'v) per head-dim element staged once through the (now idle) LDS ring — read per output element from
     // global memory they were 5·16 dependent round trips between the stores (D = 160: +10 us on a 64-row call)
     // likewise the (fake-quantised) value row of the bypassed start-peak key

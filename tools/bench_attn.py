@@ -1,6 +1,6 @@
 """Fused attention per SD1.4 shape (B=2, H=8): hipGraph replay of 20 calls -> us per call (prep + stats + pv), for the
-three operand paths: no fused quantizers (bf16x3 on raw fp32 q/k/v), aqtizer_q/k/v fused with per-token tables on
-bf16x3 (DGQ_ATTN_I8=0), and the int8 score path (per-token q/k: V_MFMA_I32_32X32X32_I8)."""
+four operand paths: no fused quantizers (bf16x3 on raw fp32 q/k/v), aqtizer_q/k/v fused with per-token tables on
+bf16x3 (DGQ_ATTN_I8=0), the int8 score path (per-token q/k: V_MFMA_I32_32X32X32_I8), and Q1K3 (per-head-dim aqtizer_q)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -36,6 +36,9 @@ for D, T, S in shapes:
     f3 = timed(lambda: ops.attention_f32(q, k, v, H, D, D ** -0.5, 1, skip, None, 8, fq=fq))
     os.environ.pop("DGQ_ATTN_I8")
     i8 = timed(lambda: ops.attention_f32(q, k, v, H, D, D ** -0.5, 1, skip, None, 8, fq=fq))
+    # per-head-dim aqtizer_q (the table most calibrated SD slots carry): one exact Q code plane against three K planes
+    fq1 = ((2,) + tab(D) + (0, 8), (1,) + tab(S - skip) + (skip, 8), (2,) + tab(D) + (0, 8))
+    q1 = timed(lambda: ops.attention_f32(q, k, v, H, D, D ** -0.5, 1, skip, None, 8, fq=fq1))
     flops = 2.0 * B * H * T * S * D * 2
-    print("D=%3d T=%5d S=%5d  raw %8.1f us | fused-fq bf16x3 %8.1f us | int8 scores %8.1f us  (%.1f TF/s algorithmic)"
-          % (D, T, S, raw, f3, i8, flops / i8 / 1e6), flush=True)
+    print("D=%3d T=%5d S=%5d  raw %8.1f us | fused-fq bf16x3 %8.1f us | int8 scores %8.1f us | Q1K3 %8.1f us  (%.1f TF/s algorithmic, int8)"
+          % (D, T, S, raw, f3, i8, q1, flops / i8 / 1e6), flush=True)
