@@ -232,23 +232,31 @@ __global__ __launch_bounds__(256) void attn3_prep_kernel(const TIn* __restrict__
         // Q1K3: centred codes c'q = c − 2^(b−1) of aqtizer_q(q) as fp32 (exact), + (q scale, zero-point multiplier) per query
         const int t0 = ((int)blockIdx.x - 2 * NT) * 32;
         constexpr int QC = D / 8;
-        float* qtab = qfq + (size_t)B * T * H * D;
+        unsigned short* qb = reinterpret_cast<unsigned short*>(qfq);          // [B][T][H][D] bf16 codes (|c'| <= 128: exact)
+        float* qtab = reinterpret_cast<float*>(qb + (size_t)B * T * H * D);
         const float off = 0.5f * (fqq.qmax + 1.0f);
-        for (int i = threadIdx.x; i < 32 * QC; i += 256) {
-            const int r = i / QC, c8 = i - r * QC;
+        constexpr int QIT = (32 * QC + 255) / 256;
+        float x[QIT][8];
+#pragma unroll
+        for (int it = 0; it < QIT; ++it) {                                    // all loads of the thread in flight together
+            const int i = threadIdx.x + 256 * it, r = i / QC, c8 = i - r * QC;
+            if (i < 32 * QC && t0 + r < T) load8<TIn>(q + ((int64_t)(b * T + t0 + r) * H + hd) * D + 8 * c8, x[it]);
+        }
+#pragma unroll
+        for (int it = 0; it < QIT; ++it) {
+            const int i = threadIdx.x + 256 * it, r = i / QC, c8 = i - r * QC;
             const int t = t0 + r;
-            if (t >= T) continue;
+            if (i >= 32 * QC || t >= T) continue;
             const int64_t row = (int64_t)(b * T + t) * H + hd;
-            float x[8];
-            load8<TIn>(q + row * D + 8 * c8, x);
+            unsigned w[4];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int idx = fqq.mode == 0 ? 0 : (fqq.mode == 1 ? t - fqq.skip : 8 * c8 + j);
                 const float dl = fqq.delta[idx];
-                x[j] = fq_code(x[j], dl, dgq_rcp(dl), fqq.zp[idx], fqq.qmax, off);
+                const unsigned bits = bf16_bits(fq_code(x[it][j], dl, dgq_rcp(dl), fqq.zp[idx], fqq.qmax, off));
+                if (j & 1) w[j >> 1] |= bits << 16; else w[j >> 1] = bits;
             }
-            *reinterpret_cast<float4*>(qfq + row * D + 8 * c8) = make_float4(x[0], x[1], x[2], x[3]);
-            *reinterpret_cast<float4*>(qfq + row * D + 8 * c8 + 4) = make_float4(x[4], x[5], x[6], x[7]);
+            *reinterpret_cast<uint4*>(qb + row * D + 8 * c8) = make_uint4(w[0], w[1], w[2], w[3]);
             if (c8 == 0) {
                 // per-d table: δq(d) lives in the K planes and z'q(d) in the per-key correction (multiplier 1);
                 // scalar / per-token: scale δq(t) outside, correction z'q(t)·Σ_d K[s][d]
@@ -376,26 +384,32 @@ __global__ __launch_bounds__(256) void attn3_prep_kernel(const TIn* __restrict__
         const int sidx = s0 + r;
         const float offq = 0.5f * (fqq.qmax + 1.0f);
         float corr = 0.0f;
-        for (int c8 = part; c8 < KC; c8 += 8) {
+        constexpr int KIT = (KC + 7) / 8;
+        float x[KIT][8];
+#pragma unroll
+        for (int it = 0; it < KIT; ++it)                     // all loads of the thread in flight together
+            if (sidx < S && 8 * (part + 8 * it) < D) load8<TIn>(kbase + sidx * HD + 8 * (part + 8 * it), x[it]);
+#pragma unroll
+        for (int it = 0; it < KIT; ++it) {
+            const int c8 = part + 8 * it;
+            if (c8 >= KC) continue;
             unsigned wh[4] = {0, 0, 0, 0}, wm[4] = {0, 0, 0, 0}, wl[4] = {0, 0, 0, 0};
             if (sidx < S && 8 * c8 < D) {
-                float x[8];
-                load8<TIn>(kbase + sidx * HD + 8 * c8, x);
-                fq_apply8(fk, x, sidx, 8 * c8);
+                fq_apply8(fk, x[it], sidx, 8 * c8);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     if (fqq.mode == 2) {
-                        x[j] *= fqq.delta[8 * c8 + j];
-                        corr += (fqq.zp[8 * c8 + j] - offq) * x[j];
+                        x[it][j] *= fqq.delta[8 * c8 + j];
+                        corr += (fqq.zp[8 * c8 + j] - offq) * x[it][j];
                     } else {
-                        corr += x[j];
+                        corr += x[it][j];
                     }
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     unsigned short h0, m0, l0, h1, m1, l1;
-                    split3(x[2 * j], h0, m0, l0);
-                    split3(x[2 * j + 1], h1, m1, l1);
+                    split3(x[it][2 * j], h0, m0, l0);
+                    split3(x[it][2 * j + 1], h1, m1, l1);
                     wh[j] = (unsigned)h0 | ((unsigned)h1 << 16);
                     wm[j] = (unsigned)m0 | ((unsigned)m1 << 16);
                     wl[j] = (unsigned)l0 | ((unsigned)l1 << 16);
@@ -445,38 +459,54 @@ __global__ __launch_bounds__(256) void attn3_prep_kernel(const TIn* __restrict__
         *reinterpret_cast<uint4*>(dst + 2 * KT * G::KLD) = make_uint4(wl[0], wl[1], wl[2], wl[3]);
     }
     constexpr int VC = G::VLD / 8;                       // 4 chunks of 8 key slots + 1 padding chunk per V^T row
-    for (int i = threadIdx.x; !do_k && i < G::DV * VC; i += 256) {
-        const int c8 = i / G::DV, d = i - c8 * G::DV;    // lanes run over d: coalesced reads of every key row
-        unsigned wh[4], wm[4], wl[4];
+    constexpr int VIT = (G::DV * VC + 255) / 256;
+    if (!do_k) {
+        float xv[VIT][8];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            unsigned short hh[2] = {0, 0}, mm[2] = {0, 0}, ll[2] = {0, 0};
+        for (int it = 0; it < VIT; ++it) {                   // all loads of the thread in flight together
+            const int i = threadIdx.x + 256 * it;
+            const int c8 = i / G::DV, d = i - c8 * G::DV;    // lanes run over d: coalesced reads of every key row
 #pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int slot8 = 2 * j + e;                               // slot within the chunk = 4a + b
-                const int key = 16 * (c8 >> 1) + 8 * (slot8 >> 2) + 4 * (c8 & 1) + (slot8 & 3);
-                const int sidx = s0 + key;
-                if (G::VONES && c8 < 4 && d == D) hh[e] = 0x3F80;          // the ones row (every slot: padding keys carry p̂ = 0)
-                if (c8 < 4 && sidx < S && d < D) {
-                    const float xv = dgq_to_float(vbase[sidx * HD + d]);
-                    if (VINT) {                                            // centred code (|c'| <= 128: exact in bf16)
-                        const int idx = fv.mode == 0 ? 0 : d;
-                        const float dl = fv.delta[idx];
-                        hh[e] = bf16_bits(fq_code(xv, dl, dgq_rcp(dl), fv.zp[idx], fv.qmax, 0.5f * (fv.qmax + 1.0f)));
-                    } else {
-                        split3(fq_apply(fv, xv, sidx, d), hh[e], mm[e], ll[e]);
+            for (int s8 = 0; s8 < 8; ++s8) {                 // slot within the chunk = 4a + b
+                const int sidx = s0 + 16 * (c8 >> 1) + 8 * (s8 >> 2) + 4 * (c8 & 1) + (s8 & 3);
+                xv[it][s8] = (c8 < 4 && sidx < S && d < D) ? dgq_to_float(vbase[sidx * HD + d]) : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < VIT; ++it) {
+            const int i = threadIdx.x + 256 * it;
+            if (i >= G::DV * VC) continue;
+            const int c8 = i / G::DV, d = i - c8 * G::DV;
+            unsigned wh[4], wm[4], wl[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                unsigned short hh[2] = {0, 0}, mm[2] = {0, 0}, ll[2] = {0, 0};
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int slot8 = 2 * j + e;
+                    const int sidx = s0 + 16 * (c8 >> 1) + 8 * (slot8 >> 2) + 4 * (c8 & 1) + (slot8 & 3);
+                    if (G::VONES && c8 < 4 && d == D) hh[e] = 0x3F80;          // the ones row (every slot: padding keys carry p̂ = 0)
+                    if (c8 < 4 && sidx < S && d < D) {
+                        const float x1 = xv[it][slot8];
+                        if (VINT) {                                            // centred code (|c'| <= 128: exact in bf16)
+                            const int idx = fv.mode == 0 ? 0 : d;
+                            const float dl = fv.delta[idx];
+                            hh[e] = bf16_bits(fq_code(x1, dl, dgq_rcp(dl), fv.zp[idx], fv.qmax, 0.5f * (fv.qmax + 1.0f)));
+                        } else {
+                            split3(fq_apply(fv, x1, sidx, d), hh[e], mm[e], ll[e]);
+                        }
                     }
                 }
+                wh[j] = (unsigned)hh[0] | ((unsigned)hh[1] << 16);
+                wm[j] = (unsigned)mm[0] | ((unsigned)mm[1] << 16);
+                wl[j] = (unsigned)ll[0] | ((unsigned)ll[1] << 16);
             }
-            wh[j] = (unsigned)hh[0] | ((unsigned)hh[1] << 16);
-            wm[j] = (unsigned)mm[0] | ((unsigned)mm[1] << 16);
-            wl[j] = (unsigned)ll[0] | ((unsigned)ll[1] << 16);
-        }
-        unsigned short* dst = vimg + d * G::VLD + 8 * c8;
-        *reinterpret_cast<uint4*>(dst) = make_uint4(wh[0], wh[1], wh[2], wh[3]);
-        if (!VINT) {
-            *reinterpret_cast<uint4*>(dst + G::DV * G::VLD) = make_uint4(wm[0], wm[1], wm[2], wm[3]);
-            *reinterpret_cast<uint4*>(dst + 2 * G::DV * G::VLD) = make_uint4(wl[0], wl[1], wl[2], wl[3]);
+            unsigned short* dst = vimg + d * G::VLD + 8 * c8;
+            *reinterpret_cast<uint4*>(dst) = make_uint4(wh[0], wh[1], wh[2], wh[3]);
+            if (!VINT) {
+                *reinterpret_cast<uint4*>(dst + G::DV * G::VLD) = make_uint4(wm[0], wm[1], wm[2], wm[3]);
+                *reinterpret_cast<uint4*>(dst + 2 * G::DV * G::VLD) = make_uint4(wl[0], wl[1], wl[2], wl[3]);
+            }
         }
     }
 }
@@ -601,6 +631,16 @@ __device__ __forceinline__ v16f score_tile_i8(const unsigned char* kimg, const v
 
 // Q1K3 S^T tile in units of the query scale: acc[r] = Σ_d c'q[t][d]·K̃[s][d] − zmul·tv[s] (three bf16 products per 16-deep
 // step: the Q plane is exact, K̃ is split three ways)
+// Q1K3: the query's bf16 code plane as B-operand fragments, straight from the pre-pass's image (no split)
+template <int D>
+__device__ __forceinline__ void load_q1(bf16x8 (&qf)[3][Geo<D>::NKK], const unsigned short* qrow, int h32) {
+#pragma unroll
+    for (int kk = 0; kk < Geo<D>::NKK; ++kk) {
+        const int d0 = 16 * kk + 8 * h32;
+        qf[0][kk] = d0 < D ? *reinterpret_cast<const bf16x8*>(qrow + d0) : __builtin_bit_cast(bf16x8, make_uint4(0u, 0u, 0u, 0u));
+    }
+}
+
 // the query's −zmul(t) = zh + zm + zl in depth slots D, D+1, D+2 of its (single) code plane (Geo::FOLDZ)
 template <int D>
 __device__ __forceinline__ void fold_zmul(bf16x8 (&qf)[3][Geo<D>::NKK], float zmul, int h32) {
@@ -684,6 +724,7 @@ __global__ __launch_bounds__(64 * NW) void attn3_stats_kernel(AttnParams p) {
     v4i qc[G::NK32];
     float4 qt = make_float4(1.0f, 0.0f, 0.0f, 0.0f);
     if constexpr (QI8) load_q_i8<D>(qc, qt, p, (int64_t)(b * p.T + tq) * p.H + hd, h32);
+    else if constexpr (QM == 2) load_q1<D>(qf, reinterpret_cast<const unsigned short*>(p.q) + ((int64_t)(b * p.T + tq) * p.H + hd) * D, h32);
     else load_q<D>(qf, p.q + ((int64_t)(b * p.T + tq) * p.H + hd) * D, h32, p.fq[0], tq);
     if constexpr (QM == 2) {                              // (query scale, zero-point multiplier) written by the pre-pass
         const float2 t2 = *reinterpret_cast<const float2*>(p.qtab + ((int64_t)(b * p.T + tq) * p.H + hd) * 2);
@@ -776,6 +817,7 @@ __global__ __launch_bounds__(64 * NW) void attn3_pv_kernel(AttnParams p) {
     v4i qc[G::NK32];
     float4 qt = make_float4(1.0f, 0.0f, 0.0f, 0.0f);
     if constexpr (QI8) load_q_i8<D>(qc, qt, p, (int64_t)(b * p.T + tq) * p.H + hd, h32);
+    else if constexpr (QM == 2) load_q1<D>(qf, reinterpret_cast<const unsigned short*>(p.q) + ((int64_t)(b * p.T + tq) * p.H + hd) * D, h32);
     else load_q<D>(qf, p.q + ((int64_t)(b * p.T + tq) * p.H + hd) * D, h32, p.fq[0], tq);
     if constexpr (QM == 2) {                              // (query scale, zero-point multiplier) written by the pre-pass
         const float2 t2 = *reinterpret_cast<const float2*>(p.qtab + ((int64_t)(b * p.T + tq) * p.H + hd) * 2);
@@ -985,8 +1027,8 @@ static int launch_attn3(AttnParams p, const void* q_raw, unsigned char* planes, 
         p.q = nullptr;
         p.fq[0].mode = -1;
     } else if (QM == 2) {
-        p.q = qfq;                                             // centred codes as fp32
-        p.qtab = qfq + (size_t)p.B * p.T * p.H * D;            // (query scale, zero-point multiplier) per query
+        p.q = qfq;                                             // centred codes as bf16
+        p.qtab = reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(qfq) + (size_t)p.B * p.T * p.H * D);   // (query scale, zero-point multiplier) per query
         p.fq[0].mode = -1;
     } else if (q_copy) {
         p.q = qfq;

@@ -36,6 +36,9 @@ orig_g, orig_q = ops.gemm_wxa8, ops.quant_act
 
 def q_wrapped(x, B, H, W, C, kh, kw, stride, pad, ab, *a, **k):
     r = orig_q(x, B, H, W, C, kh, kw, stride, pad, ab, *a, **k)
+    pre, ln = k.get("pre"), k.get("ln")
+    q_wrapped.pro = ("gn" if (pre and pre[0] is not None) else "") + ("ln" if ln else "") + \
+        ({0: "", 1: "+silu", 2: "+geglu"}[pre[2]] if pre else "")
     us = replay_us(lambda: orig_q(x, B, H, W, C, kh, kw, stride, pad, ab, *a, **k))
     q_wrapped.last = us
     return r
@@ -45,7 +48,7 @@ def g_wrapped(codes, rowsum, M, ab, out_dtype, out=None, extra=None):
     y = orig_g(codes, rowsum, M, ab, out_dtype, out, extra)
     us = replay_us(lambda: orig_g(codes, rowsum, M, ab, out_dtype, y, extra))
     key = (M, ab.pw.N, ab.Kp, ab.pw.taps, ab.mode)
-    r = rows.setdefault(key, [0, 0.0, 0.0, 2.0 * M * ab.pw.N * ab.pw.K])
+    r = rows.setdefault(key, [0, 0.0, 0.0, 2.0 * M * ab.pw.N * ab.pw.K, q_wrapped.pro])
     r[0] += 1; r[1] += q_wrapped.last; r[2] += us
     return y
 
@@ -54,9 +57,9 @@ ops.quant_act, ops.gemm_wxa8 = q_wrapped, g_wrapped
 with torch.no_grad():
     qnn(lat, 981, ctx)
 torch.cuda.synchronize()
-print("%6s %5s %6s %4s %6s %4s %9s %9s %9s %9s %8s" % ("M", "N", "Kp", "taps", "mode", "n", "qact_us", "gemm_us", "qact_tot", "gemm_tot", "TOP/s"))
+print("%6s %5s %6s %4s %6s %4s %9s %9s %9s %9s %8s %s" % ("M", "N", "Kp", "taps", "mode", "n", "qact_us", "gemm_us", "qact_tot", "gemm_tot", "TOP/s", "prologue"))
 tq = tg = 0
 for k, r in sorted(rows.items(), key=lambda kv: -kv[1][2]):
     tq += r[1]; tg += r[2]
-    print("%6d %5d %6d %4d %6s %4d %9.1f %9.1f %9.1f %9.1f %8.1f" % (*k, r[0], r[1] / r[0], r[2] / r[0], r[1], r[2], r[3] * r[0] / r[2] / 1e6))
+    print("%6d %5d %6d %4d %6s %4d %9.1f %9.1f %9.1f %9.1f %8.1f %s" % (*k, r[0], r[1] / r[0], r[2] / r[0], r[1], r[2], r[3] * r[0] / r[2] / 1e6, r[4]))
 print("total quant_act %.1f us, gemm %.1f us" % (tq, tg))
