@@ -30,6 +30,10 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 #define KT 32
+// real-time δ (the tensor-wide maximum probability): the statistics pass leaves one maximum per workgroup in slot
+// (workgroup index mod 64) of the 256-byte δ area and the P̂·V pass takes the maximum of the 64 slots — 2048 waves hitting
+// ONE address with atomicMax took 25 us of a 30 us launch (4096 queries x 77 keys)
+#define DELTA_SLOTS 64
 #define LOG2E 1.4426950408889634f
 
 // optional UniformAffineQuantizer applied to q / k / v as they are loaded (aqtizer_q/k/v, sd.py:165-181): same
@@ -333,7 +337,7 @@ __global__ __launch_bounds__(256) void attn3_prep_kernel(const TIn* __restrict__
     const bool do_k = (int)blockIdx.x < NT;
     const int tile = do_k ? (int)blockIdx.x : (int)blockIdx.x - NT;
     const int s0 = tile * KT;
-    if (delta_reset && blockIdx.x == 0 && bh == 0 && threadIdx.x == 0) *delta_reset = 0.0f;   // real-time δ: max starts at 0
+    if (delta_reset && blockIdx.x == 0 && bh == 0 && threadIdx.x < DELTA_SLOTS) delta_reset[threadIdx.x] = 0.0f;   // real-time δ: the maxima start at 0
     const TIn* kbase = k + ((int64_t)(b * S) * H + hd) * D;
     const TIn* vbase = v + ((int64_t)(b * S) * H + hd) * D;
     const int64_t HD = (int64_t)H * D;
@@ -792,7 +796,16 @@ __global__ __launch_bounds__(64 * NW) void attn3_stats_kernel(AttnParams p) {
         float pm = (t < p.T) ? exp2f(m2raw * sl2 - m) / l : 0.0f;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) pm = fmaxf(pm, __shfl_xor(pm, o, 64));
-        if (lane == 0) atomicMax(reinterpret_cast<int*>(p.delta), __float_as_int(pm));
+        float* wmax = reinterpret_cast<float*>(lds8);        // (the ring is idle: every DMA has landed, every wave is past its last read)
+        __syncthreads();
+        if (lane == 0) wmax[wid] = pm;
+        __syncthreads();
+        if (tid == 0) {
+#pragma unroll
+            for (int w = 1; w < NW; ++w) pm = fmaxf(pm, wmax[w]);
+            const int slot = (blockIdx.x + gridDim.x * blockIdx.y) & (DELTA_SLOTS - 1);
+            atomicMax(reinterpret_cast<int*>(p.delta) + slot, __float_as_int(pm));
+        }
     }
 }
 
@@ -826,7 +839,14 @@ __global__ __launch_bounds__(64 * NW) void attn3_pv_kernel(AttnParams p) {
         if constexpr (G::FOLDZ) fold_zmul<D>(qf, qt.y, h32);
     }
     const float m = p.stats[((int64_t)bh * p.T + tq) * 2], l = p.stats[((int64_t)bh * p.T + tq) * 2 + 1];
-    const float delta = p.delta[0];
+    float delta;
+    if (p.mode == 1) {                                   // real-time δ: maximum of the statistics pass's slots
+        delta = p.delta[lane];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) delta = fmaxf(delta, __shfl_xor(delta, o, 64));
+    } else {
+        delta = p.delta[0];
+    }
     const float sl2 = p.scale * LOG2E * qt.x;
     const float nsl2 = -sl2;
     const float a0 = m + log2f(l) + log2f(delta);       // −log2(p/δ) = a0 − s2
