@@ -469,18 +469,35 @@ void gemm_wxa8_kernel(GemmBatch bt) {
     constexpr int LPR = WN / 4;                              // lanes per output row (4 consecutive n each)
     constexpr int RPP = 64 / LPR;                            // rows per pass of the wave
     constexpr int PASSES = WM / RPP / WVK;                   // passes of this wave
-    constexpr int REGION = WM * EP_LD;                       // floats per wave tile
+    // The 128x256 tile's eight 64x64 wave tiles (139 KB with the padding) do not fit the 96 KB ring: such a wave stages its
+    // tile in EPH = 2 halves of 32 rows (one MFMA row tile), each a same-wave LDS round trip like the whole tile elsewhere.
+    constexpr int EPH = (NW * WM * EP_LD * 4 <= STAGES * STAGE_BYTES) ? 1 : 2;
+    static_assert(EPH == 1 || (WVK == 1 && TM % 2 == 0 && PASSES % 2 == 0), "half-tile staging: whole MFMA row tiles per half");
+    constexpr int HROWS = WM / EPH;                          // rows staged at a time
+    constexpr int REGION = HROWS * EP_LD;                    // floats per wave region
     static_assert(NW * REGION * 4 <= STAGES * STAGE_BYTES, "epilogue staging must fit the LDS ring");
     float* ep_all = reinterpret_cast<float*>(smem);
     float* ep = ep_all + wid * REGION;
+    auto stage_half = [&](int h) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM / EPH; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+            for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                ep[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh) * EP_LD + j * 32 + lr] = PER_M ? (float)acc[0][i][j][r] : accf[i][j][r];
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                for (int r = 0; r < 16; ++r) {
+                    const int ti = h * (TM / EPH) + i;
+                    ep[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh) * EP_LD + j * 32 + lr] = PER_M ? (float)acc[0][ti][j][r] : accf[ti][j][r];
+                }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
+    // before pass rr of a two-half tile: the second half replaces the first once this wave's reads of it have returned
+    auto next_half = [&](int rr) {
+        if (EPH == 2 && rr == PASSES / 2) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            stage_half(1);
+        }
+    };
+    stage_half(0);
     if (WVK > 1) __builtin_amdgcn_s_barrier();              // WVK == 1: same-wave LDS round trip, no barrier needed
     const float* ep0 = ep_all + (wave_m * WVN + wave_n) * REGION;                     // k = 0 half
     const float* ep1 = ep0 + (WVM * WVN) * REGION;                                    // k = 1 half (WVK == 2)
@@ -492,9 +509,10 @@ void gemm_wxa8_kernel(GemmBatch bt) {
     // wave: the GroupNorm partials below are per 16-row block)
     auto tile_row = [&](int rr) { return wave_k * (WM / WVK) + rr * RPP + lrow; };
     auto tile_val = [&](int row) {
-        float4 v = *reinterpret_cast<const float4*>(ep0 + row * EP_LD + c4);
+        const int sr = (EPH == 2) ? (row & (HROWS - 1)) : row;                         // row inside the staged half
+        float4 v = *reinterpret_cast<const float4*>(ep0 + sr * EP_LD + c4);
         if (WVK > 1) {
-            const float4 u = *reinterpret_cast<const float4*>(ep1 + row * EP_LD + c4);
+            const float4 u = *reinterpret_cast<const float4*>(ep1 + sr * EP_LD + c4);
             v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
         }
         return v;
@@ -504,6 +522,7 @@ void gemm_wxa8_kernel(GemmBatch bt) {
         const bool al16 = ((p.N & 3) == 0);
 #pragma unroll 4
         for (int rr = 0; rr < PASSES; ++rr) {
+            next_half(rr);
             const int row = tile_row(rr);
             const int m = m0 + wave_m * WM + row;
             if (m >= p.M || nb >= p.N) continue;
@@ -532,6 +551,7 @@ void gemm_wxa8_kernel(GemmBatch bt) {
         const bool st2 = vec_ok && (p.ldy % 2 == 0) && ((reinterpret_cast<uintptr_t>(p.y) & 7) == 0);
 #pragma unroll
         for (int rr = 0; rr < PASSES; ++rr) {
+            next_half(rr);
             const int row = tile_row(rr);
             const int m = m0 + wave_m * WM + row;
             if (m >= p.M || nb >= p.N) continue;
@@ -600,6 +620,7 @@ void gemm_wxa8_kernel(GemmBatch bt) {
     float gK[4] = {0.f, 0.f, 0.f, 0.f}, g1[4] = {0.f, 0.f, 0.f, 0.f}, g2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int rr = 0; rr < PASSES; ++rr) {
+        next_half(rr);
         const int row = tile_row(rr);
         const int m = m0 + wave_m * WM + row;
         if (m >= p.M || nb >= p.N) continue;
@@ -740,7 +761,7 @@ static void launch_ring(const GemmBatch& bt, hipStream_t st) {
 
 // Tile shapes the host may pick (BM x BN, waves m x n x k):
 //   W4: 32x64 (1x2x2), 32x128 (1x4x1), 64x64 (2x2x1), 64x128 (1x4x1: a widened int4 fragment feeds two row tiles),
-//       128x64 (2x2x1), 128x128 (2x2x1)
+//       128x64 (2x2x1), 128x128 (2x2x1), 128x256 (2x4x1: eight waves, half the operand re-reads per MFMA of 128x128)
 //   W8 (a secondary configuration): 32x64, 64x64, 128x128
 template <int WBITS, bool PER_M, typename TOut>
 static int launch_one(const GemmBatch& bt, int bm, int bn, hipStream_t st) {
@@ -756,6 +777,7 @@ static int launch_one(const GemmBatch& bt, int bm, int bn, hipStream_t st) {
                     case 128064: launch_ring<WBITS, PER_M, TOut, 128, 64, 2, 2, 1>(bt, st); break;
                     case 64128: launch_ring<WBITS, PER_M, TOut, 64, 128, 1, 4, 1>(bt, st); break;
                     case 32128: launch_ring<WBITS, PER_M, TOut, 32, 128, 1, 4, 1>(bt, st); break;
+                    case 128256: launch_ring<WBITS, PER_M, TOut, 128, 256, 2, 4, 1>(bt, st); break;
                     default: dgq_set_error("dgq_gemm_wxa8: no %dx%d tile", bm, bn); return DGQ_EINVAL;
                 }
             } else {

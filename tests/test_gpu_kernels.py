@@ -156,11 +156,13 @@ def test_gemm_exact_integer(dev):
         _gemm_exact_case(dev, M, N, Kp, wbits)
 
 
-@pytest.mark.parametrize("tile", ["32,64,1", "32,128,1", "64,64,1", "64,128,1", "128,64,1", "128,128,1", "32,64,3", "64,128,2"])
+@pytest.mark.parametrize("tile", ["32,64,1", "32,128,1", "64,64,1", "64,128,1", "128,64,1", "128,128,1", "128,256,1", "128,256,2", "32,64,3", "64,128,2"])
 def test_gemm_exact_integer_every_tile(tile, dev, monkeypatch):
     """the same on every tile shape of the family (DGQ_GEMM_FORCE = BM,BN,splits), ragged M / N edges included"""
     monkeypatch.setenv("DGQ_GEMM_FORCE", tile)
     _gemm_exact_case(dev, 203, 332, 640, 4, seed=3)
+    if tile.startswith("128,256"):
+        _gemm_exact_case(dev, 300, 700, 512, 4, seed=5)      # three column tiles, the last ragged; both staged halves of every wave
     if tile in ("32,64,1", "64,64,1", "128,128,1", "32,64,3"):
         _gemm_exact_case(dev, 170, 200, 384, 8, seed=4)
 

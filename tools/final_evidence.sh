@@ -2,7 +2,7 @@
 # Round evidence in one gpurun call: bench line, attention shapes, HBM-side traffic of the step's GEMM / quantise kernels
 # (separate --pmc FETCH_SIZE / WRITE_SIZE passes, eager launches so that every dispatch is a counter sample).
 #   tools/final_evidence.sh <tag>   -> gpurun_out/<tag>/*
-TAG=${1:-r02z}
+TAG=${1:-r03z}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$TAG; mkdir -p $O; cd $R
 python bench.py > $O/bench_line.json 2> $O/bench.err; tail -c 600 $O/bench_line.json
 python tools/bench_attn.py 2>&1 | grep -v amdgpu.ids > $O/attention_shapes.txt; cat $O/attention_shapes.txt
