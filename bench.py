@@ -54,14 +54,14 @@ CONFIGS = {
     "c4": dict(arch="sdxl", res=128, cfg=dict(wbits=4, abits=8, use_aq=True, G=16, log=True, rt=True, sp=True, time_aware=True, steps=4),
                guidance=0.0, prompts=1,
                metric="UNet denoise steps/sec @ SDXL-turbo 1024^2 W4A8 g16",
-               workload="SDXL-turbo UNet W4A8 g=16 (time-aware, log2 softmax real-time δ, start-peak), 4-step schedule, "
+               workload="SDXL-turbo UNet W4A8 g=16 (time-aware, log2 softmax real-time δ, start-peak), 4-step EulerAncestral (trailing) schedule, "
                         "1024x1024 (128x128 latents), batch = prompts per GPU, no CFG"),
     # SDXL-turbo W4A6 g=1 (scalar scales), prompts sharded over the GPUs (64 prompts over 8 GPUs = 8 per GPU)
     "c5": dict(arch="sdxl", res=128, cfg=dict(wbits=4, abits=6, use_aq=True, G=1, log=False, rt=False, sp=False, time_aware=True, steps=4),
                guidance=0.0, prompts=8,
                metric="UNet denoise steps/sec @ SDXL-turbo 1024^2 W4A6 g1, prompts sharded over GPUs",
                workload="SDXL-turbo UNet W4A6 g=1 (scalar activation scales, uniform softmax quantiser, time-aware), 4-step "
-                        "schedule, 1024x1024 (128x128 latents), batch = prompts per GPU, no CFG"),
+                        "EulerAncestral (trailing) schedule, 1024x1024 (128x128 latents), batch = prompts per GPU, no CFG"),
 }
 
 
@@ -173,7 +173,25 @@ def main(argv=None):
         tid = torch.tensor([[float(res * 8)] * 2 + [0.0, 0.0] + [float(res * 8)] * 2]).repeat(batch, 1).to(dev, adt)
         extra = {"added_cond_kwargs": {"text_embeds": te, "time_ids": tid}}
 
+    euler, noise = {}, None
+    if arch == "sdxl":
+        from dgq_amd.scheduler import EulerAncestralDiscreteScheduler
+        es = EulerAncestralDiscreteScheduler(nsteps)
+        for i, t in enumerate(int(v) for v in es.timesteps):
+            s_from, s_to = float(es.sigmas[i]), float(es.sigmas[i + 1])
+            s_up = (s_to ** 2 * (s_from ** 2 - s_to ** 2) / s_from ** 2) ** 0.5
+            s_down = (s_to ** 2 - s_up ** 2) ** 0.5
+            euler[t] = (s_from, s_down - s_from, s_up)    # x' = x + eps·(σ_down − σ) + noise·σ_up  (derivative = eps for ε-prediction)
+        assert sorted(euler) == sorted(sched_ts), (sorted(euler), sched_ts)
+        noise = synth.named_randn("euler_noise", (P, 4, res, res), 300 + rank).to(dev, adt)
+        lat = (lat.float() * float(es.init_noise_sigma)).to(adt)              # the pipeline's initial latent scale
+
     def one_step(x, t):
+        if arch == "sdxl":
+            x_in = x * (1.0 / (euler[t][0] ** 2 + 1.0) ** 0.5)                  # scale_model_input
+            eps = qnn(x_in.to(x.dtype), t, ctx, **extra)[0]
+            sg, dsg, sup = euler[t]
+            return ((x + eps * dsg) + noise * sup).to(x.dtype)
         if guidance > 0:
             eps = qnn(torch.cat([x, x], dim=0), t, ctx, **extra)[0]
             e_u, e_c = eps.chunk(2)
@@ -182,7 +200,7 @@ def main(argv=None):
             eps = qnn(x, t, ctx, **extra)[0]
         if arch == "sd":
             return sch.step(eps, t, x)
-        return x - 0.25 * eps                     # SDXL-turbo: a fixed-coefficient Euler-style update (scheduler arithmetic is not on the path)
+        raise AssertionError("unreachable: SDXL-turbo steps return above")
 
     windows = []
     with torch.no_grad():
