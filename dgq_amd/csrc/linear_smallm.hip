@@ -67,6 +67,54 @@ __global__ __launch_bounds__(256) void linear_smallm_kernel(SmallMBatch b) {
     __syncthreads();
     TOut* y = reinterpret_cast<TOut*>(P.y);
     const int row_bytes = P.w_bits == 4 ? P.Kp / 2 : P.Kp;
+    // W4 rows whose K fits one pass of the wave (K <= 2048: always, by SMALLM_MAX_K): the 16 weight rows of the wave and their
+    // epilogue vectors are loaded up front — walked row by row, each row paid its own memory latency (41 us for the 23
+    // time_emb_proj of an SD step, 12 MB of weights)
+    if (P.w_bits == 4) {
+        const int k0 = lane * 32;                           // 16 bytes = 32 k per lane
+        const bool live = k0 < Kq;
+        uint4 wq[16];
+        float al[16], zw[16], ga[16], vn[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = min(n0 + wid * 16 + r, P.N - 1);
+            wq[r] = live ? *reinterpret_cast<const uint4*>(P.wpacked + (int64_t)n * row_bytes + k0 / 2) : make_uint4(0u, 0u, 0u, 0u);
+            al[r] = P.alpha[n]; zw[r] = P.zw[n]; ga[r] = P.gamma[n]; vn[r] = P.vn[n];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = n0 + wid * 16 + r;
+            if (n >= P.N) continue;                         // wave-uniform
+            // layout 1: rows with bit 4 set store the two 8-byte halves of a 32-chunk exchanged (wave-uniform)
+            const bool sw = (n & 16) != 0;
+            const uint4 w = wq[r];
+            const unsigned ww[4] = {sw ? w.z : w.x, sw ? w.w : w.y, sw ? w.x : w.z, sw ? w.y : w.w};
+#pragma unroll
+            for (int m = 0; m < SMALLM_MAX_M; ++m) {
+                if (m >= b.M) continue;
+                int a = 0;
+                if (live) {
+                    const int4 c0 = *reinterpret_cast<const int4*>(codes + m * Kq + k0);
+                    const int4 c1 = (k0 + 16 < Kq) ? *reinterpret_cast<const int4*>(codes + m * Kq + k0 + 16) : make_int4(0, 0, 0, 0);
+                    const int cc[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {                            // dword j: k0+8j..+3 low nibbles, +4..+7 high nibbles
+                        a = __builtin_amdgcn_sdot4(cc[2 * j], (int)(ww[j] & 0x0F0F0F0Fu), a, false);
+                        a = __builtin_amdgcn_sdot4(cc[2 * j + 1], (int)((ww[j] >> 4) & 0x0F0F0F0Fu), a, false);
+                    }
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+                if (lane == 0) {
+                    // the per_m epilogue of dgq_gemm_wxa8, term for term
+                    const float rs = rsum[m];
+                    const float out = dgq_dequant<true>((float)a, md, md * rs, md * (off - mz), al[r], zw[r], ga[r], vn[r]);
+                    y[(int64_t)m * P.ldy + n] = dgq_from_float<TOut>(out);
+                }
+            }
+        }
+        return;
+    }
     for (int r = 0; r < 16; ++r) {
         const int n = n0 + wid * 16 + r;
         if (n >= P.N) break;                                // wave-uniform
@@ -74,41 +122,18 @@ __global__ __launch_bounds__(256) void linear_smallm_kernel(SmallMBatch b) {
         int acc[SMALLM_MAX_M];
 #pragma unroll
         for (int m = 0; m < SMALLM_MAX_M; ++m) acc[m] = 0;
-        if (P.w_bits == 4) {
-            for (int k0 = lane * 32; k0 < Kq; k0 += 64 * 32) {           // 16 bytes = 32 k per lane
-                const uint4 w = *reinterpret_cast<const uint4*>(wrow + k0 / 2);
-                // layout 1: rows with bit 4 set store the two 8-byte halves of a 32-chunk exchanged (wave-uniform)
-                const bool sw = (n & 16) != 0;
-                const unsigned ww[4] = {sw ? w.z : w.x, sw ? w.w : w.y, sw ? w.x : w.z, sw ? w.y : w.w};
+        for (int k0 = lane * 16; k0 < Kq; k0 += 64 * 16) {
+            const int4 w = *reinterpret_cast<const int4*>(wrow + k0);
 #pragma unroll
-                for (int m = 0; m < SMALLM_MAX_M; ++m) {
-                    if (m >= b.M) continue;                 // (no break: the loop stays unrollable and acc[] in registers)
-                    const int4 c0 = *reinterpret_cast<const int4*>(codes + m * Kq + k0);
-                    const int4 c1 = (k0 + 16 < Kq) ? *reinterpret_cast<const int4*>(codes + m * Kq + k0 + 16) : make_int4(0, 0, 0, 0);
-                    const int cc[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
-                    int a = acc[m];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {                            // dword j: k0+8j..+3 low nibbles, +4..+7 high nibbles
-                        a = __builtin_amdgcn_sdot4(cc[2 * j], (int)(ww[j] & 0x0F0F0F0Fu), a, false);
-                        a = __builtin_amdgcn_sdot4(cc[2 * j + 1], (int)((ww[j] >> 4) & 0x0F0F0F0Fu), a, false);
-                    }
-                    acc[m] = a;
-                }
-            }
-        } else {
-            for (int k0 = lane * 16; k0 < Kq; k0 += 64 * 16) {
-                const int4 w = *reinterpret_cast<const int4*>(wrow + k0);
-#pragma unroll
-                for (int m = 0; m < SMALLM_MAX_M; ++m) {
-                    if (m >= b.M) continue;
-                    const int4 c = *reinterpret_cast<const int4*>(codes + m * Kq + k0);
-                    int a = acc[m];
-                    a = __builtin_amdgcn_sdot4(c.x, w.x, a, false);
-                    a = __builtin_amdgcn_sdot4(c.y, w.y, a, false);
-                    a = __builtin_amdgcn_sdot4(c.z, w.z, a, false);
-                    a = __builtin_amdgcn_sdot4(c.w, w.w, a, false);
-                    acc[m] = a;
-                }
+            for (int m = 0; m < SMALLM_MAX_M; ++m) {
+                if (m >= b.M) continue;
+                const int4 c = *reinterpret_cast<const int4*>(codes + m * Kq + k0);
+                int a = acc[m];
+                a = __builtin_amdgcn_sdot4(c.x, w.x, a, false);
+                a = __builtin_amdgcn_sdot4(c.y, w.y, a, false);
+                a = __builtin_amdgcn_sdot4(c.z, w.z, a, false);
+                a = __builtin_amdgcn_sdot4(c.w, w.w, a, false);
+                acc[m] = a;
             }
         }
         const float al = P.alpha[n], zw = P.zw[n], ga = P.gamma[n], vn = P.vn[n];
