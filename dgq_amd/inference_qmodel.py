@@ -39,7 +39,7 @@ def parse_args(argv=None):
     p.add_argument("--t2i_start_peak", action="store_true")
     p.add_argument("--time_aware_aqtizer", action="store_true")
     # additions (no counterpart in the reference)
-    p.add_argument("--model_type", default=MODEL_TYPE, choices=["sd", "sdxl", "tiny"])
+    p.add_argument("--model_type", default=MODEL_TYPE, choices=["sd", "sdxl", "tiny", "mini"])
     p.add_argument("--unet_weights", default=None, help="HF-keyed UNet state-dict (.pt); synthetic if omitted")
     p.add_argument("--group_num", type=int, default=16, help="G of the synthetic checkpoint")
     p.add_argument("--n_prompts", type=int, default=2, help="synthetic prompts (the reference renders 2 images)")

@@ -1,0 +1,124 @@
+"""Drop-in counterpart of the reference CLI ``src/quantize_weight.py`` (same flag names, :31-84): weight PTQ of the UNet —
+initialisation + BRECQ / AdaRound reconstruction — writing ``<outdir>/<time>/cali_ckpt.pth_weight_only``.
+
+The reference builds a diffusers pipeline from pretrained weights (``prepare_pipe``) and generates calibration data by
+sampling it (``calibration_data_generation``); neither exists here, so the UNet takes ``--unet_weights`` (an HF-keyed
+state-dict) or synthetic name-keyed weights, and the calibration data a recorded ``--cali_data_path`` file or synthetic tensors
+(dgq_amd/dataset_generation.py).  Everything after that is the reference's flow (:150-207): quantizer dicts, ``QuantModel``,
+``cali_model`` with the same keyword set.  ``--multi_gpu`` raises NotImplementedError exactly as the reference does (:213)."""
+import argparse
+import datetime
+import logging
+import os
+import sys
+import types
+
+import torch
+
+MODEL_TYPE = os.environ.get("DIFFUSERS_REWRITE", "sd")
+
+
+def str2bool(v):
+    if isinstance(v, bool):
+        return v
+    if v.lower() in ("yes", "true", "t", "y", "1"):
+        return True
+    if v.lower() in ("no", "false", "f", "n", "0"):
+        return False
+    raise argparse.ArgumentTypeError("Boolean value expected.")
+
+
+def parse_args(argv=None):
+    p = argparse.ArgumentParser(description="Weight quantization (BRECQ / AdaRound) of the DGQ UNet on MI355X")
+    p.add_argument("--outdir", type=str, default="results")
+    p.add_argument("--wq", type=int, default=4)
+    p.add_argument("--aq", type=int, default=8)
+    p.add_argument("--softmax_a_bit", type=int, default=8)
+    p.add_argument("--use_aq", action="store_true")
+    p.add_argument("--resume_w", type=str, default=None)
+    p.add_argument("--cali", action="store_true")
+    p.add_argument("--cali_prompt_data_n", default=64, type=int)
+    p.add_argument("--cali_data_path", type=str, default="./data/cali_data")
+    p.add_argument("--cali_data_size", type=int, default=-1)
+    p.add_argument("--step_size", type=int, default=50)
+    p.add_argument("--tib_recon", type=str2bool, default=False)
+    p.add_argument("--no_recon", type=str2bool, default=False)
+    p.add_argument("--asym", type=str2bool, default=True)
+    p.add_argument("--running_stat", type=str2bool, default=False)
+    p.add_argument("--time_aware_aqtizer", type=str2bool)
+    p.add_argument("--t2i_log_quant", type=str2bool)
+    p.add_argument("--t2i_real_time", type=str2bool)
+    p.add_argument("--t2i_start_peak", type=str2bool)
+    p.add_argument("--rloss", type=str, default="mse")
+    p.add_argument("--iters", default=20000, type=int)
+    p.add_argument("--fast", type=str2bool, default=False)
+    p.add_argument("--debug", action="store_true", help="same as --fast true --iters 10")
+    p.add_argument("--seed", type=int, default=42)
+    p.add_argument("--coco_path", type=str, default=None)
+    p.add_argument("--multi_gpu", action="store_true")
+    p.add_argument("--dist-url", default="tcp://127.0.0.1:3367", type=str)
+    p.add_argument("--dist-backend", default="nccl", type=str)
+    p.add_argument("--rank", default=0, type=int)
+    p.add_argument("--world_size", default=1, type=int)
+    # additions (no counterpart in the reference)
+    p.add_argument("--model_type", default=MODEL_TYPE, choices=["sd", "sdxl", "tiny", "mini"])
+    p.add_argument("--unet_weights", default=None, help="HF-keyed UNet state-dict (.pt); synthetic if omitted")
+    p.add_argument("--batch_size", type=int, default=8, help="reconstruction batch (the reference hard-codes 8)")
+    opt = p.parse_args(argv)
+    if opt.debug:
+        opt.fast, opt.iters = True, 10
+    return opt
+
+
+def setup(seed, outdir):
+    now = datetime.datetime.now().strftime("%Y-%m-%d-%H-%M-%S")
+    outpath = os.path.join(outdir, now)
+    os.makedirs(outpath, exist_ok=True)
+    logging.basicConfig(level=logging.INFO, handlers=[logging.FileHandler(os.path.join(outpath, "run.log")), logging.StreamHandler()])
+    torch.manual_seed(seed)
+    return outpath, logging.getLogger(__name__)
+
+
+def build_pipe(opt):
+    from . import synth
+    from .diffusers_rewrite import UNet2DConditionModel
+    unet = UNet2DConditionModel(opt.model_type)
+    if opt.unet_weights:
+        unet.load_state_dict(torch.load(opt.unet_weights, map_location="cpu"))
+    else:
+        synth.load_synth_weights(unet, opt.model_type, 0)
+    return types.SimpleNamespace(unet=unet)
+
+
+def main(argv=None):
+    opt = parse_args(argv)
+    from .dataset_generation import calibration_data_generation
+    from .quant import QuantModel, Scaler, QMODE, RLOSS, cali_model
+    from .quant.load_qmodel_util import setup_pipe_to_calibrate
+    mt = opt.model_type
+    pipe = build_pipe(opt)
+    outpath, logger = setup(opt.seed, opt.outdir)
+    logger.info("sys.argv: %s", sys.argv)
+    w_cali_data, a_cali_data, interval = calibration_data_generation(
+        mt, pipe=pipe, cali_data_path=opt.cali_data_path, coco_path=opt.coco_path, cali_prompt_data_n=opt.cali_prompt_data_n,
+        step_size=opt.step_size, time_aware_aqtizer=opt.time_aware_aqtizer, cali_data_size=opt.cali_data_size)
+    # src/quantize_weight.py:166-181.  Scaler.MSE (the non---fast initialiser) raises NotImplementedError in QuantModel here.
+    wq_params = {"bits": opt.wq, "channel_wise": True, "scaler": Scaler.MINMAX if opt.fast else Scaler.MSE, "leaf_param": opt.no_recon}
+    aq_params = {"bits": opt.aq, "channel_wise": False, "scaler": Scaler.MSE if opt.cali else Scaler.MINMAX, "leaf_param": opt.use_aq}
+    softmax_aq_params = {"softmax_a_bit": opt.softmax_a_bit, "t2i_log_quant": opt.t2i_log_quant, "t2i_real_time": opt.t2i_real_time,
+                         "t2i_start_peak": opt.t2i_start_peak, "log_max_1": False}
+    setup_pipe_to_calibrate(mt, pipe)
+    if opt.multi_gpu:
+        raise NotImplementedError("Multi-gpu is not supported yet")              # src/quantize_weight.py:213
+    qnn = QuantModel(model=pipe.unet, wq_params=wq_params, aq_params=aq_params, softmax_aq_params=softmax_aq_params,
+                     aq_mode=[QMODE.NORMAL.value, QMODE.QDIFF.value], tib_recon=opt.tib_recon).to("cuda").eval()
+    path = os.path.join(outpath, "cali_ckpt.pth")
+    cali_model(qnn=qnn, use_aq=opt.use_aq, path=path, running_stat=opt.running_stat, interval=interval, tib_recon=opt.tib_recon,
+               w_cali_data=w_cali_data, a_cali_data=a_cali_data, iters=opt.iters, batch_size=opt.batch_size, w=0.01, asym=opt.asym,
+               warmup=0.2, opt_mode=RLOSS.MSE, multi_gpu=False, no_recon=opt.no_recon, resume_w=opt.resume_w)
+    logger.info("weight quantization is done: %s_weight_only", path)
+    return path + "_weight_only"
+
+
+if __name__ == "__main__":
+    main()
