@@ -52,23 +52,158 @@ def minmax(x: torch.Tensor, symmetric: bool = False, level: int = 256, always_ze
     return delta.to(device=x.device, dtype=x.dtype), zero_point.to(device=x.device, dtype=x.dtype)
 
 
-def _calibration_only(name):
-    def f(*a, **k):
-        raise NotImplementedError(
-            "Scaler.%s is a calibration-time scale search (quant/quant_layer.py); the inference path "
-            "only needs MINMAX (src/inference_qmodel.py:73-81)" % name)
-    f.__name__ = name.lower()
-    return f
+def lp_loss(pred: torch.Tensor, tgt: torch.Tensor, p: float = 2.0):
+    """quant_layer.py:198-209 with reduction ALL: mean |pred − tgt|^p over every element."""
+    return (pred - tgt).abs().pow(p).mean()
+
+
+def _bounds(symmetric, level, always_zero):
+    return (-level // 2, level // 2 - 1) if (symmetric and not always_zero) else (0, level - 1)
+
+
+def mse(x: torch.Tensor, symmetric: bool = False, level: int = 256, always_zero: bool = False):
+    """quant_layer.py:62-86: 80 shrink steps of the (min, max) range, the one with the smallest L2.4 reconstruction error wins
+    (the reference's default weight initialiser; ``--fast`` selects MINMAX instead)."""
+    x_min, x_max = x.min().item(), x.max().item()
+    delta, zero_point, s = None, None, 1e+10
+    NB, PB = _bounds(symmetric, level, always_zero)
+    for i in range(80):
+        new_min = x_min * (1. - (i * 0.01))
+        new_max = x_max * (1. - (i * 0.01))
+        new_delta = torch.tensor(float(new_max - new_min) / (level - 1))
+        if symmetric:
+            new_min, new_max = -max(abs(new_min), new_max), max(abs(new_min), new_max)
+            new_delta = (new_max - new_min) / (level - 2)
+        if always_zero:
+            new_delta = torch.tensor(float(new_max) / (level - 1))
+        new_zero_point = torch.round(-new_min / new_delta) if not (symmetric or always_zero) else 0
+        x_q = torch.clamp(torch.round(x / new_delta) + new_zero_point, NB, PB)
+        x_dq = new_delta * (x_q - new_zero_point)
+        new_s = lp_loss(x_dq, x, p=2.4)
+        if new_s < s:
+            s = new_s
+            delta, zero_point = new_delta, new_zero_point
+    return delta, zero_point
+
+
+def channel_mse(w: torch.Tensor, level: int):
+    """``mse`` for every output channel at once (asymmetric weights): what quant_layer.py:253-264 computes with a python loop of
+    80 full passes per channel.  Same arithmetic per channel — ranges shrunk in double precision and rounded to fp32 once,
+    z = rne(fp32(−min)/δ), error = mean |·|^2.4 — the candidates of all channels evaluated together; a channel keeps the
+    FIRST candidate with the smallest error, as the reference's strict ``<`` does."""
+    flat = w.detach().reshape(w.shape[0], -1).float()
+    mn64, mx64 = flat.min(dim=1)[0].double(), flat.max(dim=1)[0].double()
+    best = torch.full((flat.shape[0],), 1e+10, device=flat.device)
+    delta = torch.zeros_like(best)
+    zp = torch.zeros_like(best)
+    for i in range(80):
+        f = 1. - (i * 0.01)
+        new_min, new_max = mn64 * f, mx64 * f
+        nd = ((new_max - new_min) / (level - 1)).float()
+        nz = torch.round((-new_min).float() / nd)
+        x_q = torch.clamp(torch.round(flat / nd[:, None]) + nz[:, None], 0, level - 1)
+        err = (nd[:, None] * (x_q - nz[:, None]) - flat).abs().pow(2.4).mean(dim=1)
+        better = err < best
+        best = torch.where(better, err, best)
+        delta = torch.where(better, nd, delta)
+        zp = torch.where(better, nz, zp)
+    shape = (-1,) + (1,) * (w.dim() - 1)
+    return delta.view(shape).to(w.dtype), zp.view(shape).to(w.dtype)
+
+
+def kl(x: torch.Tensor, symmetric: bool = False, level: int = 256, always_zero: bool = False):
+    """quant_layer.py:89-132: clip ratio in linspace(0.5, 1, 50) whose clipped histogram is closest (KL) to the data's, then MINMAX
+    of the clipped tensor.  numpy on the host, like the reference."""
+    import numpy as np
+
+    def to_hist_with_orig_bins(targ_hist, targ_bins, orig_hist, orig_bins):
+        targ_v, targ_i, targ_bin = 0.0, 0, targ_bins[0]
+        ret = np.zeros_like(orig_hist)
+        for i, orig_bin in enumerate(orig_bins[:-1]):
+            if targ_bin <= orig_bin:
+                if targ_i < len(targ_bins) - 1:
+                    targ_v = targ_hist[targ_i]
+                    targ_i += 1
+                    targ_bin = targ_bins[targ_i]
+                else:
+                    targ_v = 0.0
+                    targ_bin = orig_bin.max() + 1.0
+            ret[i] = targ_v
+        return ret
+
+    min_kl, res_clip_ratio = 1e5, 1.0
+    np_x = x.clone().detach().cpu().numpy()
+    ref_hist, ref_bins = np.histogram(np_x, bins=level, density=True)
+    sumd = np.sum(np.diff(ref_bins))
+    smooth_ref_hist = (ref_hist + 1e-5) / (1.0 + sumd * 1e-5)
+    for clip_ratio in np.linspace(0.5, 1.0, 50):
+        clip_range = [np.min(np_x) * clip_ratio, np.max(np_x) * clip_ratio]
+        q_hist, q_bins = np.histogram(np.clip(np_x, clip_range[0], clip_range[1]), bins=level, density=True)
+        c_q_hist = to_hist_with_orig_bins(q_hist, q_bins, ref_hist, ref_bins)
+        c_q_hist = (c_q_hist + 1e-5) / (1.0 + sumd * 1e-5)
+        kl_c_q = np.sum(smooth_ref_hist * np.log(smooth_ref_hist / c_q_hist))
+        if kl_c_q < min_kl:
+            min_kl, res_clip_ratio = kl_c_q, clip_ratio
+    x_min, x_max = float(np.min(np_x) * res_clip_ratio), float(np.max(np_x) * res_clip_ratio)
+    return minmax(torch.clamp(x.clone().detach(), x_min, x_max), symmetric, level, always_zero)
+
+
+def hist(x: torch.Tensor, symmetric: bool = False, level: int = 256, always_zero: bool = False):
+    """quant_layer.py:135-155: clip at the histogram bin where the cumulative mass of |x| reaches 0.9996, then MINMAX."""
+    import numpy as np
+    np_x = x.clone().detach().cpu().numpy()
+    data_max = max(-np.min(np_x), np.max(np_x))
+    h, _ = np.histogram(np_x, bins=level, range=(0, data_max), density=True)
+    h = h.astype(np.float32) / h.sum()
+    accum, x_min, x_max = 0, None, None
+    for i in range(len(h)):
+        accum += h[i]
+        if accum >= 0.9996:
+            clip_value = (i + 0.5) * (data_max / level)
+            x_min, x_max = max(-clip_value, np.min(np_x)), min(clip_value, np.max(np_x))
+            break
+    return minmax(torch.clamp(x.clone().detach(), float(x_min), float(x_max)), symmetric, level, always_zero)
+
+
+def omse(x: torch.Tensor, symmetric: bool = False, level: int = 256, always_zero: bool = False):
+    """quant_layer.py:157-179: exhaustive (range shrink × zero point) search, 80 × level candidates (note the reference re-derives
+    the range from the already shrunk one in every step: kept)."""
+    x_min, x_max = x.min().item(), x.max().item()
+    delta, zero_point, s = None, None, 1e+10
+    for i in range(80):
+        xrange = x_max - x_min
+        x_min = 0
+        x_max = xrange * (1. - (i * 0.01))
+        tmp_delta = torch.tensor(float(x_max - x_min) / (level - 1))
+        for j in range(level):
+            x_q = torch.clamp(torch.round(x / tmp_delta) + j, 0, level - 1)
+            new_s = lp_loss(tmp_delta * (x_q - j), x, p=2.4)
+            if new_s < s:
+                s, delta, zero_point = new_s, tmp_delta, j
+    return delta, zero_point
+
+
+def logminmax(x: torch.Tensor, symmetric: bool = False, level: int = 256, always_zero: bool = False):
+    """quant_layer.py:41-59, literally (fp16 copy; candidates 0.1 … 1.0; the dequantised value is δ·2^code as written there)."""
+    x_clone = x.clone().detach().to(torch.float16)
+    delta, best_score = x_clone.max(), 1e+10
+    for i in [0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8, 0.9, 1.0]:
+        x_int = torch.round(-1 * (x_clone / i).log2())
+        x_dq = i * 2 ** torch.clamp(x_int, 0, level - 1)
+        score = lp_loss(x_clone, x_dq, p=2)
+        if score < best_score:
+            best_score, delta = score, i
+    return torch.as_tensor(delta).type_as(x)
 
 
 class Scaler(Enum):
-    """Same member names as the reference enum (quant_layer.py:187-193)."""
+    """Same members as the reference enum (quant_layer.py:187-193)."""
     MINMAX = minmax
-    MSE = _calibration_only("MSE")
-    KL = _calibration_only("KL")
-    HIST = _calibration_only("HIST")
-    OMSE = _calibration_only("OMSE")
-    LOGMINMAX = _calibration_only("LOGMINMAX")
+    MSE = mse
+    KL = kl
+    HIST = hist
+    OMSE = omse
+    LOGMINMAX = logminmax
 
 
 QMODE = Enum("QMODE", ("QDIFF", "NORMAL", "PTQD"))
@@ -227,7 +362,16 @@ class UniformAffineQuantizer(nn.Module):
     # -- initialisation -------------------------------------------------------------------------
     def _init_quantization_param(self, x: torch.Tensor, channel_wise: bool = False):
         if channel_wise:
-            return channel_minmax(x, self.level)
+            if self.scaler is Scaler.MINMAX:
+                return channel_minmax(x, self.level)
+            if self.scaler is Scaler.MSE and not self.symmetric and not self.always_zero:
+                return channel_mse(x, self.level)
+            # any other scaler: the reference's loop over output channels (quant_layer.py:253-264)
+            dz = [self.scaler(x[c].detach(), self.symmetric, self.level, self.always_zero) for c in range(x.shape[0])]
+            shape = (-1,) + (1,) * (x.dim() - 1)
+            delta = torch.stack([torch.as_tensor(d, dtype=x.dtype, device=x.device).reshape(()) for d, _ in dz]).view(shape)
+            zp = torch.stack([torch.as_tensor(z, dtype=x.dtype, device=x.device).reshape(()) for _, z in dz]).view(shape)
+            return delta, zp
         if self.leaf_param:
             self.x_min, self.x_max = x.data.min(), x.data.max()
         return self.scaler(x, self.symmetric, self.level, self.always_zero)

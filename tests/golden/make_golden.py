@@ -5,6 +5,7 @@
     python tests/golden/make_golden.py schema           # F1 ckpt schema + F6 loader side effects
     python tests/golden/make_golden.py calib | recon    # F8 DGQ activation calibration, F9 weight PTQ (mini model)
     python tests/golden/make_golden.py qstats           # F8b statistics of the calibration, quantizer by quantizer
+    python tests/golden/make_golden.py scalers          # F2b scale initialisers (MSE / KL / HIST / OMSE / LOGMINMAX)
     python tests/golden/make_golden.py unet c1|c2|c3    # F5 full SD UNet, 64x64 latents (minutes each)
     python tests/golden/make_golden.py ddim [steps]     # F5 N-step DDIM final latent (tens of minutes)
     python tests/golden/make_golden.py pndm | euler     # F7 vendored PNDM / EulerAncestral schedulers on a closed-form ε model
@@ -475,6 +476,27 @@ def make_qstats(ref):
     save("f8b_quantizer_statistics.pt", dict(meta=dict(G=G, sklearn=sklearn.__version__), cases=out))
 
 
+def make_scalers(ref):
+    """F2b: the reference's scale initialisers (quant_layer.py:22-185) — MSE per output channel through
+    UniformAffineQuantizer(channel_wise=True) exactly as a weight quantizer initialises (:253-264), and the scalar forms of
+    MSE / KL / HIST / OMSE / LOGMINMAX."""
+    out = {}
+    for name, sc, shape, level, cw in recipes.SCALER_CASES:
+        x = recipes.scaler_input(name, shape)
+        fn = getattr(ref.ql.Scaler, sc)
+        if cw:
+            bits = {16: 4, 256: 8}[level]
+            q = ref.ql.UniformAffineQuantizer(bits=bits, channel_wise=True, scaler=fn, leaf_param=False)
+            d, z = q._init_quantization_param(x, True)
+        elif sc == "LOGMINMAX":
+            d, z = fn(x, False, level, True), torch.tensor(0.0)
+        else:
+            d, z = fn(x, False, level, False)
+        out[name] = dict(delta=torch.as_tensor(d).clone().float(), zero_point=torch.as_tensor(z).clone().float())
+        print(name, sc, shape, "delta", out[name]["delta"].flatten()[:4].tolist(), "zp", out[name]["zero_point"].flatten()[:4].tolist())
+    save("f2b_scale_initialisers.pt", out)
+
+
 # --------------------------------------------------------------------------------------- weight PTQ (f4)
 RECON = dict(wbits=4, n=8, res=16, ts=(901, 301), iters=8, batch_size=4, w=0.01, warmup=0.2, seed=1234,
              full_alpha=("model.conv_in", "model.time_embedding.linear_1", "model.down_blocks.0.attentions.0.proj_in",
@@ -771,6 +793,8 @@ if __name__ == "__main__":  # noqa: C901
         make_calib(ref)
     elif what == "qstats":
         make_qstats(ref)
+    elif what == "scalers":
+        make_scalers(ref)
     elif what == "recon":
         make_recon(ref)
     elif what == "ddim":

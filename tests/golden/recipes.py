@@ -184,3 +184,26 @@ def qstat_batches(name, shape, n=3):
 def _synth():
     from dgq_amd import synth
     return synth
+
+
+# ------------------------------------------------------------------------------------------- scale initialisers (F2b)
+SCALER_CASES = [
+    # name, scaler, shape, level, channel_wise
+    ("mse_linear_w4", "MSE", (12, 96), 16, True),
+    ("mse_conv_w4", "MSE", (8, 6, 3, 3), 16, True),
+    ("mse_linear_w8", "MSE", (6, 64), 256, True),
+    ("mse_scalar_a8", "MSE", (4, 50, 24), 256, False),
+    ("kl_scalar_a8", "KL", (4, 50, 24), 256, False),
+    ("hist_scalar_a8", "HIST", (4, 50, 24), 256, False),
+    ("omse_scalar_l16", "OMSE", (3, 40), 16, False),
+    ("logminmax_probs", "LOGMINMAX", (2, 4, 16, 16), 256, False),
+]
+
+
+def scaler_input(name, shape):
+    """Heavy-tailed data (a few outliers per channel) so that the range searches actually shrink the range."""
+    x = _synth().named_randn("scaler|" + name, shape, 11)
+    x = x * (1.0 + 4.0 * (_synth().named_randn("scaler_tail|" + name, shape, 12).abs() > 2.2).float())
+    if name.startswith("logminmax"):
+        x = torch.softmax(x.reshape(shape[0], shape[1], shape[2], shape[3]) * 2.0, dim=-1)
+    return x

@@ -91,3 +91,33 @@ def test_weight_then_activation_cli_then_inference(tmp_path, monkeypatch):
                            "--t2i_real_time", "--t2i_start_peak", "--time_aware_aqtizer", "--num_inference_steps", "2", "--n_prompts", "1"])
     lat = torch.load(str(tmp_path / "latents_0.pt"))
     assert torch.isfinite(lat[0]).all()
+
+
+@pytest.mark.gpu
+def test_mse_weight_initialisation_on_the_device(tmp_path, golden_dir):
+    """Scaler.MSE (the reference's default weight initialiser, --fast false) on the GPU: the vectorised per-channel search gives
+    the reference's (δ, z) — the L2.4 error is a device reduction, so a channel whose two best candidates tie to the last bit may
+    pick the neighbouring shrink step (1 % apart); asserted: >= 95 % of channels identical, the rest within one step — and the
+    CLI runs with it (no reconstruction: the initialisation is what is under test)."""
+    from tests.golden import recipes
+    from dgq_amd.quant import quant_layer as ql
+    g = torch.load(os.path.join(golden_dir, "f2b_scale_initialisers.pt"))
+    same = total = 0
+    for name, sc, shape, level, cw in recipes.SCALER_CASES:
+        if not cw:
+            continue
+        x = recipes.scaler_input(name, shape).cuda()
+        d, z = ql.channel_mse(x, level)
+        d, z, gd = d.flatten().cpu(), z.flatten().cpu(), g[name]["delta"].flatten()
+        same += int((d == gd).sum())
+        total += d.numel()
+        assert ((d / gd - 1).abs() < 0.0125).all(), (name, (d / gd).tolist())
+    print("channel_mse on the device: %d of %d channels bit-identical to the reference" % (same, total))
+    assert same >= 0.95 * total
+    from dgq_amd import quantize_weight
+    wpath = quantize_weight.main(["--model_type", "mini", "--outdir", str(tmp_path / "res"), "--cali_data_path", str(tmp_path / "none"),
+                                  "--time_aware_aqtizer", "true", "--t2i_log_quant", "true", "--t2i_real_time", "true",
+                                  "--t2i_start_peak", "true", "--fast", "false", "--no_recon", "true"])
+    ck = torch.load(wpath)["weight"]
+    deltas = [v for k, v in ck.items() if k.endswith("wqtizer.delta")]
+    assert deltas and all(torch.isfinite(v).all() and (v > 0).all() for v in deltas)
