@@ -205,9 +205,6 @@ def cali_model(qnn: QuantModel, w_cali_data: Tuple[torch.Tensor], a_cali_data: T
     calibrated by act_group_quant — and raises."""
     from .reconstruction import block_reconstruction, layer_reconstruction
     import os
-    if use_aq:
-        raise NotImplementedError("QDiff scalar activation calibration (calibration.py:45-97); DGQ calibrates activations with "
-                                  "calibration_group_quantization.act_group_quant")
     if tib_recon:
         raise NotImplementedError("tib_recon (TFMQ time-information block)")
     kwargs = dict(kwargs)
@@ -239,4 +236,51 @@ def cali_model(qnn: QuantModel, w_cali_data: Tuple[torch.Tensor], a_cali_data: T
         os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
         torch.save(model_dict, "%s_weight_only" % path)
         logger.info("calibrated model saved to %s_weight_only", path)
+    if use_aq:                                              # calibration.py:199-206: + one scalar (δ, z) table per interval
+        model_dict = cali_model_aq(qnn, a_cali_data, model_dict, running_stat, interval)
+        if path is not None:
+            torch.save(model_dict, path)
+            logger.info("calibrated model saved to %s", path)
+    return model_dict
+
+
+@torch.no_grad()
+def cali_model_aq(qnn: QuantModel, a_cali_data, model_dict, running_stat, interval):
+    """QDiff-style scalar activation calibration (calibration.py:45-97), the ``--use_aq`` tail of the weight CLI: per interval
+    of the calibration data every activation quantizer forgets its state, initialises itself on one random batch of <= 8 samples
+    (its ``Scaler`` on the whole tensor) and — with ``running_stat`` — follows the remaining batches with the EMA of
+    ``act_momentum_update``; the (δ, z) pairs go to ``act_<interval>`` under the reference's key names.  DGQ's own recipe
+    replaces this by ``calibration_group_quantization.act_group_quant``."""
+    import numpy as np
+    from .calibration_group_quantization import collect_act_state
+    dev = qnn.device
+    qnn.eval()
+    for time in range(a_cali_data[0].shape[0] // interval):
+        t_cali = tuple(x[time * interval: (time + 1) * interval] for x in a_cali_data)
+        qnn.set_quant_state(use_wq=True, use_aq=True)
+        for name, module in qnn.model.named_modules():
+            if "aqtizer" in name and hasattr(module, "init"):
+                del module.delta
+                module.delta = None
+                if isinstance(module, UniformAffineQuantizer):
+                    del module.zero_point
+                    module.zero_point = None
+                module.init = False
+        batch_size = min(8, t_cali[0].shape[0])
+        inds = np.random.choice(t_cali[0].shape[0], batch_size, replace=False)
+        _ = qnn(*(x[inds].to(dev) for x in t_cali))
+        if running_stat:
+            logger.info("running stat for activation calibration...")
+            inds = np.arange(t_cali[0].shape[0])
+            np.random.shuffle(inds)
+            qnn.set_running_stat(True)
+            try:
+                for i in range(0, t_cali[0].shape[0], batch_size):
+                    _ = qnn(*(x[inds[i: i + batch_size]].to(dev) for x in t_cali))
+            finally:
+                qnn.set_running_stat(False)
+        for name, module in qnn.model.named_modules():
+            if "aqtizer" in name and isinstance(module, UniformAffineQuantizer) and module.delta is not None:
+                module.zero_point = _as_param(module.zero_point)
+        model_dict["act_%d" % time] = collect_act_state(qnn)
     return model_dict

@@ -121,3 +121,33 @@ def test_mse_weight_initialisation_on_the_device(tmp_path, golden_dir):
     ck = torch.load(wpath)["weight"]
     deltas = [v for k, v in ck.items() if k.endswith("wqtizer.delta")]
     assert deltas and all(torch.isfinite(v).all() and (v > 0).all() for v in deltas)
+
+
+@pytest.mark.gpu
+def test_weight_cli_use_aq_tail_writes_a_loadable_scalar_ckpt(tmp_path):
+    """--use_aq: after the weight pass the QDiff-style scalar activation calibration (calibration.py:45-97, 199-206) adds one
+    act_<interval> table per calibration interval under the reference's key names; the file loads through load_cali_model
+    without groups and runs time-aware.  (The statistics themselves — scalar self-initialisation and the EMA of
+    act_momentum_update — are pinned bit for bit by F8b.)"""
+    import types
+    from dgq_amd import quantize_weight, synth
+    from dgq_amd.diffusers_rewrite import UNet2DConditionModel
+    from dgq_amd.quant import get_qmodel, Scaler
+    common = ["--model_type", "mini", "--outdir", str(tmp_path / "res"), "--cali_data_path", str(tmp_path / "none"),
+              "--time_aware_aqtizer", "true", "--t2i_log_quant", "true", "--t2i_real_time", "true", "--t2i_start_peak", "true"]
+    wpath = quantize_weight.main(common + ["--fast", "true", "--no_recon", "true", "--use_aq", "--running_stat", "true"])
+    full = wpath[:-len("_weight_only")]
+    ck = torch.load(full)
+    assert sorted(ck) == ["act_0", "act_1", "weight"]
+    keys = list(ck["act_0"])
+    assert keys and all(k.startswith("model.") and (k.endswith(".delta") or k.endswith(".zero_point")) for k in keys)
+    assert all(v.numel() == 1 for v in ck["act_0"].values())              # scalar tables
+    unet = UNet2DConditionModel("mini")
+    synth.load_synth_weights(unet, "mini", 0)
+    wq = {"bits": 4, "channel_wise": True, "scaler": Scaler.MINMAX}
+    aq = {"bits": 8, "channel_wise": False, "scaler": Scaler.MINMAX, "leaf_param": True}
+    sm = {"softmax_a_bit": 8, "t2i_log_quant": True, "t2i_real_time": True, "t2i_start_peak": True, "log_max_1": False}
+    qnn = get_qmodel("mini", types.SimpleNamespace(unet=unet), full, wq, True, aq, sm, False, num_inference_steps=2, time_aware_aqtizer=True)
+    with torch.no_grad():
+        y = qnn(synth.named_randn("x", (2, 4, 16, 16), 1).cuda(), torch.tensor(901), synth.named_randn("c", (2, 77, 768), 2).cuda())[0]
+    assert torch.isfinite(y).all()
