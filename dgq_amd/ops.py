@@ -763,15 +763,16 @@ def attention_fuses_fakequant(D, mode):
     return bool(_lib.load().dgq_attention_fuses_fakequant(D, mode))
 
 
-def attention(q, k, v, H, D, scale, mode, skip, delta, bits, fq=None):
+def attention(q, k, v, H, D, scale, mode, skip, delta, bits, fq=None, emit: Optional[ActBinding] = None):
     """q [B,T,H*D], k/v [B,S,H*D] contiguous (fp32; fp16 / bf16 in the quantised modes) -> o [B,T,H*D]; see dgq_attention.
     fq: optional 3-tuple for q, k, v of None | (mode, delta, zp, skip, bits) — the aqtizer_q/k/v quantizers applied on
-    load (only where ``attention_fuses_fakequant(D, mode)``)."""
+    load (only where ``attention_fuses_fakequant(D, mode)``).
+    emit: the ActBinding of the Linear layer that consumes o (Attention.to_out[0]) — the call then returns
+    (codes [B*T, Kp] int8, rowsum [H, B*T]) for ``gemm_wxa8`` instead of o (dgq_attention_emit: quantise-on-store)."""
     assert q.dtype in _lib.DTYPE_CODE and k.dtype == q.dtype and v.dtype == q.dtype
     assert q.is_contiguous() and k.is_contiguous() and v.is_contiguous()
     B, T, _ = q.shape
     S = k.shape[1]
-    o = torch.empty_like(q)
     nbytes = _lib.load().dgq_attention_workspace_bytes(B, H, T, S, D)
     ws = _attn_workspace(q.device, nbytes)
     desc = None
@@ -788,6 +789,22 @@ def attention(q, k, v, H, D, scale, mode, skip, delta, bits, fq=None):
                 "q/k/v quantizer table has %d entries, kernel addresses %d" % (fd.numel(), need)
             desc[i].mode, desc[i].skip, desc[i].bits = fmode, fskip, fbits
             desc[i].delta, desc[i].zero_point = _lib.ptr(fd), _lib.ptr(fz)
+    if emit is not None:
+        ab = emit
+        per_m = 0 if ab.mode == "perK" else 1
+        assert ab.pw.K == H * D and ab.pw.taps == 1
+        e = _lib.Emit()
+        codes = torch.empty((B * T, ab.Kp), dtype=torch.int8, device=q.device)
+        rowsum = torch.empty((H, B * T), dtype=torch.float32, device=q.device)
+        e.codes, e.rowsum = codes.data_ptr(), rowsum.data_ptr()
+        e.kdst = _dp(ab.kdst(1, H * D, 1)) if not per_m else None
+        e.delta, e.zp = (ab.cdelta.data_ptr(), ab.czp.data_ptr()) if not per_m else (ab.mdelta.data_ptr(), ab.mzp.data_ptr())
+        e.Kp, e.per_m, e.L, e.bits = ab.Kp, per_m, (ab.L if per_m else 1), ab.abits
+        _lib_call("dgq_attention_emit", _lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.DTYPE_CODE[q.dtype], B, H, T, S, D,
+                  _c.c_float(scale), mode, skip, _lib.ptr(delta), bits,
+                  _c.cast(desc, _c.c_void_p) if desc is not None else None, _c.byref(e), _lib.ptr(ws), nbytes, _lib.stream())
+        return codes, rowsum
+    o = torch.empty_like(q)
     _lib_call("dgq_attention", _lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(o), _lib.DTYPE_CODE[q.dtype], B, H, T, S, D,
               _c.c_float(scale), mode, skip, _lib.ptr(delta), bits,
               _c.cast(desc, _c.c_void_p) if desc is not None else None, _lib.ptr(ws), nbytes, _lib.stream())

@@ -256,6 +256,27 @@ int dgq_attention_f32(const float* q, const float* k, const float* v, float* o, 
 int dgq_attention(const void* q, const void* k, const void* v, void* o, int dtype, int B, int H, int T, int S, int D,
                   float scale, int mode, int skip, const float* delta_in, int bits, const dgq_attn_fq_t* fq,
                   void* workspace, size_t workspace_bytes, void* stream);
+/* Quantise-on-store (round 3): instead of the tensor o, dgq_attention_emit writes what dgq_quant_act would produce from it for
+ * the NEXT quantized Linear layer (Attention.to_out[0], sd.py:203-205) — its int8 activation codes in that layer's packed K
+ * order and the row sums — so that layer needs no quantise-on-load launch and o never travels through HBM.
+ *   per-K (per_m = 0): kdst[c] = packed position of channel c (the inverse of the layer's K permutation, [H·D]), delta / zp
+ *     per 32-wide chunk ([Kp/32]); code = clamp(rne(o/δ)+z) − 2^(b−1) with o first rounded to the tensors' dtype; rowsum part of
+ *     head h: Σ_{c in h} δ_c·code.   per-M / scalar (per_m = 1): natural order (kdst = NULL), delta / zp [L] addressed by
+ *     row % L; rowsum part = Σ code (exact).
+ * rowsum is [H][B·T]: ONE PART PER HEAD, to be passed to dgq_gemm_wxa8 with rowsum_parts = H (summed there in a fixed
+ * order).  Padding positions of the code rows are not written: the packed weights are zero there.
+ * Only where dgq_attention_fuses_fakequant(D, mode) is 1; DGQ_EUNSUPPORTED otherwise. */
+typedef struct dgq_emit {
+    int8_t* codes;             /* [B·T][Kp] */
+    float* rowsum;             /* [H][B·T] */
+    const int32_t* kdst;       /* per-K: [H·D]; NULL for natural order */
+    const float* delta;
+    const float* zp;
+    int Kp, per_m, L, bits;
+} dgq_emit_t;
+int dgq_attention_emit(const void* q, const void* k, const void* v, int dtype, int B, int H, int T, int S, int D,
+                       float scale, int mode, int skip, const float* delta_in, int bits, const dgq_attn_fq_t* fq,
+                       const dgq_emit_t* emit, void* workspace, size_t workspace_bytes, void* stream);
 int dgq_attention_fuses_fakequant(int D, int mode);
 size_t dgq_attention_workspace_bytes(int B, int H, int T, int S, int D);
 
