@@ -694,12 +694,10 @@ void gemm_wxa8_kernel(GemmBatch bt) {
 template <bool PER_M, typename TOut>
 __global__ __launch_bounds__(256) void splitk_epilogue_kernel(GemmParams p) {
     const int n4 = (p.N + 3) / 4;
-    const int64_t total = (int64_t)p.M * n4;
     TOut* y = reinterpret_cast<TOut*>(p.y);
     const int64_t slab_stride = (int64_t)p.M * p.N;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int m = (int)(i / n4);
-        const int nb = (int)(i - (int64_t)m * n4) * 4;
+    // one output row segment (4 consecutive n): slabs summed in a fixed order, dequantised, stored; returns the values AS STORED
+    auto row4 = [&](int m, int nb, float (&val)[4]) {
         float a[4] = {0.f, 0.f, 0.f, 0.f};
         const bool full = (nb + 3 < p.N) && ((p.N & 3) == 0);
         for (int s = 0; s < p.splits; ++s) {
@@ -715,8 +713,70 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(GemmParams p) {
             const int n = nb + e;
             float out = dgq_epilogue<PER_M>(p, a[e], m, n, p.alpha[n], p.zw[n], p.gamma[n], PER_M ? p.vn[n] : 0.0f);
             out = dgq_extra(p.ex, out, m, n);
-            y[(int64_t)m * p.ldy + n] = dgq_from_float<TOut>(out);
+            const TOut st = dgq_from_float<TOut>(out);
+            y[(int64_t)m * p.ldy + n] = st;
+            val[e] = dgq_to_float(st);
         }
+    };
+    if (p.ex.gn_partial) {
+        // GroupNorm partials of the output (as the unsplit GEMM's epilogue writes them: per 16-row block and column the mean
+        // and the sum of squared deviations).  Sixteen lanes share a (16-row block, 4 columns) unit, one row each — the
+        // parallelism of the plain combine (four rows per lane made it 12 us slower per launch) — and merge their partials
+        // with four equal-count xor steps (Chan's formula).  A wave holds 4 adjacent column groups x 16 rows (64 contiguous
+        // bytes per row).  M % 16 == 0, N % 4 == 0: host-checked; the grid is a whole number of waves, idle lanes run a clamped
+        // unit and do not store.
+        const int64_t units = (int64_t)(p.M >> 4) * n4;
+        const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        const int lane = (int)(tid & 63);
+        const int qd = lane >> 2;                            // row of the block
+        const int64_t unit = (tid >> 6) * 4 + (lane & 3);    // units of a wave: 4 adjacent column groups of one row block
+        // (n4 % 4 != 0: the last wave of a row block would straddle into the next block — units are linear over (rb, n4), and
+        // the 16 lanes of a unit always agree on it, so that is harmless)
+        const bool live = unit < units;
+        const int64_t g = live ? unit : units - 1;
+        const int rb = (int)(g / n4);
+        const int nb = (int)(g - (int64_t)rb * n4) * 4;
+        const int m = rb * 16 + qd;
+        float a[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int sp = 0; sp < p.splits; ++sp) {
+            const float4 v = *reinterpret_cast<const float4*>(p.slab + sp * slab_stride + (int64_t)m * p.N + nb);
+            a[0] += v.x; a[1] += v.y; a[2] += v.z; a[3] += v.w;
+        }
+        float mean[4], m2[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int n = nb + e;
+            float out = dgq_epilogue<PER_M>(p, a[e], m, n, p.alpha[n], p.zw[n], p.gamma[n], PER_M ? p.vn[n] : 0.0f);
+            out = dgq_extra(p.ex, out, m, n);
+            const TOut st = dgq_from_float<TOut>(out);
+            if (live) y[(int64_t)m * p.ldy + n] = st;
+            mean[e] = dgq_to_float(st);                      // the value as stored
+            m2[e] = 0.0f;
+        }
+        float cnt = 1.0f;
+#pragma unroll
+        for (int off = 4; off < 64; off <<= 1) {             // lanes of a unit: lane & 3 fixed, lane >> 2 = row
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float om = __shfl_xor(mean[e], off, 64), o2 = __shfl_xor(m2[e], off, 64);
+                const float dd = om - mean[e];
+                m2[e] = m2[e] + o2 + dd * dd * (0.5f * cnt);
+                mean[e] = 0.5f * (mean[e] + om);
+            }
+            cnt *= 2.0f;
+        }
+        if (live && qd == 0) {
+            float* q = p.ex.gn_partial + ((int64_t)rb * p.N + nb) * 2;
+            *reinterpret_cast<float4*>(q) = make_float4(mean[0], m2[0], mean[1], m2[1]);
+            *reinterpret_cast<float4*>(q + 4) = make_float4(mean[2], m2[2], mean[3], m2[3]);
+        }
+        return;
+    }
+    const int64_t total = (int64_t)p.M * n4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int m = (int)(i / n4);
+        float val[4];
+        row4(m, (int)(i - (int64_t)m * n4) * 4, val);
     }
 }
 
@@ -787,8 +847,9 @@ static int launch_one(const GemmBatch& bt, int bm, int bn, hipStream_t st) {
     }
     if (bt.n == 1 && p.splits > 1) {
         int64_t total = (int64_t)p.M * ((p.N + 3) / 4);
+        if (p.ex.gn_partial) total = ((int64_t)(p.M / 16) * ((p.N + 3) / 4) + 3) / 4 * 64;      // 4 units per wave
         int g = (int)((total + 255) / 256);
-        if (g > 4096) g = 4096;
+        if (g > 4096 && !p.ex.gn_partial) g = 4096;           // (the partials form has no grid-stride loop: one unit per 4 lanes)
         hipLaunchKernelGGL((splitk_epilogue_kernel<PER_M, TOut>), dim3(g), dim3(256), 0, st, p);
     }
     return DGQ_OK;
@@ -964,7 +1025,7 @@ extern "C" int dgq_gemm_wxa8(const int8_t* codes, const float* rowsum, int rowsu
         DGQ_CHECK_ARG(pl.splits == 1 || (workspace && (size_t)pl.splits * M * N * 4 <= workspace_bytes),
                       "dgq_gemm_wxa8: DGQ_GEMM_FORCE split does not fit the workspace");
     }
-    if (p.ex.geglu || p.ex.gn_partial) pl.splits = 1;    // these epilogues live in the GEMM kernel, not in the combine
+    if (p.ex.geglu) pl.splits = 1;                       // this epilogue lives in the GEMM kernel, not in the combine
     p.splits = pl.splits;
     p.slab = p.splits > 1 ? reinterpret_cast<float*>(workspace) : nullptr;
     const int nk = Kp / BK;

@@ -314,6 +314,8 @@ def groupnorm_scale_shift(x_cl: torch.Tensor, B, HW, C, groups, eps, gamma, beta
 #: into the next layer's load uses them when the very same tensor object (or a channel concat of two such tensors,
 #: ``cat_channels``) reaches it.  DGQ_GN_FROM_GEMM=0 restores the standalone statistics kernels.
 GN_FROM_GEMM = os.environ.get("DGQ_GN_FROM_GEMM", "1") == "1"
+#: ... also where the producing GEMM is K-split: its combine kernel writes the partials (=0: statistics pass for those tensors)
+GN_FROM_SPLITK = os.environ.get("DGQ_GN_FROM_SPLITK", "1") == "1"
 
 
 def cat_channels(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
@@ -649,11 +651,12 @@ def quant_conv2d(x: torch.Tensor, ab: ActBinding, kh, kw, stride, pad, norm=None
     elif bias_rows is not None:                       # [B][N]: one row per image, broadcast over its Ho*Wo positions
         res2, res_div = bias_rows.contiguous(), M // B
     codes, rowsum, M = quant_act(x_store, B, H, W, C, kh, kw, stride, pad, ab, pre)
-    # GroupNorm partials of the output for whoever normalises it next — where the launch would not be K-split anyway
+    # GroupNorm partials of the output for whoever normalises it next: from the GEMM's own epilogue, or — a K-split launch —
+    # from its combine kernel (DGQ_GN_FROM_SPLITK=0: only unsplit launches, the tensor gets a statistics pass otherwise)
     N = ab.pw.N
     part = None
     if (GN_FROM_GEMM and gn_out and (Ho * Wo) % 16 == 0 and N % 4 == 0 and
-            _lib.load().dgq_gemm_plan_splits(M, N, ab.Kp, ab.pw.bits, 0 if ab.mode == "perK" else 1, WORKSPACE_BYTES) == 1):
+            (GN_FROM_SPLITK or _lib.load().dgq_gemm_plan_splits(M, N, ab.Kp, ab.pw.bits, 0 if ab.mode == "perK" else 1, WORKSPACE_BYTES) == 1)):
         part = torch.empty((M // 16, N, 2), dtype=torch.float32, device=x.device)
     y = gemm_wxa8(codes, rowsum, M, ab, x.dtype, extra=make_extra(res2, res_div=res_div, gn_partial=part))
     out = y.view(B, Ho, Wo, N).permute(0, 3, 1, 2)

@@ -693,6 +693,38 @@ def test_groupnorm_from_gemm_epilogue_partials(B, C, H, N, k, mode, dtype, dev):
     assert rel_l2(sc.cpu(), sc0.cpu()) < 1e-5 and rel_l2(sh.cpu(), sh0.cpu()) < 1e-5
 
 
+@pytest.mark.parametrize("force", ["32,64,3", "64,64,2"])
+def test_groupnorm_partials_from_the_splitk_combine(force, dev, monkeypatch):
+    """The same statistics when the producing GEMM is K-split: the combine kernel (splitk_epilogue_kernel) writes the partials
+    — four lanes per (16-row block, 4 columns) unit, merged by two equal-count Chan steps.  Output bit-identical to the combine
+    without partials; scale / shift equal to the statistics pass over the stored tensor to 1e-5."""
+    from dgq_amd import ops, synth
+    from dgq_amd.plan import plan_act
+    monkeypatch.setenv("DGQ_GEMM_FORCE", force)
+    for (B, C, H, N, k, dtype) in ((2, 64, 16, 72, 3, torch.float32), (1, 96, 8, 320, 3, torch.float32), (2, 64, 8, 64, 3, torch.bfloat16)):
+        g = torch.Generator().manual_seed(B + C + N)
+        taps = k * k
+        x = torch.randn(B, C, H, H, generator=g).to(dev, dtype)
+        w = torch.randn(N, C, k, k, generator=g) * 0.05
+        wd, wz = orc.minmax_channel(w, 4)
+        pw = ops.PackedWeight(w.to(dev), wd.to(dev), wz.to(dev), None, torch.randn(N, generator=g).to(dev), 4, C, taps)
+        d, z = synth._group_params(C * taps, 16, 8, "gnsk|%d" % N, 0)
+        ab = ops.ActBinding(plan_act(d.view(1, -1, 1), z.view(1, -1, 1), "conv", C, taps, 8, kw=k), pw, 8)
+        assert ops._lib.load().dgq_gemm_plan_splits(B * H * H, N, ab.Kp, 4, 0, ops.WORKSPACE_BYTES) > 1
+        gamma = (1 + 0.1 * torch.randn(N, generator=g)).to(dev)
+        beta = (0.1 * torch.randn(N, generator=g)).to(dev)
+        res = torch.randn(B, N, H, H, generator=g).to(dev, dtype)
+        for residual in (None, res):
+            y = ops.quant_conv2d(x, ab, k, k, 1, 1, residual=residual, gn_out=True)
+            y0 = ops.quant_conv2d(x, ab, k, k, 1, 1, residual=residual, gn_out=False)
+            assert torch.equal(y, y0) and getattr(y, "_dgq_gn", None) is not None
+            sc, sh = ops.groupnorm_from_partials(y._dgq_gn, 8, 1e-5, gamma, beta)
+            ys = y.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)
+            sc0, sh0 = ops.groupnorm_scale_shift(ys, B, H * H, N, 8, 1e-5, gamma, beta)
+            torch.cuda.synchronize()
+            assert rel_l2(sc.cpu(), sc0.cpu()) < 1e-5 and rel_l2(sh.cpu(), sh0.cpu()) < 1e-5, (force, N, rel_l2(sc.cpu(), sc0.cpu()))
+
+
 # ------------------------------------------------------------------------------------------ quantise-on-store (attention -> to_out)
 @pytest.mark.parametrize("D,T,S,skip", [(40, 200, 200, 0), (40, 96, 77, 1), (80, 64, 64, 0), (160, 70, 77, 1), (64, 130, 40, 0)])
 @pytest.mark.parametrize("kind", ["perK", "perM", "scalar"])
