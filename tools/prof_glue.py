@@ -8,7 +8,7 @@ from dgq_amd.runtime import build_synthetic_qnn
 import bench
 dev = torch.device("cuda:0")
 torch.cuda.set_device(0)
-qnn, _ = build_synthetic_qnn("sd", bench.CFG_C2, 64, 2, 1, device=dev)
+qnn, _ = build_synthetic_qnn("sd", bench.CONFIGS["c2"]["cfg"], 64, 2, 1, device=dev)
 qnn.prepare_slots([0])
 lat = synth.named_randn("latent", (2, 4, 64, 64), 1).to(dev)
 ctx = synth.named_randn("ctx", (2, 77, 768), 100).to(dev)
