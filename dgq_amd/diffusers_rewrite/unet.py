@@ -210,18 +210,27 @@ class Transformer2DModel(nn.Module):
         b, c, hh, ww = x.shape
         res = x
         fuse = getattr(self.proj_in, "can_fuse_prenorm", None)
+        fuse_t = getattr(self.proj_in, "can_fuse_tokens", None)
+        tokens_done = False
         if self.proj_kind == "conv" and fuse is not None and _fusion_on() and fuse(x):
             h = self.proj_in.forward_prenorm(x, self.norm, silu=False)     # GroupNorm folded into the quantise-on-load pass
+        elif self.proj_kind != "conv" and fuse_t is not None and _fusion_on() and fuse_t(x):
+            h = self.proj_in.forward_prenorm_tokens(x, self.norm)          # likewise for the Linear projection (SDXL): tokens
+            tokens_done = True
         else:
             h = self.norm(x)
             if self.proj_kind == "conv":
                 h = self.proj_in(h)
-        h = _cl(h).permute(0, 2, 3, 1).reshape(b, hh * ww, c)
-        if self.proj_kind != "conv":
-            h = self.proj_in(h)
+        if not tokens_done:
+            h = _cl(h).permute(0, 2, 3, 1).reshape(b, hh * ww, c)
+            if self.proj_kind != "conv":
+                h = self.proj_in(h)
         for blk in self.transformer_blocks:
             h = blk(h, encoder_hidden_states=encoder_hidden_states)
         if self.proj_kind != "conv":
+            fo = getattr(self.proj_out, "can_fuse_tokens", None)
+            if fo is not None and _residual_fusion_on() and fo(h):
+                return self.proj_out.forward_residual_tokens(h, res)   # h + res in proj_out's GEMM epilogue (+ GroupNorm partials)
             h = self.proj_out(h)
         h = h.reshape(b, hh, ww, c).permute(0, 3, 1, 2)      # NHWC storage viewed as NCHW
         if self.proj_kind == "conv":

@@ -714,6 +714,33 @@ class QuantLayer(nn.Module):
                                            residual=residual, bias_rows=bias_rows),
                     x=x, prologue=True, residual=residual, bias_rows=bias_rows)
 
+    # -- Linear projections of a Transformer2D with use_linear_projection (SDXL, sdxl.py: proj_in / proj_out are nn.Linear over the
+    #    channels of an NCHW tensor): on the integer path they are 1x1 convolutions of the channels-last tensor, so the
+    #    GroupNorm in front of proj_in folds into its quantise-on-load pass, the residual behind proj_out into its GEMM epilogue,
+    #    and proj_out leaves GroupNorm partials for the next resnet block — as the Conv2d projections of SD do.
+    def can_fuse_tokens(self, x: torch.Tensor) -> bool:
+        return (not self.is_conv and self.w.dim() == 2 and self.use_wq and self.use_aq and not self.disable_aq and x.is_cuda
+                and x.dtype in ops.FLOAT_DTYPES
+                and (self.aqtizer.init or (self._slot_ref is not None and self._slot_ref.slot in self._act_tables)))
+
+    def forward_prenorm_tokens(self, x: torch.Tensor, norm: nn.GroupNorm) -> torch.Tensor:
+        """Linear(GroupNorm(x).permute(0, 2, 3, 1).reshape(B, HW, C)) for x [B, C, H, W] -> [B, HW, N]."""
+        y = ops.quant_conv2d(x, self._binding(), 1, 1, 1, 0, norm=(norm.num_groups, norm.eps, norm.weight, norm.bias, 0), gn_out=False)
+        b, n, hh, ww = y.shape
+        return _tap(self, y.permute(0, 2, 3, 1).reshape(b, hh * ww, n), x=x, prologue=True)
+
+    def forward_residual_tokens(self, h: torch.Tensor, residual: torch.Tensor) -> torch.Tensor:
+        """Linear(h).reshape(B, H, W, N).permute(0, 3, 1, 2) + residual for tokens h [B, HW, C] and residual [B, N, H, W]."""
+        b, n, hh, ww = residual.shape
+        x = h.reshape(b, hh, ww, h.shape[-1]).permute(0, 3, 1, 2)
+        y = ops.quant_conv2d(x, self._binding(), 1, 1, 1, 0, residual=residual)
+        yt = y.permute(0, 2, 3, 1).reshape(b, hh * ww, n)
+        rt = residual.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1).reshape(b, hh * ww, n)
+        out = _tap(self, yt, x=h, prologue=False, residual=rt)
+        if out is yt:
+            return y                                        # (keeps the GroupNorm partials attached by quant_conv2d)
+        return out.reshape(b, hh, ww, n).permute(0, 3, 1, 2)
+
     def forward_residual(self, x: torch.Tensor, residual) -> torch.Tensor:
         """conv(x) + residual with the add in the GEMM epilogue (integer path), else unfused."""
         if self.is_conv and self.on_integer_path(x) and x.dtype in ops.FLOAT_DTYPES:

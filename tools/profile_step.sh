@@ -1,11 +1,11 @@
 #!/bin/bash
 # rocprofv3 kernel trace of bench.py (5 timed steps) -> per-step kernel table (tools/prof_summary.py).  Run through gpurun:
-#   tools/profile_step.sh <tag>    writes gpurun_out/<tag>_bench_kernel_stats_per_step.csv (+ the whole-process stats CSV)
+#   [BENCH_ARGS="--config c4"] tools/profile_step.sh <tag>    writes gpurun_out/<tag>_bench_kernel_stats_per_step.csv (+ the whole-process stats CSV)
 set -e
 TAG=${1:-prof}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$TAG; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --windows 1 > $O/bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --windows 1 ${BENCH_ARGS:-} > $O/bench.log 2>&1
 cd $R
 K=$(find $O/trace -name "*kernel_trace.csv" | head -1)
 S=$(find $O/trace -name "*kernel_stats.csv" | head -1)
