@@ -1,0 +1,113 @@
+// Weight-only state (use_wq = True, use_aq = False: BASELINE config 1, and the reference's --use_aq-less runs): the layer is
+// y = x · ŵᵀ + b with UNQUANTISED activations and the dequantised weight ŵ = δw·(qw − zw) (quant_layer.py:642-659 feeds
+// that to F.linear / F.conv2d).  Integer MFMA does not apply — the activations are fp32 — so this is an exact-fp32 GEMM on
+// V_MFMA_F32_32X32X2_F32 (each product and add as in an fmaf chain) with the convolution's im2col folded into the A-tile
+// load: rows = output positions, K = tap·C + c (natural order), out-of-image taps read 0 like F.conv2d's zero padding.
+// Plumbing-grade tiling (64x64 block tile, 16-deep K tiles through LDS, no ring): this state is not on the timed path; it
+// exists so that no state of a quantized model leaves this library on the GPU.
+#include "dgq_common.h"
+
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+struct ConvF32Params {
+    const void* x;       // [B][H][W][C] channels-last, x_dtype
+    const float* w;      // [N][K] fp32, K = kh·kw·C in (tap, c) order
+    const float* bias;   // [N] or nullptr
+    void* y;             // [M][ldy], y_dtype
+    int x_dtype, y_dtype;
+    int B, H, W, C, kh, kw, stride, pad, Ho, Wo, N, K, M, ldy;
+};
+
+__device__ __forceinline__ float ld_any(const void* p, int dtype, int64_t i) {
+    if (dtype == DGQ_F16) return __half2float(reinterpret_cast<const __half*>(p)[i]);
+    if (dtype == DGQ_BF16) return __bfloat162float(reinterpret_cast<const __hip_bfloat16*>(p)[i]);
+    return reinterpret_cast<const float*>(p)[i];
+}
+
+#define CF_BM 64
+#define CF_BN 64
+#define CF_BK 16
+#define CF_LD (CF_BK + 1)
+
+__global__ __launch_bounds__(256) void conv_f32w_kernel(ConvF32Params p) {
+    __shared__ float As[CF_BM][CF_LD];
+    __shared__ float Bs[CF_BN][CF_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int m0 = blockIdx.y * CF_BM, n0 = blockIdx.x * CF_BN;
+    const int wm = (wid >> 1) * 32, wn = (wid & 1) * 32;     // 2 x 2 waves, 32 x 32 each
+    // staging role of this thread: row tid / 4 of the tile, four consecutive k
+    const int srow = tid >> 2, sk = (tid & 3) * 4;
+    const int am = m0 + srow;
+    int ab = 0, aho = 0, awo = 0;
+    if (am < p.M) {
+        const int L = p.Ho * p.Wo;
+        ab = am / L;
+        const int l = am - ab * L;
+        aho = l / p.Wo;
+        awo = l - aho * p.Wo;
+    }
+    v16f acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    for (int k0 = 0; k0 < p.K; k0 += CF_BK) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = k0 + sk + j;
+            float a = 0.0f, b = 0.0f;
+            if (k < p.K) {
+                if (am < p.M) {
+                    const int tap = k / p.C, c = k - tap * p.C;
+                    const int dh = tap / p.kw, dw = tap - dh * p.kw;
+                    const int hi = aho * p.stride - p.pad + dh, wi = awo * p.stride - p.pad + dw;
+                    if (hi >= 0 && hi < p.H && wi >= 0 && wi < p.W)
+                        a = ld_any(p.x, p.x_dtype, (((int64_t)ab * p.H + hi) * p.W + wi) * p.C + c);
+                }
+                if (n0 + srow < p.N) b = p.w[(int64_t)(n0 + srow) * p.K + k];
+            }
+            As[srow][sk + j] = a;
+            Bs[srow][sk + j] = b;
+        }
+        __syncthreads();
+        // MFMA_F32_32X32X2: lane l supplies row / column l & 31 at k = l >> 5
+#pragma unroll
+        for (int kk = 0; kk < CF_BK; kk += 2) {
+            const float av = As[wm + (lane & 31)][kk + (lane >> 5)];
+            const float bv = Bs[wn + (lane & 31)][kk + (lane >> 5)];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // C/D layout: column = lane & 31, row = (r & 3) + 8·(r >> 2) + 4·(lane >> 5)
+    const int n = n0 + wn + (lane & 31);
+    if (n >= p.N) return;
+    const float bias = p.bias ? p.bias[n] : 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (m >= p.M) continue;
+        const float v = acc[r] + bias;
+        const int64_t i = (int64_t)m * p.ldy + n;
+        if (p.y_dtype == DGQ_F16) reinterpret_cast<__half*>(p.y)[i] = __float2half(v);
+        else if (p.y_dtype == DGQ_BF16) reinterpret_cast<__hip_bfloat16*>(p.y)[i] = __float2bfloat16(v);
+        else reinterpret_cast<float*>(p.y)[i] = v;
+    }
+}
+
+extern "C" int dgq_conv2d_f32w(const void* x, int x_dtype, int B, int H, int W, int C, int kh, int kw, int stride, int pad,
+                               const float* w, const float* bias, int N, void* y, int y_dtype, int ldy, void* stream) {
+    DGQ_CHECK_ARG(x && w && y, "dgq_conv2d_f32w: null pointer");
+    DGQ_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && kh > 0 && kw > 0 && stride > 0 && pad >= 0 && N > 0, "dgq_conv2d_f32w: bad geometry");
+    DGQ_CHECK_ARG((x_dtype == DGQ_F32 || x_dtype == DGQ_F16 || x_dtype == DGQ_BF16) && (y_dtype == DGQ_F32 || y_dtype == DGQ_F16 || y_dtype == DGQ_BF16),
+                  "dgq_conv2d_f32w: unknown dtype");
+    ConvF32Params p;
+    p.x = x; p.w = w; p.bias = bias; p.y = y; p.x_dtype = x_dtype; p.y_dtype = y_dtype;
+    p.B = B; p.H = H; p.W = W; p.C = C; p.kh = kh; p.kw = kw; p.stride = stride; p.pad = pad;
+    p.Ho = (H + 2 * pad - kh) / stride + 1; p.Wo = (W + 2 * pad - kw) / stride + 1;
+    DGQ_CHECK_ARG(p.Ho > 0 && p.Wo > 0, "dgq_conv2d_f32w: empty output");
+    p.N = N; p.K = kh * kw * C; p.M = B * p.Ho * p.Wo; p.ldy = ldy;
+    DGQ_CHECK_ARG(ldy >= N, "dgq_conv2d_f32w: ldy < N");
+    dim3 grid((N + CF_BN - 1) / CF_BN, (p.M + CF_BM - 1) / CF_BM);
+    DGQ_CHECK_ARG(grid.y <= 65535, "dgq_conv2d_f32w: M = %d rows exceed the grid", p.M);
+    hipLaunchKernelGGL(conv_f32w_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+    return dgq_launch_status("dgq_conv2d_f32w");
+}

@@ -14,6 +14,7 @@ Same public names and argument meaning (``Scaler``, ``UniformAffineQuantizer``, 
 There is no CPU execution path: a quantized forward on a CPU tensor raises.
 """
 import logging
+import os
 from enum import Enum
 from typing import List, Optional, Union
 
@@ -443,6 +444,10 @@ class UniformAffineQuantizer(nn.Module):
 #: ``LAYER_TAP(layer, y, x=..., prologue=bool, residual=..., bias_rows=...)`` and continues with the tensor it returns,
 #: so a test can compare every operator of the FUSED graph with the oracle and teacher-force it.  None in production.
 LAYER_TAP = None
+#: weight-only state on the library's own exact-fp32 kernel (dgq_conv2d_f32w); =0: F.linear / F.conv2d on the dequantised weight
+WEIGHT_ONLY_HIP = os.environ.get("DGQ_WEIGHT_ONLY_HIP", "1") == "1"
+#: ... and the FP state (unquantised layers: conv_in / conv_out of a quantized model) too; =1 opts in (measured slower on the step)
+FP_STATE_HIP = os.environ.get("DGQ_FP_STATE_HIP", "0") == "1"
 
 
 def _tap(layer, y, **info):
@@ -503,6 +508,7 @@ class QuantLayer(nn.Module):
         self._pw = None
         self._pw_key = None
         self._wdq = None
+        self._wnat = None
         self._bindings = {}
         self._act_tables = {}            # slot -> (δ, z) CPU tensors from the cali_ckpt
         self._slot_ref: Optional[SlotRef] = None
@@ -549,6 +555,7 @@ class QuantLayer(nn.Module):
             self._pw_key = key
             self._bindings = {}
             self._wdq = None
+            self._wnat = None
         return self._pw
 
     def _row_perm(self, dev):
@@ -571,6 +578,16 @@ class QuantLayer(nn.Module):
             if self.is_conv:
                 self._wdq = self._wdq.contiguous(memory_format=torch.channels_last)
         return self._wdq
+
+    def dequantized_weight_natural(self):
+        """(δ·(q − z) as fp32 [N][taps·C] with K in (tap, c) order, bias as fp32 or None) — the operands of dgq_conv2d_f32w."""
+        self.packed_weight()                              # (re-packs, and drops the caches below, when the weight state changed)
+        if self._wnat is None:
+            w = self.dequantized_weight(torch.float32).float()
+            if self.is_conv:
+                w = w.permute(0, 2, 3, 1)                    # [N][kh][kw][C]
+            self._wnat = (w.reshape(w.shape[0], -1).contiguous(), self.b.float().contiguous() if self.b is not None else None)
+        return self._wnat
 
     # -- activation tables ----------------------------------------------------------------------------
     def set_act_table(self, slot, delta, zero_point):
@@ -607,6 +624,22 @@ class QuantLayer(nn.Module):
             b = self.original_b.to(device=x.device, dtype=x.dtype) if self.original_b is not None else None
             if quant_act:
                 x = self.aqtizer(x)
+            if (FP_STATE_HIP and x.is_cuda and x.dtype in ops.FLOAT_DTYPES and not torch.is_grad_enabled()
+                    and (not self.is_conv or (tuple(self.fwd_kwargs.get("dilation", (1, 1)))[0] == 1 and self.fwd_kwargs.get("groups", 1) == 1))):
+                # FP state on the GPU without autograd (conv_in / conv_out of every quantized model, quant_model.py:66-73): the
+                # library's exact-fp32 kernel instead of MIOpen / rocBLAS.  Opt-in: the plumbing-grade kernel costs the SD step
+                # 0.3 ms on conv_out (N = 4 output channels in a 64-wide tile, K = 2880) against MIOpen's 0.07 ms.
+                key = (self.original_w.data_ptr(), self.original_w._version, str(x.device))
+                if getattr(self, "_wnat_fp", None) is None or self._wnat_fp[0] != key:
+                    wf = self.original_w.detach().to(device=x.device, dtype=torch.float32)
+                    if self.is_conv:
+                        wf = wf.permute(0, 2, 3, 1)
+                    bf = self.original_b.detach().to(device=x.device, dtype=torch.float32).contiguous() if self.original_b is not None else None
+                    self._wnat_fp = (key, wf.reshape(wf.shape[0], -1).contiguous(), bf)
+                if self.is_conv:
+                    return ops.conv2d_f32w(x, self._wnat_fp[1], self._wnat_fp[2], self.w.shape[2], self.w.shape[3],
+                                           self.fwd_kwargs["stride"][0], self.fwd_kwargs["padding"][0])
+                return ops.conv2d_f32w(x, self._wnat_fp[1], self._wnat_fp[2], 1, 1, 1, 0)
             if self.is_conv:
                 return F.conv2d(x, w, b, stride=self.fwd_kwargs["stride"], padding=self.fwd_kwargs["padding"])
             return F.linear(x, w, b)
@@ -623,6 +656,15 @@ class QuantLayer(nn.Module):
                 if self.is_conv:
                     w = w.contiguous(memory_format=torch.channels_last)
             else:
+                if (WEIGHT_ONLY_HIP and x.dtype in ops.FLOAT_DTYPES and not (torch.is_grad_enabled() and x.requires_grad)
+                        and (not self.is_conv or (tuple(self.fwd_kwargs.get("dilation", (1, 1)))[0] == 1 and self.fwd_kwargs.get("groups", 1) == 1))):
+                    # inference in the weight-only state: exact-fp32 MFMA kernel of this library (dgq_conv2d_f32w), not
+                    # F.linear / F.conv2d of the vendor libraries
+                    wn, bn = self.dequantized_weight_natural()
+                    if self.is_conv:
+                        return ops.conv2d_f32w(x, wn, bn, self.w.shape[2], self.w.shape[3], self.fwd_kwargs["stride"][0],
+                                               self.fwd_kwargs["padding"][0])
+                    return ops.conv2d_f32w(x, wn, bn, 1, 1, 1, 0)
                 w = self.dequantized_weight(x.dtype)
             b = self.b.to(x.dtype) if self.b is not None else None
             if self.is_conv:

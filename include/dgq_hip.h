@@ -138,6 +138,14 @@ int dgq_groupnorm_scale_shift(const void* x, int x_dtype, int B, int HW, int C, 
 int dgq_groupnorm_from_partials(const float* partial, int C1, const float* partial2, int C2, int B, int HW, int G, float eps,
                                 const float* gamma, const float* beta, float* scale, float* shift, void* stream);
 
+/* ---- weight-only state (use_wq without use_aq: quant_layer.py:642-659 with unquantised activations) -----------------
+ * y[m][n] = Σ_k x_unfolded[m][k]·w[n][k] + bias[n] in exact fp32 (V_MFMA_F32_32X32X2_F32), the im2col of a convolution folded
+ * into the operand load: x channels-last [B][H][W][C] (x_dtype), w [N][kh·kw·C] fp32 = the dequantised weight δw·(qw − zw) with
+ * K in (tap, c) order, y [B·Ho·Wo][ldy] (y_dtype).  A Linear layer is B = rows, H = W = kh = kw = stride = 1, pad = 0.
+ * Replaces F.linear / F.conv2d on the dequantised weight; not a timed path. */
+int dgq_conv2d_f32w(const void* x, int x_dtype, int B, int H, int W, int C, int kh, int kw, int stride, int pad,
+                    const float* w, const float* bias, int N, void* y, int y_dtype, int ldy, void* stream);
+
 /* ---- the hot kernel: W4A8 / W8A8 MFMA GEMM with fused dequantisation ------------------------------
  * Replaces F.linear / `w.view(N,-1) @ unfolded` / F.conv2d on fake-quantised operands
  * (quant_layer.py:652-659, :562).  Integer identity, s = qx − offset, zw' = zw − woff:

@@ -774,3 +774,28 @@ def test_attention_emit_equals_store_then_quantise(D, T, S, skip, kind, dtype, d
     y = ops.gemm_wxa8(codes, rowsum, M, ab, dtype)
     tol = (1e-5 if kind == "perK" else 1e-7) if dtype == torch.float32 else 2e-3
     assert rel_l2(y.float(), y_ref.float()) <= tol
+
+
+# ------------------------------------------------------------------------------------------ weight-only state
+@pytest.mark.parametrize("shape", [(2, 8, 9, 11, 20, 3, 1, 1), (1, 4, 16, 16, 64, 3, 2, 1), (3, 12, 7, 5, 40, 1, 1, 0), (2, 320, 8, 8, 70, 3, 1, 1)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_weight_only_conv_kernel_vs_float64(shape, dtype, dev):
+    """dgq_conv2d_f32w (exact-fp32 MFMA, im2col folded into the load) against F.conv2d evaluated in float64: ragged M / N / K
+    edges, stride 2, 1x1, padding; fp32 within 2e-6 relative (the fp32 accumulation itself), fp16 I/O within its rounding."""
+    from dgq_amd import ops
+    B, C, H, W, N, k, stride, pad = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(B, C, H, W, generator=g).to(dev, dtype)
+    w = torch.randn(N, C, k, k, generator=g) * 0.1
+    b = torch.randn(N, generator=g)
+    wn = w.permute(0, 2, 3, 1).reshape(N, -1).contiguous().to(dev)
+    y = ops.conv2d_f32w(x, wn, b.to(dev), k, k, stride, pad)
+    ref = torch.nn.functional.conv2d(x.double().cpu(), w.double(), b.double(), stride=stride, padding=pad)
+    assert y.shape == ref.shape and y.dtype == dtype
+    assert rel_l2(y.double().cpu(), ref) < (2e-6 if dtype == torch.float32 else 1e-3)
+    # Linear form
+    xl = torch.randn(5, 7, C * 3, generator=g).to(dev, dtype)
+    wl = torch.randn(N, C * 3, generator=g) * 0.1
+    yl = ops.conv2d_f32w(xl, wl.to(dev), None, 1, 1, 1, 0)
+    refl = xl.double().cpu() @ wl.double().t()
+    assert yl.shape == refl.shape and rel_l2(yl.double().cpu(), refl) < (2e-6 if dtype == torch.float32 else 1e-3)
