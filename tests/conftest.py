@@ -30,6 +30,9 @@ def _gpu_run_heartbeat():
         yield
         return
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    # the oracle's CPU forwards are the bulk of this suite's minutes; a one-GPU box exposes every host thread but grants a
+    # share of 16 cores, and torch's default (all of them) oversubscribes that share 4x (15 s instead of 4 s per oracle forward)
+    torch.set_num_threads(min(torch.get_num_threads(), int(os.environ.get("DGQ_TEST_THREADS", "16"))))
     stop = threading.Event()
 
     def beat():

@@ -53,9 +53,22 @@ def get_qnn(arch, c, res, batch, slots, ckdir):
     return _QNN[key]
 
 
+_ORACLE_CKPT = {}
+
+
 def oracle_ckpt(arch, c, res, batch, slots):
     """The same checkpoint content as the file the product loads, rebuilt in memory from the name-keyed generators
-    (shares the cached weight tensors instead of reading 10 GB back)."""
+    (shares the cached weight tensors instead of reading 10 GB back).  Kept for the last two configurations: rebuilding it took
+    ~15 s per oracle run — most of the distribution test's minutes."""
+    key = (arch, tuple(sorted(c.items())), res, batch, tuple(synth.slot_list(slots)))
+    if key not in _ORACLE_CKPT:
+        while len(_ORACLE_CKPT) >= 2:
+            _ORACLE_CKPT.pop(next(iter(_ORACLE_CKPT)))
+        _ORACLE_CKPT[key] = _build_oracle_ckpt(arch, c, res, batch, slots)
+    return _ORACLE_CKPT[key]
+
+
+def _build_oracle_ckpt(arch, c, res, batch, slots):
     return synth.build_cali_ckpt(arch, c["wbits"], c["abits"], c["G"], num_slots=slots, seed=0, batch=batch, res=res,
                                  start_peak=c["sp"], uniform_softmax=(c["use_aq"] and not c["log"]), with_act=c["use_aq"])
 
@@ -480,12 +493,17 @@ def test_pndm8_pipeline_vs_reference_golden(ckdir):
 def _deviation_row(arch, res, batch, cname, ckdir, seed, t, with_r1):
     """One (seed, t) sample of the distribution-level criterion: distances of the HIP path (fused and unfused graph) and of the
     reference's fp32 evaluation(s) from the exact-contraction oracle E, and the per-layer activation-code flip rates vs E."""
+    import time
     from dgq_amd.quant import QuantLayer, quant_block
+    t0 = time.time()
     c, slots, qnn, _ = _tf_setup(arch, res, cname, batch, ckdir)
     inp = synth.synth_inputs(arch, batch, seed, res)
     pkw = product_kwargs(arch, inp)
+    t1 = time.time()
     E, recE, omE = oracle_run(arch, c, res, batch, slots, inp, t, exact=True)
+    t2 = time.time()
     R, recR, _ = oracle_run(arch, c, res, batch, slots, inp, t)
+    t3 = time.time()
     dR1 = None
     if with_r1:
         R1, _, _ = oracle_run(arch, c, res, batch, slots, inp, t, threads=1)
@@ -515,6 +533,8 @@ def _deviation_row(arch, res, batch, cname, ckdir, seed, t, with_r1):
         fH.append((cH != cE).float().mean().item())
         fR.append((cR != cE).float().mean().item())
     fH.sort(), fR.sort()
+    print("  (seconds: setup %.1f, exact oracle %.1f, fp32 oracle %.1f, HIP runs + code comparison %.1f)"
+          % (t1 - t0, t2 - t1, t3 - t2, time.time() - t3))
     row = dict(seed=seed, t=t, dHf=rel_l2(Hf, E), dHu=rel_l2(Hu, E), dR=rel_l2(R, E), dR1=dR1,
                flipH_med=fH[len(fH) // 2], flipR_med=fR[len(fR) // 2], flipH_max=fH[-1], flipR_max=fR[-1])
     print("%s seed %d t=%d: |H_fused−E| %.3g  |H_unfused−E| %.3g  |R−E| %.3g  |R1−E| %s ; code flips vs E per layer: "
