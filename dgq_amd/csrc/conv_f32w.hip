@@ -93,6 +93,45 @@ __global__ __launch_bounds__(256) void conv_f32w_kernel(ConvF32Params p) {
     }
 }
 
+// N <= 8 output channels (conv_out of the UNets: 320 -> 4): a 64-wide column tile would idle 94 % of its MFMAs and walk K in
+// 180 barrier-separated steps; here one wave owns an output position, its lanes split K (coalesced along the channels of each
+// tap), every lane keeps N partial sums, and the wave reduces them with shuffles.  fmaf chain per lane + a fixed reduction tree.
+template <int NMAX>
+__global__ __launch_bounds__(256) void conv_f32w_smalln_kernel(ConvF32Params p) {
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= p.M) return;
+    const int L = p.Ho * p.Wo;
+    const int b = m / L, l = m - b * L;
+    const int ho = l / p.Wo, wo = l - ho * p.Wo;
+    float acc[NMAX];
+#pragma unroll
+    for (int n = 0; n < NMAX; ++n) acc[n] = 0.0f;
+    for (int k = lane; k < p.K; k += 64) {
+        const int tap = k / p.C, c = k - tap * p.C;
+        const int dh = tap / p.kw, dw = tap - dh * p.kw;
+        const int hi = ho * p.stride - p.pad + dh, wi = wo * p.stride - p.pad + dw;
+        if (hi < 0 || hi >= p.H || wi < 0 || wi >= p.W) continue;
+        const float a = ld_any(p.x, p.x_dtype, (((int64_t)b * p.H + hi) * p.W + wi) * p.C + c);
+#pragma unroll
+        for (int n = 0; n < NMAX; ++n)
+            if (n < p.N) acc[n] = __builtin_fmaf(a, p.w[(int64_t)n * p.K + k], acc[n]);
+    }
+#pragma unroll
+    for (int n = 0; n < NMAX; ++n) {
+        float v = acc[n];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (lane == 0 && n < p.N) {
+            v += p.bias ? p.bias[n] : 0.0f;
+            const int64_t i = (int64_t)m * p.ldy + n;
+            if (p.y_dtype == DGQ_F16) reinterpret_cast<__half*>(p.y)[i] = __float2half(v);
+            else if (p.y_dtype == DGQ_BF16) reinterpret_cast<__hip_bfloat16*>(p.y)[i] = __float2bfloat16(v);
+            else reinterpret_cast<float*>(p.y)[i] = v;
+        }
+    }
+}
+
 extern "C" int dgq_conv2d_f32w(const void* x, int x_dtype, int B, int H, int W, int C, int kh, int kw, int stride, int pad,
                                const float* w, const float* bias, int N, void* y, int y_dtype, int ldy, void* stream) {
     DGQ_CHECK_ARG(x && w && y, "dgq_conv2d_f32w: null pointer");
@@ -106,6 +145,10 @@ extern "C" int dgq_conv2d_f32w(const void* x, int x_dtype, int B, int H, int W, 
     DGQ_CHECK_ARG(p.Ho > 0 && p.Wo > 0, "dgq_conv2d_f32w: empty output");
     p.N = N; p.K = kh * kw * C; p.M = B * p.Ho * p.Wo; p.ldy = ldy;
     DGQ_CHECK_ARG(ldy >= N, "dgq_conv2d_f32w: ldy < N");
+    if (N <= 8) {
+        hipLaunchKernelGGL(conv_f32w_smalln_kernel<8>, dim3((p.M + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
+        return dgq_launch_status("dgq_conv2d_f32w");
+    }
     dim3 grid((N + CF_BN - 1) / CF_BN, (p.M + CF_BM - 1) / CF_BM);
     DGQ_CHECK_ARG(grid.y <= 65535, "dgq_conv2d_f32w: M = %d rows exceed the grid", p.M);
     hipLaunchKernelGGL(conv_f32w_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);

@@ -446,8 +446,8 @@ class UniformAffineQuantizer(nn.Module):
 LAYER_TAP = None
 #: weight-only state on the library's own exact-fp32 kernel (dgq_conv2d_f32w); =0: F.linear / F.conv2d on the dequantised weight
 WEIGHT_ONLY_HIP = os.environ.get("DGQ_WEIGHT_ONLY_HIP", "1") == "1"
-#: ... and the FP state (unquantised layers: conv_in / conv_out of a quantized model) too; =1 opts in (measured slower on the step)
-FP_STATE_HIP = os.environ.get("DGQ_FP_STATE_HIP", "0") == "1"
+#: ... and the FP state (unquantised layers: conv_in / conv_out of a quantized model) too, outside autograd; =0: MIOpen / rocBLAS
+FP_STATE_HIP = os.environ.get("DGQ_FP_STATE_HIP", "1") == "1"
 
 
 def _tap(layer, y, **info):
@@ -627,8 +627,8 @@ class QuantLayer(nn.Module):
             if (FP_STATE_HIP and x.is_cuda and x.dtype in ops.FLOAT_DTYPES and not torch.is_grad_enabled()
                     and (not self.is_conv or (tuple(self.fwd_kwargs.get("dilation", (1, 1)))[0] == 1 and self.fwd_kwargs.get("groups", 1) == 1))):
                 # FP state on the GPU without autograd (conv_in / conv_out of every quantized model, quant_model.py:66-73): the
-                # library's exact-fp32 kernel instead of MIOpen / rocBLAS.  Opt-in: the plumbing-grade kernel costs the SD step
-                # 0.3 ms on conv_out (N = 4 output channels in a 64-wide tile, K = 2880) against MIOpen's 0.07 ms.
+                # library's exact-fp32 kernel instead of MIOpen / rocBLAS (conv_out's four output channels take its N <= 8 form;
+                # step 9.537 vs 9.559 ms with MIOpen)
                 key = (self.original_w.data_ptr(), self.original_w._version, str(x.device))
                 if getattr(self, "_wnat_fp", None) is None or self._wnat_fp[0] != key:
                     wf = self.original_w.detach().to(device=x.device, dtype=torch.float32)

@@ -777,7 +777,8 @@ def test_attention_emit_equals_store_then_quantise(D, T, S, skip, kind, dtype, d
 
 
 # ------------------------------------------------------------------------------------------ weight-only state
-@pytest.mark.parametrize("shape", [(2, 8, 9, 11, 20, 3, 1, 1), (1, 4, 16, 16, 64, 3, 2, 1), (3, 12, 7, 5, 40, 1, 1, 0), (2, 320, 8, 8, 70, 3, 1, 1)])
+@pytest.mark.parametrize("shape", [(2, 8, 9, 11, 20, 3, 1, 1), (1, 4, 16, 16, 64, 3, 2, 1), (3, 12, 7, 5, 40, 1, 1, 0), (2, 320, 8, 8, 70, 3, 1, 1),
+                                   (2, 320, 12, 12, 4, 3, 1, 1), (1, 64, 9, 9, 7, 3, 2, 1)])      # the last two: the N <= 8 kernel (conv_out)
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
 def test_weight_only_conv_kernel_vs_float64(shape, dtype, dev):
     """dgq_conv2d_f32w (exact-fp32 MFMA, im2col folded into the load) against F.conv2d evaluated in float64: ragged M / N / K
