@@ -9,7 +9,8 @@ dtype = sys.argv[4] if len(sys.argv) > 4 else "fp32"
 CLASSES = (("dgq_gemm", ("gemm_wxa8_kernel", "splitk_epilogue_kernel", "linear_smallm_kernel")),
            ("dgq_quantise_on_load", ("quant_act_",)),
            ("dgq_attention", ("attn3_", "attn_stats", "attn_pv", "fakequant_rows", "logquant", "max_f32")),
-           ("dgq_groupnorm_statistics", ("gn_partial", "gn_finalize", "gn_from_partials")))
+           ("dgq_groupnorm_statistics", ("gn_partial", "gn_finalize", "gn_from_partials")),
+           ("dgq_fp32_conv", ("conv_f32w",)))
 lines = [l for l in open(src) if not l.startswith("#")]
 head = [l for l in open(src) if l.startswith("#")]
 rows = list(csv.DictReader(lines))
