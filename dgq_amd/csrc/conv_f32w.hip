@@ -13,10 +13,22 @@ struct ConvF32Params {
     const void* x;       // [B][H][W][C] channels-last, x_dtype
     const float* w;      // [N][K] fp32, K = kh·kw·C in (tap, c) order
     const float* bias;   // [N] or nullptr
+    const float* pre_scale;   // optional [B][C]: x·scale + shift (a folded GroupNorm) ...
+    const float* pre_shift;
+    int pre_act;              // ... followed by SiLU when 1; out-of-image taps stay 0 (the conv pads AFTER norm + activation)
     void* y;             // [M][ldy], y_dtype
     int x_dtype, y_dtype;
     int B, H, W, C, kh, kw, stride, pad, Ho, Wo, N, K, M, ldy;
 };
+
+__device__ __forceinline__ float ld_any(const void* p, int dtype, int64_t i);
+// the activation the convolution sees: optional per-(b, c) affine (GroupNorm) and SiLU applied on load
+__device__ __forceinline__ float ld_pre(const ConvF32Params& p, int b, int64_t pix, int c) {
+    float v = ld_any(p.x, p.x_dtype, pix * p.C + c);
+    if (p.pre_scale) v = v * p.pre_scale[(int64_t)b * p.C + c] + p.pre_shift[(int64_t)b * p.C + c];
+    if (p.pre_act == 1) v = dgq_silu(v);
+    return v;
+}
 
 __device__ __forceinline__ float ld_any(const void* p, int dtype, int64_t i) {
     if (dtype == DGQ_F16) return __half2float(reinterpret_cast<const __half*>(p)[i]);
@@ -60,7 +72,7 @@ __global__ __launch_bounds__(256) void conv_f32w_kernel(ConvF32Params p) {
                     const int dh = tap / p.kw, dw = tap - dh * p.kw;
                     const int hi = aho * p.stride - p.pad + dh, wi = awo * p.stride - p.pad + dw;
                     if (hi >= 0 && hi < p.H && wi >= 0 && wi < p.W)
-                        a = ld_any(p.x, p.x_dtype, (((int64_t)ab * p.H + hi) * p.W + wi) * p.C + c);
+                        a = ld_pre(p, ab, ((int64_t)ab * p.H + hi) * p.W + wi, c);
                 }
                 if (n0 + srow < p.N) b = p.w[(int64_t)(n0 + srow) * p.K + k];
             }
@@ -112,7 +124,7 @@ __global__ __launch_bounds__(256) void conv_f32w_smalln_kernel(ConvF32Params p) 
         const int dh = tap / p.kw, dw = tap - dh * p.kw;
         const int hi = ho * p.stride - p.pad + dh, wi = wo * p.stride - p.pad + dw;
         if (hi < 0 || hi >= p.H || wi < 0 || wi >= p.W) continue;
-        const float a = ld_any(p.x, p.x_dtype, (((int64_t)b * p.H + hi) * p.W + wi) * p.C + c);
+        const float a = ld_pre(p, b, ((int64_t)b * p.H + hi) * p.W + wi, c);
 #pragma unroll
         for (int n = 0; n < NMAX; ++n)
             if (n < p.N) acc[n] = __builtin_fmaf(a, p.w[(int64_t)n * p.K + k], acc[n]);
@@ -133,12 +145,15 @@ __global__ __launch_bounds__(256) void conv_f32w_smalln_kernel(ConvF32Params p) 
 }
 
 extern "C" int dgq_conv2d_f32w(const void* x, int x_dtype, int B, int H, int W, int C, int kh, int kw, int stride, int pad,
-                               const float* w, const float* bias, int N, void* y, int y_dtype, int ldy, void* stream) {
+                               const float* w, const float* bias, int N, void* y, int y_dtype, int ldy,
+                               const float* pre_scale, const float* pre_shift, int pre_act, void* stream) {
     DGQ_CHECK_ARG(x && w && y, "dgq_conv2d_f32w: null pointer");
     DGQ_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && kh > 0 && kw > 0 && stride > 0 && pad >= 0 && N > 0, "dgq_conv2d_f32w: bad geometry");
     DGQ_CHECK_ARG((x_dtype == DGQ_F32 || x_dtype == DGQ_F16 || x_dtype == DGQ_BF16) && (y_dtype == DGQ_F32 || y_dtype == DGQ_F16 || y_dtype == DGQ_BF16),
                   "dgq_conv2d_f32w: unknown dtype");
+    DGQ_CHECK_ARG((pre_scale == nullptr) == (pre_shift == nullptr) && (pre_act == 0 || pre_act == 1), "dgq_conv2d_f32w: bad prologue");
     ConvF32Params p;
+    p.pre_scale = pre_scale; p.pre_shift = pre_shift; p.pre_act = pre_act;
     p.x = x; p.w = w; p.bias = bias; p.y = y; p.x_dtype = x_dtype; p.y_dtype = y_dtype;
     p.B = B; p.H = H; p.W = W; p.C = C; p.kh = kh; p.kw = kw; p.stride = stride; p.pad = pad;
     p.Ho = (H + 2 * pad - kh) / stride + 1; p.Wo = (W + 2 * pad - kw) / stride + 1;

@@ -383,4 +383,7 @@ class UNet2DConditionModel(nn.Module):
         fuse = getattr(self.conv_out, "can_fuse_prenorm", None)
         if fuse is not None and _fusion_on() and isinstance(self.conv_act, nn.SiLU) and fuse(h):
             return [self.conv_out.forward_prenorm(h, self.conv_norm_out, silu=True)]
+        fuse_fp = getattr(self.conv_out, "can_fuse_prenorm_fp", None)
+        if fuse_fp is not None and _fusion_on() and isinstance(self.conv_act, nn.SiLU) and fuse_fp(h):
+            return [self.conv_out.forward_prenorm_fp(h, self.conv_norm_out, silu=True)]   # FP conv_out: norm + SiLU in its load
         return [self.conv_out(self.conv_act(self.conv_norm_out(h)))]

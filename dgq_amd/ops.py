@@ -665,27 +665,39 @@ def quant_conv2d(x: torch.Tensor, ab: ActBinding, kh, kw, stride, pad, norm=None
     return out
 
 
-def conv2d_f32w(x: torch.Tensor, w_nat: torch.Tensor, bias, kh, kw, stride, pad):
+def conv2d_f32w(x: torch.Tensor, w_nat: torch.Tensor, bias, kh, kw, stride, pad, norm=None):
     """Weight-only state: conv2d / linear of UNQUANTISED activations with the dequantised weight, exact fp32 MFMA with the
     im2col folded into the load (dgq_conv2d_f32w).  x logical NCHW (made channels-last) or [..., K] for a Linear layer
-    (kh = kw = 1); w_nat [N][kh·kw·C] fp32 with K in (tap, c) order; bias [N] fp32 or None."""
+    (kh = kw = 1); w_nat [N][kh·kw·C] fp32 with K in (tap, c) order; bias [N] fp32 or None.
+    norm = (groups, eps, gamma, beta, act) folds GroupNorm (+SiLU) of a 4-D x into the load, as in quant_conv2d."""
     N = w_nat.shape[0]
     if x.dim() == 4:
         B, C, H, W = x.shape
         xs = x.contiguous(memory_format=torch.channels_last)
+        sc = sh = None
+        act = 0
+        if norm is not None:
+            groups, eps, gamma, beta, act = norm
+            gn = getattr(x, "_dgq_gn", None) if GN_FROM_GEMM else None
+            if gn is not None and gn["B"] == B and gn["HW"] == H * W and gn["C"] == C and C % groups == 0:
+                sc, sh = groupnorm_from_partials(gn, groups, eps, gamma, beta)
+            else:
+                sc, sh = groupnorm_scale_shift(xs.permute(0, 2, 3, 1), B, H * W, C, groups, eps, gamma, beta)
         Ho = (H + 2 * pad - kh) // stride + 1
         Wo = (W + 2 * pad - kw) // stride + 1
         y = torch.empty((B * Ho * Wo, N), dtype=x.dtype, device=x.device)
         _lib_call("dgq_conv2d_f32w", _lib.ptr(xs), _lib.DTYPE_CODE[x.dtype], B, H, W, C, kh, kw, stride, pad,
-                  _lib.ptr(w_nat), _lib.ptr(bias), N, _lib.ptr(y), _lib.DTYPE_CODE[y.dtype], N, _lib.stream())
+                  _lib.ptr(w_nat), _lib.ptr(bias), N, _lib.ptr(y), _lib.DTYPE_CODE[y.dtype], N,
+                  _lib.ptr(sc), _lib.ptr(sh), int(act), _lib.stream())
         return y.view(B, Ho, Wo, N).permute(0, 3, 1, 2)
     K = x.shape[-1]
     x2 = x.reshape(-1, K)
     if not x2.is_contiguous():
         x2 = x2.contiguous()
     y = torch.empty((x2.shape[0], N), dtype=x.dtype, device=x.device)
+    assert norm is None
     _lib_call("dgq_conv2d_f32w", _lib.ptr(x2), _lib.DTYPE_CODE[x.dtype], x2.shape[0], 1, 1, K, 1, 1, 1, 0,
-              _lib.ptr(w_nat), _lib.ptr(bias), N, _lib.ptr(y), _lib.DTYPE_CODE[y.dtype], N, _lib.stream())
+              _lib.ptr(w_nat), _lib.ptr(bias), N, _lib.ptr(y), _lib.DTYPE_CODE[y.dtype], N, None, None, 0, _lib.stream())
     return y.view(*x.shape[:-1], N)
 
 

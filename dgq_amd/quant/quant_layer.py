@@ -629,13 +629,7 @@ class QuantLayer(nn.Module):
                 # FP state on the GPU without autograd (conv_in / conv_out of every quantized model, quant_model.py:66-73): the
                 # library's exact-fp32 kernel instead of MIOpen / rocBLAS (conv_out's four output channels take its N <= 8 form;
                 # step 9.537 vs 9.559 ms with MIOpen)
-                key = (self.original_w.data_ptr(), self.original_w._version, str(x.device))
-                if getattr(self, "_wnat_fp", None) is None or self._wnat_fp[0] != key:
-                    wf = self.original_w.detach().to(device=x.device, dtype=torch.float32)
-                    if self.is_conv:
-                        wf = wf.permute(0, 2, 3, 1)
-                    bf = self.original_b.detach().to(device=x.device, dtype=torch.float32).contiguous() if self.original_b is not None else None
-                    self._wnat_fp = (key, wf.reshape(wf.shape[0], -1).contiguous(), bf)
+                self._fp_natural(x.device)
                 if self.is_conv:
                     return ops.conv2d_f32w(x, self._wnat_fp[1], self._wnat_fp[2], self.w.shape[2], self.w.shape[3],
                                            self.fwd_kwargs["stride"][0], self.fwd_kwargs["padding"][0])
@@ -782,6 +776,28 @@ class QuantLayer(nn.Module):
         if out is yt:
             return y                                        # (keeps the GroupNorm partials attached by quant_conv2d)
         return out.reshape(b, hh, ww, n).permute(0, 3, 1, 2)
+
+    def can_fuse_prenorm_fp(self, x: torch.Tensor) -> bool:
+        """FP-state conv on the GPU outside autograd (conv_out of a quantized model): GroupNorm + SiLU fold into the load of
+        dgq_conv2d_f32w."""
+        return (FP_STATE_HIP and self.is_conv and not self.use_wq and not (self.use_aq and not self.disable_aq) and x.is_cuda
+                and x.dtype in ops.FLOAT_DTYPES and not torch.is_grad_enabled()
+                and tuple(self.fwd_kwargs.get("dilation", (1, 1)))[0] == 1 and self.fwd_kwargs.get("groups", 1) == 1)
+
+    def forward_prenorm_fp(self, x: torch.Tensor, norm: nn.GroupNorm, silu: bool = True) -> torch.Tensor:
+        wn, bn = self._fp_natural(x.device)
+        return ops.conv2d_f32w(x, wn, bn, self.w.shape[2], self.w.shape[3], self.fwd_kwargs["stride"][0], self.fwd_kwargs["padding"][0],
+                               norm=(norm.num_groups, norm.eps, norm.weight, norm.bias, 1 if silu else 0))
+
+    def _fp_natural(self, device):
+        key = (self.original_w.data_ptr(), self.original_w._version, str(device))
+        if getattr(self, "_wnat_fp", None) is None or self._wnat_fp[0] != key:
+            wf = self.original_w.detach().to(device=device, dtype=torch.float32)
+            if self.is_conv:
+                wf = wf.permute(0, 2, 3, 1)
+            bf = self.original_b.detach().to(device=device, dtype=torch.float32).contiguous() if self.original_b is not None else None
+            self._wnat_fp = (key, wf.reshape(wf.shape[0], -1).contiguous(), bf)
+        return self._wnat_fp[1], self._wnat_fp[2]
 
     def forward_residual(self, x: torch.Tensor, residual) -> torch.Tensor:
         """conv(x) + residual with the add in the GEMM epilogue (integer path), else unfused."""

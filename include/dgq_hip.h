@@ -142,9 +142,12 @@ int dgq_groupnorm_from_partials(const float* partial, int C1, const float* parti
  * y[m][n] = Σ_k x_unfolded[m][k]·w[n][k] + bias[n] in exact fp32 (V_MFMA_F32_32X32X2_F32), the im2col of a convolution folded
  * into the operand load: x channels-last [B][H][W][C] (x_dtype), w [N][kh·kw·C] fp32 = the dequantised weight δw·(qw − zw) with
  * K in (tap, c) order, y [B·Ho·Wo][ldy] (y_dtype).  A Linear layer is B = rows, H = W = kh = kw = stride = 1, pad = 0.
- * Replaces F.linear / F.conv2d on the dequantised weight; not a timed path. */
+ * Optional prologue as in dgq_quant_act: pre_scale / pre_shift [B][C] (a GroupNorm folded into the load: x·scale + shift) and
+ * pre_act = 1 (SiLU) — conv_out(SiLU(conv_norm_out(x))) of the UNets in one launch.
+ * Replaces F.linear / F.conv2d on the dequantised (or, for the FP conv_in / conv_out, the original) weight. */
 int dgq_conv2d_f32w(const void* x, int x_dtype, int B, int H, int W, int C, int kh, int kw, int stride, int pad,
-                    const float* w, const float* bias, int N, void* y, int y_dtype, int ldy, void* stream);
+                    const float* w, const float* bias, int N, void* y, int y_dtype, int ldy,
+                    const float* pre_scale, const float* pre_shift, int pre_act, void* stream);
 
 /* ---- the hot kernel: W4A8 / W8A8 MFMA GEMM with fused dequantisation ------------------------------
  * Replaces F.linear / `w.view(N,-1) @ unfolded` / F.conv2d on fake-quantised operands

@@ -800,3 +800,22 @@ def test_weight_only_conv_kernel_vs_float64(shape, dtype, dev):
     yl = ops.conv2d_f32w(xl, wl.to(dev), None, 1, 1, 1, 0)
     refl = xl.double().cpu() @ wl.double().t()
     assert yl.shape == refl.shape and rel_l2(yl.double().cpu(), refl) < (2e-6 if dtype == torch.float32 else 1e-3)
+
+
+@pytest.mark.parametrize("N", [4, 72])
+def test_weight_only_conv_kernel_with_folded_groupnorm_silu(N, dev):
+    """conv(SiLU(GroupNorm(x))) in one launch of dgq_conv2d_f32w (conv_out of the UNets: FP conv behind conv_norm_out + SiLU)
+    against the float64 composition, for the N <= 8 form and the tiled form."""
+    from dgq_amd import ops
+    g = torch.Generator().manual_seed(N)
+    B, C, H = 2, 64, 12
+    x = (torch.randn(B, C, H, H, generator=g) * 2 + 0.5).to(dev)
+    w = torch.randn(N, C, 3, 3, generator=g) * 0.1
+    b = torch.randn(N, generator=g)
+    gamma = 1 + 0.1 * torch.randn(C, generator=g)
+    beta = 0.1 * torch.randn(C, generator=g)
+    wn = w.permute(0, 2, 3, 1).reshape(N, -1).contiguous().to(dev)
+    y = ops.conv2d_f32w(x, wn, b.to(dev), 3, 3, 1, 1, norm=(8, 1e-5, gamma.to(dev), beta.to(dev), 1))
+    xn = torch.nn.functional.silu(torch.nn.functional.group_norm(x.double().cpu(), 8, gamma.double(), beta.double(), 1e-5))
+    ref = torch.nn.functional.conv2d(xn, w.double(), b.double(), padding=1)
+    assert rel_l2(y.double().cpu(), ref) < 5e-6, rel_l2(y.double().cpu(), ref)
