@@ -781,6 +781,7 @@ class QuantLayer(nn.Module):
         """FP-state conv on the GPU outside autograd (conv_out of a quantized model): GroupNorm + SiLU fold into the load of
         dgq_conv2d_f32w."""
         return (FP_STATE_HIP and self.is_conv and not self.use_wq and not (self.use_aq and not self.disable_aq) and x.is_cuda
+                and not self._forward_hooks and not self._forward_pre_hooks     # (data capture hooks must see a plain call)
                 and x.dtype in ops.FLOAT_DTYPES and not torch.is_grad_enabled()
                 and tuple(self.fwd_kwargs.get("dilation", (1, 1)))[0] == 1 and self.fwd_kwargs.get("groups", 1) == 1)
 
