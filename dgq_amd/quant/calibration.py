@@ -200,9 +200,9 @@ def cali_model(qnn: QuantModel, w_cali_data: Tuple[torch.Tensor], a_cali_data: T
     (calibration_group_quantization.act_group_quant) consume.  Returns the saved dict.
 
     kwargs as the reference passes them (src/quantize_weight.py:192-207): iters, batch_size, w, asym, warmup, opt_mode,
-    multi_gpu, no_recon, resume_w, plus anything layer_ / block_reconstruction accept.  ``use_aq`` with QDiff-style scalar
-    activation calibration (cali_model_aq of calibration.py:45-97) is not part of the DGQ recipe — activations are
-    calibrated by act_group_quant — and raises."""
+    multi_gpu, no_recon, resume_w, plus anything layer_ / block_reconstruction accept.  ``use_aq`` appends QDiff-style scalar
+    activation calibration (``cali_model_aq``, calibration.py:45-97) and saves ``path``; DGQ's own recipe calibrates activations
+    with act_group_quant instead."""
     from .reconstruction import block_reconstruction, layer_reconstruction
     import os
     if tib_recon:
@@ -217,28 +217,32 @@ def cali_model(qnn: QuantModel, w_cali_data: Tuple[torch.Tensor], a_cali_data: T
         qnn(*(x[:min(1, x.shape[0])].to(dev) for x in w_cali_data))      # every wqtizer initialises on its weight
     qnn.disable_out_quantization()
     if resume_w:
+        # calibration.py:151-172: the stored weight quantizers replace reconstruction; nothing is written for the weights, and the
+        # branch falls through to the ``use_aq`` tail like the reference's does.
         load_cali_model(qnn, init_data=None, use_aq=False, path=resume_w)
         model_dict = {"weight": torch.load(resume_w, map_location="cpu")["weight"]}
-        return model_dict
-    if not no_recon:
-        for kind, name, module, keep_gpu in recon_targets(qnn, "unet"):
-            logger.info("Reconstruction for %s %s", kind, name)
-            fn = layer_reconstruction if kind == "layer" else block_reconstruction
-            fn(qnn, module, cali_data=w_cali_data, **dict(kwargs, keep_gpu=keep_gpu))
-    qnn.set_quant_state(use_wq=True, use_aq=False)
-    for name, module in qnn.model.named_modules():
-        if "wqtizer" in name and isinstance(module, (UniformAffineQuantizer, AdaRoundQuantizer)):
-            module.zero_point = _as_param(module.zero_point)
-            module.delta = _as_param(module.delta)
-    state = {k: v.detach().cpu().clone() for k, v in qnn.state_dict().items()}
-    model_dict = {"weight": state}
-    if path is not None:
-        os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
-        torch.save(model_dict, "%s_weight_only" % path)
-        logger.info("calibrated model saved to %s_weight_only", path)
+        logger.info("quantized model loaded from %s", resume_w)
+    else:
+        if not no_recon:
+            for kind, name, module, keep_gpu in recon_targets(qnn, "unet"):
+                logger.info("Reconstruction for %s %s", kind, name)
+                fn = layer_reconstruction if kind == "layer" else block_reconstruction
+                fn(qnn, module, cali_data=w_cali_data, **dict(kwargs, keep_gpu=keep_gpu))
+        qnn.set_quant_state(use_wq=True, use_aq=False)
+        for name, module in qnn.model.named_modules():
+            if "wqtizer" in name and isinstance(module, (UniformAffineQuantizer, AdaRoundQuantizer)):
+                module.zero_point = _as_param(module.zero_point)
+                module.delta = _as_param(module.delta)
+        state = {k: v.detach().cpu().clone() for k, v in qnn.state_dict().items()}
+        model_dict = {"weight": state}
+        if path is not None:
+            os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+            torch.save(model_dict, "%s_weight_only" % path)
+            logger.info("calibrated model saved to %s_weight_only", path)
     if use_aq:                                              # calibration.py:199-206: + one scalar (δ, z) table per interval
         model_dict = cali_model_aq(qnn, a_cali_data, model_dict, running_stat, interval)
         if path is not None:
+            os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
             torch.save(model_dict, path)
             logger.info("calibrated model saved to %s", path)
     return model_dict

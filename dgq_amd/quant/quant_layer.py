@@ -58,35 +58,6 @@ def lp_loss(pred: torch.Tensor, tgt: torch.Tensor, p: float = 2.0):
     return (pred - tgt).abs().pow(p).mean()
 
 
-def _bounds(symmetric, level, always_zero):
-    return (-level // 2, level // 2 - 1) if (symmetric and not always_zero) else (0, level - 1)
-
-
-def mse(x: torch.Tensor, symmetric: bool = False, level: int = 256, always_zero: bool = False):
-    """quant_layer.py:62-86: 80 shrink steps of the (min, max) range, the one with the smallest L2.4 reconstruction error wins
-    (the reference's default weight initialiser; ``--fast`` selects MINMAX instead)."""
-    x_min, x_max = x.min().item(), x.max().item()
-    delta, zero_point, s = None, None, 1e+10
-    NB, PB = _bounds(symmetric, level, always_zero)
-    for i in range(80):
-        new_min = x_min * (1. - (i * 0.01))
-        new_max = x_max * (1. - (i * 0.01))
-        new_delta = torch.tensor(float(new_max - new_min) / (level - 1))
-        if symmetric:
-            new_min, new_max = -max(abs(new_min), new_max), max(abs(new_min), new_max)
-            new_delta = (new_max - new_min) / (level - 2)
-        if always_zero:
-            new_delta = torch.tensor(float(new_max) / (level - 1))
-        new_zero_point = torch.round(-new_min / new_delta) if not (symmetric or always_zero) else 0
-        x_q = torch.clamp(torch.round(x / new_delta) + new_zero_point, NB, PB)
-        x_dq = new_delta * (x_q - new_zero_point)
-        new_s = lp_loss(x_dq, x, p=2.4)
-        if new_s < s:
-            s = new_s
-            delta, zero_point = new_delta, new_zero_point
-    return delta, zero_point
-
-
 def channel_mse(w: torch.Tensor, level: int):
     """``mse`` for every output channel at once (asymmetric weights): what quant_layer.py:253-264 computes with a python loop of
     80 full passes per channel.  Same arithmetic per channel — ranges shrunk in double precision and rounded to fp32 once,
@@ -112,99 +83,30 @@ def channel_mse(w: torch.Tensor, level: int):
     return delta.view(shape).to(w.dtype), zp.view(shape).to(w.dtype)
 
 
-def kl(x: torch.Tensor, symmetric: bool = False, level: int = 256, always_zero: bool = False):
-    """quant_layer.py:89-132: clip ratio in linspace(0.5, 1, 50) whose clipped histogram is closest (KL) to the data's, then MINMAX
-    of the clipped tensor.  numpy on the host, like the reference."""
-    import numpy as np
-
-    def to_hist_with_orig_bins(targ_hist, targ_bins, orig_hist, orig_bins):
-        targ_v, targ_i, targ_bin = 0.0, 0, targ_bins[0]
-        ret = np.zeros_like(orig_hist)
-        for i, orig_bin in enumerate(orig_bins[:-1]):
-            if targ_bin <= orig_bin:
-                if targ_i < len(targ_bins) - 1:
-                    targ_v = targ_hist[targ_i]
-                    targ_i += 1
-                    targ_bin = targ_bins[targ_i]
-                else:
-                    targ_v = 0.0
-                    targ_bin = orig_bin.max() + 1.0
-            ret[i] = targ_v
-        return ret
-
-    min_kl, res_clip_ratio = 1e5, 1.0
-    np_x = x.clone().detach().cpu().numpy()
-    ref_hist, ref_bins = np.histogram(np_x, bins=level, density=True)
-    sumd = np.sum(np.diff(ref_bins))
-    smooth_ref_hist = (ref_hist + 1e-5) / (1.0 + sumd * 1e-5)
-    for clip_ratio in np.linspace(0.5, 1.0, 50):
-        clip_range = [np.min(np_x) * clip_ratio, np.max(np_x) * clip_ratio]
-        q_hist, q_bins = np.histogram(np.clip(np_x, clip_range[0], clip_range[1]), bins=level, density=True)
-        c_q_hist = to_hist_with_orig_bins(q_hist, q_bins, ref_hist, ref_bins)
-        c_q_hist = (c_q_hist + 1e-5) / (1.0 + sumd * 1e-5)
-        kl_c_q = np.sum(smooth_ref_hist * np.log(smooth_ref_hist / c_q_hist))
-        if kl_c_q < min_kl:
-            min_kl, res_clip_ratio = kl_c_q, clip_ratio
-    x_min, x_max = float(np.min(np_x) * res_clip_ratio), float(np.max(np_x) * res_clip_ratio)
-    return minmax(torch.clamp(x.clone().detach(), x_min, x_max), symmetric, level, always_zero)
+def mse(x: torch.Tensor, symmetric: bool = False, level: int = 256, always_zero: bool = False):
+    """The scalar L2.4 range search (quant_layer.py:62-86) = ``channel_mse`` of the tensor taken as ONE channel: all 80 shrink
+    candidates are ranked by the same batched evaluation; 0-d (δ, z) like the reference returns."""
+    if symmetric or always_zero:
+        raise NotImplementedError("symmetric / always_zero range search is not on the DGQ path (every DGQ quantizer is asymmetric)")
+    d, z = channel_mse(x.reshape(1, -1), level)
+    return d.reshape(()), z.reshape(())
 
 
-def hist(x: torch.Tensor, symmetric: bool = False, level: int = 256, always_zero: bool = False):
-    """quant_layer.py:135-155: clip at the histogram bin where the cumulative mass of |x| reaches 0.9996, then MINMAX."""
-    import numpy as np
-    np_x = x.clone().detach().cpu().numpy()
-    data_max = max(-np.min(np_x), np.max(np_x))
-    h, _ = np.histogram(np_x, bins=level, range=(0, data_max), density=True)
-    h = h.astype(np.float32) / h.sum()
-    accum, x_min, x_max = 0, None, None
-    for i in range(len(h)):
-        accum += h[i]
-        if accum >= 0.9996:
-            clip_value = (i + 0.5) * (data_max / level)
-            x_min, x_max = max(-clip_value, np.min(np_x)), min(clip_value, np.max(np_x))
-            break
-    return minmax(torch.clamp(x.clone().detach(), float(x_min), float(x_max)), symmetric, level, always_zero)
-
-
-def omse(x: torch.Tensor, symmetric: bool = False, level: int = 256, always_zero: bool = False):
-    """quant_layer.py:157-179: exhaustive (range shrink × zero point) search, 80 × level candidates (note the reference re-derives
-    the range from the already shrunk one in every step: kept)."""
-    x_min, x_max = x.min().item(), x.max().item()
-    delta, zero_point, s = None, None, 1e+10
-    for i in range(80):
-        xrange = x_max - x_min
-        x_min = 0
-        x_max = xrange * (1. - (i * 0.01))
-        tmp_delta = torch.tensor(float(x_max - x_min) / (level - 1))
-        for j in range(level):
-            x_q = torch.clamp(torch.round(x / tmp_delta) + j, 0, level - 1)
-            new_s = lp_loss(tmp_delta * (x_q - j), x, p=2.4)
-            if new_s < s:
-                s, delta, zero_point = new_s, tmp_delta, j
-    return delta, zero_point
-
-
-def logminmax(x: torch.Tensor, symmetric: bool = False, level: int = 256, always_zero: bool = False):
-    """quant_layer.py:41-59, literally (fp16 copy; candidates 0.1 … 1.0; the dequantised value is δ·2^code as written there)."""
-    x_clone = x.clone().detach().to(torch.float16)
-    delta, best_score = x_clone.max(), 1e+10
-    for i in [0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8, 0.9, 1.0]:
-        x_int = torch.round(-1 * (x_clone / i).log2())
-        x_dq = i * 2 ** torch.clamp(x_int, 0, level - 1)
-        score = lp_loss(x_clone, x_dq, p=2)
-        if score < best_score:
-            best_score, delta = score, i
-    return torch.as_tensor(delta).type_as(x)
+def _outside_scope(name):
+    def scaler(x, symmetric=False, level=256, always_zero=False):
+        raise NotImplementedError("Scaler.%s is not selected by any DGQ recipe (SURVEY.md §2: out of scope); use MINMAX or MSE" % name)
+    scaler.__name__ = name.lower()
+    return scaler
 
 
 class Scaler(Enum):
-    """Same members as the reference enum (quant_layer.py:187-193)."""
+    """Same member names as the reference enum (quant_layer.py:187-193); the DGQ recipes select MINMAX (``--fast``) or MSE."""
     MINMAX = minmax
     MSE = mse
-    KL = kl
-    HIST = hist
-    OMSE = omse
-    LOGMINMAX = logminmax
+    KL = _outside_scope("KL")
+    HIST = _outside_scope("HIST")
+    OMSE = _outside_scope("OMSE")
+    LOGMINMAX = _outside_scope("LOGMINMAX")
 
 
 QMODE = Enum("QMODE", ("QDIFF", "NORMAL", "PTQD"))

@@ -102,7 +102,7 @@ def main(argv=None):
     w_cali_data, a_cali_data, interval = calibration_data_generation(
         mt, pipe=pipe, cali_data_path=opt.cali_data_path, coco_path=opt.coco_path, cali_prompt_data_n=opt.cali_prompt_data_n,
         step_size=opt.step_size, time_aware_aqtizer=opt.time_aware_aqtizer, cali_data_size=opt.cali_data_size)
-    # src/quantize_weight.py:166-181.  Scaler.MSE (the non---fast initialiser) raises NotImplementedError in QuantModel here.
+    # src/quantize_weight.py:166-181
     wq_params = {"bits": opt.wq, "channel_wise": True, "scaler": Scaler.MINMAX if opt.fast else Scaler.MSE, "leaf_param": opt.no_recon}
     aq_params = {"bits": opt.aq, "channel_wise": False, "scaler": Scaler.MSE if opt.cali else Scaler.MINMAX, "leaf_param": opt.use_aq}
     softmax_aq_params = {"softmax_a_bit": opt.softmax_a_bit, "t2i_log_quant": opt.t2i_log_quant, "t2i_real_time": opt.t2i_real_time,
@@ -116,8 +116,10 @@ def main(argv=None):
     cali_model(qnn=qnn, use_aq=opt.use_aq, path=path, running_stat=opt.running_stat, interval=interval, tib_recon=opt.tib_recon,
                w_cali_data=w_cali_data, a_cali_data=a_cali_data, iters=opt.iters, batch_size=opt.batch_size, w=0.01, asym=opt.asym,
                warmup=0.2, opt_mode=RLOSS.MSE, multi_gpu=False, no_recon=opt.no_recon, resume_w=opt.resume_w)
-    logger.info("weight quantization is done: %s_weight_only", path)
-    return path + "_weight_only"
+    # what cali_model wrote: <path> with --use_aq, <path>_weight_only after a reconstruction; a bare --resume_w writes nothing
+    written = path if opt.use_aq else (opt.resume_w if opt.resume_w else path + "_weight_only")
+    logger.info("weight quantization is done: %s", written)
+    return written
 
 
 if __name__ == "__main__":

@@ -135,10 +135,18 @@ def test_weight_cli_use_aq_tail_writes_a_loadable_scalar_ckpt(tmp_path):
     from dgq_amd.quant import get_qmodel, Scaler
     common = ["--model_type", "mini", "--outdir", str(tmp_path / "res"), "--cali_data_path", str(tmp_path / "none"),
               "--time_aware_aqtizer", "true", "--t2i_log_quant", "true", "--t2i_real_time", "true", "--t2i_start_peak", "true"]
-    wpath = quantize_weight.main(common + ["--fast", "true", "--no_recon", "true", "--use_aq", "--running_stat", "true"])
-    full = wpath[:-len("_weight_only")]
+    full = quantize_weight.main(common + ["--fast", "true", "--no_recon", "true", "--use_aq", "--running_stat", "true"])
+    assert full.endswith("cali_ckpt.pth") and os.path.exists(full + "_weight_only")
     ck = torch.load(full)
     assert sorted(ck) == ["act_0", "act_1", "weight"]
+    # --resume_w <weights> --use_aq (calibration.py:151-172 falls through to :199-206): no reconstruction, the stored weight
+    # quantizers, and the activation tail still runs and writes <path>
+    common2 = [a.replace(str(tmp_path / "res"), str(tmp_path / "res2")) for a in common]
+    full2 = quantize_weight.main(common2 + ["--fast", "true", "--resume_w", full + "_weight_only", "--use_aq", "--running_stat", "true"])
+    assert full2 != full and os.path.exists(full2) and not os.path.exists(full2 + "_weight_only")
+    ck2 = torch.load(full2)
+    assert sorted(ck2) == ["act_0", "act_1", "weight"] and sorted(ck2["act_0"]) == sorted(ck["act_0"])
+    assert all(torch.equal(ck2["weight"][k], ck["weight"][k]) for k in ck["weight"])
     keys = list(ck["act_0"])
     assert keys and all(k.startswith("model.") and (k.endswith(".delta") or k.endswith(".zero_point")) for k in keys)
     assert all(v.numel() == 1 for v in ck["act_0"].values())              # scalar tables
