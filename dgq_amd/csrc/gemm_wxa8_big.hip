@@ -1,0 +1,295 @@
+// W4A8 GEMM for the compute-bound shapes: 256-row / 256-column workgroup tiles, eight waves in two groups that run ONE
+// BARRIER APART ("ping-pong"), a three-tile LDS-DMA ring with counted waits.  Same operands, same arithmetic and the same
+// epilogue (gemm_tile.h) as gemm_wxa8.hip's tile family — results are bit-identical — but a different loop structure:
+//
+//   * what bounds the 128x128 kernel at 8192^3 is the SIMD's issue port, not the matrix pipe: per K tile a wave issues 6
+//     LDS-DMA pieces (~100 issue cycles each) + 12 VALU per chunk of int4 widening around 16 MFMAs (512 pipe cycles), and the
+//     waves of a workgroup do so in lockstep — all of them stage, then all of them multiply (profiles/r02_gemm_pmc_*:
+//     MFMA busy 31-46 %).  Here a wave owns a 128x64 (per-M) output tile: half the DMA pieces and half the widening per MFMA;
+//   * the two waves of a SIMD belong to different GROUPS (waves 0-3 / 4-7).  Every phase is
+//         LOAD    ds_read the fragments of two chunks, issue this phase's share of tile t+2's DMA, [counted vmcnt], lgkmcnt(0)
+//         s_barrier
+//         COMPUTE the MFMAs of those two chunks (+ int4 widening, + per-K group flushes)
+//         s_barrier
+//     and group 1 runs one barrier behind group 0, so on every SIMD one wave's COMPUTE overlaps its partner's LOAD by
+//     construction instead of by the luck of two unsynchronised workgroups;
+//   * hazards are closed by construction, not by timing: a wave's ds_reads of a tile have RETURNED (lgkmcnt(0)) before the
+//     barrier it signals next, the DMA that overwrites that buffer is issued at least one barrier later by anyone; a tile's
+//     DMA is retired by every wave's counted vmcnt BEFORE a barrier that precedes its first read (cdna guide §5, "Read a
+//     staged buffer one phase AFTER the wait that retires it").
+//
+// Per-M (scalar / per-token activation scales): 256x256 tile, wave tile 128x64, int32 accumulators only (128 registers).
+// Per-K (DGQ channel groups): 128x256 tile, wave tile 64x64 — the fp32 group accumulators double the accumulator registers.
+#include "gemm_tile.h"
+
+namespace {
+
+constexpr int BIG_WVM = 2, BIG_WVN = 4, BIG_NW = 8, BIG_NT = 512;
+
+template <bool PER_M, typename TOut, int BM, int BN, int NBUF>
+__global__ __launch_bounds__(BIG_NT, 2) void gemm_big_kernel(GemmBatch bt) {
+    const GemmParams& p = bt.p[0];
+    int tile_n, tile_m;
+    {   // XCD-aware tile order (as gemm_wxa8_kernel): XCD k owns a contiguous m-major tile range
+        const int gx = gridDim.x, T = gridDim.x * gridDim.y;
+        const int bid = blockIdx.x + gx * blockIdx.y;
+        const int q = T >> 3, r = T & 7, xcd = bid & 7;
+        const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        tile_m = logical / gx;
+        tile_n = logical - tile_m * gx;
+    }
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    constexpr int WVM = BIG_WVM, WVN = BIG_WVN, NW = BIG_NW, NT = BIG_NT;
+    constexpr int WM = BM / WVM, WN = BN / WVN;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int A_BYTES = BM * BK, W_ROW = BK / 2, W_BYTES = BN * W_ROW, STAGE_BYTES = A_BYTES + W_BYTES;
+    constexpr int A_DMA = A_BYTES / 1024 / NW, W_DMA = W_BYTES / 1024 / NW, PER_TILE = A_DMA + W_DMA;
+    static_assert(A_BYTES % (1024 * NW) == 0 && W_BYTES % (1024 * NW) == 0, "whole 1-KiB pieces per wave");
+    static_assert(PER_TILE % 2 == 0 && PER_TILE * 2 <= 63, "two DMA shares per tile; vmcnt is 6 bits");
+    constexpr int NPH = 2, CPP = NCH / NPH;                  // phases per K tile, chunks per phase
+    constexpr int SHARE = PER_TILE / NPH;                    // DMA pieces a wave issues per phase
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int group = wid >> 2;                              // waves 0-3 / 4-7: the two waves of a SIMD are in different groups
+    const int wave_m = wid >> 2, wave_n = wid & 3;
+    const int n0 = tile_n * BN, m0 = tile_m * BM;
+    const int nk = p.Kp / BK;
+
+    // per-lane global source pointers of this wave's DMA pieces (k offset added per tile); swizzles as gemm_wxa8_kernel
+    const int8_t* a_src[A_DMA];
+#pragma unroll
+    for (int i = 0; i < A_DMA; ++i) {
+        const int row = (wid * A_DMA + i) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        a_src[i] = p.codes + (int64_t)min(m0 + row, p.M - 1) * p.Kp + 16 * c;
+    }
+    const uint8_t* w_src[W_DMA];
+#pragma unroll
+    for (int i = 0; i < W_DMA; ++i) {
+        const int row = (wid * W_DMA + i) * 16 + (lane >> 2);
+        const int c = (lane & 3) ^ ((row >> 2) & 3);
+        w_src[i] = p.wpacked + (int64_t)min(n0 + row, p.N - 1) * (p.Kp / 2) + 16 * c;
+    }
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(lptr_t)smem;
+    // piece q (0 .. PER_TILE-1) of K tile kt into ring stage `stage`: the A pieces first, then the W pieces
+    auto issue_piece = [&](int q, int kt, int stage) {
+        const uint32_t sa = lds_base + stage * STAGE_BYTES;
+#pragma unroll
+        for (int i = 0; i < A_DMA; ++i)
+            if (q == i) glds16(a_src[i] + (int64_t)kt * BK, __builtin_amdgcn_readfirstlane(sa + (wid * A_DMA + i) * 1024));
+#pragma unroll
+        for (int i = 0; i < W_DMA; ++i)
+            if (q == A_DMA + i) glds16(w_src[i] + (int64_t)kt * (BK / 2), __builtin_amdgcn_readfirstlane(sa + A_BYTES + (wid * W_DMA + i) * 1024));
+    };
+
+    v16i acc[TM][TN];
+    v16f accf[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0; accf[i][j][r] = 0.0f; }
+
+    // fragment addresses inside a stage: lane l holds row / column l & 31 and the 16 k of half l >> 5 of a chunk.  Row tiles are
+    // 32 rows apart — 4096 (A) / 2048 (W) bytes — and the swizzle terms do not change with them, so one address per chunk serves
+    // every row / column tile through a constant offset.
+    const int lr = lane & 31, hh = lane >> 5;
+    int a_base[NCH], w_base[NCH];
+    {
+        const int ra = wave_m * WM + lr, rw = wave_n * WN + lr;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            a_base[c] = ra * BK + (((2 * c + hh) ^ ((ra >> 1) & 7)) << 4);
+            w_base[c] = rw * W_ROW + ((c ^ ((rw >> 2) & 3)) << 4) + ((hh ^ ((rw >> 4) & 1)) << 3);
+        }
+    }
+
+    // ---- prologue: tiles 0 and 1 go out first; the epilogue vectors and the per-chunk flush coefficients are staged with ordinary
+    // loads (hipcc waits vmcnt(0) for them, which also lands tile 0 and 1: nothing else is in flight yet).
+    float* vtab = reinterpret_cast<float*>(smem + NBUF * STAGE_BYTES);     // [3][BM]: R0 R1 R2 | [4][BN]: alpha zw gamma vn
+    float* vcol = vtab + 3 * BM;
+    float* ctab = vcol + 4 * BN;                                           // per-K: [nk][NCH] flush coefficients | [nk] clear flags
+    static_assert(BM <= NT && BN <= NT, "one row / column of the epilogue vectors per thread");
+#pragma unroll
+    for (int q = 0; q < PER_TILE; ++q) issue_piece(q, 0, 0);
+    if (nk > 1) {
+#pragma unroll
+        for (int q = 0; q < PER_TILE; ++q) issue_piece(q, 1, 1);
+    }
+    {
+        if (tid < BM) {
+            const int m = min(m0 + tid, p.M - 1);
+            float rs = 0.0f;
+            for (int j = 0; j < p.rowsum_parts; ++j) rs += p.rowsum[(int64_t)j * p.M + m];
+            float r0 = 1.0f, r1 = rs, r2 = 0.0f;
+            if (PER_M) {
+                const int li = m % p.L;
+                const float md = p.mdelta[li], mz = p.mzp[li];
+                r0 = md; r1 = md * rs; r2 = md * (p.offset - mz);
+            }
+            vtab[tid] = r0; vtab[BM + tid] = r1; vtab[2 * BM + tid] = r2;
+        }
+        if (tid < BN) {
+            const int n = min(n0 + tid, p.N - 1);
+            vcol[tid] = p.alpha[n]; vcol[BN + tid] = p.zw[n]; vcol[2 * BN + tid] = p.gamma[n];
+            vcol[3 * BN + tid] = PER_M ? p.vn[n] : 0.0f;
+        }
+        if constexpr (!PER_M) {
+            // Summation by parts (gemm_wxa8.hip): accf += (δ_c − δ_next)·float(running total) at every chunk; the coefficient is
+            // non-zero at group ends only.  A clear mark on a K tile's last chunk makes that chunk's coefficient the full δ_c and
+            // asks for the totals to be cleared behind the tile.
+            const int nchunk = nk * NCH;
+            for (int e = tid; e < nchunk + nk; e += NT) {
+                if (e < nchunk) {
+                    const int tcl = (e / NCH) * NCH + NCH - 1;                  // last chunk of this chunk's K tile
+                    const bool clr = (p.cflush[tcl] & 0xFF) == 2;
+                    const float d = p.cdelta[e], dn = p.cdelta[min(e + 1, nchunk - 1)];
+                    const bool full = (e == nchunk - 1) || (e == tcl && clr);
+                    ctab[e] = full ? d : d - dn;
+                } else {
+                    const int t = e - nchunk;
+                    ctab[e] = (t + 1 < nk && (p.cflush[t * NCH + NCH - 1] & 0xFF) == 2) ? 1.0f : 0.0f;
+                }
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (group == 1) __builtin_amdgcn_s_barrier();            // group 1 runs one barrier behind group 0 from here on
+
+    int stage = 0, istage = 2 % NBUF;
+    for (int t = 0; t < nk; ++t) {
+        const uint8_t* sa = smem + stage * STAGE_BYTES;
+        const uint8_t* sw = sa + A_BYTES;
+#pragma unroll
+        for (int ph = 0; ph < NPH; ++ph) {
+            // ---------------- LOAD
+            v4i af[CPP][TM];
+            uint2 wf[CPP][TN];
+#pragma unroll
+            for (int cc = 0; cc < CPP; ++cc) {
+                const int c = ph * CPP + cc;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) wf[cc][j] = *reinterpret_cast<const uint2*>(sw + w_base[c] + j * (32 * W_ROW));
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[cc][i] = *reinterpret_cast<const v4i*>(sa + a_base[c] + i * (32 * BK));
+            }
+            float cq[CPP];
+            float tclr = 0.0f;
+            if constexpr (!PER_M) {
+#pragma unroll
+                for (int cc = 0; cc < CPP; ++cc) cq[cc] = ctab[t * NCH + ph * CPP + cc];
+                if (ph == NPH - 1) tclr = ctab[nk * NCH + t];
+            }
+            if (t + 2 < nk) {
+#pragma unroll
+                for (int q = 0; q < SHARE; ++q) issue_piece(ph * SHARE + q, t + 2, istage);
+            }
+            if (ph == NPH - 1) {
+                // tile t+1 (this wave's pieces) has landed; tile t+2, issued in this tile's two phases, stays in flight
+                if (t + 2 < nk) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PER_TILE) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            // ---------------- COMPUTE
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int cc = 0; cc < CPP; ++cc) {
+                v4i bf[TN];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const uint2 v = wf[cc][j];
+                    bf[j] = (v4i){(int)(v.x & 0x0F0F0F0Fu), (int)((v.x >> 4) & 0x0F0F0F0Fu),
+                                  (int)(v.y & 0x0F0F0F0Fu), (int)((v.y >> 4) & 0x0F0F0F0Fu)};
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+                        acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[cc][i], bf[j], acc[i][j], 0, 0, 0);
+                if constexpr (!PER_M) {
+                    const float sc = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, cq[cc])));
+                    if (sc != 0.0f) {
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+#pragma unroll
+                            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) accf[i][j][r] = __builtin_fmaf(sc, (float)acc[i][j][r], accf[i][j][r]);
+                    }
+                }
+            }
+            if constexpr (!PER_M) {
+                if (ph == NPH - 1 && __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, tclr)) != 0) {   // rare: a segment of totals ends
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
+                }
+            }
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        stage = (stage + 1 == NBUF) ? 0 : stage + 1;
+        istage = (istage + 1 == NBUF) ? 0 : istage + 1;
+    }
+    if (group == 0) __builtin_amdgcn_s_barrier();            // both groups have now passed the same number of barriers
+
+    gemm_store_tile<PER_M, TOut, BM, BN, WVM, WVN, 1, NBUF * STAGE_BYTES, TM, TN>(p, 0, smem, vtab, vcol, wid, lane, wave_m, wave_n, 0,
+                                                                                  m0, n0, acc, accf);
+}
+
+template <bool PER_M, typename TOut, int BM, int BN, int NBUF>
+void launch_big(const GemmBatch& bt, hipStream_t st) {
+    const GemmParams& p = bt.p[0];
+    constexpr int stage = BM * BK + BN * (BK / 2);
+    const int nk = p.Kp / BK;
+    const int lds = NBUF * stage + (3 * BM + 4 * BN) * 4 + (PER_M ? 0 : (((NCH + 1) * nk * 4 + 15) & ~15));
+    static std::atomic<bool> attr_set[64];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64 || !attr_set[dev].load(std::memory_order_acquire)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_big_kernel<PER_M, TOut, BM, BN, NBUF>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (dev >= 0 && dev < 64) attr_set[dev].store(true, std::memory_order_release);
+    }
+    dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, 1), block(BIG_NT);
+    hipLaunchKernelGGL((gemm_big_kernel<PER_M, TOut, BM, BN, NBUF>), grid, block, lds, st, bt);
+}
+
+template <typename TOut>
+int launch_big_dtype(const GemmBatch& bt, bool per_m, hipStream_t st) {
+    if (per_m) launch_big<true, TOut, 256, 256, 3>(bt, st);
+    else launch_big<false, TOut, 128, 256, 3>(bt, st);
+    return DGQ_OK;
+}
+
+}  // namespace
+
+// LDS the big kernel needs for a problem (the host checks it against the 160 KiB of a CU before it plans this kernel)
+size_t dgq_gemm_big_lds_bytes(bool per_m, int Kp) {
+    const int nk = Kp / BK;
+    const int bm = per_m ? 256 : 128, bn = 256;
+    return (size_t)3 * (bm * BK + bn * (BK / 2)) + (3 * bm + 4 * bn) * 4 + (per_m ? 0 : (((NCH + 1) * nk * 4 + 15) & ~15));
+}
+
+// W4 only, one problem, no K split (bt.n == 1, p.splits == 1): the caller (gemm_wxa8.hip: dispatch_gemm) has checked
+int dgq_launch_gemm_big(const GemmBatch& bt, bool per_m, int y_dtype, hipStream_t st) {
+    switch (y_dtype) {
+        case DGQ_F32: return launch_big_dtype<float>(bt, per_m, st);
+        case DGQ_F16: return launch_big_dtype<__half>(bt, per_m, st);
+        case DGQ_BF16: return launch_big_dtype<__hip_bfloat16>(bt, per_m, st);
+        default: dgq_set_error("dgq_gemm_wxa8: unknown y dtype %d", y_dtype); return DGQ_EINVAL;
+    }
+}

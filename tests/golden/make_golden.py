@@ -8,6 +8,7 @@
     python tests/golden/make_golden.py scalers          # F2b scale initialisers (MSE / KL / HIST / OMSE / LOGMINMAX)
     python tests/golden/make_golden.py unet c1|c2|c3    # F5 full SD UNet, 64x64 latents (minutes each)
     python tests/golden/make_golden.py ddim [steps]     # F5 N-step DDIM final latent (tens of minutes)
+    python tests/golden/make_golden.py ddim_traj [steps] [res]   # F5b every call of that run: ε output + the call's self-deviation
     python tests/golden/make_golden.py pndm | euler     # F7 vendored PNDM / EulerAncestral schedulers on a closed-form ε model
     python tests/golden/make_golden.py pndm_unet [steps] [res]   # F10 the reference QuantModel under the pipeline's PNDM loop
     DIFFUSERS_REWRITE=sdxl python tests/golden/make_golden.py unet xl   # SDXL (separate process)
@@ -304,6 +305,53 @@ def make_ddim(ref, steps=50, res=64, name="c2"):
     meta = dict(c)
     meta.update(arch="sd", res=res, guidance=7.5)
     save("f5_ddim%d_sd_%s_r%d.pt" % (steps, name, res), dict(meta=meta, final_latent=out))
+
+
+def make_ddim_traj(ref, steps=50, res=64, name="c2"):
+    """F5b: every UNet call of the reference's N-step DDIM run of C2, not only the final latent.  Per call:
+    the ε output of the reference QuantModel on the CFG pair [2,4,res,res] and the reference's OWN deviation on that very input
+    when only the BLAS thread count changes (a scalar: the noise floor of the call, the scale any other implementation's
+    deviation is read against).  The inputs are not stored: latent_in of call i+1 is the DDIM step (elementwise fp32, oracle.DDIM)
+    of latent_in of call i and the stored ε — the script asserts that this reconstruction is bit-identical to the trajectory it
+    ran."""
+    from oracle import dgq_oracle as orc
+    c = dict(UNET_CFG[name])
+    c["steps"] = steps
+    qnn, path = build_ref_unet_qnn(ref, "sd", c, res, 2, steps,
+                                   path="/tmp/golden_sd_ddim%d_%s_r%d.pth" % (steps, name, res))
+    lat = synth.named_randn("latent", (1, 4, res, res), 1)
+    ctx = synth.named_randn("ctx", (2, 77, 768), 2)
+    sch = orc.DDIM(steps)
+    nt = torch.get_num_threads()
+    x = lat.clone()
+    eps_all, self_dev, lat_in = [], [], []
+    for i, t in enumerate(sch.timesteps):
+        t0 = time.time()
+        inp = torch.cat([x, x], dim=0)
+        y = qnn(inp, torch.tensor(t), ctx)[0].clone()
+        t1 = time.time()
+        torch.set_num_threads(1)
+        y1 = qnn(inp, torch.tensor(t), ctx)[0]
+        torch.set_num_threads(nt)
+        sd = ((y1.double() - y.double()).norm() / y.double().norm()).item()
+        print("  call %d t=%d  %.1fs + %.1fs (1 thread)  self-deviation %.4g" % (i, t, t1 - t0, time.time() - t1, sd), flush=True)
+        lat_in.append(x.clone())
+        eps_all.append(y)
+        self_dev.append(sd)
+        e_u, e_c = y.chunk(2)
+        x = sch.step(e_u + 7.5 * (e_c - e_u), t, x)
+    # the reconstruction the test performs
+    xr = lat.clone()
+    for i, t in enumerate(sch.timesteps):
+        assert torch.equal(xr, lat_in[i]), i
+        e_u, e_c = eps_all[i].chunk(2)
+        xr = sch.step(e_u + 7.5 * (e_c - e_u), t, xr)
+    assert torch.equal(xr, x)
+    meta = dict(c)
+    meta.update(arch="sd", res=res, guidance=7.5, threads=nt)
+    save("f5b_ddim%d_traj_sd_%s_r%d.pt" % (steps, name, res),
+         dict(meta=meta, timesteps=list(sch.timesteps), eps=torch.stack(eps_all), self_dev=torch.tensor(self_dev, dtype=torch.float64),
+              final_latent=x))
 
 
 # --------------------------------------------------------------------------------------- F1/F6
@@ -797,6 +845,8 @@ if __name__ == "__main__":  # noqa: C901
         make_scalers(ref)
     elif what == "recon":
         make_recon(ref)
+    elif what == "ddim_traj":
+        make_ddim_traj(ref, int(sys.argv[2]) if len(sys.argv) > 2 else 50, int(sys.argv[3]) if len(sys.argv) > 3 else 64)
     elif what == "ddim":
         make_ddim(ref, int(sys.argv[2]) if len(sys.argv) > 2 else 50,
                   int(sys.argv[3]) if len(sys.argv) > 3 else 64)

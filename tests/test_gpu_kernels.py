@@ -167,6 +167,15 @@ def test_gemm_exact_integer_every_tile(tile, dev, monkeypatch):
         _gemm_exact_case(dev, 170, 200, 384, 8, seed=4)
 
 
+def test_gemm_exact_integer_big_kernel(dev, monkeypatch):
+    """the 256-row ping-pong kernel (gemm_wxa8_big.hip; the plan names it by BM = 256): exact integers on ragged M / N edges, one
+    and several workgroup tiles per dimension, K from a single tile (no steady state) to 17 tiles (every ring stage reused, a
+    clear of the running totals inside) — per-K on its 128x256 tile and per-M on 256x256"""
+    monkeypatch.setenv("DGQ_GEMM_FORCE", "256,256,1")
+    for (M, N, Kp, seed) in ((203, 332, 640, 3), (300, 700, 128, 5), (515, 260, 256, 6), (130, 513, 2176, 7), (700, 300, 384, 8)):
+        _gemm_exact_case(dev, M, N, Kp, 4, seed=seed)
+
+
 # ------------------------------------------------------------------------------------------ activation codes
 @pytest.mark.parametrize("case", [c for c in recipes.f3_cases() if c["state"] == "wa"], ids=lambda c: c["name"])
 def test_f3_layers_vs_reference(case, dev):

@@ -44,7 +44,15 @@ if os.environ.get("HEADLINE"):
     SHAPES = [(n, M, N, C, t, mode, od) for (n, M, N, C, t) in HEADLINE for mode in ("perK", "perM") for od in ("fp32", "bf16")]
 else:
     SHAPES = [s + ("fp32",) for s in (SHAPES_ALL[-2:] if os.environ.get("BIG_ONLY") else SHAPES_ALL)]
-print("%-40s %6s %6s %6s %5s %5s %9s %9s %7s" % ("shape", "M", "N", "K", "mode", "out", "us", "TOP/s", "frac"))
+# VARIANTS="default;128,128,1;256,256,1": each shape under several launch plans (DGQ_GEMM_FORCE, read per call) in ONE process
+VARIANTS = os.environ.get("VARIANTS", "default").split(";")
+if os.environ.get("ONLY"):
+    SHAPES = [s for s in SHAPES if any(k in s[0] for k in os.environ["ONLY"].split(";"))]
+if os.environ.get("MODES"):
+    SHAPES = [s for s in SHAPES if s[5] in os.environ["MODES"].split(";")]
+if os.environ.get("OUTS"):
+    SHAPES = [s for s in SHAPES if s[6] in os.environ["OUTS"].split(";")]
+print("%-40s %6s %6s %6s %5s %5s %12s %9s %9s %7s" % ("shape", "M", "N", "K", "mode", "out", "plan", "us", "TOP/s", "frac"))
 for name, M, N, C, taps, mode, od in SHAPES:
     odt = OUT_DTYPES[od]
     K = C * taps
@@ -64,22 +72,32 @@ for name, M, N, C, taps, mode, od in SHAPES:
     codes = torch.randint(-128, 128, (M, ab.Kp), dtype=torch.int8, device=dev)
     rowsum = torch.randn(M, device=dev)
     out = torch.empty(M, N, device=dev, dtype=odt)
-    for _ in range(3):
-        ops.gemm_wxa8(codes, rowsum, M, ab, odt, out)
-    torch.cuda.synchronize()
-    # capture `iters` launches in a hipGraph so that host launch overhead (python + ctypes ~15 us/call) is excluded
-    graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
-        for _ in range(iters):
+    for var in VARIANTS:
+        if var == "default":
+            os.environ.pop("DGQ_GEMM_FORCE", None)
+        else:
+            os.environ["DGQ_GEMM_FORCE"] = var
+        for _ in range(3):
             ops.gemm_wxa8(codes, rowsum, M, ab, odt, out)
-    graph.replay()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    graph.replay()
-    e1.record()
-    torch.cuda.synchronize()
-    us = e0.elapsed_time(e1) * 1e3 / iters
-    tops = 2.0 * M * N * K / (us * 1e-6) / 1e12
-    print("%-40s %6d %6d %6d %5s %5s %9.1f %9.1f %6.1f%%  Kp=%d" % (name, M, N, K, mode, od, us, tops, 100 * tops / PEAK, ab.Kp))
+        torch.cuda.synchronize()
+        # capture `iters` launches in a hipGraph so that host launch overhead (python + ctypes ~15 us/call) is excluded
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            for _ in range(iters):
+                ops.gemm_wxa8(codes, rowsum, M, ab, odt, out)
+        graph.replay()
+        torch.cuda.synchronize()
+        best = 1e30
+        for _rep in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            graph.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1) * 1e3 / iters)
+        us = best
+        tops = 2.0 * M * N * K / (us * 1e-6) / 1e12
+        print("%-40s %6d %6d %6d %5s %5s %12s %9.1f %9.1f %6.1f%%  Kp=%d" % (name, M, N, K, mode, od, var, us, tops, 100 * tops / PEAK, ab.Kp), flush=True)
+        del graph
+    os.environ.pop("DGQ_GEMM_FORCE", None)
     del pw, ab, codes, out
