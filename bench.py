@@ -345,6 +345,10 @@ def measure_gemm_roofline(torch, ops, qnn, run_step, args):
         e1.synchronize()
         times_ms.append(e0.elapsed_time(e1) / REP)
         layers[0] += len(problems)
+        if os.environ.get("DGQ_BENCH_GEMM_DUMP"):            # per-launch table for tools (shape, scale mode, time)
+            with open(os.environ["DGQ_BENCH_GEMM_DUMP"], "a") as f:
+                f.write("%s %.2f\n" % (";".join("%d,%d,%d,%d,%s,%d" % (M, ab.pw.N, ab.pw.K, ab.Kp, ab.mode, es) for M, ab, es in problems),
+                                       1e3 * times_ms[-1]))
         # un-unfolded input counted once at 1 B/code, int4 weights, output at its dtype
         algo_ops.append(sum(2.0 * M * ab.pw.N * ab.pw.K for M, ab, _ in problems))
         algo_bytes.append(sum(M * ab.pw.K / max(1, ab.pw.taps) + ab.pw.N * ab.pw.K * ab.pw.bits / 8 + M * ab.pw.N * es

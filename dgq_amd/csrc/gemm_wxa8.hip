@@ -457,6 +457,10 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(GemmParams p) {
     }
 }
 
+// gemm_wxa8_big.hip: the 256-row ping-pong kernel (W4, one problem, no K split); the plan names it by bm == 256
+int dgq_launch_gemm_big(const GemmBatch& bt, bool per_m, int y_dtype, hipStream_t st);
+size_t dgq_gemm_big_lds_bytes(bool per_m, int Kp);
+
 template <int WBITS, bool PER_M, typename TOut, int BM, int BN, int WVM, int WVN, int WVK, int NST>
 static void launch_tile(const GemmBatch& bt, hipStream_t st) {
     const GemmParams& p = bt.p[0];
@@ -532,10 +536,6 @@ static int launch_one(const GemmBatch& bt, int bm, int bn, hipStream_t st) {
     return DGQ_OK;
 }
 
-// gemm_wxa8_big.hip: the 256-row ping-pong kernel (W4, one problem, no K split); the plan names it by bm == 256
-int dgq_launch_gemm_big(const GemmBatch& bt, bool per_m, int y_dtype, hipStream_t st);
-size_t dgq_gemm_big_lds_bytes(bool per_m, int Kp);
-
 template <int WBITS, bool PER_M>
 static int launch_gemm(const GemmBatch& p, int bm, int bn, int y_dtype, hipStream_t st) {
     int rc;
@@ -566,7 +566,7 @@ static int launch_gemm(const GemmBatch& p, int bm, int bn, int y_dtype, hipStrea
 //   * a K split pays only when the unsplit grid cannot fill the chip (< 256 blocks) AND K is long (> 60 tiles): slabs
 //     cost S·M·N·8 B of traffic plus a combine launch; then S brings the grid to ~480 blocks.
 struct GemmPlan { int bm, bn, splits; double t; };
-static GemmPlan plan_gemm(int M, int N, int Kp, int w_bits, size_t ws_bytes, bool per_m) {
+static GemmPlan plan_gemm(int M, int N, int Kp, int w_bits, size_t ws_bytes, bool per_m, bool allow_big = true) {
     const int nk = Kp / BK;
     const double out = (double)M * N;
     GemmPlan pl = {32, 64, 1, 0.0};
@@ -589,6 +589,21 @@ static GemmPlan plan_gemm(int M, int N, int Kp, int w_bits, size_t ws_bytes, boo
         }
     } else if (M >= 4096 && nk >= 24) {
         pl = (N % 128 != 0) ? GemmPlan{64, 64, 1, 0.0} : GemmPlan{32, 128, 1, 0.0};   // 8192x320x2880: 28 -> 25 us at 64x64
+    }
+    // The 256-row ping-pong kernel (gemm_wxa8_big.hip; bm = 256 names it): W4, one unsplit problem.  One workgroup per CU and no
+    // overlap between a workgroup's store epilogue and the next one's prologue, so it needs (a) at least one full round of
+    // 256x256 (per-M) / 256x128 (per-K) tiles over the 256 CUs with N a whole number of tiles, and (b) enough work per tile:
+    // K >= 4096, or — per-M — a wide N (>= 4096).  Measured in the model (SDXL C5, fp32 outputs with residual / GroupNorm
+    // epilogues, profiles/r04_c5_gemm_big_vs_tiles.txt): 8192x10240x1280 -12 %, 32768x1280x11520 -2 %; 8192x1280x{1280,5120}
+    // (160 tiles) and 32768x640x2560 (2.5 column tiles) lose 35-100 % and stay on the tile family.  Per-K it pays on long K
+    // only (8192^3 34 -> 39 %): at K = 1280 with 16 groups the flushes bound either kernel.
+    static const bool big_on = [] { const char* e = getenv("DGQ_GEMM_BIG"); return !(e && *e == '0'); }();   // A/B hook
+    {
+        const int bn_big = per_m ? 256 : 128;
+        const long tiles = (long)((M + 255) / 256) * ((N + bn_big - 1) / bn_big);
+        if (big_on && allow_big && w_bits == 4 && pl.splits == 1 && M >= 2048 && N % bn_big == 0 && tiles >= 256 &&
+            (nk >= 32 || (per_m && nk >= 8 && N >= 4096)) && dgq_gemm_big_lds_bytes(per_m, Kp) <= 160 * 1024)
+            pl = {256, 256, 1, 0.0};
     }
     if (w_bits != 4) {                                   // W8 carries three tile shapes: nearest one
         if (pl.bm == 128 || pl.bn == 128) { pl.bm = 128; pl.bn = 128; }
@@ -685,7 +700,7 @@ extern "C" int dgq_gemm_wxa8_batch(int n, const dgq_gemm_args_t* args, void* str
                       "dgq_gemm_wxa8_batch: problem %d differs from problem 0 in weight bits / scale mode / output dtype", i);
     }
     const dgq_gemm_args_t& a0 = args[0];
-    GemmPlan pl = plan_gemm(a0.M, a0.N, a0.Kp, a0.w_bits, 0, a0.per_m != 0);
+    GemmPlan pl = plan_gemm(a0.M, a0.N, a0.Kp, a0.w_bits, 0, a0.per_m != 0, n == 1);
     forced_plan(pl);
     pl.splits = 1;
     return dispatch_gemm(bt, a0.w_bits, a0.per_m != 0, pl.bm, pl.bn, a0.y_dtype, (hipStream_t)stream);

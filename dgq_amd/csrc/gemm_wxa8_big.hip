@@ -22,7 +22,39 @@
 // Per-K (DGQ channel groups): 128x256 tile, wave tile 64x64 — the fp32 group accumulators double the accumulator registers.
 #include "gemm_tile.h"
 
+// Build-time experiment switches (tools/build_variants.sh builds one library per setting for A/B runs on one box)
+#ifndef BIG_GROUP_M
+#define BIG_GROUP_M 4          // > 0: inside an XCD's tile range, walk GROUP_M row tiles per column tile (L2 reuse of both operands)
+#endif
+#ifndef BIG_NPH_M
+#define BIG_NPH_M 2            // phases per K tile, per-M (2: two chunks = 16 MFMAs per phase and wave)
+#endif
+#ifndef BIG_NPH_K
+#define BIG_NPH_K 1            // phases per K tile, per-K (1: four chunks = 16 MFMAs per phase on the 64x64 wave tile)
+#endif
+#ifndef BIG_PRIO
+#define BIG_PRIO 1             // s_setprio 1 around the COMPUTE segment (0: not; measured neutral)
+#endif
+
+#ifndef BIG_PERK_TILE
+#define BIG_PERK_TILE 1        // per-K tile: 0 = 128x256 (wave tile 64x64), 1 = 256x128 (wave tile 128x32; measured 38.2 vs 37.3 % at 8192^3)
+#endif
+// ablations (WRONG results, timing only): what the loop costs without its DMA / fragment reads / int4 widening / flushes
+#ifndef BIG_ABL
+#define BIG_ABL 0              // bit 0: no DMA in the loop, bit 1: no fragment reads, bit 2: no widening, bit 3: no flush
+#endif
+
+#ifndef BIG_STAMP
+#define BIG_STAMP 0            // 1 (diagnostic build, WRONG output): s_memtime stamps of K tile 8 of workgroup 0, written over y row 0
+#endif
+
 namespace {
+
+__device__ __forceinline__ uint64_t big_stamp() {
+    uint64_t v;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v)::"memory");
+    return v;
+}
 
 constexpr int BIG_WVM = 2, BIG_WVN = 4, BIG_NW = 8, BIG_NT = 512;
 
@@ -35,8 +67,16 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_big_kernel(GemmBatch bt) {
         const int bid = blockIdx.x + gx * blockIdx.y;
         const int q = T >> 3, r = T & 7, xcd = bid & 7;
         const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-        tile_m = logical / gx;
-        tile_n = logical - tile_m * gx;
+        if (BIG_GROUP_M > 0) {
+            constexpr int GM = BIG_GROUP_M > 0 ? BIG_GROUP_M : 1;
+            const int gy = gridDim.y, band = logical / (GM * gx), first_m = band * GM;
+            const int gsz = min(GM, gy - first_m), in = logical - band * GM * gx;
+            tile_n = in / gsz;
+            tile_m = first_m + (in - tile_n * gsz);
+        } else {
+            tile_m = logical / gx;
+            tile_n = logical - tile_m * gx;
+        }
     }
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr int WVM = BIG_WVM, WVN = BIG_WVN, NW = BIG_NW, NT = BIG_NT;
@@ -45,9 +85,8 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_big_kernel(GemmBatch bt) {
     constexpr int A_BYTES = BM * BK, W_ROW = BK / 2, W_BYTES = BN * W_ROW, STAGE_BYTES = A_BYTES + W_BYTES;
     constexpr int A_DMA = A_BYTES / 1024 / NW, W_DMA = W_BYTES / 1024 / NW, PER_TILE = A_DMA + W_DMA;
     static_assert(A_BYTES % (1024 * NW) == 0 && W_BYTES % (1024 * NW) == 0, "whole 1-KiB pieces per wave");
-    static_assert(PER_TILE % 2 == 0 && PER_TILE * 2 <= 63, "two DMA shares per tile; vmcnt is 6 bits");
-    constexpr int NPH = 2, CPP = NCH / NPH;                  // phases per K tile, chunks per phase
-    constexpr int SHARE = PER_TILE / NPH;                    // DMA pieces a wave issues per phase
+    static_assert(PER_TILE * 2 <= 63, "vmcnt is 6 bits");
+    constexpr int NPH = PER_M ? BIG_NPH_M : BIG_NPH_K, CPP = NCH / NPH;   // phases per K tile, chunks per phase
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -160,22 +199,41 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_big_kernel(GemmBatch bt) {
     __builtin_amdgcn_s_barrier();
     if (group == 1) __builtin_amdgcn_s_barrier();            // group 1 runs one barrier behind group 0 from here on
 
+    uint64_t stamps[6 * NPH];
+    auto stamp = [&](int k, int t) {
+        if (BIG_STAMP && t == 8) stamps[k] = big_stamp();
+    };
+#pragma unroll
+    for (int k = 0; k < 6 * NPH; ++k) stamps[k] = 0;
     int stage = 0, istage = 2 % NBUF;
-    for (int t = 0; t < nk; ++t) {
+    // One K tile.  DMA = true: the steady state — tile t+2 goes out, every wait is the counted one, and the instruction stream has
+    // NO taken branch besides the loop's back edge (a taken branch costs a wave ~100 cycles of refetch: the in-line flush block of
+    // the first version made 8192^3 g16 take 646 us against 387 us without any flush code; conditionals of the tail — "is there
+    // a tile t+2?" — inside one loop body cost the LOAD segment two of them per tile).  DMA = false: the last two tiles.
+    auto tile = [&](int t, auto dma_c) {
+        constexpr bool DMA = decltype(dma_c)::value && !(BIG_ABL & 1);
         const uint8_t* sa = smem + stage * STAGE_BYTES;
         const uint8_t* sw = sa + A_BYTES;
 #pragma unroll
         for (int ph = 0; ph < NPH; ++ph) {
             // ---------------- LOAD
+            stamp(6 * ph + 0, t);
             v4i af[CPP][TM];
             uint2 wf[CPP][TN];
 #pragma unroll
             for (int cc = 0; cc < CPP; ++cc) {
                 const int c = ph * CPP + cc;
+                if (BIG_ABL & 2) {
 #pragma unroll
-                for (int j = 0; j < TN; ++j) wf[cc][j] = *reinterpret_cast<const uint2*>(sw + w_base[c] + j * (32 * W_ROW));
+                    for (int j = 0; j < TN; ++j) wf[cc][j] = make_uint2(lane + c, lane + j);
 #pragma unroll
-                for (int i = 0; i < TM; ++i) af[cc][i] = *reinterpret_cast<const v4i*>(sa + a_base[c] + i * (32 * BK));
+                    for (int i = 0; i < TM; ++i) af[cc][i] = (v4i){lane, c, i, t};
+                } else {
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) wf[cc][j] = *reinterpret_cast<const uint2*>(sw + w_base[c] + j * (32 * W_ROW));
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) af[cc][i] = *reinterpret_cast<const v4i*>(sa + a_base[c] + i * (32 * BK));
+                }
             }
             float cq[CPP];
             float tclr = 0.0f;
@@ -184,39 +242,48 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_big_kernel(GemmBatch bt) {
                 for (int cc = 0; cc < CPP; ++cc) cq[cc] = ctab[t * NCH + ph * CPP + cc];
                 if (ph == NPH - 1) tclr = ctab[nk * NCH + t];
             }
-            if (t + 2 < nk) {
+            if (DMA) {
 #pragma unroll
-                for (int q = 0; q < SHARE; ++q) issue_piece(ph * SHARE + q, t + 2, istage);
+                for (int q = 0; q < PER_TILE; ++q)
+                    if ((q * NPH) / PER_TILE == ph) issue_piece(q, t + 2, istage);
             }
+            stamp(6 * ph + 1, t);
             if (ph == NPH - 1) {
-                // tile t+1 (this wave's pieces) has landed; tile t+2, issued in this tile's two phases, stays in flight
-                if (t + 2 < nk) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PER_TILE) : "memory");
+                // tile t+1 (this wave's pieces) has landed; tile t+2, issued in this tile's phases, stays in flight
+                if (DMA) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PER_TILE) : "memory");
                 else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             } else {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-            // ---------------- COMPUTE
-            __builtin_amdgcn_s_setprio(1);
+            // int4 -> int8 here, not in COMPUTE: the fragments have just arrived, and the MFMA segment then opens with an MFMA
+            v4i bf[CPP][TN];
 #pragma unroll
-            for (int cc = 0; cc < CPP; ++cc) {
-                v4i bf[TN];
+            for (int cc = 0; cc < CPP; ++cc)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     const uint2 v = wf[cc][j];
-                    bf[j] = (v4i){(int)(v.x & 0x0F0F0F0Fu), (int)((v.x >> 4) & 0x0F0F0F0Fu),
-                                  (int)(v.y & 0x0F0F0F0Fu), (int)((v.y >> 4) & 0x0F0F0F0Fu)};
+                    if (BIG_ABL & 4) bf[cc][j] = (v4i){(int)v.x, (int)v.y, (int)v.x, (int)v.y};
+                    else bf[cc][j] = (v4i){(int)(v.x & 0x0F0F0F0Fu), (int)((v.x >> 4) & 0x0F0F0F0Fu),
+                                           (int)(v.y & 0x0F0F0F0Fu), (int)((v.y >> 4) & 0x0F0F0F0Fu)};
                 }
+            stamp(6 * ph + 2, t);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            stamp(6 * ph + 3, t);
+            __builtin_amdgcn_sched_barrier(0);
+            // ---------------- COMPUTE
+            if (BIG_PRIO == 1) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int cc = 0; cc < CPP; ++cc) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
-                        acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[cc][i], bf[j], acc[i][j], 0, 0, 0);
-                if constexpr (!PER_M) {
+                        acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[cc][i], bf[cc][j], acc[i][j], 0, 0, 0);
+                if constexpr (!PER_M && !(BIG_ABL & 8)) {
+                    // a group ends behind this chunk (coefficient != 0): out of line, the common case falls through
                     const float sc = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, cq[cc])));
-                    if (sc != 0.0f) {
+                    if (__builtin_expect(sc != 0.0f, 0)) {
 #pragma unroll
                         for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -227,7 +294,7 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_big_kernel(GemmBatch bt) {
                 }
             }
             if constexpr (!PER_M) {
-                if (ph == NPH - 1 && __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, tclr)) != 0) {   // rare: a segment of totals ends
+                if (ph == NPH - 1 && __builtin_expect(__builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, tclr)) != 0, 0)) {   // rare: a segment of totals ends
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -236,18 +303,32 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_big_kernel(GemmBatch bt) {
                             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
                 }
             }
-            __builtin_amdgcn_s_setprio(0);
+            if (BIG_PRIO == 1) __builtin_amdgcn_s_setprio(0);
+            stamp(6 * ph + 4, t);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
+            stamp(6 * ph + 5, t);
             __builtin_amdgcn_sched_barrier(0);
         }
         stage = (stage + 1 == NBUF) ? 0 : stage + 1;
         istage = (istage + 1 == NBUF) ? 0 : istage + 1;
-    }
+    };
+    int t = 0;
+    for (; t + 2 < nk; ++t) tile(t, std::true_type());
+    for (; t < nk; ++t) tile(t, std::false_type());
     if (group == 0) __builtin_amdgcn_s_barrier();            // both groups have now passed the same number of barriers
 
     gemm_store_tile<PER_M, TOut, BM, BN, WVM, WVN, 1, NBUF * STAGE_BYTES, TM, TN>(p, 0, smem, vtab, vcol, wid, lane, wave_m, wave_n, 0,
                                                                                   m0, n0, acc, accf);
+    if (BIG_STAMP) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    if (BIG_STAMP && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) {
+        uint64_t* dbg = reinterpret_cast<uint64_t*>(p.y) + wid * 16;
+#pragma unroll
+        for (int k = 0; k < 6 * NPH; ++k) dbg[k] = stamps[k];
+    }
 }
 
 template <bool PER_M, typename TOut, int BM, int BN, int NBUF>
@@ -271,7 +352,8 @@ void launch_big(const GemmBatch& bt, hipStream_t st) {
 template <typename TOut>
 int launch_big_dtype(const GemmBatch& bt, bool per_m, hipStream_t st) {
     if (per_m) launch_big<true, TOut, 256, 256, 3>(bt, st);
-    else launch_big<false, TOut, 128, 256, 3>(bt, st);
+    else if (BIG_PERK_TILE == 0) launch_big<false, TOut, 128, 256, 3>(bt, st);
+    else launch_big<false, TOut, 256, 128, 3>(bt, st);
     return DGQ_OK;
 }
 
@@ -280,7 +362,7 @@ int launch_big_dtype(const GemmBatch& bt, bool per_m, hipStream_t st) {
 // LDS the big kernel needs for a problem (the host checks it against the 160 KiB of a CU before it plans this kernel)
 size_t dgq_gemm_big_lds_bytes(bool per_m, int Kp) {
     const int nk = Kp / BK;
-    const int bm = per_m ? 256 : 128, bn = 256;
+    const int bm = (per_m || BIG_PERK_TILE) ? 256 : 128, bn = (per_m || !BIG_PERK_TILE) ? 256 : 128;
     return (size_t)3 * (bm * BK + bn * (BK / 2)) + (3 * bm + 4 * bn) * 4 + (per_m ? 0 : (((NCH + 1) * nk * 4 + 15) & ~15));
 }
 
