@@ -94,7 +94,7 @@ def spawn_ranks(args, argv):
     image); the ranks are child processes."""
     import torch
     visible = torch.cuda.device_count()
-    if visible < args.gpus:
+    if visible < args.gpus and not dry_run():
         sys.stderr.write("bench.py: --gpus %d requested but only %d GPU(s) visible; refusing to report a smaller run as "
                          "n_gpus=%d\n" % (args.gpus, visible, args.gpus))
         return 2
@@ -104,6 +104,30 @@ def spawn_ranks(args, argv):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     return subprocess.call(launch_command(args, argv, port), env=env)
+
+
+def dry_run():
+    """DGQ_BENCH_BACKEND=gloo: the LAUNCHER REHEARSAL — the same rank path (torchrun child, rank-seeded prompts, rank-0 ckpt
+    write + mmap read on the others, barriers, MAX all-reduce, one JSON line with n_gpus = N) on CPU ranks with the FP tiny
+    UNet, because the quantized kernels need a GPU.  The line is marked ``dry_run`` and is not a measurement."""
+    return os.environ.get("DGQ_BENCH_BACKEND", "nccl") == "gloo"
+
+
+class _FpDryModel:
+    """FP tiny UNet behind the few QuantModel methods main() calls (launcher rehearsal only)."""
+
+    def __init__(self, unet, laps):
+        self.unet, self._build_laps, self._graphs = unet.eval(), laps, None
+
+    def prepare_slots(self, slots):
+        pass
+
+    def enable_graphs(self, on):
+        pass
+
+    def __call__(self, x, t, ctx, **kw):
+        import torch
+        return self.unet(x, torch.tensor(int(t)), encoder_hidden_states=ctx)
 
 
 def main(argv=None):
@@ -124,19 +148,29 @@ def main(argv=None):
                          "--nproc-per-node equal to --gpus\n" % (world, args.gpus))
         return 2
     dist = None
-    torch.cuda.set_device(local_rank)
+    DRY = dry_run()
+    if not DRY:
+        torch.cuda.set_device(local_rank)
     # host-side work of the load (planning, packing tables, the synthetic ckpt): a GPU box shows every host thread but grants a
     # share of the cores — torch's default oversubscribes it (synthetic build 35.6 s against 25.1 s with 16 threads)
     torch.set_num_threads(min(torch.get_num_threads(), 16))
     if "RANK" in os.environ:          # launched by torch.distributed.run: one rank per GPU over RCCL (timing only)
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank)
+        if DRY:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group(os.environ.get("DGQ_BENCH_BACKEND", "nccl"), device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cpu") if DRY else torch.device("cuda", local_rank)
 
     from dgq_amd import ops, synth
-    from dgq_amd.runtime import build_synthetic_qnn, DDIMScheduler
+    from dgq_amd.runtime import build_synthetic_qnn, synthetic_fp_unet, DDIMScheduler
     from dgq_amd._lib import require_gpu
-    require_gpu()
+    if not DRY:
+        require_gpu()
+
+    def sync():
+        if not DRY:
+            torch.cuda.synchronize()
 
     def barrier():
         if dist is not None:
@@ -144,16 +178,25 @@ def main(argv=None):
 
     C = CONFIGS[args.config]
     arch, res, qcfg, guidance = C["arch"], C["res"], C["cfg"], C["guidance"]
+    if DRY:
+        arch, res, guidance = "tiny", 16, 7.5
+        args.no_graph = args.no_roofline = args.no_cpu_baseline = True
     K, W = args.steps, args.warmup
     P = args.prompts_per_gpu or C["prompts"]
     nsteps = qcfg["steps"]
     sch = DDIMScheduler(nsteps)
-    sched_ts = sch.timesteps if arch == "sd" else [999, 749, 499, 249]     # SDXL-turbo: src/inference_qmodel.py:49-54 trailing spacing
+    sched_ts = sch.timesteps if arch in ("sd", "tiny") else [999, 749, 499, 249]     # SDXL-turbo: src/inference_qmodel.py:49-54 trailing spacing
     n_ts = min(K + W, len(sched_ts))
     timesteps = [sched_ts[i % n_ts] for i in range(W + K)]
     slots = sorted({(1000 - t) // (1000 // nsteps) for t in timesteps})
     batch = (2 if guidance > 0 else 1) * P
-    qnn, ckpt_path = build_synthetic_qnn(arch, qcfg, res, batch, max(slots) + 1, rank=local_rank, barrier=barrier, device=dev)
+    t_model = time.perf_counter()
+    if DRY:
+        unet, ckpt_path, laps, _ = synthetic_fp_unet(arch, qcfg, res, batch, max(slots) + 1, ckpt_dir=os.environ.get("DGQ_BENCH_CKPT_DIR", "/tmp"),
+                                                     rank=rank, barrier=barrier)
+        qnn = _FpDryModel(unet, laps)
+    else:
+        qnn, ckpt_path = build_synthetic_qnn(arch, qcfg, res, batch, max(slots) + 1, rank=local_rank, barrier=barrier, device=dev)
     if args.dtype == "fp16":
         qnn.half()
     elif args.dtype == "bf16":
@@ -161,13 +204,14 @@ def main(argv=None):
     adt = {"fp32": torch.float32, "fp16": torch.float16, "bf16": torch.bfloat16}[args.dtype]
     t_prep = time.perf_counter()
     qnn.prepare_slots(slots)
-    torch.cuda.synchronize()
+    sync()
     t_prep = time.perf_counter() - t_prep
+    model_ready_s = time.perf_counter() - t_model
     if not args.no_graph:
         qnn.enable_graphs(True)
 
     # this rank's prompts (seeded by rank: rank-sliced prompt list), resident on the device
-    ctx_dim = 768 if arch == "sd" else 2048
+    ctx_dim = {"sd": 768, "sdxl": 2048, "tiny": 64}[arch]
     lat = synth.named_randn("latent", (P, 4, res, res), 1 + rank).to(dev, adt)
     ctx = synth.named_randn("ctx", (batch, 77, ctx_dim), 100 + rank).to(dev, adt)
     extra = {}
@@ -201,7 +245,7 @@ def main(argv=None):
             eps = e_u + guidance * (e_c - e_u)
         else:
             eps = qnn(x, t, ctx, **extra)[0]
-        if arch == "sd":
+        if arch in ("sd", "tiny"):
             return sch.step(eps, t, x)
         raise AssertionError("unreachable: SDXL-turbo steps return above")
 
@@ -216,15 +260,15 @@ def main(argv=None):
         x_w = x
         for _ in range(max(1, args.windows)):
             x = x_w
-            torch.cuda.synchronize()
+            sync()
             barrier()
-            torch.cuda.synchronize()
+            sync()
             t0 = time.perf_counter()
             for t in timesteps[W:]:
                 x = one_step(x, t)
-            torch.cuda.synchronize()
+            sync()
             barrier()
-            torch.cuda.synchronize()
+            sync()
             el = time.perf_counter() - t0
             if dist is not None:
                 tt = torch.tensor([el], device=dev, dtype=torch.float64)
@@ -233,6 +277,12 @@ def main(argv=None):
             windows.append(el)
     assert torch.isfinite(x).all()
     elapsed = statistics.median(windows)
+    ready_per_rank = [round(model_ready_s, 1)]
+    if dist is not None:                   # every rank's load time (they run concurrently; rank 0 also writes the ckpt)
+        tt = torch.zeros(world, device=dev, dtype=torch.float64)
+        tt[rank] = model_ready_s
+        dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+        ready_per_rank = [round(float(v), 1) for v in tt.tolist()]
 
     # ---- roofline of the dominant north-star kernel (W4A8 GEMM), measured live with HIP events ------------------
     # One eager step with the GEMM entry point wrapped: every launch (its split-K reduction included) is replayed REP
@@ -307,7 +357,8 @@ def main(argv=None):
                              "synthetic ckpt's generation ('write cali_ckpt') is test-data synthesis, not a load cost; the reference's "
                              "load_cali_model alone is 91-107 s on CPU (SURVEY.md §6)",
                      "host_max_rss_gb": round(resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1e6, 1),
-                     "device_mem_gb": round(torch.cuda.max_memory_allocated() / 1e9, 1)})
+                     "model_ready_s_per_rank": ready_per_rank,
+                     "device_mem_gb": None if DRY else round(torch.cuda.max_memory_allocated() / 1e9, 1)})
         out = {
             "metric": C["metric"], "value": round(K * n * P / elapsed, 4),
             "unit": "steps/s", "n_gpus": n, "steps": K, "warmup": W, "ms_per_step": round(1e3 * elapsed / (K * P), 3),
@@ -322,6 +373,10 @@ def main(argv=None):
             "roofline": roofline, "cpu_baseline": cpu_baseline, "load": load,
             "non_hip_kernels": glue,
         }
+        if DRY:
+            out["dry_run"] = "DGQ_BENCH_BACKEND=gloo: launcher rehearsal on CPU ranks with the FP tiny UNet — NOT a measurement"
+            out["config"]["workload"] = "dry run: FP tiny UNet 16x16 on CPU (gloo)"
+            out["dtype"] = "fp32 (dry run)"
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

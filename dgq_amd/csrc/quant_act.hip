@@ -822,6 +822,11 @@ extern "C" int dgq_quant_act_batch(int n, const dgq_quant_act_args_t* args, void
         DGQ_CHECK_ARG(v == variant && args[i].x_dtype == args[0].x_dtype && (args[i].per_m != 0) == (args[0].per_m != 0) &&
                       bt.p[i].M == bt.p[0].M,
                       "dgq_quant_act_batch: problem %d differs from problem 0 in kernel variant / dtype / scale mode / row count", i);
+        // the block-staged conv path takes its tile shape, grid and LDS size from problem 0: one geometry per launch
+        DGQ_CHECK_ARG(v != 5 || (args[i].B == args[0].B && args[i].H == args[0].H && args[i].W == args[0].W && args[i].C == args[0].C &&
+                                 args[i].kh == args[0].kh && args[i].kw == args[0].kw && args[i].stride == args[0].stride &&
+                                 args[i].pad == args[0].pad && args[i].Kp == args[0].Kp),
+                      "dgq_quant_act_batch: block-staged conv problems of one launch must share their geometry (problem %d)", i);
     }
     hipStream_t st = (hipStream_t)stream;
     const bool per_m = args[0].per_m != 0;

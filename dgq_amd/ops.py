@@ -322,10 +322,17 @@ def cat_channels(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     """torch.cat([a, b], dim=1) of two NCHW tensors that keeps the GroupNorm partials of both sources (the skip concatenation in
     front of an up block's norm1): dgq_groupnorm_from_partials takes the two partial buffers as one channel range."""
     y = torch.cat([a, b], dim=1)
-    ga, gb = getattr(a, "_dgq_gn", None), getattr(b, "_dgq_gn", None)
+    ga, gb = _gn_of(a), _gn_of(b)
     if ga is not None and gb is not None and len(ga["parts"]) == 1 and len(gb["parts"]) == 1 and ga["B"] == gb["B"] and ga["HW"] == gb["HW"]:
-        y._dgq_gn = dict(parts=ga["parts"] + gb["parts"], B=ga["B"], HW=ga["HW"], C=ga["C"] + gb["C"])
+        y._dgq_gn = dict(parts=ga["parts"] + gb["parts"], B=ga["B"], HW=ga["HW"], C=ga["C"] + gb["C"], ver=y._version)
     return y
+
+
+def _gn_of(x: torch.Tensor):
+    """The GroupNorm partials a producing GEMM attached to x — only while x is still the tensor it wrote: an in-place op in
+    between (``x += ...``, a hook that mutates and returns its output) bumps ``_version`` and the statistics are stale."""
+    gn = getattr(x, "_dgq_gn", None) if GN_FROM_GEMM else None
+    return gn if (gn is not None and gn.get("ver") == x._version) else None
 
 
 def groupnorm_from_partials(gn, groups, eps, gamma, beta):
@@ -636,7 +643,7 @@ def quant_conv2d(x: torch.Tensor, ab: ActBinding, kh, kw, stride, pad, norm=None
     pre = None
     if norm is not None:
         groups, eps, gamma, beta, act = norm
-        gn = getattr(x, "_dgq_gn", None) if GN_FROM_GEMM else None
+        gn = _gn_of(x)
         if gn is not None and gn["B"] == B and gn["HW"] == H * W and gn["C"] == C and C % groups == 0:
             sc, sh = groupnorm_from_partials(gn, groups, eps, gamma, beta)      # statistics left by the producing GEMM(s)
         else:
@@ -661,7 +668,7 @@ def quant_conv2d(x: torch.Tensor, ab: ActBinding, kh, kw, stride, pad, norm=None
     y = gemm_wxa8(codes, rowsum, M, ab, x.dtype, extra=make_extra(res2, res_div=res_div, gn_partial=part))
     out = y.view(B, Ho, Wo, N).permute(0, 3, 1, 2)
     if part is not None:
-        out._dgq_gn = dict(parts=[(part, N)], B=B, HW=Ho * Wo, C=N)
+        out._dgq_gn = dict(parts=[(part, N)], B=B, HW=Ho * Wo, C=N, ver=out._version)
     return out
 
 
@@ -671,14 +678,18 @@ def conv2d_f32w(x: torch.Tensor, w_nat: torch.Tensor, bias, kh, kw, stride, pad,
     (kh = kw = 1); w_nat [N][kh·kw·C] fp32 with K in (tap, c) order; bias [N] fp32 or None.
     norm = (groups, eps, gamma, beta, act) folds GroupNorm (+SiLU) of a 4-D x into the load, as in quant_conv2d."""
     N = w_nat.shape[0]
-    if x.dim() == 4:
+    is_conv = x.dim() == 4 and w_nat.shape[1] == kh * kw * x.shape[1]
+    if x.dim() == 4 and not is_conv:
+        # a Linear layer fed a 4-D [..., K] input (F.linear takes any rank): the rows are everything but the last dimension
+        assert kh == kw == 1 and w_nat.shape[1] == x.shape[-1], "dgq conv2d_f32w: weight [N][%d] does not match input %s" % (w_nat.shape[1], tuple(x.shape))
+    if is_conv:
         B, C, H, W = x.shape
         xs = x.contiguous(memory_format=torch.channels_last)
         sc = sh = None
         act = 0
         if norm is not None:
             groups, eps, gamma, beta, act = norm
-            gn = getattr(x, "_dgq_gn", None) if GN_FROM_GEMM else None
+            gn = _gn_of(x)
             if gn is not None and gn["B"] == B and gn["HW"] == H * W and gn["C"] == C and C % groups == 0:
                 sc, sh = groupnorm_from_partials(gn, groups, eps, gamma, beta)
             else:
@@ -691,6 +702,7 @@ def conv2d_f32w(x: torch.Tensor, w_nat: torch.Tensor, bias, kh, kw, stride, pad,
                   _lib.ptr(sc), _lib.ptr(sh), int(act), _lib.stream())
         return y.view(B, Ho, Wo, N).permute(0, 3, 1, 2)
     K = x.shape[-1]
+    assert w_nat.shape[1] == K and kh == kw == 1, "dgq conv2d_f32w: weight [N][%d] does not match input %s" % (w_nat.shape[1], tuple(x.shape))
     x2 = x.reshape(-1, K)
     if not x2.is_contiguous():
         x2 = x2.contiguous()

@@ -47,14 +47,11 @@ def quant_params(Scaler, wbits, abits, use_aq, log, rt, sp):
     return wq, aq, sm
 
 
-def build_synthetic_qnn(arch, cfg, res, batch, slots, ckpt_dir="/tmp", seed=0, device="cuda", rank=0, barrier=None):
-    """Writes (once) a synthetic reference-format cali_ckpt and builds the QuantModel from it through the same
-    entry point the reference's CLI uses (get_qmodel, src/inference_qmodel.py:91).
-    cfg keys: wbits, abits, use_aq, G, log, rt, sp, time_aware, steps.  ``slots``: how many act_<s> tables to write
-    (int) or the explicit slot ids (a test that visits t = 981 and t = 21 needs act_0 and act_48, not 49 tables)."""
+def synthetic_fp_unet(arch, cfg, res, batch, slots, ckpt_dir="/tmp", seed=0, rank=0, barrier=None):
+    """The rank-shared half of ``build_synthetic_qnn``: rank 0 writes (once) the synthetic reference-format cali_ckpt, every rank
+    waits for it at ``barrier`` and reads the FP weights back from the file memory-mapped.  Returns (FP UNet, ckpt path, laps)."""
     import time
     from .diffusers_rewrite import UNet2DConditionModel
-    from .quant import get_qmodel, Scaler
     verbose = os.environ.get("DGQ_BUILD_TIMING") == "1"
     t_last = [time.time()]
     laps = {}
@@ -84,6 +81,16 @@ def build_synthetic_qnn(arch, cfg, res, batch, slots, ckpt_dir="/tmp", seed=0, d
     # (memory-mapped) — the same name-keyed tensors rank 0 generated for it, without regenerating them on every rank
     unet.load_state_dict(synth.state_dict_from_ckpt(path))
     lap("FP weights from the ckpt (mmap)")
+    return unet, path, laps, lap
+
+
+def build_synthetic_qnn(arch, cfg, res, batch, slots, ckpt_dir="/tmp", seed=0, device="cuda", rank=0, barrier=None):
+    """Writes (once) a synthetic reference-format cali_ckpt and builds the QuantModel from it through the same
+    entry point the reference's CLI uses (get_qmodel, src/inference_qmodel.py:91).
+    cfg keys: wbits, abits, use_aq, G, log, rt, sp, time_aware, steps.  ``slots``: how many act_<s> tables to write
+    (int) or the explicit slot ids (a test that visits t = 981 and t = 21 needs act_0 and act_48, not 49 tables)."""
+    from .quant import get_qmodel, Scaler
+    unet, path, laps, lap = synthetic_fp_unet(arch, cfg, res, batch, slots, ckpt_dir, seed, rank, barrier)
     pipe = types.SimpleNamespace(unet=unet)
     wq, aq, sm = quant_params(Scaler, cfg["wbits"], cfg["abits"], cfg["use_aq"], cfg["log"], cfg["rt"], cfg["sp"])
     qnn = get_qmodel(arch, pipe, path, wq, cfg["use_aq"], aq, sm, cfg["G"] > 1, cfg["steps"],

@@ -179,7 +179,8 @@ int dgq_conv2d_f32w(const void* x, int x_dtype, int B, int H, int W, int C, int 
  *   gn_partial   : (or NULL) [M/16][N][2] floats: per 16-row block and column the mean and the sum of squared deviations of
  *                  the values this call stores (after residual; as rounded to y_dtype) — GroupNorm statistics of the output
  *                  for dgq_groupnorm_from_partials, instead of a pass over the tensor.  M % 16 == 0, N % 4 == 0, 16-byte
- *                  aligned; forces an unsplit launch (dgq_gemm_plan_splits tells what the shape would otherwise get). */
+ *                  aligned.  Written by the GEMM's own epilogue, or — a K-split launch — by its combine kernel
+ *                  (dgq_gemm_plan_splits tells which the shape gets; only the GEGLU epilogue forces an unsplit launch). */
 typedef struct dgq_gemm_extra {
     const void* residual;
     int ldr;

@@ -222,7 +222,7 @@ def fused_teacher_forced_check(qnn, io, run):
 
 N_QUANT_LAYERS = {"sd": 280, "sdxl": 792, "tiny": 119}
 # arch, res, config, batch, timesteps (1 timestep for the 2.6 B-parameter SDXL graph: the oracle re-quantises every weight)
-TF_CASES = [("tiny", 16, "C2", 2, (999, 499)), ("sd", 16, "C2", 2, (999, 499)), ("tiny", 16, "C3", 2, (999, 499)),
+TF_CASES = [("tiny", 16, "C2", 2, (999, 499)), ("sd", 16, "C2", 2, (999, 499)), ("sd", 16, "C3", 2, (999,)), ("tiny", 16, "C3", 2, (999, 499)),
             ("tiny", 16, "C5", 2, (999, 499)), ("sdxl", 32, "C2", 1, (999,)), ("sdxl", 16, "C5", 2, (999,))]
 
 
@@ -409,6 +409,84 @@ def test_ddim50_literal_c2_vs_reference_golden(ckdir):
     assert torch.isfinite(out).all()
     assert 0.5 < out.norm().item() / ref.norm().item() < 2.0
     assert e < 1.0, e
+
+
+def test_ddim50_every_call_teacher_forced_vs_reference_trajectory(ckdir):
+    """BASELINE config 2 as written, pinned PER CALL: tests/golden/f5b_ddim50_traj_sd_c2_r64.pt holds the ε
+    output of the REAL reference's QuantModel for every one of the 50 UNet calls of its DDIM run (CFG pair, 64x64 latents) and,
+    per call, the reference's own deviation on that very input when only its BLAS thread count changes.  The inputs are
+    reconstructed exactly (latent_{i+1} = DDIM step of latent_i and the stored ε — the generator asserted that).  Every call of
+    the HIP path (one hipGraph per time-aware slot) is fed the REFERENCE's latent and must answer within 2.5x that call's own
+    noise floor; the median over the 50 calls must stay within 1.5x the median floor."""
+    from oracle import dgq_oracle as orc
+    g = torch.load(os.path.join(GOLD, "f5b_ddim50_traj_sd_c2_r64.pt"))
+    m = g["meta"]
+    steps = m["steps"]
+    assert steps == 50 and m["res"] == 64 and len(g["timesteps"]) == 50
+    c = dict(C2, steps=steps)
+    qnn, _ = get_qnn("sd", c, 64, 2, steps, ckdir)
+    qnn.prepare_slots()
+    qnn.enable_graphs(True)
+    sch = orc.DDIM(steps)
+    x = synth.named_randn("latent", (1, 4, 64, 64), 1)
+    ctx = synth.named_randn("ctx", (2, 77, 768), 2).cuda()
+    ratios, errs = [], []
+    try:
+        for i, t in enumerate(g["timesteps"]):
+            with torch.no_grad():
+                y = qnn(torch.cat([x, x]).cuda(), t, ctx)[0].float().cpu()
+            ref = g["eps"][i]
+            e, floor = rel_l2(y, ref), float(g["self_dev"][i])
+            errs.append(e)
+            ratios.append(e / floor)
+            assert torch.isfinite(y).all() and e < 2.5 * floor, (i, t, e, floor)
+            e_u, e_c = ref.chunk(2)                                  # the NEXT input is the reference's, not ours
+            x = sch.step(e_u + m["guidance"] * (e_c - e_u), t, x)
+    finally:
+        qnn.enable_graphs(False)
+        _QNN.pop(("sd", tuple(sorted(c.items())), 64, 2, tuple(synth.slot_list(steps))), None)
+    assert torch.equal(x, g["final_latent"])                         # the reconstruction reproduces the reference's trajectory
+    errs_s, floors = sorted(errs), sorted(float(v) for v in g["self_dev"])
+    print("DDIM-50 teacher-forced: per-call rel-L2 median %.3g max %.3g; reference noise floor median %.3g max %.3g; worst ratio %.2f"
+          % (errs_s[25], errs_s[-1], floors[25], floors[-1], max(ratios)))
+    assert errs_s[25] <= 1.5 * floors[25]
+
+
+def test_c5_full_size_shard_properties(ckdir):
+    """BASELINE config 5's literal per-GPU shard: SDXL-turbo W4A6 g=1 (scalar scales, uniform softmax quantiser), 8 prompts,
+    1024x1024 (128x128 latents), the first and the last slot of the 4-step schedule.  At this size the oracle does not finish in
+    test time; asserted are the size-independent properties: finite output of the right shape, every one of the 792 quantized
+    layers on the HIP path exactly once per call, and the shard deterministic (two runs bit-identical: no float atomics anywhere on
+    the path).  (Batch independence — every quantizer of this config is static — holds only up to the chaos of DESIGN.md §5:
+    prompt 0 alone takes other launch plans (K splits, tile shapes) than inside the batch of 8, the 1e-7 differences of their fp32
+    epilogues flip codes, and the outputs end 0.19 apart like any two fp32 evaluations of this network; printed, not asserted.)"""
+    from dgq_amd.quant import QuantLayer, quant_layer
+    c = dict(C5, steps=4)
+    qnn, _ = get_qnn("sdxl", c, 128, 8, [0, 3], ckdir)
+    inp = synth.synth_inputs("sdxl", 8, 1, 128)
+    ack = {"text_embeds": inp["text_embeds"].cuda(), "time_ids": inp["time_ids"].cuda()}
+    n_q = sum(1 for mm in qnn.model.modules() if isinstance(mm, QuantLayer) and mm.use_wq and mm.use_aq and not mm.disable_aq)
+    assert n_q == N_QUANT_LAYERS["sdxl"]
+    try:
+        for t in (999, 249):
+            seen = []
+            quant_layer.LAYER_TAP = lambda layer, y, **kw: (seen.append(id(layer)), y)[1]
+            with torch.no_grad():
+                y = qnn(inp["sample"].cuda(), torch.tensor(t), inp["encoder_hidden_states"].cuda(), added_cond_kwargs=ack)[0]
+            quant_layer.LAYER_TAP = None
+            assert y.shape == (8, 4, 128, 128) and torch.isfinite(y).all()
+            assert len(seen) == len(set(seen)) == n_q, (len(seen), len(set(seen)), n_q)
+            with torch.no_grad():
+                y2 = qnn(inp["sample"].cuda(), torch.tensor(t), inp["encoder_hidden_states"].cuda(), added_cond_kwargs=ack)[0]
+                y1 = qnn(inp["sample"][:1].cuda(), torch.tensor(t), inp["encoder_hidden_states"][:1].cuda(),
+                         added_cond_kwargs={k: v[:1] for k, v in ack.items()})[0]
+            assert torch.equal(y, y2), "the shard is not deterministic"
+            e = rel_l2(y1.float().cpu(), y[:1].float().cpu())
+            print("c5 full size t=%d: prompt 0 alone vs inside the batch of 8: rel-L2 %.3g" % (t, e))
+            assert e < 1.0, e
+    finally:
+        quant_layer.LAYER_TAP = None
+        _QNN.pop(("sdxl", tuple(sorted(c.items())), 128, 8, tuple(synth.slot_list([0, 3]))), None)
 
 
 def test_sdxl_full_size_c4_vs_reference_golden(ckdir):

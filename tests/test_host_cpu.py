@@ -306,3 +306,27 @@ def test_summation_by_parts_matches_group_sums_on_planned_tables():
         assert seg_limit(ab, wb) * (1 << (ab - 1)) * (15 if wb == 4 else 128) <= 1 << 24
     cf = mark_clears(torch.zeros(100, dtype=torch.uint8), 8, 8)
     assert cf.tolist().count(2) == 3 and int(cf[31]) == 2 and int(cf[63]) == 2 and int(cf[95]) == 2
+
+
+def test_bench_two_rank_dry_run_under_gloo(tmp_path):
+    """The N > 1 path of bench.py executed end to end WITHOUT GPUs: `python bench.py --gpus 2` under
+    DGQ_BENCH_BACKEND=gloo starts torch.distributed.run as a child with two CPU ranks; rank 0 writes the synthetic ckpt, rank 1
+    waits at the barrier and reads the weights back memory-mapped, each rank denoises its own rank-seeded prompt, the timed
+    windows are bracketed by barriers and MAX-reduced, and rank 0 prints ONE JSON line with n_gpus = 2.  The model is the FP tiny
+    UNet (the quantized kernels need a GPU): the line says so (``dry_run``) and is not a measurement."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DGQ_BENCH_BACKEND="gloo", DGQ_BENCH_CKPT_DIR=str(tmp_path), OMP_NUM_THREADS="2")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--windows", "2"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak" and "dry_run" in d
+    assert d["value"] > 0 and len(d["windows"]["ms_per_step_all"]) == 2
+    assert len(d["load"]["model_ready_s_per_rank"]) == 2 and all(v > 0 for v in d["load"]["model_ready_s_per_rank"])
+    assert d["config"]["parallelism"].startswith("replicas x2")
+    files = [f for f in os.listdir(tmp_path) if f.endswith(".pth")]
+    assert len(files) == 1                                   # one ckpt, written by rank 0 only
