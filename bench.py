@@ -289,9 +289,9 @@ def main(argv=None):
     # times back to back from a hipGraph on the current stream and bracketed by HIP events on that stream — eager
     # per-launch events would time the host-side launch gaps, not the kernels.  Sum over the step = the kernel time
     # rocprofv3 reports for the GEMM kernels (profiles/).
-    roofline = None
+    roofline, roofline_extra = None, {}
     if rank == 0 and not args.no_roofline:
-        roofline = measure_gemm_roofline(torch, ops, qnn, lambda: one_step(lat, timesteps[W]), args)
+        roofline, roofline_extra = measure_gemm_roofline(torch, ops, qnn, lambda: one_step(lat, timesteps[W]), args)
 
     # ---- CPU baseline: the reference's op sequence (oracle port) on this box's host cores ----------------------------
     cpu_baseline = None
@@ -373,6 +373,7 @@ def main(argv=None):
             "roofline": roofline, "cpu_baseline": cpu_baseline, "load": load,
             "non_hip_kernels": glue,
         }
+        out.update(roofline_extra)                       # roofline_quant_act, roofline_attention, roofline_step
         if DRY:
             out["dry_run"] = "DGQ_BENCH_BACKEND=gloo: launcher rehearsal on CPU ranks with the FP tiny UNet — NOT a measurement"
             out["config"]["workload"] = "dry run: FP tiny UNet 16x16 on CPU (gloo)"
@@ -383,11 +384,22 @@ def main(argv=None):
     return 0
 
 
-def measure_gemm_roofline(torch, ops, qnn, run_step, args):
-    REP = 5
-    times_ms, algo_ops, algo_bytes, layers = [], [], [], [0]
+HBM_PEAK_TBS = 8.0            # MI355X_MICROARCH.md: HBM3E peak (spec); ~6.3 TB/s is what a streaming copy achieves
+BF16_PEAK_TFLOPS = 2500.0     # dense bf16 MFMA peak: what the attention matmuls are priced against
 
-    def hook(issue, problems):
+
+def measure_gemm_roofline(torch, ops, qnn, run_step, args):
+    """One eager step with the three launch hooks of dgq_amd.ops set: every GEMM launch (dgq_gemm_wxa8 / _batch, its split-K
+    combine included), every quantise-on-load launch (dgq_quant_act_batch) and every attention call (dgq_attention: pre-pass +
+    statistics + P·V) is replayed REP times from a hipGraph on the launch stream and bracketed by HIP events on that stream.
+    Returns the ``roofline`` object of the JSON line: the W4A8 GEMM family against the int8 MFMA peak as before (``frac``), plus
+    per launch the BINDING roof min(P_int8, AI·BW) -> ``ideal_ms`` = Σ max(ops/P, bytes/BW), the split of the family's time by
+    which roof binds, and the same accounting for the quantise-on-load class (HBM) and the attention class (bf16 MFMA)."""
+    REP = 5
+    rec = {"gemm": [], "quant": [], "attn": []}
+    layers = [0]
+
+    def timed(issue):
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             for _ in range(REP):
@@ -398,17 +410,22 @@ def measure_gemm_roofline(torch, ops, qnn, run_step, args):
         g.replay()
         e1.record()
         e1.synchronize()
-        times_ms.append(e0.elapsed_time(e1) / REP)
+        return e0.elapsed_time(e1) / REP
+
+    def gemm_hook(issue, problems):
+        ms = timed(issue)
         layers[0] += len(problems)
+        # un-unfolded input counted once at 1 B/code (SURVEY.md §8(d)), int4 weights, output at its dtype
+        o = sum(2.0 * M * ab.pw.N * ab.pw.K for M, ab, _ in problems)
+        by = sum(M * ab.pw.K / max(1, ab.pw.taps) + ab.pw.N * ab.pw.K * ab.pw.bits / 8 + M * ab.pw.N * es for M, ab, es in problems)
+        rec["gemm"].append((ms, o, by))
         if os.environ.get("DGQ_BENCH_GEMM_DUMP"):            # per-launch table for tools (shape, scale mode, time)
             with open(os.environ["DGQ_BENCH_GEMM_DUMP"], "a") as f:
-                f.write("%s %.2f\n" % (";".join("%d,%d,%d,%d,%s,%d" % (M, ab.pw.N, ab.pw.K, ab.Kp, ab.mode, es) for M, ab, es in problems),
-                                       1e3 * times_ms[-1]))
-        # un-unfolded input counted once at 1 B/code (SURVEY.md §8(d)), int4 weights, output at its dtype
-        algo_ops.append(sum(2.0 * M * ab.pw.N * ab.pw.K for M, ab, _ in problems))
-        algo_bytes.append(sum(M * ab.pw.K / max(1, ab.pw.taps) + ab.pw.N * ab.pw.K * ab.pw.bits / 8 + M * ab.pw.N * es
-                              for M, ab, es in problems))
-    ops.GEMM_LAUNCH_HOOK = hook
+                f.write("%s %.2f\n" % (";".join("%d,%d,%d,%d,%s,%d" % (M, ab.pw.N, ab.pw.K, ab.Kp, ab.mode, es) for M, ab, es in problems), 1e3 * ms))
+
+    ops.GEMM_LAUNCH_HOOK = gemm_hook
+    ops.QUANT_LAUNCH_HOOK = lambda issue, by: rec["quant"].append((timed(issue), 0.0, float(by)))
+    ops.ATTN_LAUNCH_HOOK = lambda issue, fl, by: rec["attn"].append((timed(issue), float(fl), float(by)))
     graphs_were = qnn._graphs
     qnn._graphs = None
     try:
@@ -417,29 +434,97 @@ def measure_gemm_roofline(torch, ops, qnn, run_step, args):
         torch.cuda.synchronize()
     finally:
         qnn._graphs = graphs_were
-        ops.GEMM_LAUNCH_HOOK = None
-    gemm_ms = sum(times_ms)
-    tops = sum(algo_ops) / (gemm_ms * 1e-3) / 1e12
-    n = len(times_ms)
-    # HBM-side bytes per launch come from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/pmc_traffic.py);
-    # a STATIC figure, valid only for the configuration it was profiled on — otherwise null
+        ops.GEMM_LAUNCH_HOOK = ops.QUANT_LAUNCH_HOOK = ops.ATTN_LAUNCH_HOOK = None
+
+    def family(rows, peak_ops_tps):
+        """time, work and the per-launch roofline of one kernel family: ideal = Σ max(ops / P, bytes / BW)"""
+        ms = sum(r[0] for r in rows)
+        ideal = [max(r[1] / (peak_ops_tps * 1e12), r[2] / (HBM_PEAK_TBS * 1e12)) * 1e3 for r in rows]
+        compute = [r[1] / (peak_ops_tps * 1e12) >= r[2] / (HBM_PEAK_TBS * 1e12) for r in rows]
+        return {"launches": len(rows), "ms_per_step": round(ms, 3), "ideal_ms_per_step": round(sum(ideal), 4),
+                "frac_of_binding_roof": round(sum(ideal) / ms, 4) if ms else None,
+                "compute_bound": {"launches": sum(compute), "ms": round(sum(r[0] for r, c in zip(rows, compute) if c), 3),
+                                  "ideal_ms": round(sum(i for i, c in zip(ideal, compute) if c), 4)},
+                "hbm_bound": {"launches": len(rows) - sum(compute), "ms": round(sum(r[0] for r, c in zip(rows, compute) if not c), 3),
+                              "ideal_ms": round(sum(i for i, c in zip(ideal, compute) if not c), 4)},
+                "ops": sum(r[1] for r in rows), "bytes": sum(r[2] for r in rows)}
+
+    G, Q, A = family(rec["gemm"], INT8_PEAK_TOPS), family(rec["quant"], INT8_PEAK_TOPS), family(rec["attn"], BF16_PEAK_TFLOPS)
+    gemm_ms = G["ms_per_step"]
+    tops = G["ops"] / (gemm_ms * 1e-3) / 1e12
+    n = G["launches"]
+    # HBM-side bytes per launch come from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/pmc_traffic.py); a STATIC
+    # figure, attached only to the configuration it was profiled on AND only while no kernel source changed after the commit it
+    # was measured at (a stale file is refused, not quoted)
     traffic, traffic_src = None, None
     import glob
     for tj in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_gemm_hbm_traffic.json")), reverse=True):
         tjd = json.load(open(tj))
         if tjd.get("config") == args.config and tjd.get("dtype") == args.dtype and tjd.get("prompts_per_gpu", 1) == (args.prompts_per_gpu or CONFIGS[args.config]["prompts"]):
-            traffic = round(tjd["traffic_bytes_per_launch"] / 1e6, 3)
-            traffic_src = "static: profiles/%s (rocprofv3 --pmc passes of this command at commit %s, not this run)" % (
-                os.path.basename(tj), tjd.get("measured_at_commit", "of round %s" % os.path.basename(tj)[1:3]))
+            if traffic_file_is_current(tjd):
+                traffic = round(tjd["traffic_bytes_per_launch"] / 1e6, 3)
+                traffic_src = "static: profiles/%s (rocprofv3 --pmc passes of this command at commit %s, not this run)" % (
+                    os.path.basename(tj), tjd.get("measured_at_commit"))
+            else:
+                traffic_src = "refused: profiles/%s (commit %s) was measured on other kernel sources than this build's (csrc digest %s)" % (
+                    os.path.basename(tj), tjd.get("measured_at_commit"), csrc_digest())
             break
-    return {"kernel": "dgq_gemm_wxa8 / dgq_gemm_wxa8_batch (gemm_wxa8_kernel<...> tile family + split-K combine where used); the "
-                      "23 time_emb_proj layers (2 rows each, 0.1 Gop) run in dgq_linear_smallm_batch and are not counted",
-            "layers_covered": layers[0], "bound": "mfma",
-            "achieved": round(tops, 2), "peak": INT8_PEAK_TOPS, "unit": "TOP/s", "frac": round(tops / INT8_PEAK_TOPS, 4),
-            "traffic": traffic, "traffic_unit": "MB of HBM-side reads+writes per launch", "traffic_source": traffic_src,
-            "launches_per_step": n, "avg_launch_us": round(1e3 * gemm_ms / n, 2), "kernel_ms_per_step": round(gemm_ms, 3),
-            "algorithmic_Gop_per_launch": round(sum(algo_ops) / n / 1e9, 3),
-            "algorithmic_MB_per_launch": round(sum(algo_bytes) / n / 1e6, 3)}
+    hbm_gemm = G["hbm_bound"]["ideal_ms"] >= G["compute_bound"]["ideal_ms"]
+    out = {"kernel": "dgq_gemm_wxa8 / dgq_gemm_wxa8_batch (gemm_wxa8_kernel<...> tile family, gemm_big_kernel<...>, split-K combine where "
+                     "used); the 23 time_emb_proj layers (2 rows each, 0.1 Gop) run in dgq_linear_smallm_batch and are not counted",
+           "layers_covered": layers[0],
+           # which roof the family's IDEAL time mostly sits under (per launch: argmin(P_int8, AI·BW)); `achieved` / `frac` stay
+           # the int8-MFMA accounting of the north star either way
+           "bound": "hbm" if hbm_gemm else "mfma",
+           "achieved": round(tops, 2), "peak": INT8_PEAK_TOPS, "unit": "TOP/s", "frac": round(tops / INT8_PEAK_TOPS, 4),
+           "traffic": traffic, "traffic_unit": "MB of HBM-side reads+writes per launch", "traffic_source": traffic_src,
+           "launches_per_step": n, "avg_launch_us": round(1e3 * gemm_ms / n, 2), "kernel_ms_per_step": round(gemm_ms, 3),
+           "algorithmic_Gop_per_launch": round(G["ops"] / n / 1e9, 3),
+           "algorithmic_MB_per_launch": round(G["bytes"] / n / 1e6, 3),
+           "per_launch_roofline": {k: v for k, v in G.items() if k not in ("ops", "bytes")},
+           "achieved_hbm_TBs": round(G["bytes"] / (gemm_ms * 1e-3) / 1e12, 3)}
+    extra = {}
+    if Q["launches"]:
+        q_ms = Q["ms_per_step"]
+        extra["roofline_quant_act"] = {"kernel": "dgq_quant_act_batch (quantise-on-load: im2col gather, GroupNorm/LayerNorm/SiLU prologue, codes + row sums)",
+                                       "bound": "hbm", "achieved": round(Q["bytes"] / (q_ms * 1e-3) / 1e12, 3), "peak": HBM_PEAK_TBS,
+                                       "unit": "TB/s", "frac": round(Q["bytes"] / (q_ms * 1e-3) / 1e12 / HBM_PEAK_TBS, 4),
+                                       "launches_per_step": Q["launches"], "kernel_ms_per_step": q_ms, "ideal_ms_per_step": Q["ideal_ms_per_step"],
+                                       "algorithmic_MB_per_launch": round(Q["bytes"] / Q["launches"] / 1e6, 3)}
+    if A["launches"]:
+        a_ms = A["ms_per_step"]
+        extra["roofline_attention"] = {"kernel": "dgq_attention (attn3_prep + attn3_stats + attn3_pv): aqtizer_q/k/v, QK^T, softmax, log2 / uniform aqtizer_w, P·V",
+                                       "bound": "mfma (bf16 dense; the int8 Q·K^T form is priced at the bf16 rate too)",
+                                       "achieved": round(A["ops"] / (a_ms * 1e-3) / 1e12, 2), "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                       "frac": round(A["ops"] / (a_ms * 1e-3) / 1e12 / BF16_PEAK_TFLOPS, 4),
+                                       "calls_per_step": A["launches"], "kernel_ms_per_step": a_ms, "ideal_ms_per_step": A["ideal_ms_per_step"],
+                                       "algorithmic_flops": "4*T*S*D per (batch, head)"}
+    tot_ms = gemm_ms + Q["ms_per_step"] + A["ms_per_step"]
+    tot_ideal = G["ideal_ms_per_step"] + Q["ideal_ms_per_step"] + A["ideal_ms_per_step"]
+    extra["roofline_step"] = {"covers": "GEMM family + quantise-on-load + attention (replayed per launch; GroupNorm finalisers, FP conv_in/out and "
+                                        "torch glue are not replayed)",
+                              "measured_ms": round(tot_ms, 3), "ideal_ms": round(tot_ideal, 4), "frac_of_binding_roofs": round(tot_ideal / tot_ms, 4),
+                              "ideal": "sum over launches of max(ops / P, algorithmic bytes / 8 TB/s), P = 5000 TOP/s int8 (GEMM) or 2500 TFLOP/s bf16 (attention)"}
+    return out, extra
+
+
+def csrc_digest():
+    """sha256 over the kernel sources (dgq_amd/csrc/*.hip, *.h, *.cpp, include/*.h): what a PMC traffic record is stamped with
+    (tools/pmc_traffic.py) — it describes THESE kernels or it is refused.  Works on a box that has no git history."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, "dgq_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "dgq_amd", "csrc", "*.h")) +
+                   glob.glob(os.path.join(ROOT, "dgq_amd", "csrc", "*.cpp")) + glob.glob(os.path.join(ROOT, "include", "*.h")))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def traffic_file_is_current(record):
+    """True when the record's ``csrc_digest`` equals the digest of the kernel sources this run was built from."""
+    return bool(record.get("csrc_digest")) and record["csrc_digest"] == csrc_digest()
 
 
 if __name__ == "__main__":

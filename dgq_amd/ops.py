@@ -381,7 +381,13 @@ def quant_act(x_cl: torch.Tensor, B, H, W, C, kh, kw, stride, pad, ab: ActBindin
     codes = torch.empty((M, ab.Kp), dtype=torch.int8, device=x_cl.device)
     rowsum = torch.empty((parts, M), dtype=torch.float32, device=x_cl.device)
     a.codes, a.rowsum = codes.data_ptr(), rowsum.data_ptr()
-    _lib_call("dgq_quant_act_batch", 1, _c.byref(a), _lib.stream())
+
+    def issue():
+        _lib_call("dgq_quant_act_batch", 1, _c.byref(a), _lib.stream())
+    issue()
+    if QUANT_LAUNCH_HOOK is not None:
+        # algorithmic bytes: the input once (un-unfolded) + the codes + the row sums
+        QUANT_LAUNCH_HOOK(issue, B * H * W * ldc * x_cl.element_size() + M * ab.Kp + 4 * parts * M)
     return codes, rowsum, M
 
 
@@ -509,7 +515,11 @@ def make_extra(residual=None, fq=None, res_div=1, geglu=False, gn_partial=None):
     return ex
 
 
-#: measurement hook (bench.py's roofline leg): when set, every GEMM launch of the dgq_gemm_wxa8 family is issued through
+#: measurement hooks (bench.py's roofline leg), None in production.  QUANT_LAUNCH_HOOK(issue, algorithmic_bytes): every
+#: dgq_quant_act_batch launch; ATTN_LAUNCH_HOOK(issue, flops, bytes): every dgq_attention call (its two or three kernels).
+QUANT_LAUNCH_HOOK = None
+ATTN_LAUNCH_HOOK = None
+#: when set, every GEMM launch of the dgq_gemm_wxa8 family is issued through
 #: ``GEMM_LAUNCH_HOOK(issue, problems)`` — ``issue()`` launches it (again) on the current stream, ``problems`` lists the
 #: (M, ActBinding, out_element_size) of the layers the launch computes.  None in production.
 GEMM_LAUNCH_HOOK = None
@@ -602,7 +612,12 @@ def quant_linear_multi(x: torch.Tensor, bindings, ln=None):
         for j0 in range(0, len(idxs), 8):
             chunk = idxs[j0:j0 + 8]
             arr = (_lib.QuantActArgs * len(chunk))(*[qa[i][2] for i in chunk])
-            _lib_call("dgq_quant_act_batch", len(chunk), _c.cast(arr, _c.c_void_p), _lib.stream())
+
+            def issue_q(arr=arr, n_chunk=len(chunk)):
+                _lib_call("dgq_quant_act_batch", n_chunk, _c.cast(arr, _c.c_void_p), _lib.stream())
+            issue_q()
+            if QUANT_LAUNCH_HOOK is not None:          # one shared input, one code matrix + row sums per problem
+                QUANT_LAUNCH_HOOK(issue_q, M * Kin * x2.element_size() + sum(M * bindings[i].Kp + 4 * qa[i][5] * M for i in chunk))
     outs = [torch.empty((M, ab.pw.N), dtype=x.dtype, device=dev) for ab in bindings]
     ggroups = {}
     for i, ab in enumerate(bindings):
@@ -856,9 +871,14 @@ def attention(q, k, v, H, D, scale, mode, skip, delta, bits, fq=None, emit: Opti
                   _c.cast(desc, _c.c_void_p) if desc is not None else None, _c.byref(e), _lib.ptr(ws), nbytes, _lib.stream())
         return codes, rowsum
     o = torch.empty_like(q)
-    _lib_call("dgq_attention", _lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(o), _lib.DTYPE_CODE[q.dtype], B, H, T, S, D,
-              _c.c_float(scale), mode, skip, _lib.ptr(delta), bits,
-              _c.cast(desc, _c.c_void_p) if desc is not None else None, _lib.ptr(ws), nbytes, _lib.stream())
+
+    def issue():
+        _lib_call("dgq_attention", _lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(o), _lib.DTYPE_CODE[q.dtype], B, H, T, S, D,
+                  _c.c_float(scale), mode, skip, _lib.ptr(delta), bits,
+                  _c.cast(desc, _c.c_void_p) if desc is not None else None, _lib.ptr(ws), nbytes, _lib.stream())
+    issue()
+    if ATTN_LAUNCH_HOOK is not None:                   # Q·Kᵀ and P·V: 4·T·S·D flops per (batch, head); q, k, v read and o written once
+        ATTN_LAUNCH_HOOK(issue, 4.0 * T * S * D * B * H, (2 * B * T + 2 * B * S) * H * D * q.element_size())
     return o
 
 
