@@ -53,7 +53,13 @@ SIGNATURES = {
 class GemmExtra(ctypes.Structure):
     """dgq_gemm_extra_t of include/dgq_hip.h"""
     _fields_ = [("residual", _vp), ("ldr", _i), ("res_div", _i), ("res_dtype", _i), ("fq_mode", _i), ("fq_delta", _vp), ("fq_zp", _vp),
-                ("fq_T", _i), ("fq_D", _i), ("fq_skip", _i), ("fq_qmax", _f), ("geglu", _i), ("gn_partial", _vp)]
+                ("fq_T", _i), ("fq_D", _i), ("fq_skip", _i), ("fq_qmax", _f), ("geglu", _i), ("gn_partial", _vp), ("conv", _vp)]
+
+
+class GemmConv(ctypes.Structure):
+    """dgq_gemm_conv_t of include/dgq_hip.h"""
+    _fields_ = [("codes_in", _vp), ("pixsum", _vp), ("fill", _vp), ("B", _i), ("H", _i), ("W", _i), ("C", _i), ("ldc", _i), ("kh", _i),
+                ("kw", _i), ("stride", _i), ("pad", _i), ("Ho", _i), ("Wo", _i), ("zero_code", _f), ("pixsum_parts", _i)]
 
 
 class SmallMProblem(ctypes.Structure):

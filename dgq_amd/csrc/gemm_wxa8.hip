@@ -37,7 +37,9 @@
 // chunks of a wave alternate between two accumulator sets, each with its own running total, and a chunk's flush is issued
 // AFTER the MFMAs of the wave's next chunk: on the small tiles (one or two MFMAs per chunk) the MFMA latency and the flush
 // VALU of one chunk then overlap the next chunk's MFMAs instead of sitting between them.
-template <int WBITS, bool PER_M, typename TOut, int BM, int BN, int WVM, int WVN, int WVK, int NST, int ACCS>
+// CONV: the A operand is the implicit im2col of an int8 NHWC code tensor (dgq_gemm_conv_t: scalar-δ convolutions) — the same LDS
+// image, filled from per-lane source addresses that walk (tap, channel) instead of a materialised [M][Kp] row.
+template <int WBITS, bool PER_M, typename TOut, int BM, int BN, int WVM, int WVN, int WVK, int NST, int ACCS, bool CONV = false>
 __global__ __launch_bounds__(64 * WVM * WVN * WVK, gemm_waves_per_simd(WBITS, BM, BN, WVM * WVN * WVK, NST))
 void gemm_wxa8_kernel(GemmBatch bt) {
     const GemmParams& p = bt.p[bt.n > 1 ? blockIdx.z : 0];
@@ -89,13 +91,37 @@ void gemm_wxa8_kernel(GemmBatch bt) {
 
     // per-lane global source pointers of this wave's DMA pieces (k offset added per tile)
     const int8_t* a_src[A_DMA];
+    // CONV: per piece the lane's 16-byte granule walks the K order kp = tap·C + c of its output position: (channel offset, tap
+    // row, tap column, k) advance by one K tile per issue_tile call (tiles are issued in increasing order)
+    int cv_cc[A_DMA], cv_dh[A_DMA], cv_dw[A_DMA], cv_k[A_DMA], cv_h[A_DMA], cv_w[A_DMA];
+    const int8_t* cv_img[A_DMA];
+    bool cv_in[A_DMA];
 #pragma unroll
     for (int i = 0; i < A_DMA; ++i) {
         const int blk = wid * A_DMA + i;                   // 1 KiB = 8 rows of 128 B
         const int row = blk * 8 + (lane >> 3);
         const int c = (lane & 7) ^ ((row >> 1) & 7);
         const int m = min(m0 + row, p.M - 1);
-        a_src[i] = p.codes + (int64_t)m * p.Kp + 16 * c;
+        if constexpr (CONV) {
+            const int L = p.cv.Ho * p.cv.Wo;
+            const int b = m / L, l = m - b * L;
+            const int ho = l / p.cv.Wo, wo = l - ho * p.cv.Wo;
+            cv_h[i] = ho * p.cv.stride - p.cv.pad;
+            cv_w[i] = wo * p.cv.stride - p.cv.pad;
+            a_src[i] = p.cv.codes_in + (int64_t)b * p.cv.H * p.cv.W * p.cv.ldc;      // the image of this row
+            const int k = kt_begin * BK + 16 * c;
+            const int tap = k / p.cv.C;
+            cv_k[i] = k;
+            cv_cc[i] = k - tap * p.cv.C;
+            cv_dh[i] = tap / p.cv.kw;
+            cv_dw[i] = tap - cv_dh[i] * p.cv.kw;
+            cv_img[i] = a_src[i];
+            const int hi = cv_h[i] + cv_dh[i], wi = cv_w[i] + cv_dw[i];
+            cv_in[i] = (unsigned)hi < (unsigned)p.cv.H && (unsigned)wi < (unsigned)p.cv.W;
+            a_src[i] = cv_img[i] + ((int64_t)hi * p.cv.W + wi) * p.cv.ldc + cv_cc[i];          // the lane's granule in the current tap
+        } else {
+            a_src[i] = p.codes + (int64_t)m * p.Kp + 16 * c;
+        }
     }
     const uint8_t* w_src[W_DMA];
 #pragma unroll
@@ -121,8 +147,31 @@ void gemm_wxa8_kernel(GemmBatch bt) {
         const int64_t ka = (int64_t)kt * BK;
         const int64_t kw = (WBITS == 4) ? ka / 2 : ka;
 #pragma unroll
-        for (int i = 0; i < A_DMA; ++i)
-            glds16(a_src[i] + ka, __builtin_amdgcn_readfirstlane(sa + (wid * A_DMA + i) * 1024));
+        for (int i = 0; i < A_DMA; ++i) {
+            if constexpr (CONV) {
+                const int8_t* src = cv_in[i] ? a_src[i] : p.cv.fill;                 // outside the image: the code of 0.0
+                if (cv_k[i] >= p.cv.C * p.cv.kh * p.cv.kw) src = p.cv.fill + 16;       // K padding: zero codes
+                glds16(src, __builtin_amdgcn_readfirstlane(sa + (wid * A_DMA + i) * 1024));
+                // one K tile further: inside a tap the granule just moves 128 bytes on; a tap boundary (every C/128 tiles; for
+                // C % 128 == 0 the whole wave at once) re-derives the pixel — out of line, the common tile falls through
+                cv_k[i] += BK;
+                cv_cc[i] += BK;
+                a_src[i] += BK;
+                if (__builtin_expect(__any(cv_cc[i] >= p.cv.C), 0)) {
+                    if (cv_cc[i] >= p.cv.C) {
+                        const int tap = cv_k[i] / p.cv.C;
+                        cv_cc[i] = cv_k[i] - tap * p.cv.C;
+                        cv_dh[i] = tap / p.cv.kw;
+                        cv_dw[i] = tap - cv_dh[i] * p.cv.kw;
+                        const int hi = cv_h[i] + cv_dh[i], wi = cv_w[i] + cv_dw[i];
+                        cv_in[i] = (unsigned)hi < (unsigned)p.cv.H && (unsigned)wi < (unsigned)p.cv.W;
+                        a_src[i] = cv_img[i] + ((int64_t)hi * p.cv.W + wi) * p.cv.ldc + cv_cc[i];
+                    }
+                }
+            } else {
+                glds16(a_src[i] + ka, __builtin_amdgcn_readfirstlane(sa + (wid * A_DMA + i) * 1024));
+            }
+        }
 #pragma unroll
         for (int i = 0; i < W_DMA; ++i)
             glds16(w_src[i] + kw, __builtin_amdgcn_readfirstlane(sw + (wid * W_DMA + i) * 1024));
@@ -377,12 +426,21 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(GemmParams p) {
     auto row4 = [&](int m, int nb, float (&val)[4]) {
         float a[4] = {0.f, 0.f, 0.f, 0.f};
         const bool full = (nb + 3 < p.N) && ((p.N & 3) == 0);
-        for (int s = 0; s < p.splits; ++s) {
-            const float* src = p.slab + s * slab_stride + (int64_t)m * p.N + nb;
-            if (full) {
-                const float4 v = *reinterpret_cast<const float4*>(src);
-                a[0] += v.x; a[1] += v.y; a[2] += v.z; a[3] += v.w;
-            } else {
+        if (full) {
+            // four slabs per round: the loads go out together (a load per iteration of a runtime-bounded loop is waited for before
+            // the next one is issued: S dependent round trips), the sums are taken in slab order as before
+            for (int s0 = 0; s0 < p.splits; s0 += 4) {
+                float4 v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    v[j] = *reinterpret_cast<const float4*>(p.slab + (int64_t)min(s0 + j, p.splits - 1) * slab_stride + (int64_t)m * p.N + nb);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (s0 + j < p.splits) { a[0] += v[j].x; a[1] += v[j].y; a[2] += v[j].z; a[3] += v[j].w; }
+            }
+        } else {
+            for (int s = 0; s < p.splits; ++s) {
+                const float* src = p.slab + s * slab_stride + (int64_t)m * p.N + nb;
                 for (int e = 0; e < 4 && nb + e < p.N; ++e) a[e] += src[e];
             }
         }
@@ -415,9 +473,14 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(GemmParams p) {
         const int nb = (int)(g - (int64_t)rb * n4) * 4;
         const int m = rb * 16 + qd;
         float a[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int sp = 0; sp < p.splits; ++sp) {
-            const float4 v = *reinterpret_cast<const float4*>(p.slab + sp * slab_stride + (int64_t)m * p.N + nb);
-            a[0] += v.x; a[1] += v.y; a[2] += v.z; a[3] += v.w;
+        for (int s0 = 0; s0 < p.splits; s0 += 4) {            // four slab loads in flight, sums in slab order (see row4)
+            float4 v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                v[j] = *reinterpret_cast<const float4*>(p.slab + (int64_t)min(s0 + j, p.splits - 1) * slab_stride + (int64_t)m * p.N + nb);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (s0 + j < p.splits) { a[0] += v[j].x; a[1] += v[j].y; a[2] += v[j].z; a[3] += v[j].w; }
         }
         float mean[4], m2[4];
 #pragma unroll
@@ -489,6 +552,18 @@ static void launch_tile(const GemmBatch& bt, hipStream_t st) {
     }
     const int lds = lds_stages + lds_vec + (PER_M ? 0 : (((NCH + 1) * max_tps * 4 + 15) & ~15));
     dim3 grid((maxN + BN - 1) / BN, (maxM + BM - 1) / BM, bt.n > 1 ? bt.n : p.splits), block(64 * NW);
+    if (p.cv.codes_in) {                                 // implicit im2col A operand: four tile shapes carry it (conv_tile)
+        if constexpr (WBITS == 4 && PER_M && ((BM == 32 && BN == 64) || (BM == 64 && BN == 64) || (BM == 64 && BN == 128) || (BM == 128 && BN == 128))) {
+            static std::atomic<bool> cattr[64];
+            if (dev < 0 || dev >= 64 || !cattr[dev].load(std::memory_order_acquire)) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_wxa8_kernel<WBITS, PER_M, TOut, BM, BN, WVM, WVN, WVK, NST, ACCS, true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+                if (dev >= 0 && dev < 64) cattr[dev].store(true, std::memory_order_release);
+            }
+            hipLaunchKernelGGL((gemm_wxa8_kernel<WBITS, PER_M, TOut, BM, BN, WVM, WVN, WVK, NST, ACCS, true>), grid, block, lds, st, bt);
+        }
+        return;                                          // (other shapes: refused by dgq_gemm_wxa8 before it gets here)
+    }
     hipLaunchKernelGGL((gemm_wxa8_kernel<WBITS, PER_M, TOut, BM, BN, WVM, WVN, WVK, NST, ACCS>), grid, block, lds, st, bt);
 }
 
@@ -613,6 +688,41 @@ static GemmPlan plan_gemm(int M, int N, int Kp, int w_bits, size_t ws_bytes, boo
     return pl;
 }
 
+// implicit-conv launches: four tile shapes carry the CONV addressing.  Measured on the C5 shapes (tools/bench_conv_implicit.py,
+// profiles/r04_conv_implicit_shapes.txt): 64x128 is the best or within 3 % of it on every one of them — the address arithmetic is
+// per DMA piece, and the 64x64 tile the materialised operand prefers at M = 8192 has half the MFMAs per piece.
+static void conv_tile(GemmPlan& pl, int M) {
+    const int key = pl.bm * 1000 + pl.bn;
+    if (M >= 2048) { pl.bm = 64; pl.bn = 128; return; }
+    if (key == 32064 || key == 64064 || key == 64128 || key == 128128) return;
+    if (pl.bm >= 128) { pl.bm = 128; pl.bn = 128; }
+    else if (pl.bn >= 128) { pl.bm = 64; pl.bn = 128; }
+    else { pl.bm = 64; pl.bn = 64; }
+}
+
+// rowsum[m] = Σ_k s[m][k] of the unfolded operand = Σ over the taps of the per-pixel sums (C·zero_code for a tap outside the image)
+__global__ __launch_bounds__(256) void conv_rowsum_kernel(dgq_gemm_conv_t c, int M, float* rowsum) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    const int L = c.Ho * c.Wo;
+    const int b = m / L, l = m - b * L;
+    const int ho = l / c.Wo, wo = l - ho * c.Wo;
+    const int64_t npix = (int64_t)c.B * c.H * c.W;
+    const float* ps = c.pixsum + (int64_t)b * c.H * c.W;
+    const float outside = (float)c.C * c.zero_code;
+    float s = 0.0f;                                          // exact: integers below 2^24
+    for (int dh = 0; dh < c.kh; ++dh)
+        for (int dw = 0; dw < c.kw; ++dw) {
+            const int hi = ho * c.stride - c.pad + dh, wi = wo * c.stride - c.pad + dw;
+            if ((unsigned)hi < (unsigned)c.H && (unsigned)wi < (unsigned)c.W) {
+                for (int q = 0; q < c.pixsum_parts; ++q) s += ps[q * npix + hi * c.W + wi];
+            } else {
+                s += outside;
+            }
+        }
+    rowsum[m] = s;
+}
+
 // Development hook: DGQ_GEMM_FORCE="BM,BN,S" overrides the plan (tile sweeps, tools/bench_gemm_sweep.py); read per call.
 static bool forced_plan(GemmPlan& pl) {
     const char* e = getenv("DGQ_GEMM_FORCE");
@@ -657,6 +767,7 @@ static int fill_gemm(const dgq_gemm_args_t& a, GemmParams& p) {
     } else {
         DGQ_CHECK_ARG(a.cdelta && a.cflush, "dgq_gemm_wxa8: per-K mode needs cdelta/cflush");
     }
+    p.cv.codes_in = nullptr;
     p.codes = a.codes; p.rowsum = a.rowsum; p.rowsum_parts = a.rowsum_parts; p.M = a.M; p.Kp = a.Kp; p.N = a.N;
     p.wpacked = reinterpret_cast<const uint8_t*>(a.wpacked);
     p.cdelta = a.cdelta; p.cflush = a.cflush; p.mdelta = a.mdelta; p.mzp = a.mzp; p.L = a.per_m ? a.L : 1; p.offset = a.offset;
@@ -669,12 +780,21 @@ static int fill_gemm(const dgq_gemm_args_t& a, GemmParams& p) {
                       "dgq_gemm_wxa8: bad residual descriptor (ldr < N, res_div < 1 or unknown dtype)");
         DGQ_CHECK_ARG(!p.ex.geglu || (a.N % 4 == 0 && !p.ex.residual && p.ex.fq_mode == 0),
                       "dgq_gemm_wxa8: the GEGLU epilogue needs N %% 4 == 0 and no other extra");
+        if (p.ex.conv) {
+            const dgq_gemm_conv_t& c = *p.ex.conv;
+            DGQ_CHECK_ARG(c.codes_in && c.pixsum && c.pixsum_parts >= 1 && c.fill && a.per_m && a.L == 1 && a.w_bits == 4 && c.C > 0 && c.C % 16 == 0 && c.ldc >= c.C &&
+                          c.ldc % 16 == 0 && c.kh >= 1 && c.kw >= 1 && c.stride >= 1 && c.Ho > 0 && c.Wo > 0 && c.B > 0 &&
+                          a.M == c.B * c.Ho * c.Wo && a.Kp >= c.C * c.kh * c.kw && a.Kp - c.C * c.kh * c.kw < DGQ_KTILE + 16 &&
+                          (reinterpret_cast<uintptr_t>(c.codes_in) & 15) == 0 && (reinterpret_cast<uintptr_t>(c.fill) & 15) == 0,
+                          "dgq_gemm_wxa8: bad implicit-conv descriptor (needs per_m with L = 1, W4, C %% 16 == 0, M = B*Ho*Wo, 16-byte aligned codes_in / fill)");
+            p.cv = c;
+        }
         DGQ_CHECK_ARG(!p.ex.gn_partial || (a.M % 16 == 0 && a.N % 4 == 0 && !p.ex.geglu && p.ex.fq_mode == 0 &&
                                            (reinterpret_cast<uintptr_t>(p.ex.gn_partial) & 15) == 0),
                       "dgq_gemm_wxa8: GroupNorm partials need M %% 16 == 0, N %% 4 == 0, a 16-byte aligned buffer and no GEGLU / fused quantizer");
     } else {
         p.ex.residual = nullptr; p.ex.ldr = 0; p.ex.res_div = 1; p.ex.res_dtype = DGQ_F32; p.ex.fq_mode = 0; p.ex.fq_delta = nullptr; p.ex.fq_zp = nullptr;
-        p.ex.fq_T = 1; p.ex.fq_D = 1; p.ex.fq_skip = 0; p.ex.fq_qmax = 255.0f; p.ex.geglu = 0; p.ex.gn_partial = nullptr;
+        p.ex.fq_T = 1; p.ex.fq_D = 1; p.ex.fq_skip = 0; p.ex.fq_qmax = 255.0f; p.ex.geglu = 0; p.ex.gn_partial = nullptr; p.ex.conv = nullptr;
     }
     p.splits = 1; p.slab = nullptr;
     p.tiles_per_split = a.Kp / BK;
@@ -696,6 +816,7 @@ extern "C" int dgq_gemm_wxa8_batch(int n, const dgq_gemm_args_t* args, void* str
     for (int i = 0; i < n; ++i) {
         const int rc = fill_gemm(args[i], bt.p[i]);
         if (rc != DGQ_OK) return rc;
+        DGQ_CHECK_ARG(!bt.p[i].cv.codes_in, "dgq_gemm_wxa8_batch: implicit-conv problems take dgq_gemm_wxa8");
         DGQ_CHECK_ARG(args[i].w_bits == args[0].w_bits && (args[i].per_m != 0) == (args[0].per_m != 0) && args[i].y_dtype == args[0].y_dtype,
                       "dgq_gemm_wxa8_batch: problem %d differs from problem 0 in weight bits / scale mode / output dtype", i);
     }
@@ -723,8 +844,17 @@ extern "C" int dgq_gemm_wxa8(const int8_t* codes, const float* rowsum, int rowsu
     GemmParams& p = bt.p[0];
     const int rc = fill_gemm(a, p);
     if (rc != DGQ_OK) return rc;
-    GemmPlan pl = plan_gemm(M, N, Kp, w_bits, workspace ? workspace_bytes : 0, per_m != 0);
+    GemmPlan pl = plan_gemm(M, N, Kp, w_bits, workspace ? workspace_bytes : 0, per_m != 0, /*allow_big=*/!p.cv.codes_in);
+    if (p.cv.codes_in) {
+        // implicit im2col: the row sums of the unfolded operand from the per-pixel sums first (a tiny launch), then one of the three
+        // tile shapes that carry the CONV addressing (the plan's nearest)
+        conv_tile(pl, M);
+        const int thr = 256;
+        hipLaunchKernelGGL(conv_rowsum_kernel, dim3((M + thr - 1) / thr), dim3(thr), 0, (hipStream_t)stream, p.cv, M, const_cast<float*>(rowsum));
+        p.rowsum_parts = 1;
+    }
     if (forced_plan(pl)) {
+        if (p.cv.codes_in) { const int fs = pl.splits; conv_tile(pl, 0); pl.splits = fs; }
         DGQ_CHECK_ARG(pl.splits == 1 || (workspace && (size_t)pl.splits * M * N * 4 <= workspace_bytes),
                       "dgq_gemm_wxa8: DGQ_GEMM_FORCE split does not fit the workspace");
     }

@@ -224,6 +224,26 @@ class ActBinding:
                 self._koff[key] = torch.where(kp < kh * kw * C, idx, torch.full_like(idx, -1)).to(torch.int32).contiguous()
         return self._koff[key]
 
+    def input_binding(self, C):
+        """This (scalar) quantizer applied to the conv's INPUT tensor as a 1x1 layer in natural order: what dgq_quant_act needs to
+        write the int8 NHWC code tensor of the implicit-im2col path (cached)."""
+        hit = self._koff.get(("input", C))
+        if hit is None:
+            import copy
+            hit = copy.copy(self)
+            hit.Kp = round_up(C, KTILE)
+            hit._koff = {}
+            self._koff[("input", C)] = hit
+        return hit
+
+    def conv_zero_code(self):
+        """centred int8 code of the value 0.0 under this scalar quantizer: clamp(rne(0/δ) + z) − offset (set at construction)"""
+        return self._zc
+
+    def conv_fill(self):
+        """32 bytes: 16 x the code of 0.0 (a tap outside the image), 16 x 0 (the K padding) — dgq_gemm_conv_t.fill"""
+        return self._fill
+
     def __init__(self, layout: ActLayout, pw: PackedWeight, abits: int):
         dev = pw.codes.device
         self.mode, self.abits, self.offset = layout.mode, abits, act_offset(abits)
@@ -248,6 +268,10 @@ class ActBinding:
             self.L = layout.L
             self.gamma = pw.bias
             self.vn = pw.vn()
+            if layout.mode == "scalar":                    # implicit-im2col convolutions: the code of 0.0 and the DMA fill line
+                z = float(layout.mzp.reshape(-1)[0])
+                self._zc = float(min(max(round(z), 0.0), 2.0 ** abits - 1.0) - self.offset)
+                self._fill = torch.tensor([int(self._zc)] * 16 + [0] * 16, dtype=torch.int8, device=dev)
 
 
 # ------------------------------------------------------------------------------------------ hot path
@@ -316,6 +340,12 @@ def groupnorm_scale_shift(x_cl: torch.Tensor, B, HW, C, groups, eps, gamma, beta
 GN_FROM_GEMM = os.environ.get("DGQ_GN_FROM_GEMM", "1") == "1"
 #: ... also where the producing GEMM is K-split: its combine kernel writes the partials (=0: statistics pass for those tensors)
 GN_FROM_SPLITK = os.environ.get("DGQ_GN_FROM_SPLITK", "1") == "1"
+
+
+#: convolutions whose activation quantizer is one (δ, z) pair (config C5 / C2U; the reference's native conv path) take the
+#: implicit-im2col GEMM (dgq_gemm_conv_t): the input is quantised once per pixel and the unfolded operand never exists.
+#: DGQ_CONV_IMPLICIT=0: the materialising pass of every other conv layer.
+CONV_IMPLICIT = os.environ.get("DGQ_CONV_IMPLICIT", "1") == "1"
 
 
 def cat_channels(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
@@ -486,14 +516,18 @@ class Fork:
         self.used = []
 
 
-def make_extra(residual=None, fq=None, res_div=1, geglu=False, gn_partial=None):
+def make_extra(residual=None, fq=None, res_div=1, geglu=False, gn_partial=None, conv=None):
     """dgq_gemm_extra_t: residual [M / res_div][N] fp32 (row stride = its stride(0); res_div > 1 broadcasts each row
     over res_div consecutive output rows); fq = (mode, delta, zp, T, D, skip, bits) with mode 1 scalar / 2 per token /
     3 per head-dim; geglu = the pair epilogue of a row-interleaved ff.net.0.  Keeps the tensors alive on the returned object."""
-    if residual is None and fq is None and not geglu and gn_partial is None:
+    if residual is None and fq is None and not geglu and gn_partial is None and conv is None:
         return None
     ex = _lib.GemmExtra()
     ex.res_div = 1
+    ex.conv = None
+    if conv is not None:                                    # (dgq_gemm_conv_t, tensors it points to)
+        ex.conv = _c.cast(_c.pointer(conv[0]), _c.c_void_p)
+        ex._conv_keep = conv
     ex.geglu = 1 if geglu else 0
     ex.gn_partial = gn_partial.data_ptr() if gn_partial is not None else None
     keep = []
@@ -672,7 +706,22 @@ def quant_conv2d(x: torch.Tensor, ab: ActBinding, kh, kw, stride, pad, norm=None
         res2 = residual.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1).reshape(M, ab.pw.N)
     elif bias_rows is not None:                       # [B][N]: one row per image, broadcast over its Ho*Wo positions
         res2, res_div = bias_rows.contiguous(), M // B
-    codes, rowsum, M = quant_act(x_store, B, H, W, C, kh, kw, stride, pad, ab, pre)
+    implicit = CONV_IMPLICIT and ab.mode == "scalar" and kh * kw > 1 and C % 16 == 0 and ab.pw.bits == 4
+    conv_desc = None
+    if implicit:
+        # ONE (δ, z) for the whole operand (the reference's native path F.conv2d(aqtizer(x), ŵ), quant_layer.py:659): every input
+        # pixel is quantised once, as a 1x1 layer in natural order, and the GEMM gathers the taps from that int8 NHWC tensor
+        # (dgq_gemm_conv_t) — the 9x unfolded operand is never written
+        abi = ab.input_binding(C)
+        codes, pixsum, _ = quant_act(x_store, B, H, W, C, 1, 1, 1, 0, abi, pre)
+        rowsum = torch.empty((1, M), dtype=torch.float32, device=x.device)
+        cv = _lib.GemmConv()
+        cv.codes_in, cv.pixsum, cv.fill = codes.data_ptr(), pixsum.data_ptr(), ab.conv_fill().data_ptr()
+        cv.B, cv.H, cv.W, cv.C, cv.ldc, cv.kh, cv.kw, cv.stride, cv.pad, cv.Ho, cv.Wo = B, H, W, C, abi.Kp, kh, kw, stride, pad, Ho, Wo
+        cv.zero_code, cv.pixsum_parts = ab.conv_zero_code(), pixsum.shape[0]
+        conv_desc = (cv, pixsum)
+    else:
+        codes, rowsum, M = quant_act(x_store, B, H, W, C, kh, kw, stride, pad, ab, pre)
     # GroupNorm partials of the output for whoever normalises it next: from the GEMM's own epilogue, or — a K-split launch —
     # from its combine kernel (DGQ_GN_FROM_SPLITK=0: only unsplit launches, the tensor gets a statistics pass otherwise)
     N = ab.pw.N
@@ -680,7 +729,7 @@ def quant_conv2d(x: torch.Tensor, ab: ActBinding, kh, kw, stride, pad, norm=None
     if (GN_FROM_GEMM and gn_out and (Ho * Wo) % 16 == 0 and N % 4 == 0 and
             (GN_FROM_SPLITK or _lib.load().dgq_gemm_plan_splits(M, N, ab.Kp, ab.pw.bits, 0 if ab.mode == "perK" else 1, WORKSPACE_BYTES) == 1)):
         part = torch.empty((M // 16, N, 2), dtype=torch.float32, device=x.device)
-    y = gemm_wxa8(codes, rowsum, M, ab, x.dtype, extra=make_extra(res2, res_div=res_div, gn_partial=part))
+    y = gemm_wxa8(codes, rowsum, M, ab, x.dtype, extra=make_extra(res2, res_div=res_div, gn_partial=part, conv=conv_desc))
     out = y.view(B, Ho, Wo, N).permute(0, 3, 1, 2)
     if part is not None:
         out._dgq_gn = dict(parts=[(part, N)], B=B, HW=Ho * Wo, C=N, ver=out._version)

@@ -181,6 +181,25 @@ int dgq_conv2d_f32w(const void* x, int x_dtype, int B, int H, int W, int C, int 
  *                  for dgq_groupnorm_from_partials, instead of a pass over the tensor.  M % 16 == 0, N % 4 == 0, 16-byte
  *                  aligned.  Written by the GEMM's own epilogue, or — a K-split launch — by its combine kernel
  *                  (dgq_gemm_plan_splits tells which the shape gets; only the GEGLU epilogue forces an unsplit launch). */
+/* Implicit im2col A operand (dgq_gemm_extra_t.conv): a convolution whose activation quantizer is ONE (δ, z) pair — the
+ * reference's native path F.conv2d(aqtizer(x), ŵ), quant_layer.py:659 — quantises every input pixel once:
+ *   codes_in [B·H·W][ldc] int8 = dgq_quant_act of the NHWC input as a 1x1 layer in natural order (ldc = its Kp >= C),
+ *   pixsum   [pixsum_parts][B·H·W] = that call's rowsum (Σ_c s of a pixel, in the K-split parts the pass wrote).
+ * dgq_gemm_wxa8 then takes the rows of the unfolded operand straight from codes_in: K order kp = tap·C + c (the natural
+ * conv order of dgq_pack_w4's kperm == NULL image of the [N][kh][kw][C] weight), row m = (b·Ho + ho)·Wo + wo, tap (dh, dw)
+ * reads pixel (ho·stride − pad + dh, wo·stride − pad + dw); a tap outside the image reads `fill` (16 bytes of the code of
+ * the value 0.0 — F.unfold pads BEFORE the quantizer, quant_layer.py:634-641 — followed by 16 zero bytes for the K padding).
+ * `codes` / `rowsum` of the call: codes is ignored (pass codes_in), rowsum [M] is an OUTPUT scratch the call fills first
+ * (Σ over the taps of pixsum, C·zero_code for a tap outside).  per_m == 1 with L == 1, C % 16 == 0, w_bits == 4. */
+typedef struct dgq_gemm_conv {
+    const int8_t* codes_in;
+    const float* pixsum;
+    const int8_t* fill;
+    int B, H, W, C, ldc, kh, kw, stride, pad, Ho, Wo;
+    float zero_code;
+    int pixsum_parts;
+} dgq_gemm_conv_t;
+
 typedef struct dgq_gemm_extra {
     const void* residual;
     int ldr;
@@ -193,6 +212,7 @@ typedef struct dgq_gemm_extra {
     float fq_qmax;
     int geglu;
     float* gn_partial;
+    const dgq_gemm_conv_t* conv;     /* (or NULL) implicit im2col A operand, see dgq_gemm_conv_t */
 } dgq_gemm_extra_t;
 
 int dgq_gemm_wxa8(const int8_t* codes, const float* rowsum, int rowsum_parts, int M, int Kp,

@@ -828,3 +828,59 @@ def test_weight_only_conv_kernel_with_folded_groupnorm_silu(N, dev):
     xn = torch.nn.functional.silu(torch.nn.functional.group_norm(x.double().cpu(), 8, gamma.double(), beta.double(), 1e-5))
     ref = torch.nn.functional.conv2d(xn, w.double(), b.double(), padding=1)
     assert rel_l2(y.double().cpu(), ref) < 5e-6, rel_l2(y.double().cpu(), ref)
+
+
+# ------------------------------------------------------------------------------------------ implicit-im2col convolution
+@pytest.mark.parametrize("case", [c for c in recipes.f3_cases() if c["kind"] == "conv" and c["state"] == "wa" and c["layout"] == "scalar"
+                                  and c["wbits"] == 4], ids=lambda c: c["name"])
+def test_implicit_conv_bit_identical_to_materialised(case, dev, monkeypatch):
+    """Scalar-δ convolutions (the reference's native path F.conv2d(aqtizer(x), ŵ), quant_layer.py:659) through the implicit-im2col
+    GEMM (dgq_gemm_conv_t: the input quantised once per pixel, taps gathered by the LDS-DMA, out-of-image taps = the code of 0.0)
+    against the materialising pass: the SAME output bit for bit (integer contraction, exact integer row sums), hence the same
+    2e-5 distance to the reference's golden; 3x3 stride 1, 3x3 stride 2 pad 1, 1x1 stays on the ordinary path."""
+    from dgq_amd import ops
+    from dgq_amd.plan import plan_act
+    g = gold("f3_layers.pt")[case["name"]]
+    inp = recipes.f3_inputs(case)
+    w = inp["w"].to(dev)
+    C, taps = w.shape[1], case["k"] ** 2
+    pw = ops.PackedWeight(w, g["wdelta"].to(dev), g["wzp"].to(dev), None, inp["b"].to(dev), 4, C, taps)
+    ab = ops.ActBinding(plan_act(inp["adelta"], inp["azp"], "conv", C, taps, case["abits"]), pw, case["abits"])
+    assert ab.mode == "scalar"
+    x = inp["x"].to(dev)
+    monkeypatch.setattr(ops, "CONV_IMPLICIT", False)
+    y0 = ops.quant_conv2d(x, ab, case["k"], case["k"], case["stride"], case["padding"])
+    monkeypatch.setattr(ops, "CONV_IMPLICIT", True)
+    y1 = ops.quant_conv2d(x, ab, case["k"], case["k"], case["stride"], case["padding"])
+    torch.cuda.synchronize()
+    assert torch.equal(y0, y1), (case["name"], (y0 - y1).abs().max().item())
+    assert rel_l2(y1.cpu(), g["y"]) < 2e-5
+
+
+@pytest.mark.parametrize("geom", [(2, 64, 24, 24, 3, 1, 1, 96), (1, 320, 16, 16, 3, 1, 1, 320), (2, 48, 17, 13, 3, 2, 1, 80), (1, 640, 8, 8, 3, 1, 1, 1280),
+                                  (3, 32, 9, 11, 5, 1, 2, 40)], ids=lambda g: "x".join(str(v) for v in g))
+def test_implicit_conv_geometries(geom, dev, monkeypatch):
+    """the implicit path on more geometries (C not a multiple of the K tile, ragged images, stride 2, 5x5, K-split shapes, a
+    zero point that makes the padded value's code non-trivial), with residual and GroupNorm prologue: bit-identical to the
+    materialising pass"""
+    from dgq_amd import ops, synth
+    from dgq_amd.plan import plan_act
+    B, C, H, W, k, stride, pad, N = geom
+    gen = torch.Generator().manual_seed(sum(geom))
+    w = (torch.randn(N, C, k, k, generator=gen) * 0.05).to(dev)
+    x = (torch.randn(B, C, H, W, generator=gen) * 1.5 + 0.3).to(dev)
+    wd, wz = synth.channel_minmax(w.cpu(), 4)
+    pw = ops.PackedWeight(w, wd.to(dev), wz.to(dev), None, torch.randn(N, generator=gen).to(dev), 4, C, k * k)
+    ab = ops.ActBinding(plan_act(torch.tensor(0.037), torch.tensor(97.0), "conv", C, k * k, 8), pw, 8)
+    assert ab.mode == "scalar"
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    res = torch.randn(B, N, Ho, Wo, generator=gen).to(dev)
+    norm = None
+    if C % 32 == 0:
+        norm = (32, 1e-5, torch.randn(C, generator=gen).to(dev), torch.randn(C, generator=gen).to(dev), 1)
+    outs = []
+    for flag in (False, True):
+        monkeypatch.setattr(ops, "CONV_IMPLICIT", flag)
+        outs.append(ops.quant_conv2d(x, ab, k, k, stride, pad, norm=norm, residual=res))
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1]), (geom, (outs[0] - outs[1]).abs().max().item())
