@@ -298,7 +298,10 @@ def test_fused_unet_teacher_forced_vs_oracle(arch, res, cname, batch, ts, ckdir)
     assert sorted(seen) == sorted(rec.io.keys()), (len(seen), len(rec.io))     # every quantized layer, exactly once
     assert len(stats["pro"]) > 0.3 * len(seen)                                   # the folded prologues really are in use
     fails = _report("fused %s/%s res=%d t=%d" % (arch, cname, res, t), stats,
-                    (("out", 1e-4, None), ("pro", 5e-4, 2e-5), ("in", 2e-5, None), ("attn", 2e-2, 1e-5), ("aout", 2e-2, 1e-5)))
+                    # "pro": a code moved by the folded norm's different rounding costs ONE quantisation step, and a 6-bit step is
+                    # four 8-bit steps: the worst-case bound scales with it (A8: 5e-4, measured 4e-4; A6: 2e-3, measured 7e-4 on sd/C3)
+                    (("out", 1e-4, None), ("pro", 5e-4 * 2 ** (8 - c["abits"]), 2e-5), ("in", 2e-5, None), ("attn", 2e-2, 1e-5),
+                     ("aout", 2e-2, 1e-5)))
     assert not fails, fails
     e = rel_l2(out["y"].float().cpu(), ref)
     print("fused %s/%s res=%d t=%d final (teacher-forced, folded conv_norm_out) rel-L2 %.3g" % (arch, cname, res, t, e))
