@@ -125,8 +125,8 @@ __device__ __forceinline__ void gemm_store_tile(const GemmParams& p, int zsplit,
     constexpr int LPR = WN / 4;                              // lanes per output row (4 consecutive n each)
     constexpr int RPP = 64 / LPR;                            // rows per pass of the wave
     constexpr int PASSES = WM / RPP / WVK;                   // passes of this wave
-    // The 128x256 tile's eight 64x64 wave tiles (139 KB with the padding) do not fit the 96 KB ring: such a wave stages its
-    // tile in EPH = 2 halves of 32 rows (one MFMA row tile), each a same-wave LDS round trip like the whole tile elsewhere.
+    // The 256-row kernel's eight wave tiles (128x64: 278 KB with the padding; 128x32 / 64x64: 139-147 KB) do not fit its ring: such
+    // a wave stages its tile in EPH = 2 halves (whole MFMA row tiles), each a same-wave LDS round trip like the whole tile elsewhere.
     constexpr int EPH = (NW * WM * EP_LD * 4 <= LDS_CAP) ? 1 : 2;
     static_assert(EPH == 1 || (WVK == 1 && TM % 2 == 0 && PASSES % 2 == 0), "half-tile staging: whole MFMA row tiles per half");
     constexpr int HROWS = WM / EPH;                          // rows staged at a time

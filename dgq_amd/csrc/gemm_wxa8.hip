@@ -577,7 +577,8 @@ static void launch_ring(const GemmBatch& bt, hipStream_t st) {
 
 // Tile shapes the host may pick (BM x BN, waves m x n x k):
 //   W4: 32x64 (1x2x2), 32x128 (1x4x1), 64x64 (2x2x1), 64x128 (1x4x1: a widened int4 fragment feeds two row tiles),
-//       128x64 (2x2x1), 128x128 (2x2x1), 128x256 (2x4x1: eight waves, half the operand re-reads per MFMA of 128x128)
+//       128x64 (2x2x1), 128x128 (2x2x1); bm = 256 names the 256-row ping-pong kernel of gemm_wxa8_big.hip (the 128x256 tile of
+//       round 3 — equal to 128x128 on every shape, never planned — is gone)
 //   W8 (a secondary configuration): 32x64, 64x64, 128x128
 template <int WBITS, bool PER_M, typename TOut>
 static int launch_one(const GemmBatch& bt, int bm, int bn, hipStream_t st) {
@@ -593,7 +594,6 @@ static int launch_one(const GemmBatch& bt, int bm, int bn, hipStream_t st) {
                     case 128064: launch_ring<WBITS, PER_M, TOut, 128, 64, 2, 2, 1>(bt, st); break;
                     case 64128: launch_ring<WBITS, PER_M, TOut, 64, 128, 1, 4, 1>(bt, st); break;
                     case 32128: launch_ring<WBITS, PER_M, TOut, 32, 128, 1, 4, 1>(bt, st); break;
-                    case 128256: launch_ring<WBITS, PER_M, TOut, 128, 256, 2, 4, 1>(bt, st); break;
                     default: dgq_set_error("dgq_gemm_wxa8: no %dx%d tile", bm, bn); return DGQ_EINVAL;
                 }
             } else {

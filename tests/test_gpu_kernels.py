@@ -156,13 +156,13 @@ def test_gemm_exact_integer(dev):
         _gemm_exact_case(dev, M, N, Kp, wbits)
 
 
-@pytest.mark.parametrize("tile", ["32,64,1", "32,128,1", "64,64,1", "64,128,1", "128,64,1", "128,128,1", "128,256,1", "128,256,2", "32,64,3", "64,128,2"])
+@pytest.mark.parametrize("tile", ["32,64,1", "32,128,1", "64,64,1", "64,128,1", "128,64,1", "128,128,1", "256,256,1", "32,64,3", "64,128,2"])
 def test_gemm_exact_integer_every_tile(tile, dev, monkeypatch):
     """the same on every tile shape of the family (DGQ_GEMM_FORCE = BM,BN,splits), ragged M / N edges included"""
     monkeypatch.setenv("DGQ_GEMM_FORCE", tile)
     _gemm_exact_case(dev, 203, 332, 640, 4, seed=3)
-    if tile.startswith("128,256"):
-        _gemm_exact_case(dev, 300, 700, 512, 4, seed=5)      # three column tiles, the last ragged; both staged halves of every wave
+    if tile.startswith("256,256"):
+        _gemm_exact_case(dev, 300, 700, 512, 4, seed=5)      # the 256-row kernel: ragged column / row tiles, both staged halves of every wave
     if tile in ("32,64,1", "64,64,1", "128,128,1", "32,64,3"):
         _gemm_exact_case(dev, 170, 200, 384, 8, seed=4)
 
@@ -170,7 +170,7 @@ def test_gemm_exact_integer_every_tile(tile, dev, monkeypatch):
 def test_gemm_exact_integer_big_kernel(dev, monkeypatch):
     """the 256-row ping-pong kernel (gemm_wxa8_big.hip; the plan names it by BM = 256): exact integers on ragged M / N edges, one
     and several workgroup tiles per dimension, K from a single tile (no steady state) to 17 tiles (every ring stage reused, a
-    clear of the running totals inside) — per-K on its 128x256 tile and per-M on 256x256"""
+    clear of the running totals inside) — per-K on its 256x128 tile and per-M on 256x256"""
     monkeypatch.setenv("DGQ_GEMM_FORCE", "256,256,1")
     for (M, N, Kp, seed) in ((203, 332, 640, 3), (300, 700, 128, 5), (515, 260, 256, 6), (130, 513, 2176, 7), (700, 300, 384, 8)):
         _gemm_exact_case(dev, M, N, Kp, 4, seed=seed)
