@@ -41,8 +41,6 @@ SIGNATURES = {
     "dgq_quant_act_variant": [_vp],
     "dgq_quant_act_conv_tile": [_i, _i, _i, _i, _i, _vp],
     "dgq_gemm_wxa8_batch": [_i, _vp, _vp],
-    "dgq_gemm_emit_supported": [_i, _i],
-    "dgq_gemm_wxa8_emit": [_vp, _i, _vp, _vp],
     "dgq_adaround_soft_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp],
     "dgq_adaround_soft_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp],
     "dgq_adaround_reg_blocks": [_i64],

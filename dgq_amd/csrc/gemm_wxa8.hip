@@ -32,28 +32,16 @@
 // caller-provided workspace; splitk_epilogue_kernel sums them in a fixed order and applies the dequantisation epilogue
 // (no float atomics: results are bit-reproducible).
 #include "gemm_tile.h"
-#include "quant_rows.h"
 
 // WVM x WVN x WVK waves; NST ring stages; ACCS int32 accumulator sets per wave (per-K mode only).  With ACCS = 2 consecutive
 // chunks of a wave alternate between two accumulator sets, each with its own running total, and a chunk's flush is issued
 // AFTER the MFMAs of the wave's next chunk: on the small tiles (one or two MFMAs per chunk) the MFMA latency and the flush
 // VALU of one chunk then overlap the next chunk's MFMAs instead of sitting between them.
-// Row-owning launches (ROWOWN: BM = 32, BN = N): the workgroup holds whole output rows, so once they are stored it quantises them
-// for the layer(s) that consume them — up to three dgq_quant_act problems whose input x IS this GEMM's y (the q / k / v
-// projections behind a LayerNorm take three tables) — instead of a quantise-on-load launch per consumer.
-#define DGQ_EMIT_MAX 3
-struct EmitArgs {
-    int n;
-    QuantActParams q[DGQ_EMIT_MAX];
-    int per_m[DGQ_EMIT_MAX];
-};
-struct NoEmit {};
-
 // CONV: the A operand is the implicit im2col of an int8 NHWC code tensor (dgq_gemm_conv_t: scalar-δ convolutions) — the same LDS
 // image, filled from per-lane source addresses that walk (tap, channel) instead of a materialised [M][Kp] row.
-template <int WBITS, bool PER_M, typename TOut, int BM, int BN, int WVM, int WVN, int WVK, int NST, int ACCS, bool CONV = false, bool ROWOWN = false>
+template <int WBITS, bool PER_M, typename TOut, int BM, int BN, int WVM, int WVN, int WVK, int NST, int ACCS, bool CONV = false>
 __global__ __launch_bounds__(64 * WVM * WVN * WVK, gemm_waves_per_simd(WBITS, BM, BN, WVM * WVN * WVK, NST))
-void gemm_wxa8_kernel(GemmBatch bt, typename std::conditional<ROWOWN, EmitArgs, NoEmit>::type em) {
+void gemm_wxa8_kernel(GemmBatch bt) {
     const GemmParams& p = bt.p[bt.n > 1 ? blockIdx.z : 0];
     const int zsplit = bt.n > 1 ? 0 : blockIdx.z;
     // XCD-aware tile order.  Workgroups are dealt round-robin over the 8 XCDs (each with its own L2): in launch order the
@@ -85,15 +73,9 @@ void gemm_wxa8_kernel(GemmBatch bt, typename std::conditional<ROWOWN, EmitArgs, 
     constexpr int W_ROW = (WBITS == 4) ? BK / 2 : BK;      // bytes per n-row per stage
     constexpr int W_BYTES = BN * W_ROW;
     constexpr int STAGE_BYTES = A_BYTES + W_BYTES;
-    // ROWOWN: the 32-row A tile has 4 pieces for 5 or 10 waves: waves 0-3 take one each, the others re-load piece 0 into a junk
-    // KiB of their own behind the ring, so that every wave issues the same number of DMAs per tile (the counted waits are
-    // compile-time constants)
-    constexpr int A_PIECES = A_BYTES / 1024;
-    static_assert(ROWOWN ? (BM == 32 && WVM == 1 && WVK == 1 && NW >= A_PIECES && W_BYTES % (1024 * NW) == 0 && !CONV)
-                         : (A_BYTES % (1024 * NW) == 0 && W_BYTES % (1024 * NW) == 0), "every wave stages whole 1-KiB pieces of each operand");
-    constexpr int A_DMA = ROWOWN ? 1 : A_BYTES / 1024 / NW;   // DMA instructions per wave per tile (1 KiB each)
+    static_assert(A_BYTES % (1024 * NW) == 0 && W_BYTES % (1024 * NW) == 0, "every wave stages whole 1-KiB pieces of each operand");
+    constexpr int A_DMA = A_BYTES / 1024 / NW;             // DMA instructions per wave per tile (1 KiB each)
     constexpr int W_DMA = W_BYTES / 1024 / NW;
-    constexpr int JUNK_BYTES = ROWOWN ? 1024 * (NW - A_PIECES) : 0;
     constexpr int DMA_PER_TILE = A_DMA + W_DMA;
 
     const int tid = threadIdx.x;
@@ -116,7 +98,7 @@ void gemm_wxa8_kernel(GemmBatch bt, typename std::conditional<ROWOWN, EmitArgs, 
     bool cv_in[A_DMA];
 #pragma unroll
     for (int i = 0; i < A_DMA; ++i) {
-        const int blk = ROWOWN ? (wid < A_PIECES ? wid : 0) : wid * A_DMA + i;   // 1 KiB = 8 rows of 128 B
+        const int blk = wid * A_DMA + i;                   // 1 KiB = 8 rows of 128 B
         const int row = blk * 8 + (lane >> 3);
         const int c = (lane & 7) ^ ((row >> 1) & 7);
         const int m = min(m0 + row, p.M - 1);
@@ -186,9 +168,6 @@ void gemm_wxa8_kernel(GemmBatch bt, typename std::conditional<ROWOWN, EmitArgs, 
                         a_src[i] = cv_img[i] + ((int64_t)hi * p.cv.W + wi) * p.cv.ldc + cv_cc[i];
                     }
                 }
-            } else if constexpr (ROWOWN) {
-                const uint32_t dst = wid < A_PIECES ? sa + wid * 1024 : lds_base + STAGES * STAGE_BYTES + (wid - A_PIECES) * 1024;
-                glds16(a_src[i] + ka, __builtin_amdgcn_readfirstlane(dst));
             } else {
                 glds16(a_src[i] + ka, __builtin_amdgcn_readfirstlane(sa + (wid * A_DMA + i) * 1024));
             }
@@ -238,7 +217,7 @@ void gemm_wxa8_kernel(GemmBatch bt, typename std::conditional<ROWOWN, EmitArgs, 
     // the younger tiles in flight.  All loads are unconditional at clamped indices: a load whose address or predicate depended
     // on another load's result cost a full round trip each (four such chains made a per-K launch 3-4 us longer than its
     // per-M twin).
-    float* vtab = reinterpret_cast<float*>(smem + STAGES * STAGE_BYTES + JUNK_BYTES);   // [3][BM]: R0 R1 R2 | [4][BN]: alpha zw gamma vn
+    float* vtab = reinterpret_cast<float*>(smem + STAGES * STAGE_BYTES);   // [3][BM]: R0 R1 R2 | [4][BN]: alpha zw gamma vn
     float* vcol = vtab + 3 * BM;
     float* ctab = vcol + 4 * BN;                                           // [WVK][nk·MYCH] flush coefficients | [nk] clear flags
     static_assert(BM <= NT && BN <= NT, "one row / column of the epilogue vectors per thread");
@@ -435,36 +414,6 @@ void gemm_wxa8_kernel(GemmBatch bt, typename std::conditional<ROWOWN, EmitArgs, 
     // epilogue (gemm_tile.h): the wave tiles are transposed through the now idle ring and stored 16 bytes per lane
     gemm_store_tile<PER_M, TOut, BM, BN, WVM, WVN, WVK, STAGES * STAGE_BYTES, TM, TN>(p, zsplit, smem, vtab, vcol, wid, lane, wave_m, wave_n,
                                                                                       wave_k, m0, n0, acc[0], accf);
-    if constexpr (ROWOWN) {
-        // The rows m0 .. m0+31 of y are complete and stored by THIS workgroup.  Quantise them for the consuming layer(s), one wave
-        // per row, with the row quantisers of quant_act.hip (quant_rows.h: same arithmetic, same order — codes and row sums are
-        // those of a dgq_quant_act launch on y).  The rows are read back from global memory (L2-hot; __syncthreads: the stores are
-        // complete and visible to the workgroup); the ring is idle and holds the per-K tables and one row image per wave.
-        for (int q = 0; q < em.n; ++q) {
-            const QuantActParams& qp = em.q[q];
-            if (qp.M < 0) break;                              // (measurement hook: dgq_gemm_wxa8_emit under DGQ_EMIT_SKIP=1)
-            __syncthreads();
-            const int nch = qp.Kp >> 5;
-            float* tdelta = reinterpret_cast<float*>(smem);
-            float* tinv = tdelta + nch;
-            float* tzp = tinv + nch;
-            uint8_t* images = smem + (((3 * nch + 4) * 4 + 15) & ~15);
-            if (qp.kdst) {
-                for (int i = tid; i < nch; i += NT) {
-                    const float d = qp.delta[i];
-                    tdelta[i] = d; tinv[i] = dgq_rcp(d); tzp[i] = qp.zp[i];
-                }
-                __syncthreads();
-            }
-            for (int r = wid; r < BM; r += NW) {
-                const int row = m0 + r;
-                if (row >= p.M) break;
-                if (qp.kdst) qa_row_scatter<TOut>(qp, row, lane, tdelta, tinv, tzp, images + (size_t)wid * qp.Kp);
-                else if (em.per_m[q]) qa_row_natural<TOut, true>(qp, row, lane);
-                else qa_row_natural<TOut, false>(qp, row, lane);
-            }
-        }
-    }
 }
 
 // Deterministic split-K combine + dequantisation epilogue: one thread per 4 consecutive n.
@@ -611,11 +560,11 @@ static void launch_tile(const GemmBatch& bt, hipStream_t st) {
                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
                 if (dev >= 0 && dev < 64) cattr[dev].store(true, std::memory_order_release);
             }
-            hipLaunchKernelGGL((gemm_wxa8_kernel<WBITS, PER_M, TOut, BM, BN, WVM, WVN, WVK, NST, ACCS, true>), grid, block, lds, st, bt, NoEmit{});
+            hipLaunchKernelGGL((gemm_wxa8_kernel<WBITS, PER_M, TOut, BM, BN, WVM, WVN, WVK, NST, ACCS, true>), grid, block, lds, st, bt);
         }
         return;                                          // (other shapes: refused by dgq_gemm_wxa8 before it gets here)
     }
-    hipLaunchKernelGGL((gemm_wxa8_kernel<WBITS, PER_M, TOut, BM, BN, WVM, WVN, WVK, NST, ACCS>), grid, block, lds, st, bt, NoEmit{});
+    hipLaunchKernelGGL((gemm_wxa8_kernel<WBITS, PER_M, TOut, BM, BN, WVM, WVN, WVK, NST, ACCS>), grid, block, lds, st, bt);
 }
 
 // Ring depth: 3 stages for every tile shape.  A 6-stage ring (five tiles in flight, counted prologue wait so that only tile 0
@@ -917,79 +866,4 @@ extern "C" int dgq_gemm_wxa8(const int8_t* codes, const float* rowsum, int rowsu
     p.splits = (nk + p.tiles_per_split - 1) / p.tiles_per_split;      // no empty split
     if (p.splits == 1) p.slab = nullptr;
     return dispatch_gemm(bt, w_bits, per_m != 0, pl.bm, pl.bn, y_dtype, (hipStream_t)stream);
-}
-
-// ---- row-owning launch: GEMM on 32 x N tiles + quantise-on-store for the consuming layer(s) --------------------------------
-template <bool PER_M, typename TOut, int BN>
-static void launch_rowown(const GemmBatch& bt, const EmitArgs& em, hipStream_t st) {
-    const GemmParams& p = bt.p[0];
-    constexpr int NW = BN / 64, NST = 3;
-    constexpr int ACCS = PER_M ? 1 : 2;
-    constexpr int lds_stages = NST * gemm_stage_bytes(4, 32, BN);
-    constexpr int junk = 1024 * (NW - 4);
-    constexpr int lds_vec = (3 * 32 + 4 * BN) * 4;
-    constexpr int lds_max = (lds_stages + junk + lds_vec + 32768) < 160 * 1024 ? (lds_stages + junk + lds_vec + 32768) : 160 * 1024;
-    static std::atomic<bool> attr_set[64];
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    auto kern = &gemm_wxa8_kernel<4, PER_M, TOut, 32, BN, 1, NW, 1, NST, ACCS, false, true>;
-    if (dev < 0 || dev >= 64 || !attr_set[dev].load(std::memory_order_acquire)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
-        if (dev >= 0 && dev < 64) attr_set[dev].store(true, std::memory_order_release);
-    }
-    const int lds = lds_stages + junk + lds_vec + (PER_M ? 0 : (((NCH + 1) * p.tiles_per_split * 4 + 15) & ~15));
-    dim3 grid(1, (p.M + 31) / 32, 1), block(64 * NW);
-    hipLaunchKernelGGL(kern, grid, block, lds, st, bt, em);
-}
-
-template <typename TOut>
-static int launch_rowown_dtype(const GemmBatch& bt, const EmitArgs& em, bool per_m, int N, hipStream_t st) {
-    if (N == 320) { if (per_m) launch_rowown<true, TOut, 320>(bt, em, st); else launch_rowown<false, TOut, 320>(bt, em, st); }
-    else { if (per_m) launch_rowown<true, TOut, 640>(bt, em, st); else launch_rowown<false, TOut, 640>(bt, em, st); }
-    return DGQ_OK;
-}
-
-extern "C" int dgq_gemm_emit_supported(int N, int w_bits) { return (w_bits == 4 && (N == 320 || N == 640)) ? 1 : 0; }
-
-// dgq_gemm_wxa8 on full-row tiles (N = 320 or 640, W4, no K split) whose workgroups then run `n_emit` (1..3) dgq_quant_act problems
-// on the rows they have just stored: emit[i].x must be g->y viewed as a Linear input (B = M rows, H = W = kh = kw = stride = 1,
-// pad = 0, C = N, x_dtype = y_dtype, ldy = N), natural order (per_m) or per-K with its kdst table, optional LayerNorm prologue,
-// ksplits = 1.  Codes and row sums are those of the same dgq_quant_act calls launched after the GEMM.
-extern "C" int dgq_gemm_wxa8_emit(const dgq_gemm_args_t* g, int n_emit, const dgq_quant_act_args_t* emit, void* stream) {
-    DGQ_CHECK_ARG(g && emit && n_emit >= 1 && n_emit <= DGQ_EMIT_MAX, "dgq_gemm_wxa8_emit: n_emit=%d (1..%d)", n_emit, DGQ_EMIT_MAX);
-    DGQ_CHECK_ARG(dgq_gemm_emit_supported(g->N, g->w_bits), "dgq_gemm_wxa8_emit: full-row tiles exist for W4 and N = 320 / 640 (N=%d)", g->N);
-    GemmBatch bt;
-    bt.n = 1;
-    GemmParams& p = bt.p[0];
-    int rc = fill_gemm(*g, p);
-    if (rc != DGQ_OK) return rc;
-    DGQ_CHECK_ARG(!p.cv.codes_in && !p.ex.geglu && !p.ex.gn_partial && g->ldy == g->N,
-                  "dgq_gemm_wxa8_emit: no implicit-conv / GEGLU / GroupNorm-partial extras, ldy == N");
-    EmitArgs em;
-    em.n = n_emit;
-    for (int i = 0; i < n_emit; ++i) {
-        const dgq_quant_act_args_t& e = emit[i];
-        rc = dgq_fill_quant_act(e, em.q[i]);
-        if (rc != DGQ_OK) return rc;
-        em.per_m[i] = e.per_m != 0;
-        const size_t need = ((((size_t)3 * (e.Kp >> 5) + 4) * 4 + 15) & ~(size_t)15) + (size_t)(g->N / 64) * e.Kp;
-        DGQ_CHECK_ARG(e.x == g->y && e.x_dtype == g->y_dtype && e.B == g->M && e.H == 1 && e.W == 1 && e.kh == 1 && e.kw == 1 && e.stride == 1 &&
-                      e.pad == 0 && e.C == g->N && e.ksplits == 1 && !e.pre_scale && e.pre_act == 0 && (e.per_m || (e.ksrc && e.kdst)) &&
-                      (!e.ksrc || e.kdst) && need <= (size_t)3 * gemm_stage_bytes(4, 32, g->N),
-                      "dgq_gemm_wxa8_emit: problem %d is not a Linear input quantisation of this GEMM's output", i);
-    }
-    if (const char* e = getenv("DGQ_EMIT_SKIP")) { if (*e == '1') em.q[0].M = -1; }      // timing of the GEMM part alone (tools/bench_emit.py)
-    p.splits = 1; p.slab = nullptr; p.tiles_per_split = g->Kp / BK;
-    DGQ_CHECK_ARG((size_t)3 * gemm_stage_bytes(4, 32, g->N) + 1024 * (g->N / 64 - 4) + (3 * 32 + 4 * g->N) * 4 +
-                  (g->per_m ? 0 : (size_t)(NCH + 1) * (g->Kp / BK) * 4 + 16) <= 160 * 1024,
-                  "dgq_gemm_wxa8_emit: Kp=%d: the flush table does not fit beside the ring", g->Kp);
-    hipStream_t st = (hipStream_t)stream;
-    switch (g->y_dtype) {
-        case DGQ_F32: rc = launch_rowown_dtype<float>(bt, em, g->per_m != 0, g->N, st); break;
-        case DGQ_F16: rc = launch_rowown_dtype<__half>(bt, em, g->per_m != 0, g->N, st); break;
-        case DGQ_BF16: rc = launch_rowown_dtype<__hip_bfloat16>(bt, em, g->per_m != 0, g->N, st); break;
-        default: dgq_set_error("dgq_gemm_wxa8_emit: unknown y dtype %d", g->y_dtype); return DGQ_EINVAL;
-    }
-    if (rc != DGQ_OK) return rc;
-    return dgq_launch_status("dgq_gemm_wxa8_emit");
 }

@@ -6,7 +6,109 @@
 #include <cstdlib>
 #include "dgq_common.h"
 
-#include "quant_rows.h"
+struct QuantActParams {
+    const void* x;
+    int B, H, W, C, kh, kw, stride, pad, Ho, Wo;
+    const int32_t* ksrc;      // [Kp] (dh<<24 | dw<<16 | c) or -1, or NULL (natural order kp = tap*C + c)
+    const int32_t* koff;      // optional [Kp]: (dh*W + dw)*ldc + c for THIS geometry, -1 for padding (interior rows)
+    const int32_t* klds;      // optional [Kp]: (dh*kw + dw)*C + c, -1 for padding (LDS-staged conv path)
+    const int32_t* kdst;      // optional [taps*C]: packed position kp of element (tap, c) — the inverse of ksrc (scatter path)
+    const int32_t* kpat;      // optional [Kp]: (dh*PW + dw)*C + c inside the input patch of a conv tile (PW of dgq_quant_act_conv_tile), -1 padding
+    int Kp, K;
+    const float* delta;       // per_m: [L]; else [Kp/32]
+    const float* zp;
+    int L;
+    float qmax, offset;
+    int8_t* codes;
+    float* rowsum;            // [ksplits][M] partial sums (the GEMM epilogue adds them in a fixed order)
+    int M;
+    int kp_per_split;         // multiple of 256
+    const float* pre_scale;   // optional [B][C]: v = x*scale + shift (fused GroupNorm), then pre_act
+    const float* pre_shift;
+    int pre_act;              // 0 none, 1 SiLU, 2 GEGLU: value = x[c]·gelu(x[C + c]) on rows of 2C elements
+    int ldc;                  // elements per input pixel/row (C, or 2C for GEGLU)
+    const float* ln_gamma;    // optional [C]: LayerNorm over the C elements of the row, v = (x − μ)·rstd·γ + β (1x1 only)
+    const float* ln_beta;
+    float ln_eps;
+};
+
+// Up to DGQ_QA_BATCH problems of ONE kernel variant and the same row count in one launch (blockIdx.z = problem): the
+// q / k / v projections of an attention quantise the same input three ways, the to_k / to_v of every cross-attention
+// quantise the same text context — one launch each instead of one per layer.
+#define DGQ_QA_BATCH 8
+struct QuantActBatch {
+    QuantActParams p[DGQ_QA_BATCH];
+};
+
+
+
+template <typename TIn>
+__device__ __forceinline__ void load4(const TIn* p, float (&v)[4]);
+template <>
+__device__ __forceinline__ void load4<float>(const float* p, float (&v)[4]) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+}
+template <>
+__device__ __forceinline__ void load4<__half>(const __half* p, float (&v)[4]) {
+    const uint2 t = *reinterpret_cast<const uint2*>(p);
+    const __half* h = reinterpret_cast<const __half*>(&t);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = __half2float(h[j]);
+}
+template <>
+__device__ __forceinline__ void load4<__hip_bfloat16>(const __hip_bfloat16* p, float (&v)[4]) {
+    const uint2 t = *reinterpret_cast<const uint2*>(p);
+    const uint16_t* h = reinterpret_cast<const uint16_t*>(&t);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = __uint_as_float(((uint32_t)h[j]) << 16);
+}
+
+// LayerNorm statistics of one row of C <= 2048 elements (C % 4 == 0), computed by the wave that quantises the row: the
+// row is read ONCE into registers (8 float4 per lane), mean first, then Σ(x − mean)² from the registers; biased
+// variance, rstd = 1/sqrt(var + eps) as nn.LayerNorm.
+#define DGQ_LN_MAX_C 2048
+template <typename TIn>
+__device__ __forceinline__ void row_layernorm_stats(const TIn* xr, int C, float eps, int lane, float& mu, float& rstd) {
+    float v[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = lane * 4 + 256 * i;
+        if (c < C) load4<TIn>(xr + c, v[i]);
+        else v[i][0] = v[i][1] = v[i][2] = v[i][3] = 0.0f;
+    }
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    mu = s / (float)C;
+    float q = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = lane * 4 + 256 * i;
+        if (c < C) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) q += (v[i][j] - mu) * (v[i][j] - mu);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+    rstd = 1.0f / sqrtf(q / (float)C + eps);
+}
+
+// Four codes q_j ∈ [0, 2^b−1] (floats) -> one dword of centred int8 codes s_j = q_j − off, 0 for padding:
+// v_cvt_pk_u8_f32 inserts u8(q − off + 128) per byte, and u8(x + 128) ^ 0x80 is the two's-complement byte of x.
+// `biased[j]` = valid ? q_j − off + 128 : 128 ; returns the dword, adds Σ biased to `fsum` (exact small integers).
+__device__ __forceinline__ uint32_t dgq_pack4(const float (&biased)[4], float& fsum) {
+    uint32_t w = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        w = __builtin_amdgcn_cvt_pk_u8_f32(biased[j], j, w);
+        fsum += biased[j];
+    }
+    return w ^ 0x80808080u;
+}
 
 // One wave per output row; each lane owns 4 consecutive kp per 256-wide step (one packed dword), so that the
 // table read (int4), the gathered loads (lane stride 16 B within a (group, tap) run) and the code store (256 B per
@@ -707,9 +809,6 @@ static int fill_quant_act(const dgq_quant_act_args_t& a, QuantActParams& p) {
     p.ldc = a.pre_act == 2 ? 2 * a.C : a.C;
     return DGQ_OK;
 }
-
-// (for the row-owning GEMM of gemm_wxa8.hip, which runs the row quantisers of quant_rows.h on its own output)
-int dgq_fill_quant_act(const dgq_quant_act_args_t& a, QuantActParams& p) { return fill_quant_act(a, p); }
 
 extern "C" int dgq_quant_act_batch(int n, const dgq_quant_act_args_t* args, void* stream) {
     DGQ_CHECK_ARG(args && n >= 1 && n <= DGQ_QA_BATCH, "dgq_quant_act_batch: n=%d (1..%d)", n, DGQ_QA_BATCH);

@@ -581,69 +581,6 @@ def gemm_wxa8(codes, rowsum, M, ab: ActBinding, out_dtype, out: Optional[torch.T
     return out
 
 
-#: quantise-on-store from row-owning GEMM tiles (dgq_gemm_wxa8_emit): a Linear / 1x1 layer with N = 320 or 640 output columns whose
-#: consumer(s) quantise its output — through a LayerNorm or not — hands them their codes and row sums itself.  DGQ_FUSE_EMIT=0 off.
-FUSE_EMIT = os.environ.get("DGQ_FUSE_EMIT", "1") == "1"
-#: rows from which the full-row tiles fill enough of the chip (32-row tiles: M / 32 workgroups)
-EMIT_MIN_ROWS = int(os.environ.get("DGQ_EMIT_MIN_ROWS", "2048"))
-
-
-def emit_supported(ab: ActBinding, M: int) -> bool:
-    return bool(FUSE_EMIT and M >= EMIT_MIN_ROWS and _lib.load().dgq_gemm_emit_supported(ab.pw.N, ab.pw.bits))
-
-
-def _emit_problem(y2: torch.Tensor, M: int, ab: ActBinding, ln):
-    """dgq_quant_act_args_t of the quantisation of y2 [M][C] for the Linear layer bound to ``ab`` (natural order, or LDS scatter)"""
-    C = y2.shape[1]
-    per_m = 0 if ab.mode == "perK" else 1
-    a = _lib.QuantActArgs()
-    a.x, a.x_dtype, a.B, a.H, a.W, a.C, a.kh, a.kw, a.stride, a.pad = y2.data_ptr(), _lib.DTYPE_CODE[y2.dtype], M, 1, 1, C, 1, 1, 1, 0
-    a.ksrc, a.koff, a.klds = _dp(ab.ksrc), _dp(ab.koff(1, C)), _dp(ab.klds(1, C))
-    a.kdst = _dp(ab.kdst(1, C, 1)) if ab.ksrc is not None else None
-    a.kpat = None
-    a.Kp, a.per_m = ab.Kp, per_m
-    a.delta, a.zp = (ab.cdelta.data_ptr(), ab.czp.data_ptr()) if not per_m else (ab.mdelta.data_ptr(), ab.mzp.data_ptr())
-    a.L, a.bits = (1 if not per_m else ab.L), ab.abits
-    a.pre_scale = a.pre_shift = None
-    a.pre_act = 0
-    lnp = (as_f32(ln[0]), as_f32(ln[1]), float(ln[2])) if ln else None
-    a.ln_gamma, a.ln_beta, a.ln_eps = (lnp[0].data_ptr(), lnp[1].data_ptr(), lnp[2]) if lnp else (None, None, 0.0)
-    a.ksplits = 1
-    codes = torch.empty((M, ab.Kp), dtype=torch.int8, device=y2.device)
-    rowsum = torch.empty((1, M), dtype=torch.float32, device=y2.device)
-    a.codes, a.rowsum = codes.data_ptr(), rowsum.data_ptr()
-    return a, codes, rowsum, lnp
-
-
-def gemm_wxa8_emit(codes, rowsum, M, ab: ActBinding, out_dtype, consumers, extra=None):
-    """gemm_wxa8 on full-row tiles + the input quantisation of the consuming layers in the same launch (dgq_gemm_wxa8_emit).
-    consumers: list of (ActBinding of the consuming Linear layer, ln = (gamma, beta, eps) | None).  Returns (y [M][N],
-    [(codes_i, rowsum_i)] ready for gemm_wxa8 of consumer i)."""
-    pw = ab.pw
-    out = torch.empty((M, pw.N), dtype=out_dtype, device=codes.device)
-    per_m = 0 if ab.mode == "perK" else 1
-    parts = rowsum.shape[0] if rowsum.dim() == 2 else 1
-    g = _lib.GemmArgs()
-    g.codes, g.rowsum, g.rowsum_parts, g.M, g.Kp = codes.data_ptr(), rowsum.data_ptr(), parts, M, ab.Kp
-    g.wpacked, g.w_bits, g.N, g.per_m = ab.wpacked.data_ptr(), pw.bits, pw.N, per_m
-    g.cdelta, g.cflush = (ab.cdelta.data_ptr(), ab.cflush.data_ptr()) if not per_m else (None, None)
-    g.mdelta, g.mzp = (ab.mdelta.data_ptr(), ab.mzp.data_ptr()) if per_m else (None, None)
-    g.L, g.offset = (ab.L if per_m else 1), ab.offset
-    g.alpha, g.zw, g.gamma, g.vn = pw.alpha.data_ptr(), pw.zw.data_ptr(), ab.gamma.data_ptr(), (ab.vn.data_ptr() if per_m else None)
-    g.y, g.y_dtype, g.ldy = out.data_ptr(), _lib.DTYPE_CODE[out.dtype], out.stride(0)
-    g.extra = _c.cast(_c.pointer(extra), _c.c_void_p) if extra is not None else None
-    probs = [_emit_problem(out, M, abc, ln) for abc, ln in consumers]
-    arr = (_lib.QuantActArgs * len(probs))(*[pr[0] for pr in probs])
-
-    def issue():
-        _lib_call("dgq_gemm_wxa8_emit", _c.byref(g), len(probs), _c.cast(arr, _c.c_void_p), _lib.stream())
-    issue()
-    if GEMM_LAUNCH_HOOK is not None:
-        GEMM_LAUNCH_HOOK(issue, [(M, ab, out.element_size())])
-    keep = (probs, extra)
-    return out, [(pr[1], pr[2]) for pr in probs], keep
-
-
 def quant_linear(x: torch.Tensor, ab: ActBinding, pre_act=0, residual=None, fq=None, ln=None, geglu=False):
     """x [..., K] -> [..., N].  pre_act: 0 none, 1 SiLU(x), 2 GEGLU (x is [..., 2K]: x[:K]·gelu(x[K:])) folded into the
     quantise-on-load pass; residual [..., N] and fq (see make_extra) folded into the GEMM epilogue.  geglu: the weight rows

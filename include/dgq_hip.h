@@ -239,15 +239,6 @@ int dgq_gemm_wxa8_batch(int n, const dgq_gemm_args_t* args, void* stream);
  * shape needs; with workspace == NULL (or too small) fewer / no splits are used — results do not depend on it
  * beyond fp32 summation order. */
 size_t dgq_gemm_workspace_bytes(int M, int N, int Kp);
-/* Row-owning form (the reference has the two steps apart: QuantLayer.forward of the producer, then x / δ ... of the consumer's
- * aqtizer, quant_layer.py:640-641 behind nn.LayerNorm, diffusers_rewrite/sd.py:245-268): dgq_gemm_wxa8 on 32 x N tiles (N = 320 or
- * 640, W4, unsplit) whose workgroups, having stored whole rows of y, run 1..3 dgq_quant_act problems on them — the input
- * quantisation of the layer(s) that consume y (three for the q / k / v projections) — instead of one launch each.  emit[i].x must
- * be g->y seen as a Linear input (B = M, H = W = kh = kw = stride = 1, pad = 0, C = N = ldy, same dtype), per_m, or per-K with
- * ksrc + kdst; LayerNorm prologue allowed; ksplits = 1.  Codes and row sums equal those of the separate calls (the per-K ones
- * those of the LDS-scatter variant).  dgq_gemm_emit_supported: 1 where such tiles exist. */
-int dgq_gemm_emit_supported(int N, int w_bits);
-int dgq_gemm_wxa8_emit(const dgq_gemm_args_t* g, int n_emit, const dgq_quant_act_args_t* emit, void* stream);
 int dgq_gemm_plan_splits(int M, int N, int Kp, int w_bits, int per_m, size_t workspace_bytes);
 
 /* ---- attention-side quantizers --------------------------------------------------------------------

@@ -884,55 +884,3 @@ def test_implicit_conv_geometries(geom, dev, monkeypatch):
         outs.append(ops.quant_conv2d(x, ab, k, k, stride, pad, norm=norm, residual=res))
     torch.cuda.synchronize()
     assert torch.equal(outs[0], outs[1]), (geom, (outs[0] - outs[1]).abs().max().item())
-
-
-# ------------------------------------------------------------------------------------------ row-owning GEMM + quantise-on-store
-def _linear_binding(dev, N, K, mode, name, abits=8, G=16, T=None):
-    from dgq_amd import ops, synth
-    from dgq_amd.plan import plan_act
-    g = torch.Generator().manual_seed(hash(name) % 1000)
-    w = torch.randn(N, K, generator=g) * 0.05
-    wd, wz = synth.channel_minmax(w, 4)
-    pw = ops.PackedWeight(w.to(dev), wd.to(dev), wz.to(dev), None, (torch.randn(N, generator=g) * 0.1).to(dev), 4, K, 1)
-    if mode == "perK":
-        d, z = synth._group_params(K, G, abits, "emit|" + name, 0)
-        lay = plan_act(d.view(1, 1, -1), z.view(1, 1, -1), "linear", K, 1, abits)
-    elif mode == "perM":
-        d, z = synth._group_params(T, G, abits, "emit|" + name, 0)
-        lay = plan_act(d.view(1, -1, 1), z.view(1, -1, 1), "linear", K, 1, abits)
-    else:
-        lay = plan_act(torch.tensor(0.031), torch.tensor(119.0), "linear", K, 1, abits)
-    return ops.ActBinding(lay, pw, abits)
-
-
-@pytest.mark.parametrize("N,K,pmode", [(320, 320, "perK"), (320, 1280, "perM"), (640, 640, "perK"), (640, 2560, "scalar")])
-def test_rowown_gemm_emit_bit_identical(N, K, pmode, dev, monkeypatch):
-    """dgq_gemm_wxa8_emit (32 x N tiles; the workgroup quantises the rows it has just stored for the consuming layers) against the
-    separate launches: y equal to dgq_gemm_wxa8's (with a residual), and for each of three consumers — per-K (LDS scatter) and
-    per-token behind a LayerNorm, scalar without: the q / k / v case — the codes AND the row sums bit-identical to dgq_quant_act on y
-    (the per-K one forced onto the scatter variant, whose row is what the fused form runs).  Ragged M (not a multiple of 32)."""
-    from dgq_amd import ops
-    monkeypatch.setenv("DGQ_QA_LINEAR_SCATTER", "2")
-    M, T = 32 * 9 + 13, 43
-    prod = _linear_binding(dev, N, K, pmode, "prod%d%d" % (N, K), T=T)
-    gen = torch.Generator().manual_seed(N + K)
-    x = (torch.randn(M, K, generator=gen) * 1.3).to(dev)
-    res = torch.randn(M, N, generator=gen).to(dev)
-    lnw, lnb = (torch.randn(N, generator=gen) * 0.3 + 1.0).to(dev), (torch.randn(N, generator=gen) * 0.2).to(dev)
-    cons = [(_linear_binding(dev, 96, N, "perK", "c0%d" % N), (lnw, lnb, 1e-5)),
-            (_linear_binding(dev, 64, N, "perM", "c1%d" % N, T=T), (lnw, lnb, 1e-5)),
-            (_linear_binding(dev, 128, N, "scalar", "c2%d" % N, abits=6), None)]
-    codes, rowsum, _ = ops.quant_act(x, M, 1, 1, K, 1, 1, 1, 0, prod)
-    y_ref = ops.gemm_wxa8(codes, rowsum, M, prod, torch.float32, extra=ops.make_extra(res))
-    y, outs, _keep = ops.gemm_wxa8_emit(codes, rowsum, M, prod, torch.float32, cons, extra=ops.make_extra(res))
-    refs = [ops.quant_act(y, M, 1, 1, N, 1, 1, 1, 0, ab, None, ln) for ab, ln in cons]
-    torch.cuda.synchronize()
-    # the GEMM itself: exact integers per group; a per-K launch adds its groups' fp32 terms in the order of its tile shape's wave
-    # layout (the 32x64 tile splits K over two waves), so two tile shapes agree to the last bits, per-M ones exactly
-    if pmode == "perK":
-        assert rel_l2(y.cpu(), y_ref.cpu()) < 1e-6
-    else:
-        assert torch.equal(y, y_ref), (y - y_ref).abs().max().item()
-    for i, ((c_e, r_e), (c_r, r_r, _m)) in enumerate(zip(outs, refs)):
-        assert torch.equal(c_e, c_r), ("codes of consumer %d" % i, (c_e.int() - c_r.int()).abs().max().item())
-        assert r_r.shape[0] == 1 and torch.equal(r_e, r_r), ("row sums of consumer %d" % i, (r_e - r_r).abs().max().item())
