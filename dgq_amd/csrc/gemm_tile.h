@@ -38,6 +38,7 @@ struct GemmParams {
     int tiles_per_split;  // K tiles (of BK) per split
     dgq_gemm_extra_t ex;  // optional epilogue extras (residual add, fused attention-side quantizer, GEGLU pairs)
     dgq_gemm_conv_t cv;   // implicit im2col A operand (cv.codes_in != nullptr); ex.conv is not used on the device
+    const float* ccoef;   // per-K, unsplit: host-formed flush coefficients + clear flags (ex.flush_coef) or nullptr
 };
 
 // Up to DGQ_GEMM_BATCH problems of one kernel instance (tile shape, weight bits, scale mode, output dtype; no K split) in

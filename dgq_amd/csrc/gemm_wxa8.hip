@@ -768,6 +768,7 @@ static int fill_gemm(const dgq_gemm_args_t& a, GemmParams& p) {
         DGQ_CHECK_ARG(a.cdelta && a.cflush, "dgq_gemm_wxa8: per-K mode needs cdelta/cflush");
     }
     p.cv.codes_in = nullptr;
+    p.ccoef = nullptr;
     p.codes = a.codes; p.rowsum = a.rowsum; p.rowsum_parts = a.rowsum_parts; p.M = a.M; p.Kp = a.Kp; p.N = a.N;
     p.wpacked = reinterpret_cast<const uint8_t*>(a.wpacked);
     p.cdelta = a.cdelta; p.cflush = a.cflush; p.mdelta = a.mdelta; p.mzp = a.mzp; p.L = a.per_m ? a.L : 1; p.offset = a.offset;
@@ -780,6 +781,10 @@ static int fill_gemm(const dgq_gemm_args_t& a, GemmParams& p) {
                       "dgq_gemm_wxa8: bad residual descriptor (ldr < N, res_div < 1 or unknown dtype)");
         DGQ_CHECK_ARG(!p.ex.geglu || (a.N % 4 == 0 && !p.ex.residual && p.ex.fq_mode == 0),
                       "dgq_gemm_wxa8: the GEGLU epilogue needs N %% 4 == 0 and no other extra");
+        if (p.ex.flush_coef && !a.per_m) {
+            DGQ_CHECK_ARG((reinterpret_cast<uintptr_t>(p.ex.flush_coef) & 15) == 0, "dgq_gemm_wxa8: flush_coef must be 16-byte aligned");
+            p.ccoef = p.ex.flush_coef;
+        }
         if (p.ex.conv) {
             const dgq_gemm_conv_t& c = *p.ex.conv;
             DGQ_CHECK_ARG(c.codes_in && c.pixsum && c.pixsum_parts >= 1 && c.fill && a.per_m && a.L == 1 && a.w_bits == 4 && c.C > 0 && c.C % 16 == 0 && c.ldc >= c.C &&
@@ -794,7 +799,7 @@ static int fill_gemm(const dgq_gemm_args_t& a, GemmParams& p) {
                       "dgq_gemm_wxa8: GroupNorm partials need M %% 16 == 0, N %% 4 == 0, a 16-byte aligned buffer and no GEGLU / fused quantizer");
     } else {
         p.ex.residual = nullptr; p.ex.ldr = 0; p.ex.res_div = 1; p.ex.res_dtype = DGQ_F32; p.ex.fq_mode = 0; p.ex.fq_delta = nullptr; p.ex.fq_zp = nullptr;
-        p.ex.fq_T = 1; p.ex.fq_D = 1; p.ex.fq_skip = 0; p.ex.fq_qmax = 255.0f; p.ex.geglu = 0; p.ex.gn_partial = nullptr; p.ex.conv = nullptr;
+        p.ex.fq_T = 1; p.ex.fq_D = 1; p.ex.fq_skip = 0; p.ex.fq_qmax = 255.0f; p.ex.geglu = 0; p.ex.gn_partial = nullptr; p.ex.conv = nullptr; p.ex.flush_coef = nullptr;
     }
     p.splits = 1; p.slab = nullptr;
     p.tiles_per_split = a.Kp / BK;

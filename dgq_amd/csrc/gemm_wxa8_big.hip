@@ -32,6 +32,12 @@
 #ifndef BIG_NPH_K
 #define BIG_NPH_K 1            // phases per K tile, per-K (1: four chunks = 16 MFMAs per phase on the 64x64 wave tile)
 #endif
+#ifndef BIG_DMA_LOAD_M
+#define BIG_DMA_LOAD_M 0       // DMA pieces of a phase issued in its LOAD segment (the rest: between the MFMAs), per-M
+#endif
+#ifndef BIG_DMA_LOAD_K
+#define BIG_DMA_LOAD_K 0       // ... per-K
+#endif
 #ifndef BIG_PRIO
 #define BIG_PRIO 1             // s_setprio 1 around the COMPUTE segment (0: not; measured neutral)
 #endif
@@ -199,6 +205,7 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_big_kernel(GemmBatch bt) {
     __builtin_amdgcn_s_barrier();
     if (group == 1) __builtin_amdgcn_s_barrier();            // group 1 runs one barrier behind group 0 from here on
 
+    const bool use_ccoef = !PER_M && p.ccoef != nullptr;      // wave-uniform (a kernel argument)
     uint64_t stamps[6 * NPH];
     auto stamp = [&](int k, int t) {
         if (BIG_STAMP && t == 8) stamps[k] = big_stamp();
@@ -210,6 +217,11 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_big_kernel(GemmBatch bt) {
     // NO taken branch besides the loop's back edge (a taken branch costs a wave ~100 cycles of refetch: the in-line flush block of
     // the first version made 8192^3 g16 take 646 us against 387 us without any flush code; conditionals of the tail — "is there
     // a tile t+2?" — inside one loop body cost the LOAD segment two of them per tile).  DMA = false: the last two tiles.
+    // pieces of a K tile are dealt to the phases in order: piece q belongs to phase (q·NPH)/PER_TILE
+    auto pieces_in_phase = [](int ph) constexpr { int n = 0; for (int q = 0; q < PER_TILE; ++q) n += ((q * NPH) / PER_TILE == ph); return n; };
+    auto pieces_before_phase = [](int ph) constexpr { int n = 0; for (int q = 0; q < PER_TILE; ++q) n += ((q * NPH) / PER_TILE < ph); return n; };
+    auto piece_rank = [](int q, int ph) constexpr { int n = 0; for (int r = 0; r < q; ++r) n += ((r * NPH) / PER_TILE == ph); return n; };
+    constexpr int DMA_LOAD = PER_M ? BIG_DMA_LOAD_M : BIG_DMA_LOAD_K;    // pieces of a phase issued in its LOAD segment
     auto tile = [&](int t, auto dma_c) {
         constexpr bool DMA = decltype(dma_c)::value && !(BIG_ABL & 1);
         const uint8_t* sa = smem + stage * STAGE_BYTES;
@@ -235,25 +247,53 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_big_kernel(GemmBatch bt) {
                     for (int i = 0; i < TM; ++i) af[cc][i] = *reinterpret_cast<const v4i*>(sa + a_base[c] + i * (32 * BK));
                 }
             }
+            // this phase's flush coefficients and the tile's clear flag, as wave-uniform bit patterns.  From the caller's table
+            // (p.ccoef) they arrive by SCALAR loads issued here and retired by the lgkmcnt(0) below — the tests between the MFMAs
+            // are then s_cmp + s_cbranch (not taken); from the LDS table they take a v_readfirstlane each.
+            int cqb[CPP];
+            int tclr_b = 0;
             float cq[CPP];
             float tclr = 0.0f;
             if constexpr (!PER_M) {
+                if (__builtin_expect(use_ccoef, 1)) {
+                    const float* cp = p.ccoef + (t * NCH + ph * CPP);
+                    if constexpr (CPP == 4) {
+                        v4i c4;
+                        asm volatile("s_load_dwordx4 %0, %1, 0x0" : "=s"(c4) : "s"(cp) : "memory");
+                        cqb[0] = c4.x; cqb[1] = c4.y; cqb[2] = c4.z; cqb[3] = c4.w;
+                    } else {
 #pragma unroll
-                for (int cc = 0; cc < CPP; ++cc) cq[cc] = ctab[t * NCH + ph * CPP + cc];
-                if (ph == NPH - 1) tclr = ctab[nk * NCH + t];
+                        for (int cc = 0; cc < CPP; ++cc) asm volatile("s_load_dword %0, %1, 0x0" : "=s"(cqb[cc]) : "s"(cp + cc) : "memory");
+                    }
+                    if (ph == NPH - 1) asm volatile("s_load_dword %0, %1, 0x0" : "=s"(tclr_b) : "s"(p.ccoef + nk * NCH + t) : "memory");
+                } else {
+#pragma unroll
+                    for (int cc = 0; cc < CPP; ++cc) cq[cc] = ctab[t * NCH + ph * CPP + cc];
+                    if (ph == NPH - 1) tclr = ctab[nk * NCH + t];
+                }
             }
+            // this phase's share of tile t+2: the first DMA_LOAD pieces here, behind the fragment reads (where a piece costs its
+            // issuing wave 100+ cycles: the LDS queue is full of reads), the rest between the MFMAs of the COMPUTE segment
             if (DMA) {
 #pragma unroll
                 for (int q = 0; q < PER_TILE; ++q)
-                    if ((q * NPH) / PER_TILE == ph) issue_piece(q, t + 2, istage);
+                    if ((q * NPH) / PER_TILE == ph && piece_rank(q, ph) < DMA_LOAD) issue_piece(q, t + 2, istage);
             }
             stamp(6 * ph + 1, t);
             if (ph == NPH - 1) {
-                // tile t+1 (this wave's pieces) has landed; tile t+2, issued in this tile's phases, stays in flight
-                if (DMA) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PER_TILE) : "memory");
+                // tile t+1 (this wave's pieces) has landed; what has been issued of tile t+2 so far stays in flight
+                constexpr int YOUNGER = pieces_before_phase(NPH - 1) + (pieces_in_phase(NPH - 1) < DMA_LOAD ? pieces_in_phase(NPH - 1) : DMA_LOAD);
+                if (DMA) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(YOUNGER) : "memory");
                 else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             } else {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            if constexpr (!PER_M) {
+                if (__builtin_expect(!use_ccoef, 0)) {
+#pragma unroll
+                    for (int cc = 0; cc < CPP; ++cc) cqb[cc] = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, cq[cc]));
+                    tclr_b = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, tclr));
+                }
             }
             // int4 -> int8 here, not in COMPUTE: the fragments have just arrived, and the MFMA segment then opens with an MFMA
             v4i bf[CPP][TN];
@@ -280,10 +320,16 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_big_kernel(GemmBatch bt) {
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
                         acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[cc][i], bf[cc][j], acc[i][j], 0, 0, 0);
+                if (DMA) {                                           // the rest of this phase's DMA share, one piece behind each chunk
+#pragma unroll
+                    for (int q = 0; q < PER_TILE; ++q)
+                        if ((q * NPH) / PER_TILE == ph && piece_rank(q, ph) >= DMA_LOAD && (piece_rank(q, ph) - DMA_LOAD) % CPP == cc)
+                            issue_piece(q, t + 2, istage);
+                }
                 if constexpr (!PER_M && !(BIG_ABL & 8)) {
                     // a group ends behind this chunk (coefficient != 0): out of line, the common case falls through
-                    const float sc = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, cq[cc])));
-                    if (__builtin_expect(sc != 0.0f, 0)) {
+                    if (__builtin_expect((cqb[cc] & 0x7FFFFFFF) != 0, 0)) {
+                        const float sc = __builtin_bit_cast(float, cqb[cc]);
 #pragma unroll
                         for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -294,7 +340,7 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_big_kernel(GemmBatch bt) {
                 }
             }
             if constexpr (!PER_M) {
-                if (ph == NPH - 1 && __builtin_expect(__builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, tclr)) != 0, 0)) {   // rare: a segment of totals ends
+                if (ph == NPH - 1 && __builtin_expect(tclr_b != 0, 0)) {   // rare: a segment of totals ends
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
 #pragma unroll

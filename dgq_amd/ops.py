@@ -8,7 +8,7 @@ from typing import Optional
 import torch
 
 from . import _lib
-from .plan import ActLayout, natural_kperm, round_up, KTILE, act_offset, mark_clears
+from .plan import ActLayout, natural_kperm, round_up, KTILE, act_offset, mark_clears, flush_coefficients
 
 _c = ctypes
 
@@ -254,7 +254,9 @@ class ActBinding:
             self._koff = {}
             self.cdelta = layout.cdelta.to(dev)
             self.czp = layout.czp.to(dev)
-            self.cflush = mark_clears(layout.cflush, abits, pw.bits).to(dev)     # + where the GEMM clears its running total
+            cfl = mark_clears(layout.cflush, abits, pw.bits)                     # + where the GEMM clears its running total
+            self.cflush = cfl.to(dev)
+            self.ccoef = flush_coefficients(layout.cdelta, cfl).to(dev)          # the same information as scalar-loadable coefficients
             self.wpacked = pack_weight(pw.codes, layout.kperm, layout.Kp, pw.bits)
             U = (pw.centered() @ layout.kcoef.to(dev)).float()             # Σ_k δ_k(o − z_k)(qw − zw)
             self.gamma = (pw.bias + pw.alpha * U).contiguous()
@@ -525,6 +527,7 @@ def make_extra(residual=None, fq=None, res_div=1, geglu=False, gn_partial=None, 
     ex = _lib.GemmExtra()
     ex.res_div = 1
     ex.conv = None
+    ex.flush_coef = None
     if conv is not None:                                    # (dgq_gemm_conv_t, tensors it points to)
         ex.conv = _c.cast(_c.pointer(conv[0]), _c.c_void_p)
         ex._conv_keep = conv
@@ -562,6 +565,11 @@ GEMM_LAUNCH_HOOK = None
 def gemm_wxa8(codes, rowsum, M, ab: ActBinding, out_dtype, out: Optional[torch.Tensor] = None, extra=None):
     pw = ab.pw
     ws = workspace(codes.device)
+    if ab.mode == "perK" and M >= 2048 and pw.N >= 128:      # shapes the 256-row kernel may take: hand it the coefficient table
+        if extra is None:
+            extra = _lib.GemmExtra()
+            extra.res_div, extra.fq_T, extra.fq_D, extra._keep = 1, 1, 1, []
+        extra.flush_coef = ab.ccoef.data_ptr()
     if out is None:
         out = torch.empty((M, pw.N // 2 if (extra is not None and extra.geglu) else pw.N), dtype=out_dtype, device=codes.device)
     per_m = 0 if ab.mode == "perK" else 1

@@ -159,6 +159,27 @@ def plan_act(delta: torch.Tensor, zp: torch.Tensor, kind: str, C: int, taps: int
                      czp=torch.from_numpy(czp), cflush=torch.from_numpy(cflush), kcoef=kcoef, Kp=Kp, n_groups=G)
 
 
+def flush_coefficients(cdelta: torch.Tensor, cflush: torch.Tensor) -> torch.Tensor:
+    """The per-chunk coefficients of the GEMM's summation by parts for an UNSPLIT launch, as the kernels form them in their
+    prologue (gemm_wxa8.hip / gemm_wxa8_big.hip): coef_c = δ_c − δ_{c+1} (non-zero at group ends only); the last chunk and the last
+    chunk of a K tile that carries a clear mark (cflush == 2 on that tile's last chunk) take the full δ_c.  Followed by one clear
+    flag per K tile (1.0 where the totals are cleared behind the tile; never behind the last).  fp32 [Kp/32 + Kp/128] — the
+    256-row kernel reads it with scalar loads instead of testing a staged LDS table between its MFMAs."""
+    d = cdelta.detach().float().cpu()
+    f = cflush.detach().cpu()
+    nch = d.numel()
+    per = KTILE // KCHUNK
+    nk = nch // per
+    dn = torch.cat([d[1:], d[-1:]])
+    last_of_tile = torch.arange(nch) % per == per - 1
+    clr_tile = (f.view(nk, per)[:, per - 1] == 2)
+    full = (torch.arange(nch) == nch - 1) | (last_of_tile & clr_tile.repeat_interleave(per))
+    coef = torch.where(full, d, d - dn)
+    flags = clr_tile.float()
+    flags[-1] = 0.0
+    return torch.cat([coef, flags]).contiguous()
+
+
 def act_offset(abits: int) -> float:
     """Code offset o = 2^(b−1): q ∈ [0, 2^b−1] -> s = q − o ∈ [−2^(b−1), 2^(b−1)−1] fits int8 for every b ≤ 8, and
     centred codes keep the fp32 epilogue free of the cancellation an all-positive operand would cause."""

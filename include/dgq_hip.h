@@ -213,6 +213,11 @@ typedef struct dgq_gemm_extra {
     int geglu;
     float* gn_partial;
     const dgq_gemm_conv_t* conv;     /* (or NULL) implicit im2col A operand, see dgq_gemm_conv_t */
+    const float* flush_coef;         /* (or NULL; per_m == 0) [Kp/32 + Kp/128] floats, 16-byte aligned: the summation-by-parts
+                                      * coefficients of an unsplit launch, coef_c = cdelta[c] − cdelta[c+1] (the last chunk, and a
+                                      * K tile's last chunk under a clear mark cflush == 2: cdelta[c]), then one clear flag per K
+                                      * tile.  Derived from cdelta / cflush (the library forms the same table itself when this
+                                      * is NULL); given here, the 256-row kernel reads it with scalar loads. */
 } dgq_gemm_extra_t;
 
 int dgq_gemm_wxa8(const int8_t* codes, const float* rowsum, int rowsum_parts, int M, int Kp,
