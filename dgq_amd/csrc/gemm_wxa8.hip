@@ -676,7 +676,8 @@ static GemmPlan plan_gemm(int M, int N, int Kp, int w_bits, size_t ws_bytes, boo
     {
         const int bn_big = per_m ? 256 : 128;
         const long tiles = (long)((M + 255) / 256) * ((N + bn_big - 1) / bn_big);
-        if (big_on && allow_big && w_bits == 4 && pl.splits == 1 && M >= 2048 && N % bn_big == 0 && tiles >= 256 &&
+        static const long min_tiles = [] { const char* e = getenv("DGQ_GEMM_BIG_TILES"); return e && *e ? atol(e) : 256L; }();   // sweep hook
+        if (big_on && allow_big && w_bits == 4 && pl.splits == 1 && M >= 2048 && N % bn_big == 0 && tiles >= min_tiles &&
             (nk >= 32 || (per_m && nk >= 8 && N >= 4096)) && dgq_gemm_big_lds_bytes(per_m, Kp) <= 160 * 1024)
             pl = {256, 256, 1, 0.0};
     }
