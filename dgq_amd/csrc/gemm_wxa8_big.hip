@@ -19,7 +19,8 @@
 //     staged buffer one phase AFTER the wait that retires it").
 //
 // Per-M (scalar / per-token activation scales): 256x256 tile, wave tile 128x64, int32 accumulators only (128 registers).
-// Per-K (DGQ channel groups): 128x256 tile, wave tile 64x64 — the fp32 group accumulators double the accumulator registers.
+// Per-K (DGQ channel groups): 256x128 tile, wave tile 128x32 (BIG_PERK_TILE = 0: 128x256, 64x64) — the fp32 group accumulators
+// double the accumulator registers, so the wave tile is half the per-M one.
 #include "gemm_tile.h"
 
 // Build-time experiment switches (tools/build_variants.sh builds one library per setting for A/B runs on one box)
