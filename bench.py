@@ -508,23 +508,27 @@ def measure_gemm_roofline(torch, ops, qnn, run_step, args):
     return out, extra
 
 
-def csrc_digest():
-    """sha256 over the kernel sources (dgq_amd/csrc/*.hip, *.h, *.cpp, include/*.h): what a PMC traffic record is stamped with
-    (tools/pmc_traffic.py) — it describes THESE kernels or it is refused.  Works on a box that has no git history."""
-    import glob
+GEMM_SOURCES = ("gemm_wxa8.hip", "gemm_wxa8_big.hip", "gemm_tile.h")
+
+
+def csrc_digest(names=GEMM_SOURCES):
+    """sha256 over the CODE of the named kernel sources under dgq_amd/csrc (``//`` comments and blank lines dropped, so a comment
+    fix does not orphan a measurement): what a PMC traffic record is stamped with (tools/pmc_traffic.py) — it describes THESE
+    kernels and their launch planner or it is refused.  Works on a box that has no git history."""
     import hashlib
     h = hashlib.sha256()
-    files = sorted(glob.glob(os.path.join(ROOT, "dgq_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "dgq_amd", "csrc", "*.h")) +
-                   glob.glob(os.path.join(ROOT, "dgq_amd", "csrc", "*.cpp")) + glob.glob(os.path.join(ROOT, "include", "*.h")))
-    for f in files:
-        h.update(os.path.basename(f).encode())
-        h.update(open(f, "rb").read())
+    for name in sorted(names):
+        h.update(name.encode())
+        for line in open(os.path.join(ROOT, "dgq_amd", "csrc", name), encoding="utf-8"):
+            code = line.split("//", 1)[0].strip()
+            if code:
+                h.update(code.encode() + b"\n")
     return h.hexdigest()[:16]
 
 
 def traffic_file_is_current(record):
     """True when the record's ``csrc_digest`` equals the digest of the kernel sources this run was built from."""
-    return bool(record.get("csrc_digest")) and record["csrc_digest"] == csrc_digest()
+    return bool(record.get("csrc_digest")) and record["csrc_digest"] == csrc_digest(tuple(record.get("digest_files") or GEMM_SOURCES))
 
 
 if __name__ == "__main__":

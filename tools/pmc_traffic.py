@@ -24,7 +24,9 @@ res["traffic_bytes_per_launch"] = res["fetch_bytes_per_launch_corrected_x2"] + r
 import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
-res["csrc_digest"] = bench.csrc_digest()
+files = ("quant_act.hip",) if "quant_act" in pat else bench.GEMM_SOURCES
+res["digest_files"] = list(files)
+res["csrc_digest"] = bench.csrc_digest(files)
 if len(sys.argv) > 5:
     res["config"] = sys.argv[5]
     res["dtype"] = sys.argv[6] if len(sys.argv) > 6 else "fp32"
