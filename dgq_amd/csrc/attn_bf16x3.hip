@@ -913,7 +913,28 @@ __global__ __launch_bounds__(64 * NW) void attn3_pv_kernel(AttnParams p) {
             }
         };
         bf16x8 pf[2];                                    // B fragments of the two 16-key steps
-        if (!UNIFORM && !edge) {
+        if (UNIFORM && !edge) {
+            // interior tiles of the uniform (always_zero) quantiser: code = min(rne(p/δ), 2^b − 1), and p/δ is ONE exponential,
+            // 2^(s2 − m − log2 l − log2 δ) (p >= 0: no lower clamp).  rne by the magic add, the clamp on the integer image, and
+            // bits(x + MAGIC) − MAGIC is the code as an exact float whose upper half is its bf16: 5.5 VALU per score (the
+            // generic form below — exp2f with its range fix-up, an IEEE division, rint, two clamps — is ~25)
+            const int cmaxu_i = MAGIC_I + (int)p.qmax;
+            float cf[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float x = __builtin_amdgcn_exp2f(fmaf(acc[r], sl2, -a0));
+                cf[r] = __int_as_float(min(__float_as_int(x + MAGIC), cmaxu_i)) - MAGIC;
+                if constexpr (VINT && !G::VONES) psum += cf[r];
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                unsigned w[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    w[i] = __builtin_amdgcn_perm(__float_as_uint(cf[8 * ks + 2 * i + 1]), __float_as_uint(cf[8 * ks + 2 * i]), 0x07060302u);
+                pf[ks] = __builtin_bit_cast(bf16x8, make_uint4(w[0], w[1], w[2], w[3]));
+            }
+        } else if (!UNIFORM && !edge) {
             // interior tiles of the log2 quantiser never form p̂ as a float: the clamped magic-number integers of a key
             // pair are merged (their low halves = the two codes), and 2^-code as a bf16 is 0x3F80 − (code << 7), so the
             // packed pair is 0x3F803F80 − 128·(c0 | c1 << 16) — one 24-bit multiply-add (codes <= 127: no borrow)
