@@ -30,10 +30,26 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 #define KT 32
+#ifndef DGQ_PV_ST64
+#define DGQ_PV_ST64 2          // P·V ring depth at D = 64 with small (int8 K + one-plane V) images
+#endif
 // real-time δ (the tensor-wide maximum probability): the statistics pass leaves one maximum per workgroup in slot
 // (workgroup index mod 64) of the 256-byte δ area and the P̂·V pass takes the maximum of the 64 slots — 2048 waves hitting
 // ONE address with atomicMax took 25 us of a 30 us launch (4096 queries x 77 keys)
 #define DELTA_SLOTS 64
+typedef float f2 __attribute__((ext_vector_type(2)));      // operand pair of v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32
+#ifndef DGQ_ATTN_PK
+#define DGQ_ATTN_PK 1          // 1: v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 on score pairs; 0: scalar instructions (A/B builds)
+#endif
+#if DGQ_ATTN_PK
+__device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f2 pk_mul(f2 a, f2 b) { return a * b; }
+__device__ __forceinline__ f2 pk_add(f2 a, f2 b) { return a + b; }
+#else
+__device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return f2{fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y)}; }
+__device__ __forceinline__ f2 pk_mul(f2 a, f2 b) { return f2{a.x * b.x, a.y * b.y}; }
+__device__ __forceinline__ f2 pk_add(f2 a, f2 b) { return f2{a.x + b.x, a.y + b.y}; }
+#endif
 #define LOG2E 1.4426950408889634f
 
 // optional UniformAffineQuantizer applied to q / k / v as they are loaded (aqtizer_q/k/v, sd.py:165-181): same
@@ -150,7 +166,7 @@ __device__ __forceinline__ void store_any(void* p, int dtype, int64_t i, float v
 // plane of centred Q codes (exact in bf16) against three K planes (pre-scaled by δq(d) for a per-head-dim aqtizer_q) with a
 // rank-1 zero-point correction per key — three products, for every aqtizer_q the int8 path cannot take.
 template <int D, int QM = 0, bool VINT = false> struct Geo {
-    static constexpr bool QI8 = QM == 1;
+    static constexpr bool QI8 = QM == 1 || QM == 3;     // 3: int8 scores with a SCALAR aqtizer_k (δk, z'k folded into per-query constants)
     static constexpr int DP = (D + 15) / 16 * 16;      // K depth of the score product
     static constexpr int NKK = DP / 16;
     static constexpr int NDT = (D + 31) / 32;          // 32-wide d tiles of O^T
@@ -187,7 +203,7 @@ template <int D, int QM = 0, bool VINT = false> struct Geo {
     // ring depths: prefetch distance STAGES-1 tiles; sized so that two blocks share a CU's 160 KB where the grid is
     // large (D = 40: 3 x 26 KB) and by what fits otherwise
     static constexpr int STATS_STAGES = D <= 80 ? 4 : 3;
-    static constexpr int PV_STAGES = (D <= 40 || D == 80) ? 3 : 2;
+    static constexpr int PV_STAGES = D == 64 ? (IMG_BYTES <= 16 * 1024 ? DGQ_PV_ST64 : 2) : ((D <= 40 || D == 80) ? 3 : 2);
 };
 
 template <int D> using GeoI8 = Geo<D, 1, false>;        // the K part does not depend on VINT
@@ -608,9 +624,12 @@ __device__ __forceinline__ void load_q_i8(v4i (&qc)[GeoI8<D>::NK32], float4& qt,
 
 // QI8 S^T tile in units of δq: acc[r] = δk(s)·(Σ_d c'k c'q − z'q Σ_d c'k − z'k (Σ_d c'q − D z'q)), s = key_of(r, h);
 // the bypassed start-peak key (tile 0, key 0: r = 0 of the lower half-wave) gets its exact fp32 rank-1 score.
-template <int D>
+// KS (scalar aqtizer_k: one δk and one z'k for every key): the tile is returned in units of δq·δk and WITHOUT the constant
+// cq = −z'k·(Σ_d c'q − D z'q) of its query — acc[r] = Σ_d c'k c'q − z'q Σ_d c'k — the caller folds δk into its log2 scale and
+// cq into its offsets (the softmax is shift-invariant): one packed fma per score pair instead of two and a multiply.
+template <int D, bool KS>
 __device__ __forceinline__ v16f score_tile_i8(const unsigned char* kimg, const v4i (&qc)[GeoI8<D>::NK32], const float4& qt,
-                                              int lane, bool bypass_key0) {
+                                              int lane, bool bypass_key0, float inv_dk, float cq) {
     using G = Geo<D, true>;
     v16i acc;
 #pragma unroll
@@ -623,21 +642,29 @@ __device__ __forceinline__ v16f score_tile_i8(const unsigned char* kimg, const v
     }
     const float* ktab = reinterpret_cast<const float*>(kimg + G::K8_BYTES);
     const int h32 = lane >> 5;
+    const f2 zq = {qt.y, qt.y}, zs = {qt.z, qt.z};
     v16f out;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {                          // keys 8g + 4h .. +3: four consecutive table entries
-        const float4 dk = *reinterpret_cast<const float4*>(ktab + 8 * g + 4 * h32);
-        const float4 nz = *reinterpret_cast<const float4*>(ktab + KT + 8 * g + 4 * h32);
         const float4 ns = *reinterpret_cast<const float4*>(ktab + 2 * KT + 8 * g + 4 * h32);
-        const float dks[4] = {dk.x, dk.y, dk.z, dk.w}, nzs[4] = {nz.x, nz.y, nz.z, nz.w}, nss[4] = {ns.x, ns.y, ns.z, ns.w};
+        float4 dk, nz;
+        if constexpr (!KS) {
+            dk = *reinterpret_cast<const float4*>(ktab + 8 * g + 4 * h32);
+            nz = *reinterpret_cast<const float4*>(ktab + KT + 8 * g + 4 * h32);
+        }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float v = fmaf(qt.y, nss[e], (float)acc[4 * g + e]);      // Σ c'k c'q − z'q·Σ c'k
-            v = fmaf(qt.z, nzs[e], v);                                // − z'k·(Σ c'q − D z'q)
-            out[4 * g + e] = v * dks[e];
+        for (int e = 0; e < 4; e += 2) {
+            const f2 a = {(float)acc[4 * g + e], (float)acc[4 * g + e + 1]};
+            f2 v = pk_fma(zq, e ? f2{ns.z, ns.w} : f2{ns.x, ns.y}, a);        // Σ c'k c'q − z'q·Σ c'k
+            if constexpr (!KS) {
+                v = pk_fma(zs, e ? f2{nz.z, nz.w} : f2{nz.x, nz.y}, v);       // − z'k·(Σ c'q − D z'q)
+                v = pk_mul(v, e ? f2{dk.z, dk.w} : f2{dk.x, dk.y});
+            }
+            out[4 * g + e] = v.x;
+            out[4 * g + e + 1] = v.y;
         }
     }
-    if (bypass_key0 && h32 == 0) out[0] = qt.w;
+    if (bypass_key0 && h32 == 0) out[0] = KS ? fmaf(qt.w, inv_dk, -cq) : qt.w;
     return out;
 }
 
@@ -716,7 +743,7 @@ __device__ __forceinline__ void attn_block_coords(int xcd_remap, int& bx, int& b
 template <int D, int NW, int QM>
 __global__ __launch_bounds__(64 * NW) void attn3_stats_kernel(AttnParams p) {
     using G = Geo<D, QM>;
-    constexpr bool QI8 = QM == 1;
+    constexpr bool QI8 = G::QI8, KS = QM == 3;
     constexpr int ST = G::STATS_STAGES, NP = G::K_PIECES, SB = NP * 1024;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds8[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, h32 = lane >> 5;
@@ -744,7 +771,14 @@ __global__ __launch_bounds__(64 * NW) void attn3_stats_kernel(AttnParams p) {
         qt.y = t2.y;
         if constexpr (G::FOLDZ) fold_zmul<D>(qf, qt.y, h32);
     }
-    const float sl2 = p.scale * LOG2E * qt.x;            // scores in log2 units: p = 2^(s2 − m)/l  (QI8: δq folded in, > 0)
+    // KS: δk joins the log2 scale, cq = −z'k·(Σ c'q − D z'q) is a per-query shift of every score (added to the maxima at the end)
+    float inv_dk = 1.0f, cq = 0.0f, dk = 1.0f;
+    if constexpr (KS) {
+        dk = p.fq[1].delta[0];
+        inv_dk = 1.0f / dk;
+        cq = -(p.fq[1].zp[0] - 0.5f * (p.fq[1].qmax + 1.0f)) * qt.z;
+    }
+    const float sl2 = p.scale * LOG2E * qt.x * dk;       // scores in log2 units: p = 2^(s2 − m)/l  (QI8: δq folded in, > 0)
     float mraw = -INFINITY, l = 0.0f, m2raw = -INFINITY; // running maxima of the UNSCALED scores (scale > 0)
     wait_image<NP, ST - 2, NW>(wid);
     __builtin_amdgcn_s_barrier();
@@ -753,7 +787,7 @@ __global__ __launch_bounds__(64 * NW) void attn3_stats_kernel(AttnParams p) {
         issue_image<NP, NW>(img_lane + (int64_t)min(i + ST - 1, p.NT - 1) * p.img_bytes, lds_base + istage * SB, wid);
         const int s0 = i * KT;
         v16f acc;
-        if constexpr (QI8) acc = score_tile_i8<D>(lds8 + stage * SB, qc, qt, lane, i == 0 && p.kskip > 0);
+        if constexpr (QI8) acc = score_tile_i8<D, KS>(lds8 + stage * SB, qc, qt, lane, i == 0 && p.kskip > 0, inv_dk, cq);
         else if constexpr (QM == 2) acc = score_tile_q1<D>(reinterpret_cast<const unsigned short*>(lds8 + stage * SB), qf, qt.y, lane);
         else acc = score_tile<D>(reinterpret_cast<const unsigned short*>(lds8 + stage * SB), qf, lane);
         const bool edge = (s0 + KT > p.S) || (s0 < p.skip);      // block-uniform: only the first / a partial last tile
@@ -775,10 +809,14 @@ __global__ __launch_bounds__(64 * NW) void attn3_stats_kernel(AttnParams p) {
         // loop; merged once behind it.  A half-wave that has seen no key yet (S < 8) holds max = −inf: offset 0 then.
         const float mn = fmaxf(mraw, tmax);
         const float nb = (mn == -INFINITY) ? 0.0f : -(mn * sl2);
-        float part = 0.0f;
+        f2 part = {0.0f, 0.0f};
+        const f2 sl2v = {sl2, sl2}, nbv = {nb, nb};
 #pragma unroll
-        for (int r = 0; r < 16; ++r) part += __builtin_amdgcn_exp2f(fmaf(acc[r], sl2, nb));   // args <= 0: no range fix-up needed
-        l = l * __builtin_amdgcn_exp2f(fmaf(mraw, sl2, nb)) + part;
+        for (int r = 0; r < 16; r += 2) {                    // args <= 0: no range fix-up needed
+            const f2 a = pk_fma(f2{acc[r], acc[r + 1]}, sl2v, nbv);
+            part = pk_add(part, f2{__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)});
+        }
+        l = l * __builtin_amdgcn_exp2f(fmaf(mraw, sl2, nb)) + (part.x + part.y);
         mraw = mn;
         m2raw = fmaxf(m2raw, tmax2);
         wait_image<NP, ST - 2, NW>(wid);                      // tile i+1 (this wave's pieces) has landed
@@ -794,6 +832,8 @@ __global__ __launch_bounds__(64 * NW) void attn3_stats_kernel(AttnParams p) {
         mraw = mm;
         m2raw = fmaxf(m2raw, __shfl_xor(m2raw, 32, 64));
     }
+    mraw += cq;
+    m2raw += cq;
     const float m = mraw * sl2;
     if (t < p.T && h32 == 0) {
         float* st = p.stats + ((int64_t)bh * p.T + t) * 2;
@@ -820,7 +860,7 @@ __global__ __launch_bounds__(64 * NW) void attn3_stats_kernel(AttnParams p) {
 template <int D, bool UNIFORM, int NW, int QM, bool VINT>
 __global__ __launch_bounds__(64 * NW) void attn3_pv_kernel(AttnParams p) {
     using G = Geo<D, QM, VINT>;
-    constexpr bool QI8 = QM == 1;
+    constexpr bool QI8 = G::QI8, KS = QM == 3;
     constexpr int ST = G::PV_STAGES, NP = G::IMG_PIECES, SB = G::IMG_BYTES;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds8[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, h32 = lane >> 5;
@@ -846,7 +886,13 @@ __global__ __launch_bounds__(64 * NW) void attn3_pv_kernel(AttnParams p) {
         qt.y = t2.y;
         if constexpr (G::FOLDZ) fold_zmul<D>(qf, qt.y, h32);
     }
-    const float m = p.stats[((int64_t)bh * p.T + tq) * 2], l = p.stats[((int64_t)bh * p.T + tq) * 2 + 1];
+    float inv_dk = 1.0f, cq = 0.0f, dk = 1.0f;              // KS: see attn3_stats_kernel
+    if constexpr (KS) {
+        dk = p.fq[1].delta[0];
+        inv_dk = 1.0f / dk;
+        cq = -(p.fq[1].zp[0] - 0.5f * (p.fq[1].qmax + 1.0f)) * qt.z;
+    }
+    const float l = p.stats[((int64_t)bh * p.T + tq) * 2 + 1];
     float delta;
     if (p.mode == 1) {                                   // real-time δ: maximum of the statistics pass's slots
         delta = p.delta[lane];
@@ -855,8 +901,9 @@ __global__ __launch_bounds__(64 * NW) void attn3_pv_kernel(AttnParams p) {
     } else {
         delta = p.delta[0];
     }
-    const float sl2 = p.scale * LOG2E * qt.x;
+    const float sl2 = p.scale * LOG2E * qt.x * dk;
     const float nsl2 = -sl2;
+    const float m = p.stats[((int64_t)bh * p.T + tq) * 2] - cq * sl2;      // the row maximum in the units of the score tiles
     const float a0 = m + log2f(l) + log2f(delta);       // −log2(p/δ) = a0 − s2
     const float inv_l = 1.0f / l;
     // log2 codes by the magic-number route: rne(x) = bits(x + 1.5·2^23) − bits(1.5·2^23); clamp as integers to
@@ -881,7 +928,7 @@ __global__ __launch_bounds__(64 * NW) void attn3_pv_kernel(AttnParams p) {
         const unsigned short* kbc = reinterpret_cast<const unsigned short*>(lds8 + stage * SB);
         const unsigned short* vtc = kbc + G::K_ELEMS;
         v16f acc;
-        if constexpr (QI8) acc = score_tile_i8<D>(lds8 + stage * SB, qc, qt, lane, i == 0 && p.kskip > 0);
+        if constexpr (QI8) acc = score_tile_i8<D, KS>(lds8 + stage * SB, qc, qt, lane, i == 0 && p.kskip > 0, inv_dk, cq);
         else if constexpr (QM == 2) acc = score_tile_q1<D>(kbc, qf, qt.y, lane);
         else acc = score_tile<D>(kbc, qf, lane);
         // interior tiles carry no per-key conditions; only the first tile (bypassed column) and a partial last tile do
@@ -919,31 +966,32 @@ __global__ __launch_bounds__(64 * NW) void attn3_pv_kernel(AttnParams p) {
             // bits(x + MAGIC) − MAGIC is the code as an exact float whose upper half is its bf16: 5.5 VALU per score (the
             // generic form below — exp2f with its range fix-up, an IEEE division, rint, two clamps — is ~25)
             const int cmaxu_i = MAGIC_I + (int)p.qmax;
-            float cf[16];
+            const f2 sl2v = {sl2, sl2}, na0v = {-a0, -a0}, magic = {MAGIC, MAGIC}, nmagic = {-MAGIC, -MAGIC};
+            f2 ps2 = {0.0f, 0.0f};
+            unsigned w[8];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float x = __builtin_amdgcn_exp2f(fmaf(acc[r], sl2, -a0));
-                cf[r] = __int_as_float(min(__float_as_int(x + MAGIC), cmaxu_i)) - MAGIC;
-                if constexpr (VINT && !G::VONES) psum += cf[r];
+            for (int r = 0; r < 16; r += 2) {
+                const f2 a = pk_fma(f2{acc[r], acc[r + 1]}, sl2v, na0v);
+                const f2 y = pk_add(f2{__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)}, magic);
+                const f2 c = pk_add(f2{__int_as_float(min(__float_as_int(y.x), cmaxu_i)), __int_as_float(min(__float_as_int(y.y), cmaxu_i))}, nmagic);
+                if constexpr (VINT && !G::VONES) ps2 = pk_add(ps2, c);
+                w[r >> 1] = __builtin_amdgcn_perm(__float_as_uint(c.y), __float_as_uint(c.x), 0x07060302u);
             }
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                unsigned w[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    w[i] = __builtin_amdgcn_perm(__float_as_uint(cf[8 * ks + 2 * i + 1]), __float_as_uint(cf[8 * ks + 2 * i]), 0x07060302u);
-                pf[ks] = __builtin_bit_cast(bf16x8, make_uint4(w[0], w[1], w[2], w[3]));
-            }
+            if constexpr (VINT && !G::VONES) psum += ps2.x + ps2.y;
+            pf[0] = __builtin_bit_cast(bf16x8, make_uint4(w[0], w[1], w[2], w[3]));
+            pf[1] = __builtin_bit_cast(bf16x8, make_uint4(w[4], w[5], w[6], w[7]));
         } else if (!UNIFORM && !edge) {
             // interior tiles of the log2 quantiser never form p̂ as a float: the clamped magic-number integers of a key
             // pair are merged (their low halves = the two codes), and 2^-code as a bf16 is 0x3F80 − (code << 7), so the
             // packed pair is 0x3F803F80 − 128·(c0 | c1 << 16) — one 24-bit multiply-add (codes <= 127: no borrow)
             int ci[16];
+            const f2 nsl2v = {nsl2, nsl2}, a0m = {a0, a0}, magic = {MAGIC, MAGIC};
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float x = fmaf(acc[r], nsl2, a0);
-                ci[r] = min(max(__float_as_int(x + MAGIC), MAGIC_I), cmax_i);
-                if constexpr (VINT && !G::VONES) psum += __int_as_float(0x3F800000 - (ci[r] << 23));
+            for (int r = 0; r < 16; r += 2) {
+                const f2 y = pk_add(pk_fma(f2{acc[r], acc[r + 1]}, nsl2v, a0m), magic);
+                ci[r] = min(max(__float_as_int(y.x), MAGIC_I), cmax_i);
+                ci[r + 1] = min(max(__float_as_int(y.y), MAGIC_I), cmax_i);
+                if constexpr (VINT && !G::VONES) psum += __int_as_float(0x3F800000 - (ci[r] << 23)) + __int_as_float(0x3F800000 - (ci[r + 1] << 23));
             }
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
@@ -1078,7 +1126,8 @@ __global__ __launch_bounds__(64 * NW) void attn3_pv_kernel(AttnParams p) {
 template <int D, int QM, bool VINT>
 static int launch_attn3(AttnParams p, const void* q_raw, unsigned char* planes, float* qfq, hipStream_t st) {
     using G = Geo<D, QM, VINT>;
-    constexpr bool QI8 = QM == 1;
+    constexpr bool QI8 = G::QI8;
+    constexpr int PQM = QM == 3 ? 1 : QM;                  // the pre-pass writes the same images for both int8-score forms
     p.planes = planes;
     p.img_bytes = G::IMG_BYTES;
     constexpr int stats_lds = G::STATS_STAGES * G::K_PIECES * 1024;
@@ -1104,7 +1153,7 @@ static int launch_attn3(AttnParams p, const void* q_raw, unsigned char* planes, 
     const bool q_copy = QM != 0 || ((p.fq[0].mode >= 0 || p.io_dtype != DGQ_F32) && qfq != nullptr);
     const dim3 pgrid(2 * p.NT + (q_copy ? (p.T + 31) / 32 : 0), p.B * p.H);   // K tiles, V tiles, Q row blocks
     float* dreset = p.mode == 1 ? p.delta : nullptr;
-#define DGQ_PREP(TT) hipLaunchKernelGGL((attn3_prep_kernel<D, TT, QM, VINT>), pgrid, dim3(256), 0, st, (const TT*)p.k, (const TT*)p.v, planes, \
+#define DGQ_PREP(TT) hipLaunchKernelGGL((attn3_prep_kernel<D, TT, PQM, VINT>), pgrid, dim3(256), 0, st, (const TT*)p.k, (const TT*)p.v, planes, \
                                         p.B, p.H, p.S, p.NT, p.fq[1], p.fq[2], dreset, (const TT*)q_raw, qfq, p.T, p.fq[0])
     if (p.io_dtype == DGQ_F16) DGQ_PREP(__half);
     else if (p.io_dtype == DGQ_BF16) DGQ_PREP(__hip_bfloat16);
@@ -1131,7 +1180,14 @@ static int launch_attn3(AttnParams p, const void* q_raw, unsigned char* planes, 
     }
     // 8-wave blocks (256 query rows) when they still give one block per CU; register budgets allow it for D <= 64
     static const bool force4 = getenv("DGQ_ATTN_NW4") != nullptr;
-    const bool wide = D <= 64 && !force4 && (long)((p.T + 255) / 256) * p.B * p.H >= 256;
+    // ... unless the 8-wave grid ends in a mostly empty round: two 8-wave workgroups share a CU (512 resident), and e.g. 640 of
+    // them (T = 1024, B·H = 160) run as 1.25 rounds in the time of 2 — the 4-wave grid's last round costs a fraction of that
+    // (its lone workgroups have their SIMDs to themselves): 165 -> 152 us for that call, while 4096 rows at B·H = 80 (2.5
+    // rounds) stay on the wide form (762 against 813 us)
+    const long nblk8 = (long)((p.T + 255) / 256) * p.B * p.H;
+    const long rounds8 = (nblk8 + 511) / 512;
+    const bool tail_ok = nblk8 <= 512 || 10 * nblk8 >= 8 * 512 * rounds8;
+    const bool wide = D <= 64 && !force4 && nblk8 >= 256 && tail_ok;
     if (wide) {
         if constexpr (D <= 64) {
             dim3 grid((p.T + 255) / 256, p.B * p.H), block(512);
@@ -1209,10 +1265,11 @@ int dgq_attention_bf16x3(const void* q, const void* k, const void* v, void* o, i
     // any other fused aqtizer_q (a per-head-dim table on q or k, or an unquantised k): one exact plane of centred Q codes
     // against three K planes — three products instead of six
     const int qm = qi8 ? 1 : ((!i8_off && qfq != nullptr && p.fq[0].mode >= 0 && p.fq[0].skip == 0) ? 2 : 0);
+    const bool kscalar = qi8 && p.fq[1].mode == 0;         // one (δk, z'k) for every key: folded into per-query constants
     // single-plane integer V: aqtizer_v fused and scalar / per-head-dim (its scale is outside the sum over keys)
     const bool vint = !i8_off && (p.fq[2].mode == 0 || p.fq[2].mode == 2);
 #define DGQ_ATTN_V(DD, QQ) (vint ? launch_attn3<DD, QQ, true>(p, q, img, qfq, st) : launch_attn3<DD, QQ, false>(p, q, img, qfq, st))
-#define DGQ_ATTN_CASE(DD) case DD: return qm == 1 ? DGQ_ATTN_V(DD, 1) : (qm == 2 ? DGQ_ATTN_V(DD, 2) : DGQ_ATTN_V(DD, 0))
+#define DGQ_ATTN_CASE(DD) case DD: return qm == 1 ? (kscalar ? DGQ_ATTN_V(DD, 3) : DGQ_ATTN_V(DD, 1)) : (qm == 2 ? DGQ_ATTN_V(DD, 2) : DGQ_ATTN_V(DD, 0))
     switch (D) {
         DGQ_ATTN_CASE(8);
         DGQ_ATTN_CASE(16);
