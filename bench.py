@@ -424,8 +424,15 @@ def measure_gemm_roofline(torch, ops, qnn, run_step, args):
                 f.write("%s %.2f\n" % (";".join("%d,%d,%d,%d,%s,%d" % (M, ab.pw.N, ab.pw.K, ab.Kp, ab.mode, es) for M, ab, es in problems), 1e3 * ms))
 
     ops.GEMM_LAUNCH_HOOK = gemm_hook
-    ops.QUANT_LAUNCH_HOOK = lambda issue, by: rec["quant"].append((timed(issue), 0.0, float(by)))
-    ops.ATTN_LAUNCH_HOOK = lambda issue, fl, by: rec["attn"].append((timed(issue), float(fl), float(by)))
+    def dump(kind, ms, work):                                # per-launch tables for tools: DGQ_BENCH_QUANT_DUMP / _ATTN_DUMP=<file>
+        path = os.environ.get("DGQ_BENCH_%s_DUMP" % kind)
+        if path:
+            with open(path, "a") as f:
+                f.write("%.0f %.2f\n" % (work, 1e3 * ms))
+        return ms
+
+    ops.QUANT_LAUNCH_HOOK = lambda issue, by: rec["quant"].append((dump("QUANT", timed(issue), by), 0.0, float(by)))
+    ops.ATTN_LAUNCH_HOOK = lambda issue, fl, by: rec["attn"].append((dump("ATTN", timed(issue), fl), float(fl), float(by)))
     graphs_were = qnn._graphs
     qnn._graphs = None
     try:

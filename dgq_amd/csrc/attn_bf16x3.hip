@@ -102,6 +102,8 @@ struct AttnParams {
     int skip;
     float qmax;
     float* stats;          // [B*H][T][2] : m (log2 units), l
+    float* stats_part;     // key-split launches (gridDim.z = 2): [2][B*H][T][4] = m, l, m2 (maximum without the bypassed keys) per key half
+    float* o_part;         // key-split launches: the second key half's part of o ([B][T][H][D] fp32; attn3_add_kernel adds it to o)
     float* delta;
     const unsigned char* planes;   // [B*H][NT] tile images of the bf16 split planes (Geo<D>::IMG_BYTES each)
     int NT;                        // 32-key tiles per (batch, head)
@@ -756,9 +758,11 @@ __global__ __launch_bounds__(64 * NW) void attn3_stats_kernel(AttnParams p) {
     const uint32_t lds_base = (uint32_t)(uintptr_t)(lptr_t)lds8;
     // ring invariant at the top of iteration i: tiles i .. i+ST-2 are issued (indices clamped to the last tile, so
     // the in-flight count is the same in every iteration), tile i has landed
+    // key-split launches: workgroup z walks the key tiles [i0, i1) of its half (under-filled grids, see launch_attn3)
+    const int nsp = gridDim.z, i0 = (int)((long)p.NT * blockIdx.z / nsp), i1 = (int)((long)p.NT * (blockIdx.z + 1) / nsp);
 #pragma unroll
     for (int i = 0; i < ST - 1; ++i)
-        issue_image<NP, NW>(img_lane + (int64_t)min(i, p.NT - 1) * p.img_bytes, lds_base + i * SB, wid);
+        issue_image<NP, NW>(img_lane + (int64_t)min(i0 + i, i1 - 1) * p.img_bytes, lds_base + i * SB, wid);
     bf16x8 qf[3][QI8 ? 1 : G::NKK];
     v4i qc[G::NK32];
     float4 qt = make_float4(1.0f, 0.0f, 0.0f, 0.0f);
@@ -783,8 +787,8 @@ __global__ __launch_bounds__(64 * NW) void attn3_stats_kernel(AttnParams p) {
     wait_image<NP, ST - 2, NW>(wid);
     __builtin_amdgcn_s_barrier();
     int stage = 0, istage = ST - 1;
-    for (int i = 0; i < p.NT; ++i) {
-        issue_image<NP, NW>(img_lane + (int64_t)min(i + ST - 1, p.NT - 1) * p.img_bytes, lds_base + istage * SB, wid);
+    for (int i = i0; i < i1; ++i) {
+        issue_image<NP, NW>(img_lane + (int64_t)min(i + ST - 1, i1 - 1) * p.img_bytes, lds_base + istage * SB, wid);
         const int s0 = i * KT;
         v16f acc;
         if constexpr (QI8) acc = score_tile_i8<D, KS>(lds8 + stage * SB, qc, qt, lane, i == 0 && p.kskip > 0, inv_dk, cq);
@@ -827,7 +831,7 @@ __global__ __launch_bounds__(64 * NW) void attn3_stats_kernel(AttnParams p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // no DMA may outlive the block's LDS allocation
     {
         const float mo = __shfl_xor(mraw, 32, 64), lo = __shfl_xor(l, 32, 64);
-        const float mm = fmaxf(mraw, mo), nb = -(mm * sl2);                   // finite: key 0 exists for every query
+        const float mm = fmaxf(mraw, mo), nb = -(mm * sl2);                   // finite: every key range holds >= 8 keys
         l = l * __builtin_amdgcn_exp2f(fmaf(mraw, sl2, nb)) + lo * __builtin_amdgcn_exp2f(fmaf(mo, sl2, nb));
         mraw = mm;
         m2raw = fmaxf(m2raw, __shfl_xor(m2raw, 32, 64));
@@ -835,6 +839,11 @@ __global__ __launch_bounds__(64 * NW) void attn3_stats_kernel(AttnParams p) {
     mraw += cq;
     m2raw += cq;
     const float m = mraw * sl2;
+    if (nsp > 1) {                                       // partial statistics of this key half; attn3_merge_kernel finishes them
+        if (t < p.T && h32 == 0)
+            *reinterpret_cast<float4*>(p.stats_part + (((int64_t)blockIdx.z * p.B * p.H + bh) * p.T + t) * 4) = make_float4(m, l, m2raw * sl2, 0.0f);
+        return;
+    }
     if (t < p.T && h32 == 0) {
         float* st = p.stats + ((int64_t)bh * p.T + t) * 2;
         st[0] = m;
@@ -857,6 +866,44 @@ __global__ __launch_bounds__(64 * NW) void attn3_stats_kernel(AttnParams p) {
     }
 }
 
+__global__ __launch_bounds__(256) void attn3_add_kernel(float* __restrict__ o, const float* __restrict__ part, int64_t n4) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n4) {
+        float4 a = reinterpret_cast<float4*>(o)[i];
+        const float4 c = reinterpret_cast<const float4*>(part)[i];
+        a.x += c.x; a.y += c.y; a.z += c.z; a.w += c.w;
+        reinterpret_cast<float4*>(o)[i] = a;
+    }
+}
+
+// Key-split launches: merges the two halves' (m, l, m2) per query row into the statistics the P·V pass reads and takes the
+// real-time δ maximum over the merged rows (mode 1).  One thread per (batch·head, query).  The P·V halves use the merged
+// (m, l, δ), so their parts of o simply add (attn3_add_kernel).
+__global__ __launch_bounds__(256) void attn3_merge_kernel(AttnParams p) {
+    const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x, rows = (int64_t)p.B * p.H * p.T;
+    float pm = 0.0f;
+    if (row < rows) {
+        const float4 a = *reinterpret_cast<const float4*>(p.stats_part + row * 4);
+        const float4 c = *reinterpret_cast<const float4*>(p.stats_part + (rows + row) * 4);
+        const float m = fmaxf(a.x, c.x);
+        const float l = a.y * exp2f(a.x - m) + c.y * exp2f(c.x - m);
+        p.stats[row * 2] = m;
+        p.stats[row * 2 + 1] = l;
+        if (p.mode == 1) pm = exp2f(fmaxf(a.z, c.z) - m) / l;
+    }
+    if (p.mode == 1) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) pm = fmaxf(pm, __shfl_xor(pm, o, 64));
+        __shared__ float wmax[4];
+        if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = pm;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            pm = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+            atomicMax(reinterpret_cast<int*>(p.delta) + (blockIdx.x & (DELTA_SLOTS - 1)), __float_as_int(pm));
+        }
+    }
+}
+
 template <int D, bool UNIFORM, int NW, int QM, bool VINT>
 __global__ __launch_bounds__(64 * NW) void attn3_pv_kernel(AttnParams p) {
     using G = Geo<D, QM, VINT>;
@@ -871,9 +918,10 @@ __global__ __launch_bounds__(64 * NW) void attn3_pv_kernel(AttnParams p) {
     const int tq = min(t, p.T - 1);
     const unsigned char* img_lane = p.planes + (int64_t)bh * p.NT * G::IMG_BYTES + lane * 16;
     const uint32_t lds_base = (uint32_t)(uintptr_t)(lptr_t)lds8;
+    const int nsp = gridDim.z, i0 = (int)((long)p.NT * blockIdx.z / nsp), i1 = (int)((long)p.NT * (blockIdx.z + 1) / nsp);   // key-split launches
 #pragma unroll
     for (int i = 0; i < ST - 1; ++i)
-        issue_image<NP, NW>(img_lane + (int64_t)min(i, p.NT - 1) * G::IMG_BYTES, lds_base + i * SB, wid);
+        issue_image<NP, NW>(img_lane + (int64_t)min(i0 + i, i1 - 1) * G::IMG_BYTES, lds_base + i * SB, wid);
     bf16x8 qf[3][QI8 ? 1 : G::NKK];
     v4i qc[G::NK32];
     float4 qt = make_float4(1.0f, 0.0f, 0.0f, 0.0f);
@@ -922,8 +970,8 @@ __global__ __launch_bounds__(64 * NW) void attn3_pv_kernel(AttnParams p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the stats / δ loads above share the counter: drain once)
     __builtin_amdgcn_s_barrier();
     int stage = 0, istage = ST - 1;
-    for (int i = 0; i < p.NT; ++i) {
-        issue_image<NP, NW>(img_lane + (int64_t)min(i + ST - 1, p.NT - 1) * G::IMG_BYTES, lds_base + istage * SB, wid);
+    for (int i = i0; i < i1; ++i) {
+        issue_image<NP, NW>(img_lane + (int64_t)min(i + ST - 1, i1 - 1) * G::IMG_BYTES, lds_base + istage * SB, wid);
         const int s0 = i * KT;
         const unsigned short* kbc = reinterpret_cast<const unsigned short*>(lds8 + stage * SB);
         const unsigned short* vtc = kbc + G::K_ELEMS;
@@ -1117,7 +1165,8 @@ __global__ __launch_bounds__(64 * NW) void attn3_pv_kernel(AttnParams p) {
                         o = delta * oacc[j][r];
                     }
                     if (p.skip > 0) o += p_bypass * vtab[2 * G::DV + d];
-                    store_any(p.o, p.io_dtype, ob + d, o);
+                    if (blockIdx.z > 0) p.o_part[ob + d] = o;      // second key half of a split launch (fp32 o): added by attn3_add_kernel
+                    else store_any(p.o, p.io_dtype, ob + d, o);
                 }
             }
     }
@@ -1188,6 +1237,17 @@ static int launch_attn3(AttnParams p, const void* q_raw, unsigned char* planes, 
     const long rounds8 = (nblk8 + 511) / 512;
     const bool tail_ok = nblk8 <= 512 || 10 * nblk8 >= 8 * 512 * rounds8;
     const bool wide = D <= 64 && !force4 && nblk8 >= 256 && tail_ok;
+    // Key split: a grid that leaves the chip under-filled (fewer 128-row workgroups than ~0.9 per CU) runs each (query block,
+    // batch·head) as TWO workgroups over the two halves of the key tiles.  The statistics halves are merged by attn3_merge_kernel
+    // ; the P·V halves use the merged (m, l, δ), so their parts simply add (the second half's part goes to a scratch tensor,
+    // attn3_add_kernel adds it — float atomics into o were 2x slower than the unsplit call).  fp32 o only, no code emission,
+    // >= 4 key tiles per half, D % 4 == 0.
+    // Measured: 1024 x 1024, D = 80, B·H = 16: 86 -> 65 us; SDXL 4096 x 4096 at B·H = 10 (320 workgroups): 333 -> 282 us; 8-wave
+    // grids (one workgroup per CU already) gain nothing and stay unsplit.
+    const char* se = getenv("DGQ_ATTN_SPLIT");                 // grids below this many 4-wave workgroups split (0: never); read per call: tests toggle it
+    const long split_below = se ? atol(se) : 448L;
+    const long nblk4 = (long)((p.T + 127) / 128) * p.B * p.H;
+    const int nsp = (!wide && nblk4 < split_below && p.NT >= 8 && p.io_dtype == DGQ_F32 && p.e_codes == nullptr) ? 2 : 1;
     if (wide) {
         if constexpr (D <= 64) {
             dim3 grid((p.T + 255) / 256, p.B * p.H), block(512);
@@ -1196,10 +1256,15 @@ static int launch_attn3(AttnParams p, const void* q_raw, unsigned char* planes, 
             else hipLaunchKernelGGL((attn3_pv_kernel<D, false, 8, QM, VINT>), grid, block, pv_lds, st, p);
         }
     } else {
-        dim3 grid((p.T + 127) / 128, p.B * p.H), block(256);
+        dim3 grid((p.T + 127) / 128, p.B * p.H, nsp), block(256);
         hipLaunchKernelGGL((attn3_stats_kernel<D, 4, QM>), grid, block, stats_lds, st, p);
+        if (nsp > 1) hipLaunchKernelGGL(attn3_merge_kernel, dim3((unsigned)(((long)p.B * p.H * p.T + 255) / 256)), dim3(256), 0, st, p);
         if (p.mode == 3) hipLaunchKernelGGL((attn3_pv_kernel<D, true, 4, QM, VINT>), grid, block, pv_lds, st, p);
         else hipLaunchKernelGGL((attn3_pv_kernel<D, false, 4, QM, VINT>), grid, block, pv_lds, st, p);
+    }
+    if (nsp > 1) {
+        const int64_t n4 = (int64_t)p.B * p.T * p.H * D / 4;
+        hipLaunchKernelGGL(attn3_add_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, reinterpret_cast<float*>(p.o), p.o_part, n4);
     }
     return dgq_launch_status("dgq_attention_f32(bf16x3)");
 }
@@ -1233,8 +1298,10 @@ size_t dgq_attention_bf16x3_bytes(int B, int H, int S, int D) {
 // called from dgq_attention_f32 (attn_fused.hip) for the quantised modes; returns 1 when D is not instantiated here
 int dgq_attention_bf16x3(const void* q, const void* k, const void* v, void* o, int io_dtype, int B, int H, int T, int S, int D,
                          float scale, int mode, int skip, float qmax, float* stats_ws, float* delta_ws, void* planes,
-                         float* qfq, const dgq_attn_fq_t* fq, const dgq_emit_t* emit, hipStream_t st) {
+                         float* qfq, float* o_part, const dgq_attn_fq_t* fq, const dgq_emit_t* emit, hipStream_t st) {
     AttnParams p;
+    p.stats_part = stats_ws + (size_t)B * H * T * 2;      // (the statistics area holds 10 floats per row: 2 merged + 2 x 4 partial)
+    p.o_part = o_part;
     p.e_codes = nullptr; p.e_rowsum = nullptr; p.e_kdst = nullptr; p.e_delta = nullptr; p.e_zp = nullptr;
     p.e_Kp = 0; p.e_L = 1; p.e_qmax = 0.0f; p.e_off = 0.0f;
     if (emit) {

@@ -215,14 +215,14 @@ static int launch_attn(const AttnParams& p, hipStream_t st) {
 
 int dgq_attention_bf16x3(const void* q, const void* k, const void* v, void* o, int io_dtype, int B, int H, int T, int S, int D,
                          float scale, int mode, int skip, float qmax, float* stats_ws, float* delta_ws, void* planes,
-                         float* qfq, const dgq_attn_fq_t* fq, const dgq_emit_t* emit, hipStream_t st);
+                         float* qfq, float* o_part, const dgq_attn_fq_t* fq, const dgq_emit_t* emit, hipStream_t st);
 size_t dgq_attention_bf16x3_bytes(int B, int H, int S, int D);
 size_t dgq_attention_qi8_bytes(int B, int H, int T, int D);
 
-// workspace layout: [0,256) δ scalar | stats B·H·T·2 floats (256-byte aligned) | tile images of the bf16 split planes of
-// K and V | fake-quantised copy of q (used when aqtizer_q is fused)
+// workspace layout: [0,256) δ scalar | stats B·H·T·10 floats (2 merged + 2 x 4 per key half of a split launch; 256-byte aligned) | tile images of the bf16 split planes of
+// K and V | fake-quantised copy of q (used when aqtizer_q is fused) | the second key half's part of o (split launches)
 static size_t attn_stats_off() { return 256; }
-static size_t attn_planes_off(int B, int H, int T) { return 256 + (((size_t)B * H * T * 2 * sizeof(float) + 255) / 256) * 256; }
+static size_t attn_planes_off(int B, int H, int T) { return 256 + (((size_t)B * H * T * 10 * sizeof(float) + 255) / 256) * 256; }
 
 // query scratch: an fp32 (fake-quantised) copy of q, or the int8 codes + per-query table of the QI8 path
 static size_t attn_q_scratch(int B, int H, int T, int D) {
@@ -231,7 +231,8 @@ static size_t attn_q_scratch(int B, int H, int T, int D) {
 }
 
 extern "C" size_t dgq_attention_workspace_bytes(int B, int H, int T, int S, int D) {
-    return attn_planes_off(B, H, T) + dgq_attention_bf16x3_bytes(B, H, S, D) + attn_q_scratch(B, H, T, D);
+    return attn_planes_off(B, H, T) + dgq_attention_bf16x3_bytes(B, H, S, D) + attn_q_scratch(B, H, T, D) +
+           ((size_t)B * T * H * D * sizeof(float) + 255) / 256 * 256;
 }
 
 extern "C" int dgq_attention_fuses_fakequant(int D, int mode) {
@@ -281,7 +282,7 @@ static int attention_impl(const void* q_, const void* k_, const void* v_, void* 
     }
     if (mode == 1 && !use3) {                                  // (the bf16x3 pre-pass resets δ itself)
         if (hipMemsetAsync(delta_ws, 0, sizeof(float), st) != hipSuccess) { dgq_set_error("dgq_attention_f32: memset"); return DGQ_ELAUNCH; }
-    } else if (mode >= 2) {
+    } else if (mode >= 2 && !use3) {                           // (the bf16x3 kernels read the caller's δ in place)
         if (hipMemcpyAsync(delta_ws, delta_in, sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) {
             dgq_set_error("dgq_attention_f32: memcpy"); return DGQ_ELAUNCH;
         }
@@ -298,7 +299,9 @@ static int attention_impl(const void* q_, const void* k_, const void* v_, void* 
             return DGQ_EUNSUPPORTED;
         }
     }
-    if (use3) return dgq_attention_bf16x3(q_, k_, v_, o_, dtype, B, H, T, S, D, scale, mode, skip, p.qmax, stats_ws, delta_ws, planes, qfq, fq, emit, st);
+    if (use3) return dgq_attention_bf16x3(q_, k_, v_, o_, dtype, B, H, T, S, D, scale, mode, skip, p.qmax, stats_ws,
+                                          mode >= 2 ? const_cast<float*>(delta_in) : delta_ws, planes, qfq,
+                                          reinterpret_cast<float*>(reinterpret_cast<char*>(qfq) + attn_q_scratch(B, H, T, D)), fq, emit, st);
     switch (D) {
         case 8: return launch_attn<8>(p, st);
         case 16: return launch_attn<16>(p, st);

@@ -535,6 +535,44 @@ def test_attention_half_io_equals_fp32_path(D, T, S, H, mode, skip, dtype, dev):
     assert torch.equal(o_h, o_f.to(dtype))
 
 
+@pytest.mark.parametrize("D,T,S,mode,skip,fused", [(80, 256, 1024, 1, 1, True), (64, 320, 300, 3, 0, True), (160, 64, 256, 2, 0, False),
+                                                  (40, 512, 2048 - 5, 1, 0, True)])
+def test_attention_key_split_equals_unsplit(D, T, S, mode, skip, fused, dev, monkeypatch):
+    """Under-filled grids run every (query block, batch·head) as two workgroups over the two halves of the key tiles
+    (attn_bf16x3.hip: launch_attn3): statistics halves merged by a small kernel, the second half's part of o added by another.
+    Against the same call unsplit (DGQ_ATTN_SPLIT=0): the row statistics merge in another order, so l differs in its last bits
+    (and with it the real-time δ) and a log2 / uniform code of a probability on a rounding tie may move — one such flip changes
+    that p̂ by a factor 2.  Asserted: relative L2 within the 4e-3 every attention test grants the float64 formula (measured
+    6e-4 with the real-time δ, <= 1e-6 with a static one), >= 99 % (static δ: 99.9 %) of the elements within 1e-5 of the output's
+    scale (the flips are isolated: an ulp of a0 ~ 2e-6 in log2 units is also their rate), the split call deterministic; unfused cases also against the float64 formula."""
+    from dgq_amd import ops
+    B, H, bits = 2, 4, 8
+    g = torch.Generator().manual_seed(D + T + S)
+    q, k, v = (torch.randn(B, n, H * D, generator=g).to(dev) for n in (T, S, S))
+    scale = D ** -0.5
+    delta = None if mode == 1 else torch.tensor([1.0 if mode == 2 else 1.0 / 255.0], device=dev)
+    fq = None
+    if fused:
+        tab = lambda n: (torch.rand(n, generator=g).to(dev) * 0.02 + 0.02, torch.randint(100, 156, (n,), generator=g).float().to(dev))
+        fq = ((1,) + tab(T) + (0, 8), (1,) + tab(S - skip) + (skip, 8), (2,) + tab(D) + (0, 8))
+    monkeypatch.setenv("DGQ_ATTN_SPLIT", "0")
+    o1 = ops.attention(q, k, v, H, D, scale, mode, skip, delta, bits, fq=fq).clone()
+    monkeypatch.setenv("DGQ_ATTN_SPLIT", "100000")
+    o2 = ops.attention(q, k, v, H, D, scale, mode, skip, delta, bits, fq=fq).clone()
+    o3 = ops.attention(q, k, v, H, D, scale, mode, skip, delta, bits, fq=fq).clone()
+    torch.cuda.synchronize()
+    assert torch.equal(o2, o3), "the split call is not deterministic"
+    err = (o1 - o2).abs()
+    assert rel_l2(o2.cpu(), o1.cpu()) < (4e-3 if mode == 1 else 2e-4), rel_l2(o2.cpu(), o1.cpu())
+    assert float((err <= 1e-5 * float(o1.abs().max())).float().mean()) >= (0.99 if mode == 1 else 0.999)
+    if not fused:
+        qh, kh, vh = (x.double().view(B, -1, H, D).transpose(1, 2) for x in (q, k, v))
+        p = torch.softmax(torch.matmul(qh, kh.transpose(-2, -1)) * scale, dim=-1).float()
+        pq = orc.log_quant(p.cpu(), delta[0].cpu(), bits).to(dev) if mode == 2 else orc.uaq(p.cpu(), delta[0].cpu(), torch.tensor(0.0), bits).to(dev)
+        ref = torch.matmul(pq.double(), vh).transpose(1, 2).reshape(B, T, H * D).float()
+        assert rel_l2(o2.cpu(), ref.cpu()) < 4e-3
+
+
 @pytest.mark.parametrize("D,mode,skip", [(40, 1, 1), (64, 1, 0), (40, 3, 0)])
 def test_attention_wide_blocks(D, mode, skip, dev):
     """T = 2048 with 32 (batch, head) pairs selects the 8-wave (256-row) blocks of the bf16x3 kernels; checked against the
