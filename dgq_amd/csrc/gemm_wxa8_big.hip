@@ -68,6 +68,7 @@ constexpr int BIG_WVM = 2, BIG_WVN = 4, BIG_NW = 8, BIG_NT = 512;
 template <bool PER_M, typename TOut, int BM, int BN, int NBUF>
 __global__ __launch_bounds__(BIG_NT, 2) void gemm_big_kernel(GemmBatch bt) {
     const GemmParams& p = bt.p[0];
+    const uint64_t st_entry = BIG_STAMP == 2 ? big_stamp() : 0;      // BIG_STAMP = 2: block timeline (entry / loop start / loop end / stores issued / done)
     int tile_n, tile_m;
     {   // XCD-aware tile order (as gemm_wxa8_kernel): XCD k owns a contiguous m-major tile range
         const int gx = gridDim.x, T = gridDim.x * gridDim.y;
@@ -207,6 +208,7 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_big_kernel(GemmBatch bt) {
     if (group == 1) __builtin_amdgcn_s_barrier();            // group 1 runs one barrier behind group 0 from here on
 
     const bool use_ccoef = !PER_M && p.ccoef != nullptr;      // wave-uniform (a kernel argument)
+    const uint64_t st_loop0 = BIG_STAMP == 2 ? big_stamp() : 0;
     uint64_t stamps[6 * NPH];
     auto stamp = [&](int k, int t) {
         if (BIG_STAMP && t == 8) stamps[k] = big_stamp();
@@ -364,12 +366,19 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_big_kernel(GemmBatch bt) {
     for (; t + 2 < nk; ++t) tile(t, std::true_type());
     for (; t < nk; ++t) tile(t, std::false_type());
     if (group == 0) __builtin_amdgcn_s_barrier();            // both groups have now passed the same number of barriers
+    const uint64_t st_loop1 = BIG_STAMP == 2 ? big_stamp() : 0;
 
     gemm_store_tile<PER_M, TOut, BM, BN, WVM, WVN, 1, NBUF * STAGE_BYTES, TM, TN>(p, 0, smem, vtab, vcol, wid, lane, wave_m, wave_n, 0,
                                                                                   m0, n0, acc, accf);
+    const uint64_t st_issued = BIG_STAMP == 2 ? big_stamp() : 0;
     if (BIG_STAMP) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+    }
+    if (BIG_STAMP == 2 && lane == 0 && blockIdx.y == 0 && (blockIdx.x == 0 || blockIdx.x == 8)) {
+        uint64_t* dbg = reinterpret_cast<uint64_t*>(p.y) + (blockIdx.x ? 128 : 0) + wid * 16;
+        dbg[0] = st_entry; dbg[1] = st_loop0; dbg[2] = st_loop1; dbg[3] = st_issued; dbg[4] = big_stamp();
+        return;
     }
     if (BIG_STAMP && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) {
         uint64_t* dbg = reinterpret_cast<uint64_t*>(p.y) + wid * 16;

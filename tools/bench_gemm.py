@@ -44,6 +44,10 @@ if os.environ.get("HEADLINE"):
     SHAPES = [(n, M, N, C, t, mode, od) for (n, M, N, C, t) in HEADLINE for mode in ("perK", "perM") for od in ("fp32", "bf16")]
 else:
     SHAPES = [s + ("fp32",) for s in (SHAPES_ALL[-2:] if os.environ.get("BIG_ONLY") else SHAPES_ALL)]
+# SHAPE="M,N,C,taps[;M,N,C,taps...]": custom shapes instead (per-K g16 and per-M, fp32 and bf16 outputs)
+if os.environ.get("SHAPE"):
+    SHAPES = [("custom %s" % sh, *(int(x) for x in sh.split(",")), mode, od) for sh in os.environ["SHAPE"].split(";")
+              for mode in ("perK", "perM") for od in ("fp32", "bf16")]
 # VARIANTS="default;128,128,1;256,256,1": each shape under several launch plans (DGQ_GEMM_FORCE, read per call) in ONE process
 VARIANTS = os.environ.get("VARIANTS", "default").split(";")
 if os.environ.get("ONLY"):
