@@ -208,6 +208,11 @@ UNET_CFG = {
                ts=(981, 481)),
     "c3": dict(wbits=4, abits=6, use_aq=True, G=8, log=True, rt=True, sp=True, time_aware=True, steps=50,
                ts=(981, 21)),
+    # c2 without the time-aware reload (the reference's --fp16 mode cannot run WITH it: load_act_ckpt_with_difference_shape puts
+    # fp32 deltas back at every forward, the quantizer output is promoted to fp32 and the next matmul raises "expected scalar type
+    # Float but found Half", quant_layer.py:562 / F.linear)
+    "c2n": dict(wbits=4, abits=8, use_aq=True, G=16, log=True, rt=True, sp=True, time_aware=False, steps=50,
+                ts=(981,)),
     "c2u": dict(wbits=4, abits=8, use_aq=True, G=1, log=False, rt=False, sp=False, time_aware=True, steps=50,
                 ts=(981,)),
 }
@@ -284,6 +289,31 @@ def make_unet(ref, arch, name, res=None, batch=2):
         blob["outputs_1thread"] = outs1
         blob["meta"]["threads"] = nt
     save("f5_unet_%s_%s_r%d.pt" % (arch, name, res), blob)
+
+
+def make_unet_half(ref, arch="sd", name="c2", res=16, batch=2):
+    """The reference's own --fp16 mode (src/inference_qmodel.py:96-97 -> QuantModel.half(), quant_model.py:183-192) on the CPU: the
+    same model / inputs as f5_unet_<arch>_<name>_r<res>.pt, cast by the reference's half() and fed fp16 tensors.  Recorded: its
+    output per timestep (and the fp32 run beside it), so that the HIP path's fp16 mode is compared with what the reference's fp16
+    mode does to this network instead of with a tolerance read off our own measurement."""
+    c = UNET_CFG[name]
+    res = res or synth.ARCH[arch]["sample_size"]
+    need_slots = 1 + max((1000 - t) // (1000 // c["steps"]) for t in c["ts"]) if c["time_aware"] else 1
+    qnn, path = build_ref_unet_qnn(ref, arch, c, res, batch, need_slots)
+    inp = synth.synth_inputs(arch, batch, 1, res)
+    out32, out16 = {}, {}
+    for t in c["ts"]:
+        out32[t] = qnn(inp["sample"], torch.tensor(t), inp["encoder_hidden_states"])[0].clone()
+    qnn.half()
+    for t in c["ts"]:
+        t0 = time.time()
+        y = qnn(inp["sample"].half(), torch.tensor(t), inp["encoder_hidden_states"].half())[0]
+        assert y.dtype == torch.float16
+        out16[t] = y.clone()
+        print("fp16 t=%d  %.1fs  rel-L2 vs the fp32 run: %.4g" % (t, time.time() - t0, ((y.float() - out32[t]).norm() / out32[t].norm()).item()))
+    meta = dict(c)
+    meta.update(arch=arch, res=res, batch=batch, seed=0, input_seed=1, threads=torch.get_num_threads())
+    save("f5c_unet_%s_%s_r%d_fp16.pt" % (arch, name, res), dict(meta=meta, outputs_fp32=out32, outputs_fp16=out16))
 
 
 def make_ddim(ref, steps=50, res=64, name="c2"):
@@ -837,6 +867,8 @@ if __name__ == "__main__":  # noqa: C901
     elif what == "unet":
         res = int(sys.argv[3]) if len(sys.argv) > 3 else None
         make_unet(ref, arch, sys.argv[2], res=res)
+    elif what == "unet_half":
+        make_unet_half(ref, arch, sys.argv[2] if len(sys.argv) > 2 else "c2", int(sys.argv[3]) if len(sys.argv) > 3 else 16)
     elif what == "calib":
         make_calib(ref)
     elif what == "qstats":

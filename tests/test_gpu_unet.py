@@ -771,6 +771,39 @@ def test_fused_unet_teacher_forced_half_modes(dtype, tmp_path_factory):
     assert e < tol["final"], e
 
 
+C2N = dict(C2, time_aware=False)
+
+
+def test_fp16_mode_vs_reference_fp16_mode_golden(tmp_path_factory):
+    """The reference's own --fp16 mode (src/inference_qmodel.py:96-97 -> QuantModel.half(), quant_model.py:183-192) as the yardstick
+    for ours: tests/golden/f5c_unet_sd_c2n_r16_fp16.pt = the reference SD UNet W4A8 g16 at 16x16 run on the CPU
+    in fp32 and, after its half(), in fp16 — WITHOUT the time-aware reload, because with it the reference's fp16 mode cannot run at
+    all (load_act_ckpt_with_difference_shape puts fp32 deltas back at every forward, the quantizer output is promoted to fp32 and
+    the next matmul raises 'expected scalar type Float but found Half', quant_layer.py:562; make_golden.py 'unet_half c2').  The
+    reference's fp16 output is 0.149 rel-L2 from its own fp32 output (the chaos of DESIGN.md §5 seeded by fp16 rounding instead of
+    by summation order).  Asserted for the HIP path's fp16 mode, free-running: fp16 tensors out, no farther from the reference's
+    fp32 output than 2x what the reference's fp16 mode is, and within 2.5x that of the reference's fp16 output (two independent
+    samples of the same divergence); our fp32 mode printed beside it."""
+    from dgq_amd.runtime import build_synthetic_qnn
+    g = torch.load(os.path.join(GOLD, "f5c_unet_sd_c2n_r16_fp16.pt"))
+    assert g["meta"]["time_aware"] is False and g["meta"]["res"] == 16
+    tmp = str(tmp_path_factory.mktemp("ckfp16"))
+    qnn, _ = build_synthetic_qnn("sd", C2N, 16, 2, 1, ckpt_dir=tmp)                  # not cached: the model is recast
+    inp = synth.synth_inputs("sd", 2, 1, 16)
+    for t, ref32 in g["outputs_fp32"].items():
+        ref16 = g["outputs_fp16"][t].float()
+        d_ref = rel_l2(ref16, ref32)
+        with torch.no_grad():
+            y32 = qnn.float()(inp["sample"].cuda(), torch.tensor(t), inp["encoder_hidden_states"].cuda())[0].float().cpu()
+            y16 = qnn.half()(inp["sample"].cuda().half(), torch.tensor(t), inp["encoder_hidden_states"].cuda().half())[0]
+        assert y16.dtype == torch.float16
+        y16 = y16.float().cpu()
+        e32, e16, e0 = rel_l2(y16, ref32), rel_l2(y16, ref16), rel_l2(y32, ref32)
+        print("t=%d: reference fp16 vs its fp32 %.3g | HIP fp16 vs reference fp32 %.3g, vs reference fp16 %.3g | HIP fp32 vs reference fp32 %.3g"
+              % (t, d_ref, e32, e16, e0))
+        assert torch.isfinite(y16).all() and e32 < 2.0 * d_ref and e16 < 2.5 * d_ref, (t, d_ref, e32, e16)
+
+
 def test_graph_cache_is_invalidated_by_state_changes(ckdir):
     """a captured hipGraph bakes in the quantisation state; set_quant_state / dtype casts must drop it."""
     from dgq_amd.runtime import build_synthetic_qnn
