@@ -19,7 +19,7 @@ SIGNATURES = {
     "dgq_pack_w8": [_vp, _i, _i, _vp, _i, _vp, _vp],
     "dgq_quant_act": [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _i,
                       _vp, _vp, _i, _vp, _vp, _f, _vp],
-    "dgq_groupnorm_scale_shift": [_vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp],
+    "dgq_groupnorm_scale_shift": [_vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "dgq_quant_act_parts": [_i, _i],
     "dgq_gemm_wxa8": [_vp, _vp, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _vp, _i, _i,
                       _vp, ctypes.c_size_t, _vp, _vp],
@@ -32,7 +32,6 @@ SIGNATURES = {
     "dgq_attention_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _vp, _i, _vp, _vp, ctypes.c_size_t, _vp],
     "dgq_attention": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _i, _vp, _i, _vp, _vp, ctypes.c_size_t, _vp],
     "dgq_conv2d_f32w": [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _i, _vp, _vp, _i, _vp],
-    "dgq_attention_emit": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _i, _vp, _i, _vp, _vp, _vp, ctypes.c_size_t, _vp],
     "dgq_attention_fuses_fakequant": [_i, _i],
     "dgq_attention_workspace_bytes": [_i, _i, _i, _i, _i],
     "dgq_minmax_rows_cols": [_vp, _i, _i, _i, _i64, _vp, _vp, _vp, _vp, _vp, _i, _vp],
@@ -87,12 +86,6 @@ class GemmArgs(ctypes.Structure):
 class AttnFq(ctypes.Structure):
     """dgq_attn_fq_t of include/dgq_hip.h"""
     _fields_ = [("mode", _i), ("skip", _i), ("bits", _i), ("delta", _vp), ("zero_point", _vp)]
-
-
-class Emit(ctypes.Structure):
-    """dgq_emit_t of include/dgq_hip.h"""
-    _fields_ = [("codes", _vp), ("rowsum", _vp), ("kdst", _vp), ("delta", _vp), ("zp", _vp),
-                ("Kp", _i), ("per_m", _i), ("L", _i), ("bits", _i)]
 
 
 _lib = None

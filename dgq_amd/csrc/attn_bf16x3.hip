@@ -112,14 +112,6 @@ struct AttnParams {
     int img_bytes;                 // bytes of one tile image in global memory (depends on the K / V plane formats)
     int kskip;                     // QI8: leading keys that bypass aqtizer_k (start-peak key 0: exact fp32 rank-1 score)
     int xcd;                       // 1: workgroups of one (batch, head) share an XCD (its K/V tile images stay in one L2)
-    // quantise-on-store (dgq_attention_emit): the next layer's activation codes + per-head row sums instead of o
-    int8_t* e_codes;               // [B·T][e_Kp]; nullptr = store o
-    float* e_rowsum;               // [H][B·T]
-    const int32_t* e_kdst;         // per-K: [H·D] packed position of channel c; nullptr = natural order (per-M / scalar)
-    const float* e_delta;          // per-K: per 32-chunk; per-M: [e_L] by row % e_L
-    const float* e_zp;
-    int e_Kp, e_L;
-    float e_qmax, e_off;
 };
 
 __device__ __forceinline__ unsigned short bf16_bits(float x) {
@@ -1094,12 +1086,7 @@ __global__ __launch_bounds__(64 * NW) void attn3_pv_kernel(AttnParams p) {
     // global memory they were 5·16 dependent round trips between the stores (D = 160: +10 us on a 64-row call)
     // likewise the (fake-quantised) value row of the bypassed start-peak key
     float* vtab = reinterpret_cast<float*>(lds8);
-    const bool emit = p.e_codes != nullptr;
-    // emission tables of this head's D channels: packed position, and (per-K) the (δ, z) of its chunk
-    int* ekd = reinterpret_cast<int*>(vtab + 3 * G::DV);
-    float* edl = vtab + 4 * G::DV;
-    float* ezp = vtab + 5 * G::DV;
-    if (VINT || p.skip > 0 || emit) {
+    if (VINT || p.skip > 0) {
         __syncthreads();                                 // every wave's DMA has landed (its own vmcnt(0) above): the ring is free
         for (int d = tid; d < G::DV; d += 64 * NW) {
             if (VINT) {
@@ -1109,46 +1096,8 @@ __global__ __launch_bounds__(64 * NW) void attn3_pv_kernel(AttnParams p) {
             }
             if (p.skip > 0)
                 vtab[2 * G::DV + d] = d < D ? fq_apply(p.fq[2], load_any(p.v, p.io_dtype, ((int64_t)(b * p.S) * p.H + hd) * D + d), 0, d) : 0.0f;
-            if (emit && d < D) {
-                const int c = hd * D + d;
-                const int dst = p.e_kdst ? p.e_kdst[c] : c;
-                ekd[d] = dst;
-                if (p.e_kdst) { edl[d] = p.e_delta[dst >> 5]; ezp[d] = p.e_zp[dst >> 5]; }
-            }
         }
         __syncthreads();
-    }
-    if (emit) {
-        // quantise-on-store: what dgq_quant_act would make of o (rounded to the tensors' dtype first, as a stored-and-reloaded o
-        // would be) for the next Linear layer, byte by byte at its packed position; one row-sum part per head
-        const int64_t m = (int64_t)b * p.T + tq;
-        float mdl = 1.0f, mz = 0.0f;
-        if (!p.e_kdst) { const int li = (int)(m % p.e_L); mdl = p.e_delta[li]; mz = p.e_zp[li]; }
-        const float minv = dgq_rcp(mdl);
-        float part = 0.0f;
-        int8_t* crow = p.e_codes + m * p.e_Kp;
-#pragma unroll
-        for (int j = 0; j < G::NDT; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int d = j * 32 + key_of(r, h32);
-                if (d < D) {
-                    float o;
-                    if (VINT) o = delta * (vtab[d] * (oacc[j][r] - vtab[G::DV + d] * psum));
-                    else o = delta * oacc[j][r];
-                    if (p.skip > 0) o += p_bypass * vtab[2 * G::DV + d];
-                    if (p.io_dtype == DGQ_F16) o = __half2float(__float2half(o));
-                    else if (p.io_dtype == DGQ_BF16) o = __bfloat162float(__float2bfloat16(o));
-                    float dl = mdl, z = mz, inv = minv;
-                    if (p.e_kdst) { dl = edl[d]; z = ezp[d]; inv = dgq_rcp(dl); }
-                    const float code = dgq_affine_code_fast(o, dl, inv, z, p.e_qmax) - p.e_off;
-                    if (t < p.T) crow[ekd[d]] = (int8_t)(int)code;
-                    part += p.e_kdst ? dl * code : code;
-                }
-            }
-        part += __shfl_xor(part, 32, 64);                    // the two half-waves hold the two halves of a head's channels
-        if (t < p.T && h32 == 0) p.e_rowsum[(int64_t)hd * p.B * p.T + m] = part;
-        return;
     }
     if (t < p.T) {
         const int64_t ob = ((int64_t)(b * p.T + t) * p.H + hd) * D;
@@ -1240,14 +1189,14 @@ static int launch_attn3(AttnParams p, const void* q_raw, unsigned char* planes, 
     // Key split: a grid that leaves the chip under-filled (fewer 128-row workgroups than ~0.9 per CU) runs each (query block,
     // batch·head) as TWO workgroups over the two halves of the key tiles.  The statistics halves are merged by attn3_merge_kernel
     // ; the P·V halves use the merged (m, l, δ), so their parts simply add (the second half's part goes to a scratch tensor,
-    // attn3_add_kernel adds it — float atomics into o were 2x slower than the unsplit call).  fp32 o only, no code emission,
+    // attn3_add_kernel adds it — float atomics into o were 2x slower than the unsplit call).  fp32 o only,
     // >= 4 key tiles per half, D % 4 == 0.
     // Measured: 1024 x 1024, D = 80, B·H = 16: 86 -> 65 us; SDXL 4096 x 4096 at B·H = 10 (320 workgroups): 333 -> 282 us; 8-wave
     // grids (one workgroup per CU already) gain nothing and stay unsplit.
     const char* se = getenv("DGQ_ATTN_SPLIT");                 // grids below this many 4-wave workgroups split (0: never); read per call: tests toggle it
     const long split_below = se ? atol(se) : 448L;
     const long nblk4 = (long)((p.T + 127) / 128) * p.B * p.H;
-    const int nsp = (!wide && nblk4 < split_below && p.NT >= 8 && p.io_dtype == DGQ_F32 && p.e_codes == nullptr) ? 2 : 1;
+    const int nsp = (!wide && nblk4 < split_below && p.NT >= 8 && p.io_dtype == DGQ_F32) ? 2 : 1;
     if (wide) {
         if constexpr (D <= 64) {
             dim3 grid((p.T + 255) / 256, p.B * p.H), block(512);
@@ -1298,17 +1247,10 @@ size_t dgq_attention_bf16x3_bytes(int B, int H, int S, int D) {
 // called from dgq_attention_f32 (attn_fused.hip) for the quantised modes; returns 1 when D is not instantiated here
 int dgq_attention_bf16x3(const void* q, const void* k, const void* v, void* o, int io_dtype, int B, int H, int T, int S, int D,
                          float scale, int mode, int skip, float qmax, float* stats_ws, float* delta_ws, void* planes,
-                         float* qfq, float* o_part, const dgq_attn_fq_t* fq, const dgq_emit_t* emit, hipStream_t st) {
+                         float* qfq, float* o_part, const dgq_attn_fq_t* fq, hipStream_t st) {
     AttnParams p;
     p.stats_part = stats_ws + (size_t)B * H * T * 2;      // (the statistics area holds 10 floats per row: 2 merged + 2 x 4 partial)
     p.o_part = o_part;
-    p.e_codes = nullptr; p.e_rowsum = nullptr; p.e_kdst = nullptr; p.e_delta = nullptr; p.e_zp = nullptr;
-    p.e_Kp = 0; p.e_L = 1; p.e_qmax = 0.0f; p.e_off = 0.0f;
-    if (emit) {
-        p.e_codes = emit->codes; p.e_rowsum = emit->rowsum; p.e_kdst = emit->per_m ? nullptr : emit->kdst;
-        p.e_delta = emit->delta; p.e_zp = emit->zp; p.e_Kp = emit->Kp; p.e_L = emit->per_m ? emit->L : 1;
-        p.e_qmax = (float)((1 << emit->bits) - 1); p.e_off = (float)(1 << (emit->bits - 1));
-    }
     for (int i = 0; i < 3; ++i) {
         p.fq[i].mode = -1; p.fq[i].skip = 0; p.fq[i].qmax = 0.0f; p.fq[i].delta = nullptr; p.fq[i].zp = nullptr;
         if (fq && fq[i].mode >= 0) {
@@ -1320,7 +1262,7 @@ int dgq_attention_bf16x3(const void* q, const void* k, const void* v, void* o, i
     p.mode = mode; p.skip = skip;
     p.qmax = qmax; p.stats = stats_ws; p.delta = delta_ws;
     p.NT = (S + KT - 1) / KT;
-    { static const int xcd = [] { const char* e = getenv("DGQ_ATTN_XCD"); return (e && *e == '0') ? 0 : 1; }(); p.xcd = xcd; }
+    p.xcd = 1;
     p.qcodes = nullptr; p.qtab = nullptr; p.kskip = 0;
     unsigned char* img = reinterpret_cast<unsigned char*>(planes);
     // int8 score path: aqtizer_q and aqtizer_k both fused and scalar / per-token (one scale per token outside the d sum);

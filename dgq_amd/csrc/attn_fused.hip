@@ -215,7 +215,7 @@ static int launch_attn(const AttnParams& p, hipStream_t st) {
 
 int dgq_attention_bf16x3(const void* q, const void* k, const void* v, void* o, int io_dtype, int B, int H, int T, int S, int D,
                          float scale, int mode, int skip, float qmax, float* stats_ws, float* delta_ws, void* planes,
-                         float* qfq, float* o_part, const dgq_attn_fq_t* fq, const dgq_emit_t* emit, hipStream_t st);
+                         float* qfq, float* o_part, const dgq_attn_fq_t* fq, hipStream_t st);
 size_t dgq_attention_bf16x3_bytes(int B, int H, int S, int D);
 size_t dgq_attention_qi8_bytes(int B, int H, int T, int D);
 
@@ -242,7 +242,7 @@ extern "C" int dgq_attention_fuses_fakequant(int D, int mode) {
 
 static int attention_impl(const void* q_, const void* k_, const void* v_, void* o_, int dtype, int B, int H, int T, int S,
                           int D, float scale, int mode, int skip, const float* delta_in, int bits,
-                          const dgq_attn_fq_t* fq, const dgq_emit_t* emit, void* workspace, size_t workspace_bytes, void* stream) {
+                          const dgq_attn_fq_t* fq, void* workspace, size_t workspace_bytes, void* stream) {
     DGQ_CHECK_ARG(dtype == DGQ_F32 || dtype == DGQ_F16 || dtype == DGQ_BF16, "dgq_attention: unknown dtype %d", dtype);
     if (dtype != DGQ_F32 && !dgq_attention_fuses_fakequant(D, mode)) {
         dgq_set_error("dgq_attention: fp16 / bf16 tensors are served by the quantised modes only (mode %d, head_dim %d)", mode, D);
@@ -252,7 +252,7 @@ static int attention_impl(const void* q_, const void* k_, const void* v_, void* 
     const float* k = reinterpret_cast<const float*>(k_);
     const float* v = reinterpret_cast<const float*>(v_);
     float* o = reinterpret_cast<float*>(o_);
-    DGQ_CHECK_ARG(q && k && v && (o || emit) && workspace, "dgq_attention_f32: null pointer");
+    DGQ_CHECK_ARG(q && k && v && o && workspace, "dgq_attention_f32: null pointer");
     DGQ_CHECK_ARG((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, "dgq_attention_f32: workspace must be 256-byte aligned");
     DGQ_CHECK_ARG(workspace_bytes >= dgq_attention_workspace_bytes(B, H, T, S, D), "dgq_attention_f32: workspace too small");
     float* delta_ws = reinterpret_cast<float*>(workspace);
@@ -288,20 +288,9 @@ static int attention_impl(const void* q_, const void* k_, const void* v_, void* 
         }
     }
     float* qfq = reinterpret_cast<float*>(reinterpret_cast<char*>(planes) + dgq_attention_bf16x3_bytes(B, H, S, D));
-    if (emit) {
-        DGQ_CHECK_ARG(emit->codes && emit->rowsum && emit->delta && emit->zp, "dgq_attention_emit: null pointer");
-        DGQ_CHECK_ARG(emit->Kp > 0 && emit->Kp % DGQ_KCHUNK == 0 && emit->bits >= 2 && emit->bits <= 8 && (emit->per_m == 0 || emit->per_m == 1),
-                      "dgq_attention_emit: bad descriptor");
-        DGQ_CHECK_ARG(emit->per_m ? (emit->L >= 1 && emit->Kp >= H * D && !emit->kdst) : (emit->kdst != nullptr),
-                      "dgq_attention_emit: per-K needs kdst, per-M the natural order with Kp >= H*D");
-        if (!use3) {
-            dgq_set_error("dgq_attention_emit: served where dgq_attention_fuses_fakequant(D, mode) is 1 (mode %d, head_dim %d)", mode, D);
-            return DGQ_EUNSUPPORTED;
-        }
-    }
     if (use3) return dgq_attention_bf16x3(q_, k_, v_, o_, dtype, B, H, T, S, D, scale, mode, skip, p.qmax, stats_ws,
                                           mode >= 2 ? const_cast<float*>(delta_in) : delta_ws, planes, qfq,
-                                          reinterpret_cast<float*>(reinterpret_cast<char*>(qfq) + attn_q_scratch(B, H, T, D)), fq, emit, st);
+                                          reinterpret_cast<float*>(reinterpret_cast<char*>(qfq) + attn_q_scratch(B, H, T, D)), fq, st);
     switch (D) {
         case 8: return launch_attn<8>(p, st);
         case 16: return launch_attn<16>(p, st);
@@ -316,15 +305,9 @@ static int attention_impl(const void* q_, const void* k_, const void* v_, void* 
 extern "C" int dgq_attention(const void* q, const void* k, const void* v, void* o, int dtype, int B, int H, int T, int S,
                              int D, float scale, int mode, int skip, const float* delta_in, int bits,
                              const dgq_attn_fq_t* fq, void* workspace, size_t workspace_bytes, void* stream) {
-    return attention_impl(q, k, v, o, dtype, B, H, T, S, D, scale, mode, skip, delta_in, bits, fq, nullptr, workspace, workspace_bytes, stream);
+    return attention_impl(q, k, v, o, dtype, B, H, T, S, D, scale, mode, skip, delta_in, bits, fq, workspace, workspace_bytes, stream);
 }
 
-extern "C" int dgq_attention_emit(const void* q, const void* k, const void* v, int dtype, int B, int H, int T, int S, int D,
-                                  float scale, int mode, int skip, const float* delta_in, int bits, const dgq_attn_fq_t* fq,
-                                  const dgq_emit_t* emit, void* workspace, size_t workspace_bytes, void* stream) {
-    DGQ_CHECK_ARG(emit, "dgq_attention_emit: null descriptor");
-    return attention_impl(q, k, v, nullptr, dtype, B, H, T, S, D, scale, mode, skip, delta_in, bits, fq, emit, workspace, workspace_bytes, stream);
-}
 
 extern "C" int dgq_attention_f32(const float* q, const float* k, const float* v, float* o, int B, int H, int T, int S,
                                  int D, float scale, int mode, int skip, const float* delta_in, int bits,

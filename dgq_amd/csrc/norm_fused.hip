@@ -28,8 +28,7 @@ template <typename T, bool FINAL>
 __global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x, int HW, int C, int G, int rows_per,
                                                          float* __restrict__ part, float eps,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                         float* __restrict__ scale, float* __restrict__ shift,
-                                                         unsigned* __restrict__ counters) {
+                                                         float* __restrict__ scale, float* __restrict__ shift) {
     const int bg = blockIdx.x, b = bg / G, g = bg - b * G;
     const int Cg = C / G;
     const int r0 = blockIdx.y * rows_per, r1 = min(HW, r0 + rows_per);
@@ -71,32 +70,7 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x
         int fin_here = FINAL ? 1 : 0;
         if (!FINAL) {
             float* p = part + ((int64_t)bg * gridDim.y + blockIdx.y) * 3;
-            if (counters) {
-                // single-launch variant: the block that arrives last at this (batch, group)'s counter merges all partials
-                // in slice order (deterministic) and finishes the statistic.  Partials travel through agent-scope
-                // atomics + release/acquire fences: the per-XCD L2s are not coherent for plain accesses.
-                __hip_atomic_store(p, m.n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(p + 1, m.mean, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(p + 2, m.m2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __threadfence();
-                const unsigned prev = __hip_atomic_fetch_add(counters + bg, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-                if (prev == gridDim.y - 1) {
-                    __threadfence();
-                    Moments t = {0.0f, 0.0f, 0.0f};
-                    for (int sidx = 0; sidx < (int)gridDim.y; ++sidx) {
-                        const float* q = part + ((int64_t)bg * gridDim.y + sidx) * 3;
-                        Moments o = {__hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
-                                     __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
-                                     __hip_atomic_load(q + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)};
-                        t = merge(t, o);
-                    }
-                    m = t;
-                    __hip_atomic_store(counters + bg, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
-                    fin_here = 1;
-                }
-            } else {
-                p[0] = m.n; p[1] = m.mean; p[2] = m.m2;
-            }
+            p[0] = m.n; p[1] = m.mean; p[2] = m.m2;
         }
         if (fin_here) {
             fin[0] = m.mean;
@@ -216,7 +190,7 @@ extern "C" int dgq_groupnorm_from_partials(const float* partial, int C1, const f
 
 extern "C" int dgq_groupnorm_scale_shift(const void* x, int x_dtype, int B, int HW, int C, int G, float eps,
                                          const float* gamma, const float* beta, float* scale, float* shift,
-                                         float* partial_ws, int slices, unsigned* counters, void* stream) {
+                                         float* partial_ws, int slices, void* stream) {
     DGQ_CHECK_ARG(x && gamma && beta && scale && shift && partial_ws, "dgq_groupnorm_scale_shift: null pointer");
     DGQ_CHECK_ARG(B > 0 && HW > 0 && C > 0 && G > 0 && C % G == 0 && slices >= 1 && slices <= 256,
                   "dgq_groupnorm_scale_shift: bad shape");
@@ -225,7 +199,7 @@ extern "C" int dgq_groupnorm_scale_shift(const void* x, int x_dtype, int B, int 
     const int S = (HW + rows_per - 1) / rows_per;
     dim3 grid(B * G, S), block(256);
 #define DGQ_GN_LAUNCH(TT, FIN) hipLaunchKernelGGL((gn_partial_kernel<TT, FIN>), grid, block, 0, st, (const TT*)x, HW, C, G, \
-                                                  rows_per, partial_ws, eps, gamma, beta, scale, shift, counters)
+                                                  rows_per, partial_ws, eps, gamma, beta, scale, shift)
     switch (x_dtype) {
         case DGQ_F32: if (S == 1) DGQ_GN_LAUNCH(float, true); else DGQ_GN_LAUNCH(float, false); break;
         case DGQ_F16: if (S == 1) DGQ_GN_LAUNCH(__half, true); else DGQ_GN_LAUNCH(__half, false); break;
@@ -233,7 +207,7 @@ extern "C" int dgq_groupnorm_scale_shift(const void* x, int x_dtype, int B, int 
         default: dgq_set_error("dgq_groupnorm_scale_shift: unknown dtype %d", x_dtype); return DGQ_EINVAL;
     }
 #undef DGQ_GN_LAUNCH
-    if (S > 1 && !counters)
+    if (S > 1)
         hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * G), dim3(64), 0, st, partial_ws, S, C, G, eps, gamma, beta, scale, shift);
     return dgq_launch_status("dgq_groupnorm_scale_shift");
 }

@@ -690,10 +690,7 @@ static int quant_act_variant(const QuantActParams& p, bool table) {
     }
     const bool stage_conv = taps_ > 1 && p.pre_act != 2 && !p.ln_gamma && ks == 1;
     const bool stage_lin = taps_ == 1 && (!p.ln_gamma || p.C <= DGQ_LN_MAX_C);
-    // DGQ_QA_CONV_SCATTER=1 (A/B hook): per-K convs whose strips would fit take the scatter path below instead
-    static const bool conv_scatter = [] { const char* e = getenv("DGQ_QA_CONV_SCATTER"); return e && *e == '1'; }();
-    const bool prefer_scatter = conv_scatter && stage_conv && p.kdst != nullptr;
-    if (!prefer_scatter && table && p.klds && p.C % 4 == 0 && strip_bytes <= 16 * 1024 && (stage_conv || stage_lin)) return 0;
+    if (table && p.klds && p.C % 4 == 0 && strip_bytes <= 16 * 1024 && (stage_conv || stage_lin)) return 0;
     // scatter path: per-K table, more than one tap, the whole row in one wave/block (no K split), no LN / GEGLU prologue
     const size_t sc_tab = (((size_t)3 * (p.Kp >> 5) + 4) * 4 + 15) & ~(size_t)15;
     if (table && p.kdst && taps_ > 1 && p.C % 4 == 0 && ks == 1 && p.pre_act != 2 && !p.ln_gamma && sc_tab + (size_t)p.Kp <= 150 * 1024)

@@ -299,26 +299,6 @@ def as_f32(t: torch.Tensor) -> torch.Tensor:
     return hit[1]
 
 
-#: one launch per GroupNorm statistic (last-arriving block merges the slices) instead of partial + merge kernels.
-#: Measured: 63.5 -> 57.8 steps/s — the agent-scope release/acquire each of the ~2000 blocks needs (the per-XCD L2s are
-#: not coherent) writes back / invalidates L2 every time and costs far more than the 6 us merge launch.  OFF.
-GN_SINGLE_LAUNCH = os.environ.get("DGQ_GN_SINGLE_LAUNCH", "0") == "1"
-_GN_COUNTERS = {}
-
-
-def _gn_counters(dev, n):
-    """Zero-initialised arrival counters (every launch returns them to zero); one buffer per device and stream branch,
-    like the workspace, allocated outside graph capture by the first eager forward."""
-    key = str(dev)                       # GroupNorm statistics are only issued from the main chain of a device
-    buf = _GN_COUNTERS.get(key)
-    if buf is None or buf.numel() < n:
-        if torch.cuda.is_current_stream_capturing():
-            return None                  # never allocate inside a capture: fall back to the two-launch form
-        buf = torch.zeros((max(n, 4096),), dtype=torch.int32, device=dev)
-        _GN_COUNTERS[key] = buf
-    return buf
-
-
 def groupnorm_scale_shift(x_cl: torch.Tensor, B, HW, C, groups, eps, gamma, beta):
     """GN(x) = x*scale + shift with scale/shift [B][C] (see dgq_groupnorm_scale_shift)."""
     dev = x_cl.device
@@ -328,10 +308,9 @@ def groupnorm_scale_shift(x_cl: torch.Tensor, B, HW, C, groups, eps, gamma, beta
     scale = torch.empty((B, C), dtype=torch.float32, device=dev)
     shift = torch.empty((B, C), dtype=torch.float32, device=dev)
     part = torch.empty((B * groups * slices * 3,), dtype=torch.float32, device=dev)
-    counters = _gn_counters(dev, B * groups) if (GN_SINGLE_LAUNCH and slices > 1) else None
     _lib_call("dgq_groupnorm_scale_shift", _lib.ptr(x_cl), _lib.DTYPE_CODE[x_cl.dtype], B, HW, C, groups,
               _c.c_float(eps), _lib.ptr(as_f32(gamma)), _lib.ptr(as_f32(beta)), _lib.ptr(scale), _lib.ptr(shift),
-              _lib.ptr(part), slices, _lib.ptr(counters), _lib.stream())
+              _lib.ptr(part), slices, _lib.stream())
     return scale, shift
 
 
@@ -886,12 +865,10 @@ def attention_fuses_fakequant(D, mode):
     return bool(_lib.load().dgq_attention_fuses_fakequant(D, mode))
 
 
-def attention(q, k, v, H, D, scale, mode, skip, delta, bits, fq=None, emit: Optional[ActBinding] = None):
+def attention(q, k, v, H, D, scale, mode, skip, delta, bits, fq=None):
     """q [B,T,H*D], k/v [B,S,H*D] contiguous (fp32; fp16 / bf16 in the quantised modes) -> o [B,T,H*D]; see dgq_attention.
     fq: optional 3-tuple for q, k, v of None | (mode, delta, zp, skip, bits) — the aqtizer_q/k/v quantizers applied on
-    load (only where ``attention_fuses_fakequant(D, mode)``).
-    emit: the ActBinding of the Linear layer that consumes o (Attention.to_out[0]) — the call then returns
-    (codes [B*T, Kp] int8, rowsum [H, B*T]) for ``gemm_wxa8`` instead of o (dgq_attention_emit: quantise-on-store)."""
+    load (only where ``attention_fuses_fakequant(D, mode)``)."""
     assert q.dtype in _lib.DTYPE_CODE and k.dtype == q.dtype and v.dtype == q.dtype
     assert q.is_contiguous() and k.is_contiguous() and v.is_contiguous()
     B, T, _ = q.shape
@@ -912,21 +889,6 @@ def attention(q, k, v, H, D, scale, mode, skip, delta, bits, fq=None, emit: Opti
                 "q/k/v quantizer table has %d entries, kernel addresses %d" % (fd.numel(), need)
             desc[i].mode, desc[i].skip, desc[i].bits = fmode, fskip, fbits
             desc[i].delta, desc[i].zero_point = _lib.ptr(fd), _lib.ptr(fz)
-    if emit is not None:
-        ab = emit
-        per_m = 0 if ab.mode == "perK" else 1
-        assert ab.pw.K == H * D and ab.pw.taps == 1
-        e = _lib.Emit()
-        codes = torch.empty((B * T, ab.Kp), dtype=torch.int8, device=q.device)
-        rowsum = torch.empty((H, B * T), dtype=torch.float32, device=q.device)
-        e.codes, e.rowsum = codes.data_ptr(), rowsum.data_ptr()
-        e.kdst = _dp(ab.kdst(1, H * D, 1)) if not per_m else None
-        e.delta, e.zp = (ab.cdelta.data_ptr(), ab.czp.data_ptr()) if not per_m else (ab.mdelta.data_ptr(), ab.mzp.data_ptr())
-        e.Kp, e.per_m, e.L, e.bits = ab.Kp, per_m, (ab.L if per_m else 1), ab.abits
-        _lib_call("dgq_attention_emit", _lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.DTYPE_CODE[q.dtype], B, H, T, S, D,
-                  _c.c_float(scale), mode, skip, _lib.ptr(delta), bits,
-                  _c.cast(desc, _c.c_void_p) if desc is not None else None, _c.byref(e), _lib.ptr(ws), nbytes, _lib.stream())
-        return codes, rowsum
     o = torch.empty_like(q)
 
     def issue():

@@ -32,12 +32,6 @@ FUSE_NORM = True
 #   aqtizer_{q,k,v} in the attention pre-pass                                                         +0.3 %
 #   aqtizer_{q,k,v} in the projection GEMM's epilogue (exact division per output inside under-filled grids)  slower: off
 _F_RES = _os.environ.get("DGQ_FUSE_RESIDUAL", "1") == "1"
-#: quantise-on-store: the fused attention writes to_out[0]'s activation codes + row sums instead of its output tensor, and
-#: that layer runs its GEMM only (dgq_attention_emit).  Parity-green (tests/test_gpu_kernels.py) and measured NEUTRAL on the SD
-#: step (9.753 vs 9.749 ms with all 32 attentions emitting): a head's channels are scattered over the consumer's group-sorted
-#: K order, so every 64-byte line of a code row collects single bytes from all eight heads' workgroups (eight XCDs), and
-#: those byte stores cost what the 32 saved launches gain.  Opt-in (=1); off under a LAYER_TAP either way.
-_F_EMIT = _os.environ.get("DGQ_FUSE_ATTN_EMIT", "0") == "1"
 _F_FQ = _os.environ.get("DGQ_FUSE_FQ", "0") == "1"
 _F_GEGLU = _os.environ.get("DGQ_FUSE_GEGLU", "1") == "1"
 # ... or (round 3) in ff.net.0's GEMM epilogue: half the stores of the widest layer, no GEGLU pass in front of ff.net.2
@@ -405,17 +399,6 @@ def quant_attention_forward(attn, hidden_states, encoder_hidden_states=None, res
                     _init_static_softmax_delta(attn, wq, q, k, b, t, s, H, D, skip)
                 mode, delta = 3, wq.delta.detach().reshape(1).float().to(q.device)
         fq = tuple(pending.get(n) for n in ("aqtizer_q", "aqtizer_k", "aqtizer_v")) if pending else None
-        first = attn.to_out[0]
-        from . import quant_layer as _ql
-        if (FUSION and _F_EMIT and use_aq and _ql.LAYER_TAP is None and isinstance(first, QuantLayer) and not first.is_conv
-                and first.on_integer_path(q) and ops.attention_fuses_fakequant(D, mode) and len(attn.to_out) <= 2
-                and (residual is None or _F_RES)):
-            codes, rowsum = ops.attention(q.contiguous(), k.contiguous(), v.contiguous(), H, D, float(attn.scale), mode, skip,
-                                          delta, bits, fq, emit=first._binding())
-            o = first.forward_from_codes(codes, rowsum, (b, t), q.dtype, residual=residual)
-            for layer in list(attn.to_out)[1:]:
-                o = layer(o)
-            return o
         o = ops.attention(q.contiguous(), k.contiguous(), v.contiguous(), H, D, float(attn.scale), mode, skip,
                               delta, bits, fq)
         return _attn_out(attn, o, residual)

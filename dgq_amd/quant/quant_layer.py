@@ -624,18 +624,6 @@ class QuantLayer(nn.Module):
         return _tap(self, ops.quant_linear(x, self._binding(), pre_act=pre_act, residual=residual, fq=fq, ln=lnp, geglu=geglu),
                     x=x, prologue=bool(pre_act or lnp is not None), residual=residual, fq=fq, geglu=geglu)
 
-    def forward_from_codes(self, codes: torch.Tensor, rowsum: torch.Tensor, lead_shape, dtype, residual=None) -> torch.Tensor:
-        """The GEMM half of forward_fused for an input that arrives already quantised — ``codes`` / ``rowsum`` written by the
-        PRODUCING kernel for this layer's table (ops.attention(..., emit=self._binding()): quantise-on-store)."""
-        ab = self._binding()
-        res2 = None
-        if residual is not None:
-            res2 = residual.reshape(-1, ab.pw.N)
-            if not res2.is_contiguous():
-                res2 = res2.contiguous()
-        y = ops.gemm_wxa8(codes, rowsum, codes.shape[0], ab, dtype, extra=ops.make_extra(res2))
-        return y.view(*lead_shape, y.shape[-1])
-
     def can_fuse_prenorm(self, x: torch.Tensor) -> bool:
         """True when this layer runs on the integer path, so a preceding GroupNorm(+SiLU) can be folded into its
         quantise-on-load pass (dgq_groupnorm_scale_shift + dgq_quant_act prologue)."""

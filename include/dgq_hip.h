@@ -123,13 +123,11 @@ int dgq_quant_act_conv_tile(int C, int kh, int kw, int stride, int Kp, int* patc
 
 /* GroupNorm of a channels-last tensor x [B][HW][C] as per-(b,c) scale/shift (biased variance, eps as F.group_norm):
  * GN(x) = x·scale + shift.  Replaces norm1/norm2 of QuantResnetBlock2D.forward (quant_block.py:98-119) together with
- * the SiLU that follows, which dgq_quant_act applies while loading.  partial_ws: B·G·slices·3 floats.
- * counters (optional): B·G zero-initialised uint32 owned by the caller; with it the statistic is ONE launch — the block
- * that arrives last at a (batch, group) merges the slices in slice order and leaves its counter at zero again — otherwise
- * a second merge kernel is launched.  Results are identical either way. */
+ * the SiLU that follows, which dgq_quant_act applies while loading.  partial_ws: B·G·slices·3 floats;
+ * slices > 1: a second small kernel merges the slices in slice order. */
 int dgq_groupnorm_scale_shift(const void* x, int x_dtype, int B, int HW, int C, int G, float eps,
                               const float* gamma, const float* beta, float* scale, float* shift,
-                              float* partial_ws, int slices, unsigned* counters, void* stream);
+                              float* partial_ws, int slices, void* stream);
 /* The same scale / shift from the partial statistics a producing dgq_gemm_wxa8 left behind (dgq_gemm_extra_t.gn_partial):
  * partial [B·HW/16][C][2] = (mean, Σ(x − mean)²) per 16-row block and channel; HW % 16 == 0.  One small launch, no pass
  * over the tensor; the blocks and channels of a (batch, group) are merged in a fixed order (Chan), biased variance.
@@ -293,27 +291,6 @@ int dgq_attention_f32(const float* q, const float* k, const float* v, float* o, 
 int dgq_attention(const void* q, const void* k, const void* v, void* o, int dtype, int B, int H, int T, int S, int D,
                   float scale, int mode, int skip, const float* delta_in, int bits, const dgq_attn_fq_t* fq,
                   void* workspace, size_t workspace_bytes, void* stream);
-/* Quantise-on-store (round 3): instead of the tensor o, dgq_attention_emit writes what dgq_quant_act would produce from it for
- * the NEXT quantized Linear layer (Attention.to_out[0], sd.py:203-205) — its int8 activation codes in that layer's packed K
- * order and the row sums — so that layer needs no quantise-on-load launch and o never travels through HBM.
- *   per-K (per_m = 0): kdst[c] = packed position of channel c (the inverse of the layer's K permutation, [H·D]), delta / zp
- *     per 32-wide chunk ([Kp/32]); code = clamp(rne(o/δ)+z) − 2^(b−1) with o first rounded to the tensors' dtype; rowsum part of
- *     head h: Σ_{c in h} δ_c·code.   per-M / scalar (per_m = 1): natural order (kdst = NULL), delta / zp [L] addressed by
- *     row % L; rowsum part = Σ code (exact).
- * rowsum is [H][B·T]: ONE PART PER HEAD, to be passed to dgq_gemm_wxa8 with rowsum_parts = H (summed there in a fixed
- * order).  Padding positions of the code rows are not written: the packed weights are zero there.
- * Only where dgq_attention_fuses_fakequant(D, mode) is 1; DGQ_EUNSUPPORTED otherwise. */
-typedef struct dgq_emit {
-    int8_t* codes;             /* [B·T][Kp] */
-    float* rowsum;             /* [H][B·T] */
-    const int32_t* kdst;       /* per-K: [H·D]; NULL for natural order */
-    const float* delta;
-    const float* zp;
-    int Kp, per_m, L, bits;
-} dgq_emit_t;
-int dgq_attention_emit(const void* q, const void* k, const void* v, int dtype, int B, int H, int T, int S, int D,
-                       float scale, int mode, int skip, const float* delta_in, int bits, const dgq_attn_fq_t* fq,
-                       const dgq_emit_t* emit, void* workspace, size_t workspace_bytes, void* stream);
 int dgq_attention_fuses_fakequant(int D, int mode);
 size_t dgq_attention_workspace_bytes(int B, int H, int T, int S, int D);
 

@@ -772,57 +772,6 @@ def test_groupnorm_partials_from_the_splitk_combine(force, dev, monkeypatch):
             assert rel_l2(sc.cpu(), sc0.cpu()) < 1e-5 and rel_l2(sh.cpu(), sh0.cpu()) < 1e-5, (force, N, rel_l2(sc.cpu(), sc0.cpu()))
 
 
-# ------------------------------------------------------------------------------------------ quantise-on-store (attention -> to_out)
-@pytest.mark.parametrize("D,T,S,skip", [(40, 200, 200, 0), (40, 96, 77, 1), (80, 64, 64, 0), (160, 70, 77, 1), (64, 130, 40, 0)])
-@pytest.mark.parametrize("kind", ["perK", "perM", "scalar"])
-@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
-def test_attention_emit_equals_store_then_quantise(D, T, S, skip, kind, dtype, dev):
-    """dgq_attention_emit (the fused attention writing to_out[0]'s activation codes + per-head row sums instead of o) against
-    the two-launch sequence it replaces: dgq_attention -> dgq_quant_act on the stored o.  Codes bit-identical at every
-    non-padding position; the row sums (per-M: exact integers; per-K: Σ δ·code in another order) equal to 1e-6; and the
-    to_out GEMM fed either way gives the same output to 1e-5 (the row sum enters as zw·rowsum next to the integer term: its
-    last-bit differences are amplified by that cancellation; per-M / scalar: identical)."""
-    from dgq_amd import ops, synth
-    from dgq_amd.plan import plan_act
-    B, H = 2, 4
-    C = H * D
-    g = torch.Generator().manual_seed(D + T + skip)
-    q, k, v = (torch.randn(B, n, C, generator=g).to(dev, dtype) for n in (T, S, S))
-    tab = lambda n: (torch.rand(n, generator=g).to(dev) * 0.02 + 0.02, torch.randint(100, 156, (n,), generator=g).float().to(dev))
-    fq = ((2,) + tab(D) + (0, 8), (1,) + tab(S - skip) + (skip, 8), (2,) + tab(D) + (0, 8))
-    # the consumer: a Linear C -> N with the given activation table
-    N = 96
-    w = torch.randn(N, C, generator=g) * 0.05
-    wd, wz = synth.channel_minmax(w, 4)
-    pw = ops.PackedWeight(w.to(dev), wd.to(dev), wz.to(dev), None, torch.zeros(N, device=dev), 4, C, 1)
-    if kind == "perK":
-        lab = torch.randint(0, 6, (C,), generator=g)                       # six groups of scattered channels
-        d = 0.01 + 0.003 * lab.float()
-        z = 120.0 + lab.float()
-        lay = plan_act(d.view(1, 1, -1), z.view(1, 1, -1), "linear", C, 1, 8)
-    elif kind == "perM":
-        lay = plan_act(torch.rand(1, T, 1, generator=g) * 0.01 + 0.01, torch.randint(110, 140, (1, T, 1), generator=g).float(), "linear", C, 1, 8)
-    else:
-        lay = plan_act(torch.tensor(0.012).view(1, 1, 1), torch.tensor(127.0).view(1, 1, 1), "linear", C, 1, 8)
-    ab = ops.ActBinding(lay, pw, 8)
-    o = ops.attention(q, k, v, H, D, D ** -0.5, 1, skip, None, 8, fq=fq)
-    codes_ref, rowsum_ref, M = ops.quant_act(o.view(B * T, C), B * T, 1, 1, C, 1, 1, 1, 0, ab)
-    codes, rowsum = ops.attention(q, k, v, H, D, D ** -0.5, 1, skip, None, 8, fq=fq, emit=ab)
-    assert codes.shape == codes_ref.shape and rowsum.shape == (H, B * T)
-    if kind == "perK":
-        real = torch.zeros(ab.Kp, dtype=torch.bool, device=dev)
-        real[ab.kdst(1, C, 1).long().flatten()] = True
-    else:
-        real = torch.arange(ab.Kp, device=dev) < C
-    assert torch.equal(codes[:, real], codes_ref[:, real])
-    rs, rs_ref = rowsum.sum(0), rowsum_ref.reshape(-1, M).sum(0)
-    assert (rs - rs_ref).abs().max() <= 1e-6 * rs_ref.abs().max().clamp_min(1.0), (rs - rs_ref).abs().max()
-    y_ref = ops.gemm_wxa8(codes_ref, rowsum_ref, M, ab, dtype)
-    y = ops.gemm_wxa8(codes, rowsum, M, ab, dtype)
-    tol = (1e-5 if kind == "perK" else 1e-7) if dtype == torch.float32 else 2e-3
-    assert rel_l2(y.float(), y_ref.float()) <= tol
-
-
 # ------------------------------------------------------------------------------------------ weight-only state
 @pytest.mark.parametrize("shape", [(2, 8, 9, 11, 20, 3, 1, 1), (1, 4, 16, 16, 64, 3, 2, 1), (3, 12, 7, 5, 40, 1, 1, 0), (2, 320, 8, 8, 70, 3, 1, 1),
                                    (2, 320, 12, 12, 4, 3, 1, 1), (1, 64, 9, 9, 7, 3, 2, 1)])      # the last two: the N <= 8 kernel (conv_out)
