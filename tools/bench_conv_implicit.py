@@ -8,6 +8,8 @@ from dgq_amd.plan import plan_act
 dev = torch.device("cuda:0")
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 SHAPES = [(8, 320, 128, 128, 320), (8, 640, 64, 64, 640), (8, 1280, 32, 32, 1280), (8, 1920, 32, 32, 1280), (8, 960, 64, 64, 640), (8, 640, 128, 128, 320)]
+if os.environ.get("ONLY_SHAPE"):
+    SHAPES = [SHAPES[int(os.environ["ONLY_SHAPE"])]]
 PLANS = os.environ.get("PLANS", "default;64,64,1;64,128,1;128,128,1").split(";")
 print("%-28s %-10s %-10s %10s %10s %10s" % ("B,C,H,W->N", "operand", "plan", "quant us", "gemm us", "total us"))
 for (B, C, H, W, N) in SHAPES:
