@@ -1,5 +1,5 @@
 """HBM-side bytes of a kernel family from rocprofv3 --pmc passes (counter_collection CSVs).
-usage: pmc_traffic.py <fetch_pass.csv> <write_pass.csv> <kernel substring> <out.json> [config dtype commit]
+usage: pmc_traffic.py <fetch_pass.csv> <write_pass.csv> <kernel substring> <out.json> [config dtype commit [prompts_per_gpu]]
 FETCH_SIZE / WRITE_SIZE are in KiB (rocprofv3 derived metrics); on gfx950 FETCH_SIZE tallies the 128-byte requests of
 wide (16 B/lane) reads at 64 B, so it is doubled (MI355X_MICROARCH.md, HBM section); WRITE_SIZE is exact for 16-byte stores."""
 import collections, csv, json, sys
@@ -31,5 +31,7 @@ if len(sys.argv) > 5:
     res["config"] = sys.argv[5]
     res["dtype"] = sys.argv[6] if len(sys.argv) > 6 else "fp32"
     res["measured_at_commit"] = sys.argv[7] if len(sys.argv) > 7 else None
+    if len(sys.argv) > 8:
+        res["prompts_per_gpu"] = int(sys.argv[8])
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res, indent=1))
