@@ -450,23 +450,27 @@ __global__ __launch_bounds__(256) void quant_act_staged_kernel(QuantActBatch bt)
 // chunk (tables staged in LDS once per block), and the code byte is SCATTERED into the row's image in LDS at its packed
 // position kdst[tap][c]; the finished row leaves LDS as 16-byte coalesced stores.  RPB rows per block: 4 (one wave per
 // row) for large M; 1 (the four waves take the taps round-robin and share the row image) where M alone cannot fill the chip.
-template <typename TIn, int RPB>
-__global__ __launch_bounds__(256) void quant_act_scatter_kernel(QuantActBatch bt) {
+// (round 4) RPB == 1 runs NWV = 8 or 16 waves per row: with four, a wave walked up to 3 taps x C/256 dependent load rounds (16.6 us for
+// 128 x 11904 codes against 6.0 us for the per-M form of the same layer); the (tap, 256-channel step) units are dealt round-robin instead.
+template <typename TIn, int RPB, int NWV = 4>
+__global__ __launch_bounds__(64 * NWV) void quant_act_scatter_kernel(QuantActBatch bt) {
+    static_assert(RPB == 1 || NWV == 4, "four rows per block: one wave each");
     const QuantActParams& p = bt.p[blockIdx.z];
     extern __shared__ __attribute__((aligned(16))) uint8_t sc_smem[];
-    constexpr int WPR = 4 / RPB;                             // waves per row
+    constexpr int WPR = NWV / RPB;                           // waves per row
+    constexpr int NT_ = 64 * NWV;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int nch = p.Kp >> 5;
     float* tdelta = reinterpret_cast<float*>(sc_smem);
     float* tinv = tdelta + nch;
     float* tzp = tinv + nch;
-    float* psum = tzp + nch;                                 // [4] per-wave partial row sums (RPB == 1)
-    uint8_t* images = sc_smem + (((3 * nch + 4) * 4 + 15) & ~15);
-    for (int i = tid; i < nch; i += 256) {
+    float* psum = tzp + nch;                                 // [16] per-wave partial row sums (RPB == 1)
+    uint8_t* images = sc_smem + (((3 * nch + 16) * 4 + 15) & ~15);
+    for (int i = tid; i < nch; i += NT_) {
         const float d = p.delta[i];
         tdelta[i] = d; tinv[i] = dgq_rcp(d); tzp[i] = p.zp[i];
     }
-    for (int i = tid; i < RPB * (p.Kp >> 4); i += 256) reinterpret_cast<uint4*>(images)[i] = make_uint4(0, 0, 0, 0);   // padding = code 0
+    for (int i = tid; i < RPB * (p.Kp >> 4); i += NT_) reinterpret_cast<uint4*>(images)[i] = make_uint4(0, 0, 0, 0);   // padding = code 0
     __syncthreads();
     const int rslot = wv / WPR, wsub = wv % WPR;
     const int row = blockIdx.x * RPB + rslot;
@@ -484,13 +488,13 @@ __global__ __launch_bounds__(256) void quant_act_scatter_kernel(QuantActBatch bt
         const int taps = p.kh * p.kw;
         float ln_mu = 0.0f, ln_rstd = 1.0f;                 // Linear inputs (taps == 1, one wave per row): LayerNorm over the row
         if (p.ln_gamma) row_layernorm_stats<TIn>(img + (int64_t)(hbase * p.W + wbase) * p.ldc, p.C, p.ln_eps, lane, ln_mu, ln_rstd);
-        for (int tap = wsub; tap < taps; tap += WPR) {
+        // one (tap, 256-channel step) unit of the row
+        auto unit = [&](int tap, int c) {
             const int dh = tap / p.kw, dw = tap - dh * p.kw;
             const int hi = hbase + dh, wi = wbase + dw;
             const bool inb = hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;     // wave-uniform
             const TIn* src = img + ((int64_t)hi * p.W + wi) * p.ldc;
             const int32_t* kd = p.kdst + tap * p.C;
-            for (int c = lane * 4; c < p.C; c += 256) {
                 float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
                 if (inb) {
                     load4<TIn>(src + c, v);
@@ -525,6 +529,16 @@ __global__ __launch_bounds__(256) void quant_act_scatter_kernel(QuantActBatch bt
                     image[dst[j]] = (uint8_t)(int)sc;
                     partial += d * sc;
                 }
+        };
+        if constexpr (WPR == 1) {                            // one wave per row: taps in order, channel steps inside (loads of a tap overlap)
+            for (int tap = 0; tap < taps; ++tap)
+                for (int c = lane * 4; c < p.C; c += 256) unit(tap, c);
+        } else {                                             // several waves per row: the units dealt round-robin
+            const int csteps = (p.C + 255) >> 8;
+            for (int u = wsub; u < taps * csteps; u += WPR) {
+                const int tap = u / csteps;
+                const int c = ((u - tap * csteps) << 8) + lane * 4;
+                if (c < p.C) unit(tap, c);
             }
         }
     }
@@ -536,7 +550,15 @@ __global__ __launch_bounds__(256) void quant_act_scatter_kernel(QuantActBatch bt
         uint4* out = reinterpret_cast<uint4*>(p.codes + (int64_t)row * p.Kp);
         const uint4* im = reinterpret_cast<const uint4*>(image);
         for (int i = wsub * 64 + lane; i < (p.Kp >> 4); i += 64 * WPR) out[i] = im[i];
-        if (lane == 0 && wsub == 0) p.rowsum[row] = RPB == 1 ? ((psum[0] + psum[1]) + (psum[2] + psum[3])) : partial;
+        if (lane == 0 && wsub == 0) {
+            float tot = partial;
+            if (RPB == 1) {                                  // fixed order: pairs, then a chain
+                tot = 0.0f;
+#pragma unroll
+                for (int w = 0; w < NWV; w += 2) tot += psum[w] + psum[w + 1];
+            }
+            p.rowsum[row] = tot;
+        }
     }
 }
 
@@ -711,7 +733,7 @@ static int quant_act_variant(const QuantActParams& p, bool table) {
     // drops the byte into the row image in LDS.  One wave per row (RPB = 4).  DGQ_QA_LINEAR_SCATTER = 0 off, 2 always.
     {
         static const int mode = [] { const char* e = getenv("DGQ_QA_LINEAR_SCATTER"); return e && *e ? atoi(e) : 1; }();
-        const size_t tab_b = (((size_t)3 * (p.Kp >> 5) + 4) * 4 + 15) & ~(size_t)15;
+        const size_t tab_b = (((size_t)3 * (p.Kp >> 5) + 16) * 4 + 15) & ~(size_t)15;
         if (mode && table && p.kdst && taps_ == 1 && p.C % 4 == 0 && ks == 1 && (!p.ln_gamma || p.C <= DGQ_LN_MAX_C) &&
             tab_b + 4 * (size_t)p.Kp <= 150 * 1024 && (mode == 2 || 4 * p.Kp >= 5 * p.K))
             return 3;
@@ -727,9 +749,9 @@ static int quant_act_variant(const QuantActParams& p, bool table) {
     const bool stage_lin = taps_ == 1 && (!p.ln_gamma || p.C <= DGQ_LN_MAX_C);
     if (table && p.klds && p.C % 4 == 0 && strip_bytes <= 16 * 1024 && (stage_conv || stage_lin)) return 0;
     // scatter path: per-K table, more than one tap, the whole row in one wave/block (no K split), no LN / GEGLU prologue
-    const size_t sc_tab = (((size_t)3 * (p.Kp >> 5) + 4) * 4 + 15) & ~(size_t)15;
+    const size_t sc_tab = (((size_t)3 * (p.Kp >> 5) + 16) * 4 + 15) & ~(size_t)15;
     if (table && p.kdst && taps_ > 1 && p.C % 4 == 0 && ks == 1 && p.pre_act != 2 && !p.ln_gamma && sc_tab + (size_t)p.Kp <= 150 * 1024)
-        return (p.M >= 2048 && sc_tab + 4 * (size_t)p.Kp <= 150 * 1024) ? 3 : 4;
+        return (p.M >= 4096 && sc_tab + 4 * (size_t)p.Kp <= 150 * 1024) ? 3 : 4;     // (2048 rows x 17536: 79 us with one wave per row, see below)
     return table ? 1 : 2;
 }
 
@@ -768,7 +790,7 @@ static void launch_quant_act(const QuantActBatch& bt, int n, int variant, bool p
     if (variant == 3 || variant == 4) {
         size_t lds = 0;
         for (int i = 0; i < n; ++i) {
-            const size_t tab = (((size_t)3 * (bt.p[i].Kp >> 5) + 4) * 4 + 15) & ~(size_t)15;
+            const size_t tab = (((size_t)3 * (bt.p[i].Kp >> 5) + 16) * 4 + 15) & ~(size_t)15;
             lds = std::max(lds, tab + (variant == 3 ? 4 : 1) * (size_t)bt.p[i].Kp);
         }
         static std::atomic<bool> attr_set[64];
@@ -776,11 +798,13 @@ static void launch_quant_act(const QuantActBatch& bt, int n, int variant, bool p
         (void)hipGetDevice(&dev);
         if (dev < 0 || dev >= 64 || !attr_set[dev].load(std::memory_order_acquire)) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&quant_act_scatter_kernel<TIn, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&quant_act_scatter_kernel<TIn, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&quant_act_scatter_kernel<TIn, 1, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&quant_act_scatter_kernel<TIn, 1, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
             if (dev >= 0 && dev < 64) attr_set[dev].store(true, std::memory_order_release);
         }
         if (variant == 3) hipLaunchKernelGGL((quant_act_scatter_kernel<TIn, 4>), dim3((p0.M + 3) / 4, 1, n), dim3(256), lds, st, bt);
-        else hipLaunchKernelGGL((quant_act_scatter_kernel<TIn, 1>), dim3(p0.M, 1, n), dim3(256), lds, st, bt);
+        else if ((long)p0.M * n <= 256) hipLaunchKernelGGL((quant_act_scatter_kernel<TIn, 1, 16>), dim3(p0.M, 1, n), dim3(1024), lds, st, bt);
+        else hipLaunchKernelGGL((quant_act_scatter_kernel<TIn, 1, 8>), dim3(p0.M, 1, n), dim3(512), lds, st, bt);
         return;
     }
     if (variant == 0) {
