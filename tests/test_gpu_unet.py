@@ -35,8 +35,29 @@ C3 = dict(wbits=4, abits=6, use_aq=True, G=8, log=True, rt=True, sp=True, time_a
 C5 = dict(wbits=4, abits=6, use_aq=True, G=1, log=False, rt=False, sp=False, time_aware=True, steps=50)
 CFGS = {"C2": C2, "C3": C3, "C5": C5, "C1": C1, "C2U": C2U}
 
-_QNN = {}
+import collections
+import gc
+import shutil
+
+_QNN = collections.OrderedDict()       # least recently used first; at most _QNN_KEEP models (and their ckpt files) at a time
+_QNN_KEEP = 2
 _ORACLE = {}
+
+
+def _drop_qnn(key):
+    """Forgets a cached model AND deletes its synthetic checkpoint: every such file repeats the FP weights (3.4 GB for SD, 10 GB for
+    SDXL) and the model keeps it memory-mapped (qnn.ckpt, as the reference keeps its torch.load), so the space only comes back once
+    the model is gone.  Without this the suite's ~20 configurations filled the GPU box's 79 GB disk (seen in round 4: a test failed
+    with 'No space left on device')."""
+    ent = _QNN.pop(key, None)
+    if ent is None:
+        return
+    path = ent[1]
+    del ent
+    gc.collect()
+    torch.cuda.empty_cache()
+    if path and os.path.exists(path):
+        os.remove(path)
 
 
 @pytest.fixture(scope="module")
@@ -48,8 +69,12 @@ def get_qnn(arch, c, res, batch, slots, ckdir):
     """(QuantModel, ckpt path) built once per module through get_qmodel (src/inference_qmodel.py:91)."""
     from dgq_amd.runtime import build_synthetic_qnn
     key = (arch, tuple(sorted(c.items())), res, batch, tuple(synth.slot_list(slots)))
-    if key not in _QNN:
-        _QNN[key] = build_synthetic_qnn(arch, c, res, batch, slots, ckpt_dir=ckdir)
+    if key in _QNN:
+        _QNN.move_to_end(key)
+        return _QNN[key]
+    while len(_QNN) >= _QNN_KEEP:
+        _drop_qnn(next(iter(_QNN)))
+    _QNN[key] = build_synthetic_qnn(arch, c, res, batch, slots, ckpt_dir=ckdir)
     return _QNN[key]
 
 
@@ -405,7 +430,7 @@ def test_ddim50_literal_c2_vs_reference_golden(ckdir):
         out = denoise_loop(lambda x, t, cc: qnn(x, t, cc)[0], lat, ctx, 50, guidance=7.5).float().cpu()
     finally:
         qnn.enable_graphs(False)
-        _QNN.pop(("sd", tuple(sorted(c.items())), 64, 2, tuple(synth.slot_list(50))), None)    # 50 slots of tables: free them
+        _drop_qnn(("sd", tuple(sorted(c.items())), 64, 2, tuple(synth.slot_list(50))))    # 50 slots of tables: free them
     ref = g["final_latent"]
     e = rel_l2(out, ref)
     print("DDIM-50 final latent: rel-L2 vs reference %.3g, |out| %.3g |ref| %.3g" % (e, out.norm().item(), ref.norm().item()))
@@ -447,7 +472,7 @@ def test_ddim50_every_call_teacher_forced_vs_reference_trajectory(ckdir):
             x = sch.step(e_u + m["guidance"] * (e_c - e_u), t, x)
     finally:
         qnn.enable_graphs(False)
-        _QNN.pop(("sd", tuple(sorted(c.items())), 64, 2, tuple(synth.slot_list(steps))), None)
+        _drop_qnn(("sd", tuple(sorted(c.items())), 64, 2, tuple(synth.slot_list(steps))))
     # the reconstruction reproduces the reference's trajectory (50 elementwise fp32 steps: identical up to the host's vector maths,
     # which differs between the box that wrote the golden and this one in the last bit per step)
     assert rel_l2(x, g["final_latent"]) < 1e-4
@@ -491,7 +516,7 @@ def test_c5_full_size_shard_properties(ckdir):
             assert e < 1.0, e
     finally:
         quant_layer.LAYER_TAP = None
-        _QNN.pop(("sdxl", tuple(sorted(c.items())), 128, 8, tuple(synth.slot_list([0, 3]))), None)
+        _drop_qnn(("sdxl", tuple(sorted(c.items())), 128, 8, tuple(synth.slot_list([0, 3]))))
 
 
 def test_sdxl_full_size_c4_vs_reference_golden(ckdir):
@@ -518,7 +543,7 @@ def test_sdxl_full_size_c4_vs_reference_golden(ckdir):
             assert torch.isfinite(y).all() and e < 2.5 * self_dev, (t, e, self_dev)
     finally:
         quant_layer.LAYER_TAP = None
-        _QNN.pop(("sdxl", tuple(sorted(c.items())), 128, 1, tuple(synth.slot_list([0, 3]))), None)
+        _drop_qnn(("sdxl", tuple(sorted(c.items())), 128, 1, tuple(synth.slot_list([0, 3]))))
     n_q = sum(1 for m in qnn.model.modules() if isinstance(m, QuantLayer) and m.use_wq and m.use_aq and not m.disable_aq)
     assert len(seen) == n_q == N_QUANT_LAYERS["sdxl"], (len(seen), n_q)
 
@@ -750,7 +775,8 @@ def test_fused_unet_teacher_forced_half_modes(dtype, tmp_path_factory):
     arch, res, batch, t = "sd", 16, 2, 999
     c = dict(CFGS["C2"], steps=2)
     tmp = str(tmp_path_factory.mktemp("ckhalf"))
-    qnn, _ = build_synthetic_qnn(arch, c, res, batch, 2, ckpt_dir=tmp)               # not cached: the model is recast
+    qnn, ck = build_synthetic_qnn(arch, c, res, batch, 2, ckpt_dir=tmp)              # not cached: the model is recast
+    os.remove(ck)                                                                    # (3.4 GB; the space returns with the model, see _drop_qnn)
     qnn = qnn.half() if dtype == torch.float16 else qnn.to(torch.bfloat16)
     inp = synth.synth_inputs(arch, batch, 1, res)
     ref, rec, _ = oracle_run(arch, c, res, batch, 2, inp, t, cache_key="tf")
@@ -788,7 +814,8 @@ def test_fp16_mode_vs_reference_fp16_mode_golden(tmp_path_factory):
     g = torch.load(os.path.join(GOLD, "f5c_unet_sd_c2n_r16_fp16.pt"))
     assert g["meta"]["time_aware"] is False and g["meta"]["res"] == 16
     tmp = str(tmp_path_factory.mktemp("ckfp16"))
-    qnn, _ = build_synthetic_qnn("sd", C2N, 16, 2, 1, ckpt_dir=tmp)                  # not cached: the model is recast
+    qnn, ck = build_synthetic_qnn("sd", C2N, 16, 2, 1, ckpt_dir=tmp)                 # not cached: the model is recast
+    os.remove(ck)                                                                    # (the space returns with the model, see _drop_qnn)
     inp = synth.synth_inputs("sd", 2, 1, 16)
     for t, ref32 in g["outputs_fp32"].items():
         ref16 = g["outputs_fp16"][t].float()
