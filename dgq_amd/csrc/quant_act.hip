@@ -752,6 +752,13 @@ static int quant_act_variant(const QuantActParams& p, bool table) {
     const size_t sc_tab = (((size_t)3 * (p.Kp >> 5) + 16) * 4 + 15) & ~(size_t)15;
     if (table && p.kdst && taps_ > 1 && p.C % 4 == 0 && ks == 1 && p.pre_act != 2 && !p.ln_gamma && sc_tab + (size_t)p.Kp <= 150 * 1024)
         return (p.M >= 4096 && sc_tab + 4 * (size_t)p.Kp <= 150 * 1024) ? 3 : 4;     // (2048 rows x 17536: 79 us with one wave per row, see below)
+    // per-K Linear inputs too wide for a staged strip (K > 4096: SDXL's ff.net.2 at 5120): the multi-wave scatter form instead of the
+    // global gather (one L1 access per code)
+    {
+        const size_t tab_b = (((size_t)3 * (p.Kp >> 5) + 16) * 4 + 15) & ~(size_t)15;
+        if (table && p.kdst && taps_ == 1 && p.C % 4 == 0 && ks == 1 && !p.ln_gamma && p.pre_act != 2 && tab_b + (size_t)p.Kp <= 150 * 1024)
+            return 4;
+    }
     return table ? 1 : 2;
 }
 
