@@ -25,6 +25,7 @@ SIGNATURES = {
                       _vp, ctypes.c_size_t, _vp, _vp],
     "dgq_gemm_workspace_bytes": [_i, _i, _i],
     "dgq_gemm_plan_splits": [_i, _i, _i, _i, _i, ctypes.c_size_t],
+    "dgq_gemm_act_fuses": [_i, _i, _i, _i, _i, _i, _i, _i, _i],
     "dgq_groupnorm_from_partials": [_vp, _i, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp],
     "dgq_fakequant_rows": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp],
     "dgq_max_f32": [_vp, _i64, _i, _i, _vp, _vp],
@@ -52,7 +53,14 @@ SIGNATURES = {
 class GemmExtra(ctypes.Structure):
     """dgq_gemm_extra_t of include/dgq_hip.h"""
     _fields_ = [("residual", _vp), ("ldr", _i), ("res_div", _i), ("res_dtype", _i), ("fq_mode", _i), ("fq_delta", _vp), ("fq_zp", _vp),
-                ("fq_T", _i), ("fq_D", _i), ("fq_skip", _i), ("fq_qmax", _f), ("geglu", _i), ("gn_partial", _vp), ("conv", _vp), ("flush_coef", _vp)]
+                ("fq_T", _i), ("fq_D", _i), ("fq_skip", _i), ("fq_qmax", _f), ("geglu", _i), ("gn_partial", _vp), ("conv", _vp), ("flush_coef", _vp), ("wfrag", _vp), ("act", _vp)]
+
+
+class GemmAct(ctypes.Structure):
+    """dgq_gemm_act_t of include/dgq_hip.h"""
+    _fields_ = [("x", _vp), ("x_dtype", _i), ("ldx", _i), ("K", _i), ("kdst", _vp), ("czp", _vp), ("bits", _i),
+                ("pre_scale", _vp), ("pre_shift", _vp), ("rows_per_image", _i), ("pre_act", _i),
+                ("ln_gamma", _vp), ("ln_beta", _vp), ("ln_eps", _f)]
 
 
 class GemmConv(ctypes.Structure):

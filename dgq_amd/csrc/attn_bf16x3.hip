@@ -24,6 +24,9 @@
 #include <atomic>
 #include <type_traits>
 #include "dgq_common.h"
+#include "diag.h"
+
+DGQ_DIAG_BUFFER(attn)
 
 typedef float v16f __attribute__((ext_vector_type(16)));
 typedef int v16i __attribute__((ext_vector_type(16)));
@@ -250,6 +253,14 @@ __global__ __launch_bounds__(256) void attn3_prep_kernel(const TIn* __restrict__
     constexpr bool QI8 = QM == 1;
     static_assert(D % 8 == 0, "head_dim must be a multiple of 8");
     const int bh = blockIdx.y, b = bh / H, hd = bh - b * H;
+    DGQ_DIAG_DECL
+    DGQ_STAMP(0); DGQ_STAMP_REAL(1); DGQ_STAMP_WHERE(2);
+#ifdef DGQ_DIAG
+    dg.t[13] = 1;                                           // kernel tag: 1 pre-pass, 2 statistics, 3 P·V
+#define DGQ_ATTN_PREP_DONE() do { DGQ_STAMP(9); DGQ_DIAG_DRAIN(); DGQ_STAMP(10); DGQ_STAMP_REAL(11); DGQ_DIAG_FLUSH(attn, 4, threadIdx.x >> 6, threadIdx.x & 63); } while (0)
+#else
+#define DGQ_ATTN_PREP_DONE() do {} while (0)
+#endif
     if (QM == 2 && (int)blockIdx.x >= 2 * NT) {
         // Q1K3: centred codes c'q = c − 2^(b−1) of aqtizer_q(q) as fp32 (exact), + (q scale, zero-point multiplier) per query
         const int t0 = ((int)blockIdx.x - 2 * NT) * 32;
@@ -287,7 +298,7 @@ __global__ __launch_bounds__(256) void attn3_prep_kernel(const TIn* __restrict__
                 qtab[row * 2 + 1] = fqq.mode == 2 ? 1.0f : fqq.zp[idx] - off;
             }
         }
-        return;
+        DGQ_ATTN_PREP_DONE(); return;
     }
     if (QI8 && (int)blockIdx.x >= 2 * NT) {
         // QI8: int8 codes of aqtizer_q(q) for 32 query rows + (δq, z'q, Σc'q − D·z'q, start-peak score/δq) per query.
@@ -329,7 +340,7 @@ __global__ __launch_bounds__(256) void attn3_prep_kernel(const TIn* __restrict__
             }
             if (part == 0) *reinterpret_cast<float4*>(qtab + row * 4) = make_float4(dl, zc, csum - (float)D * zc, sp);
         }
-        return;
+        DGQ_ATTN_PREP_DONE(); return;
     }
     if ((int)blockIdx.x >= 2 * NT) {
         // extra blocks (only when aqtizer_q is fused): fake-quantised copy of 32 query rows of this (batch, head), so
@@ -347,7 +358,7 @@ __global__ __launch_bounds__(256) void attn3_prep_kernel(const TIn* __restrict__
             *reinterpret_cast<float4*>(qfq + o) = make_float4(x[0], x[1], x[2], x[3]);
             *reinterpret_cast<float4*>(qfq + o + 4) = make_float4(x[4], x[5], x[6], x[7]);
         }
-        return;
+        DGQ_ATTN_PREP_DONE(); return;
     }
     // K and V images of a key tile are written by DIFFERENT workgroups (x < NT: K, NT <= x < 2·NT: V): each is a chain of
     // a few dependent load rounds, and run back to back in one workgroup they set the duration of this launch (18-23 us
@@ -531,6 +542,7 @@ __global__ __launch_bounds__(256) void attn3_prep_kernel(const TIn* __restrict__
             }
         }
     }
+    DGQ_ATTN_PREP_DONE();
 }
 
 // Q rows of this lane as B-operand fragments: qf[split][kk] holds Q[t][16kk + 8h + j], j = 0..7
@@ -741,6 +753,11 @@ __global__ __launch_bounds__(64 * NW) void attn3_stats_kernel(AttnParams p) {
     constexpr int ST = G::STATS_STAGES, NP = G::K_PIECES, SB = NP * 1024;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds8[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, h32 = lane >> 5;
+    DGQ_DIAG_DECL
+    DGQ_STAMP(0); DGQ_STAMP_REAL(1); DGQ_STAMP_WHERE(2);
+#ifdef DGQ_DIAG
+    dg.t[13] = 2;
+#endif
     int bx, bh;
     attn_block_coords(p.xcd, bx, bh);
     const int b = bh / p.H, hd = bh - b * p.H;
@@ -776,8 +793,10 @@ __global__ __launch_bounds__(64 * NW) void attn3_stats_kernel(AttnParams p) {
     }
     const float sl2 = p.scale * LOG2E * qt.x * dk;       // scores in log2 units: p = 2^(s2 − m)/l  (QI8: δq folded in, > 0)
     float mraw = -INFINITY, l = 0.0f, m2raw = -INFINITY; // running maxima of the UNSCALED scores (scale > 0)
+    DGQ_STAMP(3);
     wait_image<NP, ST - 2, NW>(wid);
     __builtin_amdgcn_s_barrier();
+    DGQ_STAMP(4);
     int stage = 0, istage = ST - 1;
     for (int i = i0; i < i1; ++i) {
         issue_image<NP, NW>(img_lane + (int64_t)min(i + ST - 1, i1 - 1) * p.img_bytes, lds_base + istage * SB, wid);
@@ -821,6 +840,7 @@ __global__ __launch_bounds__(64 * NW) void attn3_stats_kernel(AttnParams p) {
         istage = (istage + 1 == ST) ? 0 : istage + 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // no DMA may outlive the block's LDS allocation
+    DGQ_STAMP(5);
     {
         const float mo = __shfl_xor(mraw, 32, 64), lo = __shfl_xor(l, 32, 64);
         const float mm = fmaxf(mraw, mo), nb = -(mm * sl2);                   // finite: every key range holds >= 8 keys
@@ -834,6 +854,8 @@ __global__ __launch_bounds__(64 * NW) void attn3_stats_kernel(AttnParams p) {
     if (nsp > 1) {                                       // partial statistics of this key half; attn3_merge_kernel finishes them
         if (t < p.T && h32 == 0)
             *reinterpret_cast<float4*>(p.stats_part + (((int64_t)blockIdx.z * p.B * p.H + bh) * p.T + t) * 4) = make_float4(m, l, m2raw * sl2, 0.0f);
+        DGQ_STAMP(9); DGQ_DIAG_DRAIN(); DGQ_STAMP(10); DGQ_STAMP_REAL(11);
+        DGQ_DIAG_FLUSH(attn, NW, wid, lane);
         return;
     }
     if (t < p.T && h32 == 0) {
@@ -856,6 +878,8 @@ __global__ __launch_bounds__(64 * NW) void attn3_stats_kernel(AttnParams p) {
             atomicMax(reinterpret_cast<int*>(p.delta) + slot, __float_as_int(pm));
         }
     }
+    DGQ_STAMP(9); DGQ_DIAG_DRAIN(); DGQ_STAMP(10); DGQ_STAMP_REAL(11);
+    DGQ_DIAG_FLUSH(attn, NW, wid, lane);
 }
 
 __global__ __launch_bounds__(256) void attn3_add_kernel(float* __restrict__ o, const float* __restrict__ part, int64_t n4) {
@@ -903,6 +927,11 @@ __global__ __launch_bounds__(64 * NW) void attn3_pv_kernel(AttnParams p) {
     constexpr int ST = G::PV_STAGES, NP = G::IMG_PIECES, SB = G::IMG_BYTES;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds8[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, h32 = lane >> 5;
+    DGQ_DIAG_DECL
+    DGQ_STAMP(0); DGQ_STAMP_REAL(1); DGQ_STAMP_WHERE(2);
+#ifdef DGQ_DIAG
+    dg.t[13] = 3;
+#endif
     int bx, bh;
     attn_block_coords(p.xcd, bx, bh);
     const int b = bh / p.H, hd = bh - b * p.H;
@@ -959,8 +988,10 @@ __global__ __launch_bounds__(64 * NW) void attn3_pv_kernel(AttnParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[j][r] = 0.0f;
     constexpr int VPL = G::DV * G::VLD;
+    DGQ_STAMP(3);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the stats / δ loads above share the counter: drain once)
     __builtin_amdgcn_s_barrier();
+    DGQ_STAMP(4);
     int stage = 0, istage = ST - 1;
     for (int i = i0; i < i1; ++i) {
         issue_image<NP, NW>(img_lane + (int64_t)min(i + ST - 1, i1 - 1) * G::IMG_BYTES, lds_base + istage * SB, wid);
@@ -1075,6 +1106,7 @@ __global__ __launch_bounds__(64 * NW) void attn3_pv_kernel(AttnParams p) {
         istage = (istage + 1 == ST) ? 0 : istage + 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // no DMA may outlive the block's LDS allocation
+    DGQ_STAMP(5);
     if (p.skip > 0) p_bypass = __shfl(p_bypass, lane & 31, 64);   // key 0 lives in the lower half-wave
     if constexpr (G::VONES) {                            // Σ p̂/δ over ALL keys = O^T[D] (the ones row): d = D sits in one half-wave
         constexpr int kd = D % 32, rr = (kd & 3) + 4 * (kd >> 3), hh = (kd >> 2) & 1;
@@ -1099,6 +1131,7 @@ __global__ __launch_bounds__(64 * NW) void attn3_pv_kernel(AttnParams p) {
         }
         __syncthreads();
     }
+    DGQ_STAMP(6);
     if (t < p.T) {
         const int64_t ob = ((int64_t)(b * p.T + t) * p.H + hd) * D;
 #pragma unroll
@@ -1119,6 +1152,8 @@ __global__ __launch_bounds__(64 * NW) void attn3_pv_kernel(AttnParams p) {
                 }
             }
     }
+    DGQ_STAMP(9); DGQ_DIAG_DRAIN(); DGQ_STAMP(10); DGQ_STAMP_REAL(11);
+    DGQ_DIAG_FLUSH(attn, NW, wid, lane);
 }
 
 template <int D, int QM, bool VINT>

@@ -8,6 +8,7 @@
 #include <type_traits>
 #include "dgq_common.h"
 #include "gemm_device.h"
+#include "diag.h"
 
 #define BK 128
 #define NCH 4                 // 32-wide chunks per K tile
@@ -39,6 +40,8 @@ struct GemmParams {
     dgq_gemm_extra_t ex;  // optional epilogue extras (residual add, fused attention-side quantizer, GEGLU pairs)
     dgq_gemm_conv_t cv;   // implicit im2col A operand (cv.codes_in != nullptr); ex.conv is not used on the device
     const float* ccoef;   // per-K, unsplit: host-formed flush coefficients + clear flags (ex.flush_coef) or nullptr
+    const uint8_t* wfrag; // the same W4 weights fragment-major (dgq_pack_w4 layout 2; ex.wfrag) or nullptr: what gemm_panel.hip reads
+    dgq_gemm_act_t act;   // quantise-on-load inside the panel kernel (act.x != nullptr; ex.act), see include/dgq_hip.h
 };
 
 // Up to DGQ_GEMM_BATCH problems of one kernel instance (tile shape, weight bits, scale mode, output dtype; no K split) in
@@ -48,6 +51,17 @@ struct GemmBatch {
     GemmParams p[DGQ_GEMM_BATCH];
     int n;                 // 1: p[0], blockIdx.z = K split;  > 1: blockIdx.z = problem, no split
 };
+
+// Every scalar a GEMM workgroup needs from its kernel arguments, fetched in ONE burst at kernel entry.  hipcc otherwise emits each
+// s_load where the field is first used — behind early-exit branches, one `s_waitcnt lgkmcnt(0)` each: eight dependent scalar-cache
+// round trips (1100-2600 cycles from entry to the first vector load, profiles/r05_small_launch_timeline.txt).  An asm statement that
+// takes the values as inputs pins their loads in front of it; later reads of the same (invariant) fields reuse them.
+__device__ __forceinline__ void gemm_prefetch_params(const GemmParams& p) {
+    asm volatile("" ::"s"(p.M), "s"(p.N), "s"(p.Kp), "s"(p.tiles_per_split), "s"(p.splits), "s"(p.codes), "s"(p.wpacked), "s"(p.rowsum),
+                 "s"(p.rowsum_parts), "s"(p.alpha), "s"(p.zw), "s"(p.gamma), "s"(p.vn), "s"(p.cdelta), "s"(p.cflush), "s"(p.mdelta),
+                 "s"(p.mzp), "s"(p.L), "s"(p.offset), "s"(p.y), "s"(p.ldy), "s"(p.slab), "s"(p.ex.residual), "s"(p.ex.ldr),
+                 "s"(p.ex.res_div), "s"(p.ex.res_dtype), "s"(p.ex.fq_mode), "s"(p.ex.geglu), "s"(p.ex.gn_partial), "s"(p.wfrag));
+}
 
 template <bool PER_M>
 __device__ __forceinline__ float dgq_epilogue(const GemmParams& p, float acc, int m, int n, float al, float zw, float ga,
@@ -111,7 +125,7 @@ __device__ __forceinline__ void wait_ring(int tiles) {
 template <bool PER_M, typename TOut, int BM, int BN, int WVM, int WVN, int WVK, int LDS_CAP, int TM, int TN>
 __device__ __forceinline__ void gemm_store_tile(const GemmParams& p, int zsplit, uint8_t* smem, const float* vtab, const float* vcol,
                                                 int wid, int lane, int wave_m, int wave_n, int wave_k, int m0, int n0,
-                                                const v16i (&acc0)[TM][TN], const v16f (&accf)[TM][TN]) {
+                                                const v16i (&acc0)[TM][TN], const v16f (&accf)[TM][TN] DGQ_DIAG_PARAM) {
     constexpr int NW = WVM * WVN * WVK;
     constexpr int WM = BM / WVM, WN = BN / WVN;
     static_assert(TM == WM / 32 && TN == WN / 32, "wave tile");
@@ -156,6 +170,7 @@ __device__ __forceinline__ void gemm_store_tile(const GemmParams& p, int zsplit,
     };
     stage_half(0);
     if (WVK > 1) __builtin_amdgcn_s_barrier();              // WVK == 1: same-wave LDS round trip, no barrier needed
+    DGQ_STAMP(8);
     const float* ep0 = ep_all + (wave_m * WVN + wave_n) * REGION;                     // k = 0 half
     const float* ep1 = ep0 + (WVM * WVN) * REGION;                                    // k = 1 half (WVK == 2)
     const int c4 = (lane % LPR) * 4;                         // 4 consecutive n per lane

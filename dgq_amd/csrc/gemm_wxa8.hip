@@ -33,6 +33,8 @@
 // (no float atomics: results are bit-reproducible).
 #include "gemm_tile.h"
 
+DGQ_DIAG_BUFFER(gemm)
+
 // WVM x WVN x WVK waves; NST ring stages; ACCS int32 accumulator sets per wave (per-K mode only).  With ACCS = 2 consecutive
 // chunks of a wave alternate between two accumulator sets, each with its own running total, and a chunk's flush is issued
 // AFTER the MFMAs of the wave's next chunk: on the small tiles (one or two MFMAs per chunk) the MFMA latency and the flush
@@ -44,6 +46,7 @@ __global__ __launch_bounds__(64 * WVM * WVN * WVK, gemm_waves_per_simd(WBITS, BM
 void gemm_wxa8_kernel(GemmBatch bt) {
     const GemmParams& p = bt.p[bt.n > 1 ? blockIdx.z : 0];
     const int zsplit = bt.n > 1 ? 0 : blockIdx.z;
+    gemm_prefetch_params(p);
     // XCD-aware tile order.  Workgroups are dealt round-robin over the 8 XCDs (each with its own L2): in launch order the
     // n tiles of one m tile — which all read the same activation rows — would sit on 8 different XCDs, and every XCD would
     // fetch the whole activation matrix through the fabric (PMC: 4.4x the algorithmic bytes per launch).  Remapped so that
@@ -59,6 +62,8 @@ void gemm_wxa8_kernel(GemmBatch bt) {
         tile_n = logical - tile_m * gx;
     }
     if (tile_n * BN >= p.N || tile_m * BM >= p.M) return;   // batch: a narrower problem than the grid (whole block)
+    DGQ_DIAG_DECL
+    DGQ_STAMP(0); DGQ_STAMP_REAL(1); DGQ_STAMP_WHERE(2);
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr int STAGES = NST;
     constexpr int NW = WVM * WVN * WVK, NT = 64 * NW;
@@ -272,7 +277,9 @@ void gemm_wxa8_kernel(GemmBatch bt) {
         for (int i = 0; i < STAGES - 1; ++i)
             if (i < nk) { issue_tile(kt_begin + i, i); ++issued; }
         // table loads + tile 0 done; up to NST − 2 younger tiles stay in flight
+        DGQ_STAMP(3);
         wait_ring<DMA_PER_TILE, STAGES - 2>(issued - 1);
+        DGQ_STAMP(4);
         // the loaded registers become defined HERE for the compiler (volatile asm statements keep their order)
         if (PER_M) asm volatile("" : "+v"(rs), "+v"(md), "+v"(mz), "+v"(c_al), "+v"(c_zw), "+v"(c_ga), "+v"(c_vn));
         else asm volatile("" : "+v"(rs), "+v"(c_al), "+v"(c_zw), "+v"(c_ga), "+v"(c_d), "+v"(c_dn), "+v"(c_cf));
@@ -360,6 +367,7 @@ void gemm_wxa8_kernel(GemmBatch bt) {
     v4i af0[TM], af1[TM];
     wfrag_t wf0[TN], wf1[TN];
     int stage = 0, istage = STAGES - 1;
+    DGQ_STAMP(5);
     load_frags(smem, smem + A_BYTES, 0, af0, wf0);
     for (int t = 0; t < nk; ++t) {
         if (t + STAGES - 1 < nk) issue_tile(kt_begin + t + STAGES - 1, istage);
@@ -386,8 +394,11 @@ void gemm_wxa8_kernel(GemmBatch bt) {
         // tile t+1 must have landed (this wave's pieces) before anyone reads it; the STAGES-2 younger tiles may stay
         // in flight (vmcnt counts the wave's DMA instructions in issue order).  lgkmcnt(0): this wave's reads of tile t
         // are complete, so after the barrier its stage may be overwritten.
+        DGQ_STAMP_NOW(dg_w0);
         wait_ring<DMA_PER_TILE, STAGES - 2>(min(STAGES - 2, nk - 2 - t));
+        DGQ_STAMP_ACC(12, dg_w0);
         __builtin_amdgcn_s_barrier();
+        DGQ_STAMP_ACC(7, dg_w0);
         stage = (stage + 1 == STAGES) ? 0 : stage + 1;
         istage = (istage + 1 == STAGES) ? 0 : istage + 1;
         if (t + 1 < nk) {
@@ -410,10 +421,18 @@ void gemm_wxa8_kernel(GemmBatch bt) {
         }
     }
     if constexpr (!PER_M && ACCS == 2) flush(acc[1], pend);
+    DGQ_STAMP(6);
 
     // epilogue (gemm_tile.h): the wave tiles are transposed through the now idle ring and stored 16 bytes per lane
     gemm_store_tile<PER_M, TOut, BM, BN, WVM, WVN, WVK, STAGES * STAGE_BYTES, TM, TN>(p, zsplit, smem, vtab, vcol, wid, lane, wave_m, wave_n,
-                                                                                      wave_k, m0, n0, acc[0], accf);
+                                                                                      wave_k, m0, n0, acc[0], accf DGQ_DIAG_ARG);
+    DGQ_STAMP(9);
+    DGQ_DIAG_DRAIN();
+    DGQ_STAMP(10); DGQ_STAMP_REAL(11);
+#ifdef DGQ_DIAG
+    dg.t[13] = (unsigned long long)nk | ((unsigned long long)tile_m << 16) | ((unsigned long long)tile_n << 32) | ((unsigned long long)wid << 48);
+#endif
+    DGQ_DIAG_FLUSH(gemm, NW, wid, lane);
 }
 
 // Deterministic split-K combine + dequantisation epilogue: one thread per 4 consecutive n.
@@ -523,6 +542,15 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(GemmParams p) {
 // gemm_wxa8_big.hip: the 256-row ping-pong kernel (W4, one problem, no K split); the plan names it by bm == 256
 int dgq_launch_gemm_big(const GemmBatch& bt, bool per_m, int y_dtype, hipStream_t st);
 size_t dgq_gemm_big_lds_bytes(bool per_m, int Kp);
+// gemm_panel.hip: the short-K kernel (whole K slice of the activations in LDS, weights streamed fragment-major into registers); the
+// plan names it by bm = PANEL_BM0 + TM (wave tile rows / 32), bn = waves per workgroup
+#define PANEL_BM0 1000
+int dgq_launch_gemm_panel(const GemmBatch& bt, bool per_m, int y_dtype, int tm, int nw, int kw, bool fuse, hipStream_t st);
+size_t dgq_gemm_panel_lds_bytes(int tm, int nw, int kw, bool per_m, bool fuse, int tiles);
+
+template <bool PER_M, typename TOut>
+static void launch_combine(const GemmParams& p, hipStream_t st);
+struct GemmPlan { int bm, bn, splits; double t; int kw = 1; bool fuse = false; };   // kw / fuse: the panel kernel's K waves / quantise-on-load
 
 template <int WBITS, bool PER_M, typename TOut, int BM, int BN, int WVM, int WVN, int WVK, int NST>
 static void launch_tile(const GemmBatch& bt, hipStream_t st) {
@@ -601,24 +629,50 @@ static int launch_one(const GemmBatch& bt, int bm, int bn, hipStream_t st) {
                 return DGQ_EINVAL;
             }
     }
-    if (bt.n == 1 && p.splits > 1) {
-        int64_t total = (int64_t)p.M * ((p.N + 3) / 4);
-        if (p.ex.gn_partial) total = ((int64_t)(p.M / 16) * ((p.N + 3) / 4) + 3) / 4 * 64;      // 4 units per wave
-        int g = (int)((total + 255) / 256);
-        if (g > 4096 && !p.ex.gn_partial) g = 4096;           // (the partials form has no grid-stride loop: one unit per 4 lanes)
-        hipLaunchKernelGGL((splitk_epilogue_kernel<PER_M, TOut>), dim3(g), dim3(256), 0, st, p);
-    }
+    if (bt.n == 1 && p.splits > 1) launch_combine<PER_M, TOut>(p, st);
     return DGQ_OK;
 }
 
+template <bool PER_M, typename TOut>
+static void launch_combine(const GemmParams& p, hipStream_t st) {
+    int64_t total = (int64_t)p.M * ((p.N + 3) / 4);
+    if (p.ex.gn_partial) total = ((int64_t)(p.M / 16) * ((p.N + 3) / 4) + 3) / 4 * 64;      // 4 units per wave
+    int g = (int)((total + 255) / 256);
+    if (g > 4096 && !p.ex.gn_partial) g = 4096;           // (the partials form has no grid-stride loop: one unit per 4 lanes)
+    hipLaunchKernelGGL((splitk_epilogue_kernel<PER_M, TOut>), dim3(g), dim3(256), 0, st, p);
+}
+
 template <int WBITS, bool PER_M>
-static int launch_gemm(const GemmBatch& p, int bm, int bn, int y_dtype, hipStream_t st) {
+static int launch_gemm(const GemmBatch& p, const GemmPlan& pl, int y_dtype, hipStream_t st) {
+    const int bm = pl.bm, bn = pl.bn;
     int rc;
     if (bm == 256) {
         DGQ_CHECK_ARG(WBITS == 4 && p.n == 1 && p.p[0].splits == 1 && dgq_gemm_big_lds_bytes(PER_M, p.p[0].Kp) <= 160 * 1024,
                       "dgq_gemm_wxa8: the 256-row kernel takes one unsplit W4 problem whose tables fit the LDS");
         rc = dgq_launch_gemm_big(p, PER_M, y_dtype, st);
         if (rc != DGQ_OK) return rc;
+        return dgq_launch_status("dgq_gemm_wxa8");
+    }
+    if (bm > PANEL_BM0) {
+        const int tm = bm - PANEL_BM0, nw = bn;
+        DGQ_CHECK_ARG(WBITS == 4, "dgq_gemm_wxa8: the panel kernel takes W4 weights");
+        for (int i = 0; i < p.n; ++i) {
+            DGQ_CHECK_ARG(p.p[i].wfrag && !p.p[i].cv.codes_in, "dgq_gemm_wxa8: the panel kernel needs the fragment-major weights (extra.wfrag) and a materialised operand");
+            const size_t need = dgq_gemm_panel_lds_bytes(tm, nw, pl.kw, PER_M, pl.fuse, p.p[i].tiles_per_split);
+            DGQ_CHECK_ARG(need > 0 && need <= 160 * 1024, "dgq_gemm_wxa8: no panel configuration TM=%d NW=%d KW=%d fuse=%d for K slices of %d tiles",
+                          tm, nw, pl.kw, (int)pl.fuse, p.p[i].tiles_per_split);
+            DGQ_CHECK_ARG(pl.fuse == (p.p[i].act.x != nullptr), "dgq_gemm_wxa8: quantise-on-load (extra.act) and the launch plan disagree");
+            DGQ_CHECK_ARG(!pl.fuse || p.p[i].splits == 1, "dgq_gemm_wxa8: quantise-on-load takes the whole K extent in one workgroup");
+        }
+        rc = dgq_launch_gemm_panel(p, PER_M, y_dtype, tm, nw, pl.kw, pl.fuse, st);
+        if (rc != DGQ_OK) return rc;
+        if (p.n == 1 && p.p[0].splits > 1) {
+            switch (y_dtype) {
+                case DGQ_F32: launch_combine<PER_M, float>(p.p[0], st); break;
+                case DGQ_F16: launch_combine<PER_M, __half>(p.p[0], st); break;
+                default: launch_combine<PER_M, __hip_bfloat16>(p.p[0], st); break;
+            }
+        }
         return dgq_launch_status("dgq_gemm_wxa8");
     }
     switch (y_dtype) {
@@ -640,7 +694,6 @@ static int launch_gemm(const GemmBatch& p, int bm, int bn, int y_dtype, hipStrea
 //   * large outputs (M·N > 3M) are bound by their own stores: 64x128 (128x128 from 30M outputs on);
 //   * a K split pays only when the unsplit grid cannot fill the chip (< 256 blocks) AND K is long (> 60 tiles): slabs
 //     cost S·M·N·8 B of traffic plus a combine launch; then S brings the grid to ~480 blocks.
-struct GemmPlan { int bm, bn, splits; double t; };
 static GemmPlan plan_gemm(int M, int N, int Kp, int w_bits, size_t ws_bytes, bool per_m, bool allow_big = true) {
     const int nk = Kp / BK;
     const double out = (double)M * N;
@@ -689,6 +742,38 @@ static GemmPlan plan_gemm(int M, int N, int Kp, int w_bits, size_t ws_bytes, boo
     return pl;
 }
 
+// Quantise-on-load inside the GEMM (dgq_gemm_act_t): the panel kernel's configuration for a Linear / 1x1 layer, or false where the
+// layer stays on the two-launch form.  One 32-row tile per workgroup, NW column waves x KW K waves: enough waves to give every SIMD
+// two or three (the quantising prologue and the K loop are latency chains), the whole padded K in the LDS panel.
+static bool plan_panel_fuse(int M, int N, int Kp, bool per_m, GemmPlan& pl) {
+    static const bool on = [] { const char* e = getenv("DGQ_GEMM_FUSE"); return !(e && *e == '0'); }();      // A/B hook
+    if (!on) return false;
+    const int nk = Kp / BK;
+    const long mb = (M + 31) / 32, nt = (N + 31) / 32;
+    int kw = 1;
+    while (kw < 4 && mb * nt * kw < 2048 && nk >= 4 * kw) kw *= 2;
+    int nw;
+    if (kw == 1) nw = (N % 320 == 0) ? 10 : 5;
+    else if (kw == 2) nw = (N % 160 == 0) ? 5 : ((N % 256 == 0) ? 8 : 4);
+    else nw = 4;
+    const size_t need = dgq_gemm_panel_lds_bytes(1, nw, kw, per_m, true, nk);
+    if (need == 0 || need > 150 * 1024) return false;
+    // every column block of a row block quantises the rows again: the fused form pays while that redundancy is small and the row
+    // blocks alone fill the chip (tools/bench_fused.py, profiles/r05_fused_linear_shapes.txt); DGQ_GEMM_FUSE_ALL=1: wherever it fits
+    const char* ea = getenv("DGQ_GEMM_FUSE_ALL");        // (read per call: the test suite switches it)
+    const bool all = ea && *ea == '1';
+    if (!all && ((N + 32 * nw - 1) / (32 * nw) > 2 || M < 2048)) return false;
+    pl.bm = PANEL_BM0 + 1; pl.bn = nw; pl.kw = kw; pl.fuse = true; pl.splits = 1;
+    return true;
+}
+
+extern "C" int dgq_gemm_act_fuses(int M, int N, int K, int Kp, int w_bits, int per_m, int n_problems, int x_dtype, int y_dtype) {
+    if (w_bits != 4 || x_dtype != y_dtype || M < 1 || N < 1 || K < 4 || K % 4 != 0 || Kp < K || Kp % BK != 0 || n_problems < 1 || n_problems > DGQ_GEMM_BATCH)
+        return 0;
+    GemmPlan pl = {32, 64, 1, 0.0};
+    return plan_panel_fuse(M, N, Kp, per_m != 0, pl) ? 1 : 0;
+}
+
 // implicit-conv launches: four tile shapes carry the CONV addressing.  Measured on the C5 shapes (tools/bench_conv_implicit.py,
 // profiles/r04_conv_implicit_shapes.txt): 64x128 is the best or within 3 % of it on every one of them — the address arithmetic is
 // per DMA piece, and the 64x64 tile the materialised operand prefers at M = 8192 has half the MFMAs per piece.
@@ -725,11 +810,20 @@ __global__ __launch_bounds__(256) void conv_rowsum_kernel(dgq_gemm_conv_t c, int
 }
 
 // Development hook: DGQ_GEMM_FORCE="BM,BN,S" overrides the plan (tile sweeps, tools/bench_gemm_sweep.py); read per call.
+// "P<TM>,<NW>,S[,KW]" names the panel kernel (gemm_panel.hip): wave tile of 32·TM rows, NW x KW waves per workgroup.
 static bool forced_plan(GemmPlan& pl) {
     const char* e = getenv("DGQ_GEMM_FORCE");
     if (!e || !*e) return false;
     int bm = 0, bn = 0, s = 0;
-    if (sscanf(e, "%d,%d,%d", &bm, &bn, &s) != 3) return false;
+    if (*e == 'P' || *e == 'F') {                          // F: with quantise-on-load (honoured only for calls that carry extra.act)
+        int kw = 1;
+        if (sscanf(e + 1, "%d,%d,%d,%d", &bm, &bn, &s, &kw) < 3) return false;
+        bm += PANEL_BM0;
+        pl.kw = kw < 1 ? 1 : kw;
+        pl.fuse = (*e == 'F');
+    } else if (sscanf(e, "%d,%d,%d", &bm, &bn, &s) != 3) {
+        return false;
+    }
     pl.bm = bm; pl.bn = bn; pl.splits = s < 1 ? 1 : s;
     return true;
 }
@@ -770,6 +864,8 @@ static int fill_gemm(const dgq_gemm_args_t& a, GemmParams& p) {
     }
     p.cv.codes_in = nullptr;
     p.ccoef = nullptr;
+    p.wfrag = nullptr;
+    p.act.x = nullptr;
     p.codes = a.codes; p.rowsum = a.rowsum; p.rowsum_parts = a.rowsum_parts; p.M = a.M; p.Kp = a.Kp; p.N = a.N;
     p.wpacked = reinterpret_cast<const uint8_t*>(a.wpacked);
     p.cdelta = a.cdelta; p.cflush = a.cflush; p.mdelta = a.mdelta; p.mzp = a.mzp; p.L = a.per_m ? a.L : 1; p.offset = a.offset;
@@ -782,6 +878,20 @@ static int fill_gemm(const dgq_gemm_args_t& a, GemmParams& p) {
                       "dgq_gemm_wxa8: bad residual descriptor (ldr < N, res_div < 1 or unknown dtype)");
         DGQ_CHECK_ARG(!p.ex.geglu || (a.N % 4 == 0 && !p.ex.residual && p.ex.fq_mode == 0),
                       "dgq_gemm_wxa8: the GEGLU epilogue needs N %% 4 == 0 and no other extra");
+        if (p.ex.wfrag) {
+            DGQ_CHECK_ARG(a.w_bits == 4 && (reinterpret_cast<uintptr_t>(p.ex.wfrag) & 15) == 0, "dgq_gemm_wxa8: wfrag is the W4 layout-2 image, 16-byte aligned");
+            p.wfrag = reinterpret_cast<const uint8_t*>(p.ex.wfrag);
+        }
+        if (p.ex.act) {
+            const dgq_gemm_act_t& q = *p.ex.act;
+            DGQ_CHECK_ARG(q.x && p.ex.wfrag && q.K > 0 && q.K % 4 == 0 && q.K <= a.Kp && q.ldx >= q.K && q.bits >= 2 && q.bits <= 8 &&
+                          q.x_dtype == a.y_dtype && (a.per_m || (q.kdst && q.czp)) && (q.pre_scale == nullptr) == (q.pre_shift == nullptr) &&
+                          (!q.pre_scale || q.rows_per_image >= 1) && (q.pre_act == 0 || q.pre_act == 1) &&
+                          (q.ln_gamma == nullptr) == (q.ln_beta == nullptr) && (!q.ln_gamma || (q.ln_eps > 0.0f && !q.pre_scale && q.pre_act == 0)) &&
+                          (reinterpret_cast<uintptr_t>(q.x) & 15) == 0 && (q.ldx * (q.x_dtype == DGQ_F32 ? 4 : 2)) % 8 == 0,
+                          "dgq_gemm_wxa8: bad quantise-on-load descriptor (needs wfrag, x of the output dtype, K %% 4 == 0, per-K: kdst + czp)");
+            p.act = q;
+        }
         if (p.ex.flush_coef && !a.per_m) {
             DGQ_CHECK_ARG((reinterpret_cast<uintptr_t>(p.ex.flush_coef) & 15) == 0, "dgq_gemm_wxa8: flush_coef must be 16-byte aligned");
             p.ccoef = p.ex.flush_coef;
@@ -800,7 +910,7 @@ static int fill_gemm(const dgq_gemm_args_t& a, GemmParams& p) {
                       "dgq_gemm_wxa8: GroupNorm partials need M %% 16 == 0, N %% 4 == 0, a 16-byte aligned buffer and no GEGLU / fused quantizer");
     } else {
         p.ex.residual = nullptr; p.ex.ldr = 0; p.ex.res_div = 1; p.ex.res_dtype = DGQ_F32; p.ex.fq_mode = 0; p.ex.fq_delta = nullptr; p.ex.fq_zp = nullptr;
-        p.ex.fq_T = 1; p.ex.fq_D = 1; p.ex.fq_skip = 0; p.ex.fq_qmax = 255.0f; p.ex.geglu = 0; p.ex.gn_partial = nullptr; p.ex.conv = nullptr; p.ex.flush_coef = nullptr;
+        p.ex.fq_T = 1; p.ex.fq_D = 1; p.ex.fq_skip = 0; p.ex.fq_qmax = 255.0f; p.ex.geglu = 0; p.ex.gn_partial = nullptr; p.ex.conv = nullptr; p.ex.flush_coef = nullptr; p.ex.wfrag = nullptr; p.ex.act = nullptr;
     }
     p.splits = 1; p.slab = nullptr;
     p.tiles_per_split = a.Kp / BK;
@@ -808,9 +918,9 @@ static int fill_gemm(const dgq_gemm_args_t& a, GemmParams& p) {
 }
 
 template <typename B>
-static int dispatch_gemm(const B& bt, int w_bits, bool per_m, int bm, int bn, int y_dtype, hipStream_t st) {
-    if (w_bits == 4) return per_m ? launch_gemm<4, true>(bt, bm, bn, y_dtype, st) : launch_gemm<4, false>(bt, bm, bn, y_dtype, st);
-    return per_m ? launch_gemm<8, true>(bt, bm, bn, y_dtype, st) : launch_gemm<8, false>(bt, bm, bn, y_dtype, st);
+static int dispatch_gemm(const B& bt, int w_bits, bool per_m, const GemmPlan& pl, int y_dtype, hipStream_t st) {
+    if (w_bits == 4) return per_m ? launch_gemm<4, true>(bt, pl, y_dtype, st) : launch_gemm<4, false>(bt, pl, y_dtype, st);
+    return per_m ? launch_gemm<8, true>(bt, pl, y_dtype, st) : launch_gemm<8, false>(bt, pl, y_dtype, st);
 }
 
 // 2..8 problems in one launch: same weight bits, scale mode, output dtype and launch plan (tile shape) — the plan of the
@@ -828,9 +938,20 @@ extern "C" int dgq_gemm_wxa8_batch(int n, const dgq_gemm_args_t* args, void* str
     }
     const dgq_gemm_args_t& a0 = args[0];
     GemmPlan pl = plan_gemm(a0.M, a0.N, a0.Kp, a0.w_bits, 0, a0.per_m != 0, n == 1);
-    forced_plan(pl);
+    const bool fuse = bt.p[0].act.x != nullptr;
+    for (int i = 1; i < n; ++i) DGQ_CHECK_ARG((bt.p[i].act.x != nullptr) == fuse, "dgq_gemm_wxa8_batch: quantise-on-load for all problems of a launch or none");
+    if (fuse) {
+        int maxKp = 0;
+        for (int i = 0; i < n; ++i) maxKp = args[i].Kp > maxKp ? args[i].Kp : maxKp;
+        DGQ_CHECK_ARG(plan_panel_fuse(a0.M, a0.N, maxKp, a0.per_m != 0, pl), "dgq_gemm_wxa8_batch: this shape does not take quantise-on-load (dgq_gemm_act_fuses)");
+        GemmPlan f = pl;
+        if (forced_plan(f) && f.fuse) pl = f;
+    } else {
+        forced_plan(pl);
+        DGQ_CHECK_ARG(!pl.fuse, "dgq_gemm_wxa8_batch: DGQ_GEMM_FORCE names quantise-on-load, the call carries codes");
+    }
     pl.splits = 1;
-    return dispatch_gemm(bt, a0.w_bits, a0.per_m != 0, pl.bm, pl.bn, a0.y_dtype, (hipStream_t)stream);
+    return dispatch_gemm(bt, a0.w_bits, a0.per_m != 0, pl, a0.y_dtype, (hipStream_t)stream);
 }
 
 extern "C" int dgq_gemm_wxa8(const int8_t* codes, const float* rowsum, int rowsum_parts, int M, int Kp,
@@ -851,6 +972,13 @@ extern "C" int dgq_gemm_wxa8(const int8_t* codes, const float* rowsum, int rowsu
     const int rc = fill_gemm(a, p);
     if (rc != DGQ_OK) return rc;
     GemmPlan pl = plan_gemm(M, N, Kp, w_bits, workspace ? workspace_bytes : 0, per_m != 0, /*allow_big=*/!p.cv.codes_in);
+    if (p.act.x) {                                       // quantise-on-load: the panel kernel, whole K in one workgroup
+        DGQ_CHECK_ARG(!p.cv.codes_in && plan_panel_fuse(M, N, Kp, per_m != 0, pl), "dgq_gemm_wxa8: this shape does not take quantise-on-load (dgq_gemm_act_fuses)");
+        GemmPlan f = pl;
+        if (forced_plan(f) && f.fuse) pl = f;
+        p.splits = 1; p.slab = nullptr; p.tiles_per_split = Kp / BK;
+        return dispatch_gemm(bt, w_bits, per_m != 0, pl, y_dtype, (hipStream_t)stream);
+    }
     if (p.cv.codes_in) {
         // implicit im2col: the row sums of the unfolded operand from the per-pixel sums first (a tiny launch), then one of the three
         // tile shapes that carry the CONV addressing (the plan's nearest)
@@ -860,6 +988,7 @@ extern "C" int dgq_gemm_wxa8(const int8_t* codes, const float* rowsum, int rowsu
         p.rowsum_parts = 1;
     }
     if (forced_plan(pl)) {
+        DGQ_CHECK_ARG(!pl.fuse, "dgq_gemm_wxa8: DGQ_GEMM_FORCE names quantise-on-load, the call carries codes");
         if (p.cv.codes_in) { const int fs = pl.splits; conv_tile(pl, 0); pl.splits = fs; }
         DGQ_CHECK_ARG(pl.splits == 1 || (workspace && (size_t)pl.splits * M * N * 4 <= workspace_bytes),
                       "dgq_gemm_wxa8: DGQ_GEMM_FORCE split does not fit the workspace");
@@ -871,5 +1000,5 @@ extern "C" int dgq_gemm_wxa8(const int8_t* codes, const float* rowsum, int rowsu
     p.tiles_per_split = (nk + p.splits - 1) / p.splits;
     p.splits = (nk + p.tiles_per_split - 1) / p.tiles_per_split;      // no empty split
     if (p.splits == 1) p.slab = nullptr;
-    return dispatch_gemm(bt, w_bits, per_m != 0, pl.bm, pl.bn, y_dtype, (hipStream_t)stream);
+    return dispatch_gemm(bt, w_bits, per_m != 0, pl, y_dtype, (hipStream_t)stream);
 }

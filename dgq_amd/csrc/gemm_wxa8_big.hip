@@ -54,6 +54,11 @@
 #ifndef BIG_STAMP
 #define BIG_STAMP 0            // 1 (diagnostic build, WRONG output): s_memtime stamps of K tile 8 of workgroup 0, written over y row 0
 #endif
+// the two switches above produce WRONG output: they exist in diagnostic builds (-DDGQ_DIAG, `make diag` / tools/build_variants.sh)
+// only — the shipped library cannot be built with them
+#if !defined(DGQ_DIAG) && (BIG_ABL != 0 || BIG_STAMP != 0)
+#error "BIG_ABL / BIG_STAMP change the kernel's results: diagnostic builds only (add -DDGQ_DIAG)"
+#endif
 
 namespace {
 
@@ -368,8 +373,9 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_big_kernel(GemmBatch bt) {
     if (group == 0) __builtin_amdgcn_s_barrier();            // both groups have now passed the same number of barriers
     const uint64_t st_loop1 = BIG_STAMP == 2 ? big_stamp() : 0;
 
+    DGQ_DIAG_DECL                                            // (this kernel has its own BIG_STAMP timeline; the shared epilogue's stamp goes nowhere)
     gemm_store_tile<PER_M, TOut, BM, BN, WVM, WVN, 1, NBUF * STAGE_BYTES, TM, TN>(p, 0, smem, vtab, vcol, wid, lane, wave_m, wave_n, 0,
-                                                                                  m0, n0, acc, accf);
+                                                                                  m0, n0, acc, accf DGQ_DIAG_ARG);
     const uint64_t st_issued = BIG_STAMP == 2 ? big_stamp() : 0;
     if (BIG_STAMP) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -5,6 +5,10 @@
 #include <atomic>
 #include <cstdlib>
 #include "dgq_common.h"
+#include "quant_common.h"
+#include "diag.h"
+
+DGQ_DIAG_BUFFER(quant)
 
 struct QuantActParams {
     const void* x;
@@ -46,28 +50,6 @@ struct QuantActBatch {
 
 
 
-template <typename TIn>
-__device__ __forceinline__ void load4(const TIn* p, float (&v)[4]);
-template <>
-__device__ __forceinline__ void load4<float>(const float* p, float (&v)[4]) {
-    const float4 t = *reinterpret_cast<const float4*>(p);
-    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-}
-template <>
-__device__ __forceinline__ void load4<__half>(const __half* p, float (&v)[4]) {
-    const uint2 t = *reinterpret_cast<const uint2*>(p);
-    const __half* h = reinterpret_cast<const __half*>(&t);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] = __half2float(h[j]);
-}
-template <>
-__device__ __forceinline__ void load4<__hip_bfloat16>(const __hip_bfloat16* p, float (&v)[4]) {
-    const uint2 t = *reinterpret_cast<const uint2*>(p);
-    const uint16_t* h = reinterpret_cast<const uint16_t*>(&t);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] = __uint_as_float(((uint32_t)h[j]) << 16);
-}
-
 // LayerNorm statistics of one row of C <= 2048 elements (C % 4 == 0), computed by the wave that quantises the row: the
 // row is read ONCE into registers (8 float4 per lane), mean first, then Σ(x − mean)² from the registers; biased
 // variance, rstd = 1/sqrt(var + eps) as nn.LayerNorm.
@@ -101,19 +83,6 @@ __device__ __forceinline__ void row_layernorm_stats(const TIn* xr, int C, float 
     rstd = 1.0f / sqrtf(q / (float)C + eps);
 }
 
-// Four codes q_j ∈ [0, 2^b−1] (floats) -> one dword of centred int8 codes s_j = q_j − off, 0 for padding:
-// v_cvt_pk_u8_f32 inserts u8(q − off + 128) per byte, and u8(x + 128) ^ 0x80 is the two's-complement byte of x.
-// `biased[j]` = valid ? q_j − off + 128 : 128 ; returns the dword, adds Σ biased to `fsum` (exact small integers).
-__device__ __forceinline__ uint32_t dgq_pack4(const float (&biased)[4], float& fsum) {
-    uint32_t w = 0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        w = __builtin_amdgcn_cvt_pk_u8_f32(biased[j], j, w);
-        fsum += biased[j];
-    }
-    return w ^ 0x80808080u;
-}
-
 // One wave per output row; each lane owns 4 consecutive kp per 256-wide step (one packed dword), so that the
 // table read (int4), the gathered loads (lane stride 16 B within a (group, tap) run) and the code store (256 B per
 // wave instruction) are all coalesced.  The 4 kp of a lane share one 32-wide chunk, hence one (δ, z).
@@ -125,6 +94,8 @@ __global__ __launch_bounds__(256) void quant_act_kernel(QuantActBatch bt) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= p.M) return;                                 // whole wave leaves; no barriers below
+    DGQ_DIAG_DECL
+    DGQ_STAMP(0); DGQ_STAMP_REAL(1); DGQ_STAMP_WHERE(2);
     const TIn* x = reinterpret_cast<const TIn*>(p.x);
     const int L = p.Ho * p.Wo;
     const int b = row / L;
@@ -162,6 +133,7 @@ __global__ __launch_bounds__(256) void quant_act_kernel(QuantActBatch bt) {
     float ln_mu = 0.0f, ln_rstd = 1.0f;
     if (p.ln_gamma) row_layernorm_stats<TIn>(img + rowoff, p.C, p.ln_eps, lane, ln_mu, ln_rstd);   // 1x1: the row itself
     uint32_t* out = reinterpret_cast<uint32_t*>(p.codes + (int64_t)row * p.Kp);
+    DGQ_STAMP(3);
     // K range of this wave (blockIdx.y): low-M layers would otherwise leave the chip empty (M=512: 2 waves per CU)
     const int k_begin = blockIdx.y * p.kp_per_split;
     const int k_end = min(p.Kp, k_begin + p.kp_per_split);
@@ -242,12 +214,10 @@ __global__ __launch_bounds__(256) void quant_act_kernel(QuantActBatch bt) {
                         z = p.zp[kp0 >> 5];
                         inv = dgq_rcp(d);
                     }
-                    float biased[4], fsum = 0.0f;
+                    float biased[4], qv[4], fsum = 0.0f;
+                    dgq_affine_code4_fast(v[u], d, inv, z, p.qmax, qv);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float q = dgq_affine_code_fast(v[u][j], d, inv, z, p.qmax);
-                        biased[j] = idx[u][j] != -1 ? q + bias : 128.0f;
-                    }
+                    for (int j = 0; j < 4; ++j) biased[j] = idx[u][j] != -1 ? qv[j] + bias : 128.0f;
                     out[kp0 >> 2] = dgq_pack4(biased, fsum);
                     fsum -= 512.0f;                                              // Σ (biased − 128) = Σ s
                     partial += PER_M ? fsum : d * fsum;
@@ -297,25 +267,25 @@ __global__ __launch_bounds__(256) void quant_act_kernel(QuantActBatch bt) {
         }
         nc += 256;
         while (nc >= p.C) { nc -= p.C; ++ntap; }
-        float biased[4], fsum = 0.0f;
+        float biased[4], qv[4], fsum = 0.0f;
+        dgq_affine_code4_fast(v, d, inv, z, p.qmax, qv);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float q = dgq_affine_code_fast(v[j], d, inv, z, p.qmax);
-            biased[j] = in_k ? q + bias : 128.0f;
-        }
+        for (int j = 0; j < 4; ++j) biased[j] = in_k ? qv[j] + bias : 128.0f;
         out[kp0 >> 2] = dgq_pack4(biased, fsum);
         fsum -= 512.0f;
         partial += PER_M ? fsum : d * fsum;
 #pragma unroll
         for (int q = 1; q < NSH; ++q) {
-            float bq[4], fs = 0.0f;
+            float bq[4], qs[4], fs = 0.0f;
+            dgq_affine_code4_fast(v, mdS[q], minvS[q], mzS[q], qmaxS[q], qs);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bq[j] = in_k ? dgq_affine_code_fast(v[j], mdS[q], minvS[q], mzS[q], qmaxS[q]) + biasS[q] : 128.0f;
+            for (int j = 0; j < 4; ++j) bq[j] = in_k ? qs[j] + biasS[q] : 128.0f;
             outS[q][kp0 >> 2] = dgq_pack4(bq, fs);
             partS[q] += fs - 512.0f;
         }
     }
     }
+    DGQ_STAMP(4);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) partial += __shfl_down(partial, o, 64);
     if (lane == 0) p.rowsum[(int64_t)blockIdx.y * p.M + row] = partial;
@@ -326,6 +296,10 @@ __global__ __launch_bounds__(256) void quant_act_kernel(QuantActBatch bt) {
         for (int o = 32; o > 0; o >>= 1) ps_ += __shfl_down(ps_, o, 64);
         if (lane == 0) bt.p[q].rowsum[(int64_t)blockIdx.y * bt.p[q].M + row] = ps_;
     }
+    DGQ_STAMP(9);
+    DGQ_DIAG_DRAIN();
+    DGQ_STAMP(10); DGQ_STAMP_REAL(11);
+    DGQ_DIAG_FLUSH(quant, 4, threadIdx.x >> 6, lane);
 }
 
 // Per-K conv layers (the quantizer sees the unfolded operand, so each (c, tap) may carry its own group): the table
@@ -426,12 +400,10 @@ __global__ __launch_bounds__(256) void quant_act_staged_kernel(QuantActBatch bt)
                     z = p.zp[kp0 >> 5];
                     inv = dgq_rcp(d);
                 }
-                float biased[4], fsum = 0.0f;
+                float biased[4], qv[4], fsum = 0.0f;
+                dgq_affine_code4_fast(v[u], d, inv, z, p.qmax, qv);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float q = dgq_affine_code_fast(v[u][j], d, inv, z, p.qmax);
-                    biased[j] = idx[u][j] >= 0 ? q + bias : 128.0f;
-                }
+                for (int j = 0; j < 4; ++j) biased[j] = idx[u][j] >= 0 ? qv[j] + bias : 128.0f;
                 out[kp0 >> 2] = dgq_pack4(biased, fsum);
                 fsum -= 512.0f;
                 partial += PER_M ? fsum : d * fsum;
@@ -460,6 +432,8 @@ __global__ __launch_bounds__(64 * NWV) void quant_act_scatter_kernel(QuantActBat
     constexpr int WPR = NWV / RPB;                           // waves per row
     constexpr int NT_ = 64 * NWV;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    DGQ_DIAG_DECL
+    DGQ_STAMP(0); DGQ_STAMP_REAL(1); DGQ_STAMP_WHERE(2);
     const int nch = p.Kp >> 5;
     float* tdelta = reinterpret_cast<float*>(sc_smem);
     float* tinv = tdelta + nch;
@@ -472,6 +446,7 @@ __global__ __launch_bounds__(64 * NWV) void quant_act_scatter_kernel(QuantActBat
     }
     for (int i = tid; i < RPB * (p.Kp >> 4); i += NT_) reinterpret_cast<uint4*>(images)[i] = make_uint4(0, 0, 0, 0);   // padding = code 0
     __syncthreads();
+    DGQ_STAMP(3);
     const int rslot = wv / WPR, wsub = wv % WPR;
     const int row = blockIdx.x * RPB + rslot;
     uint8_t* image = images + (size_t)rslot * p.Kp;
@@ -488,6 +463,7 @@ __global__ __launch_bounds__(64 * NWV) void quant_act_scatter_kernel(QuantActBat
         const int taps = p.kh * p.kw;
         float ln_mu = 0.0f, ln_rstd = 1.0f;                 // Linear inputs (taps == 1, one wave per row): LayerNorm over the row
         if (p.ln_gamma) row_layernorm_stats<TIn>(img + (int64_t)(hbase * p.W + wbase) * p.ldc, p.C, p.ln_eps, lane, ln_mu, ln_rstd);
+        DGQ_STAMP(4);
         // one (tap, 256-channel step) unit of the row
         auto unit = [&](int tap, int c) {
             const int dh = tap / p.kw, dw = tap - dh * p.kw;
@@ -521,13 +497,18 @@ __global__ __launch_bounds__(64 * NWV) void quant_act_scatter_kernel(QuantActBat
                 }
                 const int4 d4 = *reinterpret_cast<const int4*>(kd + c);
                 const int dst[4] = {d4.x, d4.y, d4.z, d4.w};
+                float dd[4], di[4], dz[4], qv[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int ch = dst[j] >> 5;
-                    const float d = tdelta[ch];
-                    const float sc = dgq_affine_code_fast(v[j], d, tinv[ch], tzp[ch], p.qmax) - p.offset;
+                    dd[j] = tdelta[ch]; di[j] = tinv[ch]; dz[j] = tzp[ch];
+                }
+                dgq_affine_code4_fast(v, dd, di, dz, p.qmax, qv);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float sc = qv[j] - p.offset;
                     image[dst[j]] = (uint8_t)(int)sc;
-                    partial += d * sc;
+                    partial += dd[j] * sc;
                 }
         };
         if constexpr (WPR == 1) {                            // one wave per row: taps in order, channel steps inside (loads of a tap overlap)
@@ -542,10 +523,12 @@ __global__ __launch_bounds__(64 * NWV) void quant_act_scatter_kernel(QuantActBat
             }
         }
     }
+    DGQ_STAMP(5);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) partial += __shfl_down(partial, o, 64);
     if (RPB == 1 && lane == 0) psum[wv] = partial;
     __syncthreads();                                        // every wave's bytes of the shared image(s) are in LDS
+    DGQ_STAMP(6);
     if (row < p.M) {
         uint4* out = reinterpret_cast<uint4*>(p.codes + (int64_t)row * p.Kp);
         const uint4* im = reinterpret_cast<const uint4*>(image);
@@ -560,6 +543,10 @@ __global__ __launch_bounds__(64 * NWV) void quant_act_scatter_kernel(QuantActBat
             p.rowsum[row] = tot;
         }
     }
+    DGQ_STAMP(9);
+    DGQ_DIAG_DRAIN();
+    DGQ_STAMP(10); DGQ_STAMP_REAL(11);
+    DGQ_DIAG_FLUSH(quant, NWV, wv, lane);
 }
 
 // Convolutions (kh·kw > 1), block-staged.  The quantizer sees the UNFOLDED operand, so every input element is quantised once
@@ -667,12 +654,10 @@ __global__ __launch_bounds__(64 * NW) void quant_act_conv_kernel(QuantActBatch b
                         z = tzp[kp0 >> 5];
                         inv = dgq_rcp(d);
                     }
-                    float biased[4], fsum = 0.0f;
+                    float biased[4], qv[4], fsum = 0.0f;
+                    dgq_affine_code4_fast(v[u], d, inv, z, p.qmax, qv);
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const float qq = dgq_affine_code_fast(v[u][q], d, inv, z, p.qmax);
-                        biased[q] = idx[u][q] != 0xFFFF ? qq + bias : 128.0f;
-                    }
+                    for (int q = 0; q < 4; ++q) biased[q] = idx[u][q] != 0xFFFF ? qv[q] + bias : 128.0f;
                     out[kp0 >> 2] = dgq_pack4(biased, fsum);
                     fsum -= 512.0f;
                     partial += PER_M ? fsum : d * fsum;

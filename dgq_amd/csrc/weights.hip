@@ -20,8 +20,16 @@ __global__ void quantize_weight_kernel(const float* __restrict__ w, const float*
 
 // layout 1 (dgq_gemm_wxa8): rows with (n & 16) keep the two 8-byte halves of every 16 packed bytes exchanged — word w of a
 // row sits at w ^ 2 (see include/dgq_hip.h)
+// layout 2 (gemm_panel.hip): fragment-major — word w of row n goes to block (n / 32, chunk pair), lane (K half << 5) | (n & 31),
+// word (chunk & 1)·2 + (w & 1) of the lane's 16 bytes
 __device__ __forceinline__ int64_t w4_word_index(int64_t i, int wpr, int layout) {
     if (layout == 1 && (((i / wpr) >> 4) & 1)) return i ^ 2;
+    if (layout == 2) {
+        const int64_t n = i / wpr;
+        const int w = (int)(i - n * wpr);
+        const int c = w >> 2, pairs = wpr >> 3;
+        return ((n >> 5) * pairs + (c >> 1)) * 256 + ((((w & 3) >> 1) * 32 + (int)(n & 31)) * 4 + (c & 1) * 2 + (w & 1));
+    }
     return i;
 }
 
@@ -29,7 +37,8 @@ __device__ __forceinline__ int64_t w4_word_index(int64_t i, int wpr, int layout)
 __global__ void pack_w4_kernel(const uint8_t* __restrict__ codes, int N, int K, const int32_t* __restrict__ kperm,
                                int Kp, int layout, uint32_t* __restrict__ packed) {
     int wpr = Kp / 8;
-    int64_t total = (int64_t)N * wpr;
+    const int rows = layout == 2 ? (N + 31) / 32 * 32 : N;       // layout 2 pads N to whole 32-column tiles (zero rows)
+    int64_t total = (int64_t)rows * wpr;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (int64_t)gridDim.x * blockDim.x) {
         int n = (int)(i / wpr);
@@ -39,7 +48,7 @@ __global__ void pack_w4_kernel(const uint8_t* __restrict__ codes, int N, int K, 
         for (int j = 0; j < 8; ++j) {
             int kp = kp0 + j;
             int k = kperm ? kperm[kp] : (kp < K ? kp : -1);
-            uint32_t c = (k >= 0) ? (codes[(int64_t)n * K + k] & 0xF) : 0u;
+            uint32_t c = (k >= 0 && n < N) ? (codes[(int64_t)n * K + k] & 0xF) : 0u;
             int byte = j & 3, hi = j >> 2;
             word |= c << (8 * byte + 4 * hi);
         }
@@ -91,17 +100,18 @@ extern "C" int dgq_quantize_weight(const float* w, const float* delta, const flo
 extern "C" int dgq_pack_w4(const uint8_t* codes, int N, int K, const int32_t* kperm, int Kp, int layout, uint8_t* packed,
                            void* stream) {
     DGQ_CHECK_ARG(codes && packed, "dgq_pack_w4: null pointer");
-    DGQ_CHECK_ARG(layout == 0 || layout == 1, "dgq_pack_w4: layout=%d", layout);
+    DGQ_CHECK_ARG(layout >= 0 && layout <= 2, "dgq_pack_w4: layout=%d", layout);
     DGQ_CHECK_ARG(N > 0 && K > 0 && Kp > 0 && Kp % DGQ_KTILE == 0, "dgq_pack_w4: Kp=%d must be a multiple of %d", Kp, DGQ_KTILE);
     DGQ_CHECK_ARG(kperm || Kp >= K, "dgq_pack_w4: identity order needs Kp >= K");
-    hipLaunchKernelGGL(pack_w4_kernel, dim3(grid_for((int64_t)N * Kp / 8, 256)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(pack_w4_kernel, dim3(grid_for((int64_t)((N + 31) / 32 * 32) * Kp / 8, 256)), dim3(256), 0, (hipStream_t)stream,
                        codes, N, K, kperm, Kp, layout, reinterpret_cast<uint32_t*>(packed));
     return dgq_launch_status("dgq_pack_w4");
 }
 
 extern "C" int dgq_unpack_w4(const uint8_t* packed, int N, int Kp, int layout, uint8_t* out, void* stream) {
     DGQ_CHECK_ARG(packed && out, "dgq_unpack_w4: null pointer");
-    DGQ_CHECK_ARG(N > 0 && Kp > 0 && Kp % 8 == 0 && (layout == 0 || (layout == 1 && Kp % 32 == 0)), "dgq_unpack_w4: bad shape / layout");
+    DGQ_CHECK_ARG(N > 0 && Kp > 0 && Kp % 8 == 0 && (layout == 0 || (layout == 1 && Kp % 32 == 0) || (layout == 2 && Kp % 64 == 0)),
+                  "dgq_unpack_w4: bad shape / layout");
     hipLaunchKernelGGL(unpack_w4_kernel, dim3(grid_for((int64_t)N * Kp / 8, 256)), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<const uint32_t*>(packed), N, Kp, layout, out);
     return dgq_launch_status("dgq_unpack_w4");

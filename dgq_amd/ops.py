@@ -108,12 +108,20 @@ def adaround_reg(alpha: torch.Tensor, b: float):
 W4_LAYOUT = 1
 
 
-def pack_weight(codes: torch.Tensor, kperm: Optional[torch.Tensor], Kp: int, bits: int):
+#: dgq_pack_w4 layout of the short-K kernel's weight image (gemm_panel.hip): fragment-major, N padded to 32-column tiles
+W4_FRAG_LAYOUT = 2
+#: keep a fragment-major copy of every W4 weight beside the row-major one, so that dgq_gemm_wxa8 may take its short-K kernel
+#: (DGQ_GEMM_PANEL=0: never — the tile family alone, as in round 4)
+GEMM_PANEL = os.environ.get("DGQ_GEMM_PANEL", "1") == "1"
+
+
+def pack_weight(codes: torch.Tensor, kperm: Optional[torch.Tensor], Kp: int, bits: int, layout: int = W4_LAYOUT):
     N, K = codes.shape
     kp = kperm.to(codes.device, torch.int32).contiguous() if kperm is not None else None
     if bits == 4:
-        out = torch.empty((N, Kp // 2), dtype=torch.uint8, device=codes.device)
-        _lib_call("dgq_pack_w4", _lib.ptr(codes), N, K, _lib.ptr(kp), Kp, W4_LAYOUT, _lib.ptr(out), _lib.stream())
+        rows = (N + 31) // 32 * 32 if layout == W4_FRAG_LAYOUT else N
+        out = torch.empty((rows, Kp // 2), dtype=torch.uint8, device=codes.device)
+        _lib_call("dgq_pack_w4", _lib.ptr(codes), N, K, _lib.ptr(kp), Kp, layout, _lib.ptr(out), _lib.stream())
     elif bits == 8:
         out = torch.empty((N, Kp), dtype=torch.int8, device=codes.device)
         _lib_call("dgq_pack_w8", _lib.ptr(codes), N, K, _lib.ptr(kp), Kp, _lib.ptr(out), _lib.stream())
@@ -146,7 +154,15 @@ class PackedWeight:
         self.bias = (bias.detach().float().contiguous().to(dev) if bias is not None
                      else torch.zeros(self.N, device=dev))
         self._natural = None
+        self._natural_frag = None
         self._vn = None
+
+    def natural_frag(self):
+        """the natural-order weights fragment-major (dgq_pack_w4 layout 2), W4 only; None otherwise"""
+        if self._natural_frag is None and self.bits == 4 and GEMM_PANEL:
+            perm = natural_kperm(self.C, self.taps)
+            self._natural_frag = pack_weight(self.codes, perm, perm.numel(), 4, W4_FRAG_LAYOUT)
+        return self._natural_frag
 
     def natural(self):
         if self._natural is None:
@@ -258,11 +274,13 @@ class ActBinding:
             self.cflush = cfl.to(dev)
             self.ccoef = flush_coefficients(layout.cdelta, cfl).to(dev)          # the same information as scalar-loadable coefficients
             self.wpacked = pack_weight(pw.codes, layout.kperm, layout.Kp, pw.bits)
+            self.wfrag = pack_weight(pw.codes, layout.kperm, layout.Kp, 4, W4_FRAG_LAYOUT) if (pw.bits == 4 and GEMM_PANEL) else None
             U = (pw.centered() @ layout.kcoef.to(dev)).float()             # Σ_k δ_k(o − z_k)(qw − zw)
             self.gamma = (pw.bias + pw.alpha * U).contiguous()
             self.n_groups = layout.n_groups
         else:
             self.wpacked, self.Kp = pw.natural()
+            self.wfrag = pw.natural_frag()
             self.ksrc = None
             self._koff = {}
             self.mdelta = layout.mdelta.to(dev).contiguous()
@@ -541,18 +559,80 @@ ATTN_LAUNCH_HOOK = None
 GEMM_LAUNCH_HOOK = None
 
 
-def gemm_wxa8(codes, rowsum, M, ab: ActBinding, out_dtype, out: Optional[torch.Tensor] = None, extra=None):
+def with_layer_tables(extra, ab: "ActBinding", M):
+    """extra (or a blank one) carrying the layer's optional operand images: the flush-coefficient table for the shapes the 256-row
+    kernel may take, the fragment-major weights for the short-K kernel"""
+    need_coef = ab.mode == "perK" and M >= 2048 and ab.pw.N >= 128
+    wfrag = getattr(ab, "wfrag", None)
+    if not need_coef and wfrag is None:
+        return extra
+    if extra is None:
+        extra = _lib.GemmExtra()
+        extra.res_div, extra.fq_T, extra.fq_D, extra._keep = 1, 1, 1, []
+    if need_coef:
+        extra.flush_coef = ab.ccoef.data_ptr()
+    if wfrag is not None:
+        extra.wfrag = wfrag.data_ptr()
+    return extra
+
+
+#: Linear / 1x1 layers whose whole padded K fits the short-K kernel's LDS panel run as ONE launch: the GEMM quantises its own rows
+#: (dgq_gemm_act_t) instead of reading the codes a dgq_quant_act launch wrote.  DGQ_GEMM_FUSE=0: the two-launch form everywhere.
+GEMM_FUSE = os.environ.get("DGQ_GEMM_FUSE", "1") == "1"
+
+
+def act_fuses(ab: "ActBinding", M, K, dtype, n_problems=1):
+    """True where quant_linear / quant_conv2d (1x1) may hand the layer to dgq_gemm_wxa8 with quantise-on-load"""
+    if not (GEMM_FUSE and GEMM_PANEL) or getattr(ab, "wfrag", None) is None or ab.pw.taps != 1 or K % 4 != 0 or dtype not in _lib.DTYPE_CODE:
+        return False
+    dt = _lib.DTYPE_CODE[dtype]
+    return bool(_lib.load().dgq_gemm_act_fuses(M, ab.pw.N, K, ab.Kp, ab.pw.bits, 0 if ab.mode == "perK" else 1, n_problems, dt, dt))
+
+
+def make_act(x2: torch.Tensor, ab: "ActBinding", pre=None, ln=None, rows_per_image=1):
+    """dgq_gemm_act_t for the rows x2 [M][K] (row stride = stride(0)) under the layer's activation quantizer; pre = (scale, shift,
+    act) a folded GroupNorm (+ SiLU), ln = (gamma, beta, eps) a folded LayerNorm.  Keeps its tensors alive on the struct."""
+    K = ab.pw.K
+    a = _lib.GemmAct()
+    a.x, a.x_dtype, a.ldx, a.K = x2.data_ptr(), _lib.DTYPE_CODE[x2.dtype], x2.stride(0), K
+    keep = [x2]
+    if ab.mode == "perK":
+        kd = ab.kdst(1, K, 1)
+        a.kdst, a.czp = kd.data_ptr(), ab.czp.data_ptr()
+        keep.append(kd)
+    a.bits = ab.abits
+    a.rows_per_image, a.pre_act = rows_per_image, 0
+    if pre is not None:
+        if pre[0] is not None:
+            a.pre_scale, a.pre_shift = pre[0].data_ptr(), pre[1].data_ptr()
+            keep += [pre[0], pre[1]]
+        a.pre_act = pre[2]
+    if ln is not None:
+        g, b = as_f32(ln[0]), as_f32(ln[1])
+        a.ln_gamma, a.ln_beta, a.ln_eps = g.data_ptr(), b.data_ptr(), float(ln[2])
+        keep += [g, b]
+    a._keep = keep
+    return a
+
+
+def gemm_act(x2, M, ab: "ActBinding", out_dtype, extra=None, pre=None, ln=None, rows_per_image=1, out=None):
+    """one launch: aqtizer(x2) @ Wᵀ with the layer's epilogue — dgq_gemm_wxa8 with quantise-on-load (see act_fuses)"""
+    act = make_act(x2, ab, pre, ln, rows_per_image)
+    extra = with_layer_tables(extra, ab, M)
+    extra.act = _c.cast(_c.pointer(act), _c.c_void_p)
+    extra._act_keep = act
+    dummy = ab.wfrag                                          # codes / rowsum are ignored under quantise-on-load: any device pointer
+    return gemm_wxa8(dummy, dummy, M, ab, out_dtype, out=out, extra=extra, _fused_bytes=x2.element_size() * M * ab.pw.K)
+
+
+def gemm_wxa8(codes, rowsum, M, ab: ActBinding, out_dtype, out: Optional[torch.Tensor] = None, extra=None, _fused_bytes=0):
     pw = ab.pw
     ws = workspace(codes.device)
-    if ab.mode == "perK" and M >= 2048 and pw.N >= 128:      # shapes the 256-row kernel may take: hand it the coefficient table
-        if extra is None:
-            extra = _lib.GemmExtra()
-            extra.res_div, extra.fq_T, extra.fq_D, extra._keep = 1, 1, 1, []
-        extra.flush_coef = ab.ccoef.data_ptr()
+    extra = with_layer_tables(extra, ab, M)
     if out is None:
         out = torch.empty((M, pw.N // 2 if (extra is not None and extra.geglu) else pw.N), dtype=out_dtype, device=codes.device)
     per_m = 0 if ab.mode == "perK" else 1
-    parts = rowsum.shape[0] if rowsum.dim() == 2 else 1
+    parts = rowsum.shape[0] if (rowsum.dim() == 2 and not _fused_bytes) else 1
     def issue():
         _lib_call("dgq_gemm_wxa8", _lib.ptr(codes), _lib.ptr(rowsum), parts, M, ab.Kp, _lib.ptr(ab.wpacked), pw.bits, pw.N,
                   per_m,
@@ -584,9 +664,48 @@ def quant_linear(x: torch.Tensor, ab: ActBinding, pre_act=0, residual=None, fq=N
         res2 = residual.reshape(-1, ab.pw.N)
         if not res2.is_contiguous():
             res2 = res2.contiguous()
+    if pre_act != 2 and act_fuses(ab, rows, K, x.dtype):
+        y = gemm_act(x2, rows, ab, x.dtype, extra=make_extra(res2, fq, geglu=geglu), pre=pre, ln=ln)
+        return y.view(*x.shape[:-1], y.shape[-1])
     codes, rowsum, M = quant_act(x2, rows, 1, 1, K, 1, 1, 1, 0, ab, pre, ln)
     y = gemm_wxa8(codes, rowsum, M, ab, x.dtype, extra=make_extra(res2, fq, geglu=geglu))
     return y.view(*x.shape[:-1], y.shape[-1])
+
+
+def _quant_linear_multi_fused(x, x2, M, bindings, ln):
+    """quant_linear_multi as dgq_gemm_wxa8_batch launches with quantise-on-load: one launch per scale mode and 8 layers"""
+    dev = x2.device
+    outs = [torch.empty((M, ab.pw.N), dtype=x.dtype, device=dev) for ab in bindings]
+    groups = {}
+    for i, ab in enumerate(bindings):
+        groups.setdefault(0 if ab.mode == "perK" else 1, []).append(i)
+    for per_m, idxs in groups.items():
+        for j0 in range(0, len(idxs), 8):
+            chunk = idxs[j0:j0 + 8]
+            arr = (_lib.GemmArgs * len(chunk))()
+            extras = []
+            for g, i in zip(arr, chunk):
+                ab, pw = bindings[i], bindings[i].pw
+                act = make_act(x2, ab, None, ln)
+                ex = with_layer_tables(None, ab, 0)
+                ex.act = _c.cast(_c.pointer(act), _c.c_void_p)
+                extras.append((ex, act))
+                g.codes, g.rowsum, g.rowsum_parts, g.M, g.Kp = ab.wfrag.data_ptr(), ab.wfrag.data_ptr(), 1, M, ab.Kp
+                g.wpacked, g.w_bits, g.N, g.per_m = ab.wpacked.data_ptr(), pw.bits, pw.N, per_m
+                g.cdelta, g.cflush = (ab.cdelta.data_ptr(), ab.cflush.data_ptr()) if not per_m else (None, None)
+                g.mdelta, g.mzp = (ab.mdelta.data_ptr(), ab.mzp.data_ptr()) if per_m else (None, None)
+                g.L, g.offset = (ab.L if per_m else 1), ab.offset
+                g.alpha, g.zw, g.gamma, g.vn = pw.alpha.data_ptr(), pw.zw.data_ptr(), ab.gamma.data_ptr(), (ab.vn.data_ptr() if per_m else None)
+                g.y, g.y_dtype, g.ldy = outs[i].data_ptr(), _lib.DTYPE_CODE[outs[i].dtype], outs[i].stride(0)
+                g.extra = _c.cast(_c.pointer(ex), _c.c_void_p)
+            n_chunk = len(chunk)
+
+            def issue(arr=arr, n_chunk=n_chunk, _keep=extras):
+                _lib_call("dgq_gemm_wxa8_batch", n_chunk, _c.cast(arr, _c.c_void_p), _lib.stream())
+            issue()
+            if GEMM_LAUNCH_HOOK is not None:
+                GEMM_LAUNCH_HOOK(issue, [(M, bindings[i], outs[i].element_size()) for i in chunk])
+    return [o.view(*x.shape[:-1], o.shape[-1]) for o in outs]
 
 
 def quant_linear_multi(x: torch.Tensor, bindings, ln=None):
@@ -601,6 +720,8 @@ def quant_linear_multi(x: torch.Tensor, bindings, ln=None):
     M = x2.shape[0]
     dev = x2.device
     lib = _lib.load()
+    if all(ab.pw.K == Kin and act_fuses(ab, M, Kin, x.dtype, min(len(bindings), 8)) for ab in bindings):
+        return _quant_linear_multi_fused(x, x2, M, bindings, ln)
     lnp = (as_f32(ln[0]), as_f32(ln[1]), float(ln[2])) if ln else None
     qa, keep = [], []
     for ab in bindings:
@@ -647,6 +768,7 @@ def quant_linear_multi(x: torch.Tensor, bindings, ln=None):
         for j0 in range(0, len(idxs), 8):
             chunk = idxs[j0:j0 + 8]
             arr = (_lib.GemmArgs * len(chunk))()
+            extras = []
             for g, i in zip(arr, chunk):
                 ab, pw = bindings[i], bindings[i].pw
                 _v, _pm, _a, codes, rowsum, parts = qa[i]
@@ -656,10 +778,13 @@ def quant_linear_multi(x: torch.Tensor, bindings, ln=None):
                 g.mdelta, g.mzp = (ab.mdelta.data_ptr(), ab.mzp.data_ptr()) if per_m else (None, None)
                 g.L, g.offset = (ab.L if per_m else 1), ab.offset
                 g.alpha, g.zw, g.gamma, g.vn = pw.alpha.data_ptr(), pw.zw.data_ptr(), ab.gamma.data_ptr(), (ab.vn.data_ptr() if per_m else None)
-                g.y, g.y_dtype, g.ldy, g.extra = outs[i].data_ptr(), _lib.DTYPE_CODE[outs[i].dtype], outs[i].stride(0), None
+                ex = with_layer_tables(None, ab, 0)
+                extras.append(ex)
+                g.y, g.y_dtype, g.ldy = outs[i].data_ptr(), _lib.DTYPE_CODE[outs[i].dtype], outs[i].stride(0)
+                g.extra = _c.cast(_c.pointer(ex), _c.c_void_p) if ex is not None else None
             n_chunk = len(chunk)
 
-            def issue(arr=arr, n_chunk=n_chunk):
+            def issue(arr=arr, n_chunk=n_chunk, _keep=extras):
                 _lib_call("dgq_gemm_wxa8_batch", n_chunk, _c.cast(arr, _c.c_void_p), _lib.stream())
             issue()
             if GEMM_LAUNCH_HOOK is not None:
@@ -693,6 +818,15 @@ def quant_conv2d(x: torch.Tensor, ab: ActBinding, kh, kw, stride, pad, norm=None
         res2 = residual.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1).reshape(M, ab.pw.N)
     elif bias_rows is not None:                       # [B][N]: one row per image, broadcast over its Ho*Wo positions
         res2, res_div = bias_rows.contiguous(), M // B
+    N = ab.pw.N
+    if kh == 1 and kw == 1 and stride == 1 and pad == 0 and act_fuses(ab, M, C, x.dtype):
+        # a 1x1 convolution is a Linear layer over the pixels: one launch, the GEMM quantises its own rows (dgq_gemm_act_t)
+        part = torch.empty((M // 16, N, 2), dtype=torch.float32, device=x.device) if (GN_FROM_GEMM and gn_out and (Ho * Wo) % 16 == 0 and N % 4 == 0) else None
+        y = gemm_act(x_store.reshape(M, C), M, ab, x.dtype, extra=make_extra(res2, res_div=res_div, gn_partial=part), pre=pre, rows_per_image=H * W)
+        out = y.view(B, Ho, Wo, N).permute(0, 3, 1, 2)
+        if part is not None:
+            out._dgq_gn = dict(parts=[(part, N)], B=B, HW=Ho * Wo, C=N, ver=out._version)
+        return out
     implicit = CONV_IMPLICIT and ab.mode == "scalar" and kh * kw > 1 and C % 16 == 0 and ab.pw.bits == 4
     conv_desc = None
     if implicit:

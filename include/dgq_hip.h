@@ -48,6 +48,9 @@ int dgq_quantize_weight(const float* w, const float* delta, const float* zp, con
  * packed position the source k (or -1 = zero padding); NULL = identity (Kp == K).  Layout per 8
  * consecutive kp: one 32-bit word, byte j holds kp+j in its low nibble and kp+4+j in its high nibble,
  * so that (word & 0x0F0F0F0F) and ((word >> 4) & 0x0F0F0F0F) are 4 consecutive int8 each.
+ * layout 2 (dgq_gemm_extra_t.wfrag): fragment-major for V_MFMA_I32_32X32X32_I8 B operands — N padded to 32-column tiles (zero
+ * rows), [ceil(N/32)][Kp/64] blocks of 1 KiB; in block (j, p) lane l = (k half h << 5) | (n & 31) owns the 16 bytes at l·16: the two
+ * words of K half h of chunk 2p, then those of chunk 2p + 1, column n = 32j + (l & 31).  `packed` holds ceil(N/32)·32·Kp/2 bytes.
  * layout 0: rows as described.  layout 1 (what dgq_gemm_wxa8 and dgq_linear_smallm_batch read): in rows n with (n & 16) != 0 the two
  * 8-byte halves of every 16 packed bytes (= one 32-wide chunk) are exchanged — the GEMM stages 16-byte pieces into LDS by
  * DMA and a lane reads the 8 bytes of its K half; with the exchange the 32 lanes of a read cover all 64 LDS banks. */
@@ -198,6 +201,23 @@ typedef struct dgq_gemm_conv {
     int pixsum_parts;
 } dgq_gemm_conv_t;
 
+/* Quantise-on-load INSIDE the GEMM (dgq_gemm_extra_t.act; Linear / 1x1 layers): instead of reading the int8 codes a dgq_quant_act
+ * launch wrote, the short-K kernel quantises the rows of its own workgroup tile straight from the floating-point input into its LDS
+ * operand panel — `x = self.aqtizer(x)` (quant_layer.py:640-641) and F.linear (:659) in ONE launch, no code matrix in HBM.  Same
+ * quantiser arithmetic as dgq_quant_act (exact-division codes, the same folded prologues); `codes` / `rowsum` of the call are
+ * ignored (pass any non-NULL pointers).  The library takes it only where dgq_gemm_act_fuses() says so; otherwise DGQ_EINVAL.
+ *   x [M][ldx] of x_dtype (the layer's input rows; K = C source channels, ldx >= K, 16-byte aligned rows);
+ *   per_m == 0: kdst [K] = packed position kp of source channel c (the inverse of dgq_quant_act's ksrc), czp [Kp/32] the chunks'
+ *               zero points (the scales are the call's cdelta); per_m == 1: natural order, tables mdelta / mzp / L of the call;
+ *   bits: activation bits; pre_scale / pre_shift [M / rows_per_image][K] (or NULL) + pre_act (0 / 1 = SiLU): a GroupNorm folded
+ *   into the load as in dgq_quant_act; ln_gamma / ln_beta [K] (or NULL) + ln_eps: a LayerNorm over each row folded into the load. */
+typedef struct dgq_gemm_act {
+    const void* x; int x_dtype; int ldx; int K;
+    const int32_t* kdst; const float* czp; int bits;
+    const float* pre_scale; const float* pre_shift; int rows_per_image; int pre_act;
+    const float* ln_gamma; const float* ln_beta; float ln_eps;
+} dgq_gemm_act_t;
+
 typedef struct dgq_gemm_extra {
     const void* residual;
     int ldr;
@@ -216,6 +236,11 @@ typedef struct dgq_gemm_extra {
                                       * K tile's last chunk under a clear mark cflush == 2: cdelta[c]), then one clear flag per K
                                       * tile.  Derived from cdelta / cflush (the library forms the same table itself when this
                                       * is NULL); given here, the 256-row kernel reads it with scalar loads. */
+    const void* wfrag;               /* (or NULL; w_bits == 4) the SAME weights as `wpacked` in dgq_pack_w4 layout 2 (fragment-major,
+                                      * [ceil(N/32)·32][Kp/2] bytes, 16-byte aligned): lets the library take its short-K kernel
+                                      * (gemm_panel.hip: the activations' whole K slice in LDS, weights streamed straight into MFMA
+                                      * B fragments) for the launches it is faster on; results are those of the other kernels. */
+    const dgq_gemm_act_t* act;       /* (or NULL) quantise-on-load inside the GEMM, see dgq_gemm_act_t; needs wfrag */
 } dgq_gemm_extra_t;
 
 int dgq_gemm_wxa8(const int8_t* codes, const float* rowsum, int rowsum_parts, int M, int Kp,
@@ -225,6 +250,9 @@ int dgq_gemm_wxa8(const int8_t* codes, const float* rowsum, int rowsum_parts, in
                   const float* alpha, const float* zw, const float* gamma, const float* vn,
                   void* y, int y_dtype, int ldy, void* workspace, size_t workspace_bytes,
                   const dgq_gemm_extra_t* extra, void* stream);
+/* 1 where dgq_gemm_wxa8 / _batch accept dgq_gemm_extra_t.act for a layer of this shape (n_problems of one launch, all alike): the
+ * whole padded K must fit the short-K kernel's LDS panel and the launch must be one it would give that kernel anyway. */
+int dgq_gemm_act_fuses(int M, int N, int K, int Kp, int w_bits, int per_m, int n_problems, int x_dtype, int y_dtype);
 /* The same with the arguments in a struct, for 1..8 problems in ONE launch (dgq_gemm_wxa8_batch): problems that share
  * weight bits, scale mode (per_m) and output dtype, e.g. the q / k / v projections of one attention or the to_k / to_v of
  * every cross-attention (same text context).  The launch plan (tile shape) of problem 0 serves all; no K split. */

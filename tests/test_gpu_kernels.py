@@ -78,7 +78,8 @@ def test_weight_codes_match_oracle(dev):
 
 
 # ------------------------------------------------------------------------------------------ MFMA layout
-def _gemm_exact_case(dev, M, N, Kp, wbits, seed=1):
+def _gemm_exact_case(dev, M, N, Kp, wbits, seed=1, frag=False):
+    """frag: also hand the library the fragment-major weight image (dgq_gemm_extra_t.wfrag) — what the short-K panel kernel reads"""
     from dgq_amd import _lib, ops
     import ctypes
     g = torch.Generator().manual_seed(seed)
@@ -117,12 +118,19 @@ def _gemm_exact_case(dev, M, N, Kp, wbits, seed=1):
         wp = qs.to(torch.int8).to(dev)
     y = torch.empty(M, N, dtype=torch.float32, device=dev)
     lib = _lib.load()
+    extra = None
+    if frag:
+        wf = ops.pack_weight(q.to(torch.uint8).to(dev), None, Kp, 4, ops.W4_FRAG_LAYOUT)
+        ex = _lib.GemmExtra()
+        ex.res_div, ex.fq_T, ex.fq_D = 1, 1, 1
+        ex.wfrag = wf.data_ptr()
+        extra = ctypes.byref(ex)
     t = lambda x: x.to(dev).contiguous()
     cdg, flg, al, zwg, ga, rs = t(gscale), t(fl), t(alpha), t(zw), t(gamma), t(rowsum)
     rc = lib.dgq_gemm_wxa8(_lib.ptr(codes), _lib.ptr(rs), 1, M, Kp, _lib.ptr(wp), wbits, N, 0,
                            _lib.ptr(cdg), _lib.ptr(flg), None, None, 1, ctypes.c_float(128.0),
                            _lib.ptr(al), _lib.ptr(zwg), _lib.ptr(ga), None,
-                           _lib.ptr(y), 0, N, _lib.ptr(ws), ws.numel(), None, _lib.stream())
+                           _lib.ptr(y), 0, N, _lib.ptr(ws), ws.numel(), extra, _lib.stream())
     _lib.check(rc, "dgq_gemm_wxa8")
     torch.cuda.synchronize()
     assert torch.equal(y.cpu().double(), expect), (M, N, Kp, wbits, (y.cpu().double() - expect).abs().max())
@@ -140,7 +148,7 @@ def _gemm_exact_case(dev, M, N, Kp, wbits, seed=1):
     rc = lib.dgq_gemm_wxa8(_lib.ptr(codes), _lib.ptr(rs), 1, M, Kp, _lib.ptr(wp), wbits, N, 1,
                            None, None, _lib.ptr(mdg), _lib.ptr(mzg), L, ctypes.c_float(128.0),
                            _lib.ptr(al), _lib.ptr(zwg), _lib.ptr(ga), _lib.ptr(vng),
-                           _lib.ptr(y), 0, N, _lib.ptr(ws), ws.numel(), None, _lib.stream())
+                           _lib.ptr(y), 0, N, _lib.ptr(ws), ws.numel(), extra, _lib.stream())
     _lib.check(rc, "dgq_gemm_wxa8")
     torch.cuda.synchronize()
     got = y.cpu().double()
@@ -174,6 +182,191 @@ def test_gemm_exact_integer_big_kernel(dev, monkeypatch):
     monkeypatch.setenv("DGQ_GEMM_FORCE", "256,256,1")
     for (M, N, Kp, seed) in ((203, 332, 640, 3), (300, 700, 128, 5), (515, 260, 256, 6), (130, 513, 2176, 7), (700, 300, 384, 8)):
         _gemm_exact_case(dev, M, N, Kp, 4, seed=seed)
+
+
+PANEL_PLANS = ["P1,5,1", "P1,10,1", "P2,5,1", "P1,4,1", "P1,8,1", "P2,4,1", "P2,8,1", "P1,5,3", "P2,4,2", "P1,10,4"]
+
+
+@pytest.mark.parametrize("plan", PANEL_PLANS)
+def test_gemm_exact_integer_panel_kernel(plan, dev, monkeypatch):
+    """the short-K panel kernel (gemm_panel.hip; DGQ_GEMM_FORCE = P<TM>,<NW>,<splits>): exact integers on ragged M / N edges, a
+    single K tile, more K tiles than the weight ring is deep (clears of the running totals inside), K split over workgroups with
+    the slab combine; per-K and per-M epilogues"""
+    monkeypatch.setenv("DGQ_GEMM_FORCE", plan)
+    splits = int(plan.split(",")[2])
+    for (M, N, Kp, seed) in ((203, 332, 640, 3), (64, 320, 128, 5), (300, 136, 1024, 6), (100, 200, 2048, 7), (33, 1290, 384, 8)):
+        if splits > 1 and Kp // 128 < 2 * splits:
+            continue
+        _gemm_exact_case(dev, M, N, Kp, 4, seed=seed, frag=True)
+
+
+FUSED_PLANS = ["F1,10,1,1", "F1,5,1,1", "F1,5,1,2", "F1,4,1,4", "F1,8,1,2", "F1,4,1,2"]
+
+
+@pytest.mark.parametrize("plan", FUSED_PLANS)
+@pytest.mark.parametrize("mode", ["perM", "perK"])
+def test_gemm_quantise_on_load_exact_integer(plan, mode, dev, monkeypatch):
+    """dgq_gemm_act_t (gemm_panel.hip, FUSE): the GEMM quantises its own rows.  Inputs are exact multiples of power-of-two scales, so
+    the codes, the row sums and every fp32 step are exact: y must EQUAL the float64 evaluation of quant_layer.py:295-299 + :659 on
+    integer data — per-M (natural K order, K padding written as zero codes) and per-K (codes scattered through kdst into their DGQ
+    groups, group padding zero), ragged M / N, every fused configuration incl. K waves."""
+    from dgq_amd import _lib, ops
+    import ctypes
+    monkeypatch.setenv("DGQ_GEMM_FORCE", plan)
+    monkeypatch.setenv("DGQ_GEMM_FUSE_ALL", "1")           # wherever it fits, not only where the planner finds it faster
+    g = torch.Generator().manual_seed(11)
+    lib = _lib.load()
+    ws = ops.workspace(dev)
+    for (M, N, K, Kp) in ((203, 332, 320, 640 if mode == "perK" else 384), (64, 320, 100, 256 if mode == "perK" else 128), (97, 1290, 1280, 1664 if mode == "perK" else 1280)):
+        nch = Kp // 32
+        s = torch.randint(-16, 16, (M, K), generator=g, dtype=torch.int32)          # the centred codes the quantiser must find
+        s[::7, ::13] = -128
+        s[3::11, 5::17] = 127
+        q = torch.randint(0, 16, (N, Kp), generator=g, dtype=torch.int32)
+        alpha = torch.tensor([2.0 ** ((n % 3) - 1) for n in range(N)])
+        zw = torch.tensor([float((n * 7) % 16) for n in range(N)])
+        gamma = torch.tensor([float(n % 11) - 5 for n in range(N)])
+        t = lambda v: v.to(dev).contiguous()
+        wp = ops.pack_weight(q.to(torch.uint8).to(dev), None, Kp, 4)
+        wf = ops.pack_weight(q.to(torch.uint8).to(dev), None, Kp, 4, ops.W4_FRAG_LAYOUT)
+        act = _lib.GemmAct()
+        ex = _lib.GemmExtra()
+        ex.res_div, ex.fq_T, ex.fq_D = 1, 1, 1
+        ex.wfrag = wf.data_ptr()
+        y = torch.empty(M, N, dtype=torch.float32, device=dev)
+        al, zwg, ga = t(alpha), t(zw), t(gamma)
+        if mode == "perM":
+            L = 5
+            md = torch.tensor([2.0 ** (i - 2) for i in range(L)])
+            mz = torch.tensor([float(100 + 9 * i) for i in range(L)])
+            mi = torch.arange(M) % L
+            x = (s.double() + 128.0 - mz[mi][:, None].double()) * md[mi][:, None].double()          # rne(x/δ) + z = s + 128 exactly
+            vn = torch.tensor([float((n * 5) % 23) - 11 for n in range(N)])
+            acc = s.double() @ q[:, :K].double().T
+            rowsum = s.double().sum(1)
+            expect = alpha[None].double() * md[mi][:, None].double() * (acc - zw[None].double() * rowsum[:, None]
+                                                                       + (128.0 - mz[mi][:, None].double()) * vn[None].double()) + gamma[None].double()
+            xg, mdg, mzg, vng = t(x.float()), t(md), t(mz), t(vn)
+            act.x, act.x_dtype, act.ldx, act.K, act.bits, act.rows_per_image = xg.data_ptr(), 0, K, K, 8, 1
+            ex.act = ctypes.cast(ctypes.pointer(act), ctypes.c_void_p)
+            rc = lib.dgq_gemm_wxa8(_lib.ptr(wf), _lib.ptr(wf), 1, M, Kp, _lib.ptr(wp), 4, N, 1, None, None, _lib.ptr(mdg), _lib.ptr(mzg), L,
+                                   ctypes.c_float(128.0), _lib.ptr(al), _lib.ptr(zwg), _lib.ptr(ga), _lib.ptr(vng), _lib.ptr(y), 0, N,
+                                   _lib.ptr(ws), ws.numel(), ctypes.byref(ex), _lib.stream())
+        else:
+            # K source channels spread over the nch chunks (chunk c gets every channel k with k % nch == c: a permutation with holes)
+            pos = []
+            fill = [0] * nch
+            for k in range(K):
+                c = k % nch
+                pos.append(32 * c + fill[c])
+                fill[c] += 1
+            assert max(fill) <= 32
+            kdst = torch.tensor(pos, dtype=torch.int32)
+            cd = torch.tensor([2.0 ** ((i % 5) - 2) for i in range(nch)])
+            gend = torch.tensor([(i % 3 == 1 or i == nch - 1) for i in range(nch)])
+            gscale = cd.clone()
+            for i in range(nch - 2, -1, -1):
+                if not gend[i]:
+                    gscale[i] = gscale[i + 1]
+            czp = torch.tensor([float(90 + 7 * (i % 9)) for i in range(nch)])
+            for i in range(nch - 2, -1, -1):
+                if not gend[i]:
+                    czp[i] = czp[i + 1]
+            ch = kdst.long() // 32
+            x = (s.double() + 128.0 - czp[ch][None].double()) * gscale[ch][None].double()
+            sp = torch.zeros(M, Kp, dtype=torch.float64)
+            sp[:, kdst.long()] = s.double()
+            acc = torch.zeros(M, N, dtype=torch.float64)
+            for c in range(nch):
+                acc += gscale[c].double() * (sp[:, 32 * c:32 * c + 32] @ q[:, 32 * c:32 * c + 32].double().T)
+            rowsum = (sp * gscale.double().repeat_interleave(32)[None]).sum(1)
+            expect = alpha[None].double() * (acc - zw[None].double() * rowsum[:, None]) + gamma[None].double()
+            xg, cdg, flg, kdg, czg = t(x.float()), t(gscale), t(gend.to(torch.uint8)), t(kdst), t(czp)
+            act.x, act.x_dtype, act.ldx, act.K, act.bits, act.rows_per_image = xg.data_ptr(), 0, K, K, 8, 1
+            act.kdst, act.czp = kdg.data_ptr(), czg.data_ptr()
+            ex.act = ctypes.cast(ctypes.pointer(act), ctypes.c_void_p)
+            rc = lib.dgq_gemm_wxa8(_lib.ptr(wf), _lib.ptr(wf), 1, M, Kp, _lib.ptr(wp), 4, N, 0, _lib.ptr(cdg), _lib.ptr(flg), None, None, 1,
+                                   ctypes.c_float(128.0), _lib.ptr(al), _lib.ptr(zwg), _lib.ptr(ga), None, _lib.ptr(y), 0, N,
+                                   _lib.ptr(ws), ws.numel(), ctypes.byref(ex), _lib.stream())
+        _lib.check(rc, "dgq_gemm_wxa8")
+        torch.cuda.synchronize()
+        got = y.cpu().double()
+        assert torch.equal(got, expect), (plan, mode, M, N, K, (got - expect).abs().max())
+
+
+@pytest.mark.parametrize("M,K,N,mode,fold", [(8192, 320, 320, "perK", "ln"), (8192, 320, 320, "perM", "ln"), (2048, 640, 640, "perK", None),
+                                            (512, 1280, 1280, "perM", None), (512, 1280, 1280, "perK", "ln"), (154, 768, 320, "perK", None),
+                                            (2048, 640, 5120, "perK", "geglu_out"), (8192, 320, 320, "scalar", "gn_silu")])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_quant_linear_fused_equals_two_launches(M, K, N, mode, fold, dtype, dev, monkeypatch):
+    """ops.quant_linear / quant_conv2d (1x1) with quantise-on-load inside the GEMM against the dgq_quant_act + dgq_gemm_wxa8 pair on the
+    same layer: per-M without a folded norm the codes and the int32 sums are the same numbers -> equal outputs; per-K differs in
+    the order of the fp32 group sums, a folded LayerNorm / GroupNorm in the rounding of the statistics (isolated code flips)."""
+    from dgq_amd import ops, synth
+    from dgq_amd.plan import plan_act
+    monkeypatch.setenv("DGQ_GEMM_FUSE_ALL", "1")
+    g = torch.Generator().manual_seed(3)
+    w = torch.randn(N, K, generator=g) * 0.05
+    wd, wz = synth.channel_minmax(w, 4)
+    pw = ops.PackedWeight(w.to(dev), wd.to(dev), wz.to(dev), None, torch.randn(N, generator=g).to(dev), 4, K, 1)
+    if mode == "perK":
+        d, z = synth._group_params(K, 16, 8, "fused|%d" % K, 0)
+        lay = plan_act(d.view(1, 1, -1), z.view(1, 1, -1), "linear", K, 1, 8)
+    elif mode == "perM":
+        d, z = synth._group_params(64, 16, 8, "fused|%d" % K, 0)
+        lay = plan_act(d.view(1, -1, 1), z.view(1, -1, 1), "linear", K, 1, 8)
+    else:
+        lay = plan_act(torch.tensor(0.031), torch.tensor(117.0), "linear", K, 1, 8)
+    ab = ops.ActBinding(lay, pw, 8)
+    x = torch.randn(M, K, generator=g).to(dev).to(dtype)
+    res = torch.randn(M, N if fold != "geglu_out" else N // 2, generator=g).to(dev).to(dtype)
+
+    def run():
+        if fold == "gn_silu":                                  # a 1x1 convolution behind GroupNorm + SiLU (Transformer2D proj_in, shortcuts)
+            xi = x.view(2, 64, 64, K).permute(0, 3, 1, 2)
+            gam, bet = torch.linspace(0.5, 1.5, K, device=dev), torch.linspace(-0.2, 0.2, K, device=dev)
+            return ops.quant_conv2d(xi, ab, 1, 1, 1, 0, norm=(32, 1e-5, gam, bet, 1)).permute(0, 2, 3, 1).reshape(M, N)
+        ln = (torch.linspace(0.5, 1.5, K, device=dev), torch.linspace(-0.1, 0.1, K, device=dev), 1e-5) if fold == "ln" else None
+        if fold == "geglu_out":
+            return ops.quant_linear(x, ab, geglu=True)
+        return ops.quant_linear(x, ab, residual=res, ln=ln)
+    assert ops.act_fuses(ab, M, K, dtype)
+    y1 = run()
+    monkeypatch.setattr(ops, "GEMM_FUSE", False)
+    y0 = run()
+    torch.cuda.synchronize()
+    assert y1.shape == y0.shape and torch.isfinite(y1.float()).all()
+    if mode != "perK" and fold is None and dtype == torch.float32:
+        assert torch.equal(y1, y0)
+    else:
+        tol = 2e-3 if fold in ("ln", "gn_silu") else (3e-3 if dtype != torch.float32 else 2e-6)
+        assert rel_l2(y1, y0) < tol, rel_l2(y1, y0)
+
+
+def test_int4_fragment_major_layout(dev):
+    """dgq_pack_w4 layout 2 (the panel kernel's weight image): unpacks to the same codes; block (j, p), lane (h << 5) | (n & 31) holds
+    the two words of K half h of chunk 2p, then of chunk 2p + 1, of column 32j + (n & 31); columns past N are zero"""
+    from dgq_amd import ops
+    g = torch.Generator().manual_seed(2)
+    N, K, Kp = 77, 200, 256
+    codes = torch.randint(0, 16, (N, K), generator=g, dtype=torch.uint8)
+    p1 = ops.pack_weight(codes.to(dev), None, Kp, 4)
+    p2 = ops.pack_weight(codes.to(dev), None, Kp, 4, ops.W4_FRAG_LAYOUT)
+    assert p2.shape == (96, Kp // 2)
+    assert torch.equal(ops.unpack_w4(p2, Kp, layout=2).cpu()[:N], ops.unpack_w4(p1, Kp).cpu())
+    # explicit image check against layout 0
+    from dgq_amd import _lib
+    p0 = torch.empty_like(p1)
+    _lib.check(_lib.load().dgq_pack_w4(_lib.ptr(codes.to(dev)), N, K, None, Kp, 0, _lib.ptr(p0), _lib.stream()), "dgq_pack_w4")
+    w0 = torch.zeros(96, Kp // 8, dtype=torch.int32)
+    w0[:N] = p0.cpu().view(torch.int32).view(N, Kp // 8)
+    img = p2.cpu().view(torch.int32).view(3, Kp // 64, 64, 4)            # [column tile][chunk pair][lane][word]
+    for j in range(3):
+        for pr in range(Kp // 64):
+            for lane in (0, 5, 31, 32, 47, 63):
+                n, h = 32 * j + (lane & 31), lane >> 5
+                expect = [w0[n, (2 * pr) * 4 + 2 * h], w0[n, (2 * pr) * 4 + 2 * h + 1], w0[n, (2 * pr + 1) * 4 + 2 * h], w0[n, (2 * pr + 1) * 4 + 2 * h + 1]]
+                assert img[j, pr, lane].tolist() == [int(e) for e in expect]
 
 
 # ------------------------------------------------------------------------------------------ activation codes
