@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256) void attn3_prep_kernel(const TIn* __restrict__
     DGQ_STAMP(0); DGQ_STAMP_REAL(1); DGQ_STAMP_WHERE(2);
 #ifdef DGQ_DIAG
     dg.t[13] = 1;                                           // kernel tag: 1 pre-pass, 2 statistics, 3 P·V
-#define DGQ_ATTN_PREP_DONE() do { DGQ_STAMP(9); DGQ_DIAG_DRAIN(); DGQ_STAMP(10); DGQ_STAMP_REAL(11); DGQ_DIAG_FLUSH(attn, 4, threadIdx.x >> 6, threadIdx.x & 63); } while (0)
+#define DGQ_ATTN_PREP_DONE() do { DGQ_STAMP(9); DGQ_DIAG_DRAIN(); DGQ_STAMP(10); DGQ_STAMP_REAL(11); DGQ_DIAG_FLUSH(attn, 4, (threadIdx.x >> 6) + 32768, threadIdx.x & 63); } while (0)
 #else
 #define DGQ_ATTN_PREP_DONE() do {} while (0)
 #endif
@@ -855,7 +855,7 @@ __global__ __launch_bounds__(64 * NW) void attn3_stats_kernel(AttnParams p) {
         if (t < p.T && h32 == 0)
             *reinterpret_cast<float4*>(p.stats_part + (((int64_t)blockIdx.z * p.B * p.H + bh) * p.T + t) * 4) = make_float4(m, l, m2raw * sl2, 0.0f);
         DGQ_STAMP(9); DGQ_DIAG_DRAIN(); DGQ_STAMP(10); DGQ_STAMP_REAL(11);
-        DGQ_DIAG_FLUSH(attn, NW, wid, lane);
+        DGQ_DIAG_FLUSH(attn, NW, wid + 16384, lane);
         return;
     }
     if (t < p.T && h32 == 0) {
@@ -879,7 +879,7 @@ __global__ __launch_bounds__(64 * NW) void attn3_stats_kernel(AttnParams p) {
         }
     }
     DGQ_STAMP(9); DGQ_DIAG_DRAIN(); DGQ_STAMP(10); DGQ_STAMP_REAL(11);
-    DGQ_DIAG_FLUSH(attn, NW, wid, lane);
+    DGQ_DIAG_FLUSH(attn, NW, wid + 16384, lane);
 }
 
 __global__ __launch_bounds__(256) void attn3_add_kernel(float* __restrict__ o, const float* __restrict__ part, int64_t n4) {
@@ -961,7 +961,8 @@ __global__ __launch_bounds__(64 * NW) void attn3_pv_kernel(AttnParams p) {
         inv_dk = 1.0f / dk;
         cq = -(p.fq[1].zp[0] - 0.5f * (p.fq[1].qmax + 1.0f)) * qt.z;
     }
-    const float l = p.stats[((int64_t)bh * p.T + tq) * 2 + 1];
+    const float2 ml = *reinterpret_cast<const float2*>(p.stats + ((int64_t)bh * p.T + tq) * 2);      // (m, l) of the row: ONE load, issued with the others
+    const float l = ml.y;
     float delta;
     if (p.mode == 1) {                                   // real-time δ: maximum of the statistics pass's slots
         delta = p.delta[lane];
@@ -972,7 +973,7 @@ __global__ __launch_bounds__(64 * NW) void attn3_pv_kernel(AttnParams p) {
     }
     const float sl2 = p.scale * LOG2E * qt.x * dk;
     const float nsl2 = -sl2;
-    const float m = p.stats[((int64_t)bh * p.T + tq) * 2] - cq * sl2;      // the row maximum in the units of the score tiles
+    const float m = ml.x - cq * sl2;                      // the row maximum in the units of the score tiles
     const float a0 = m + log2f(l) + log2f(delta);       // −log2(p/δ) = a0 − s2
     const float inv_l = 1.0f / l;
     // log2 codes by the magic-number route: rne(x) = bits(x + 1.5·2^23) − bits(1.5·2^23); clamp as integers to
@@ -1118,39 +1119,86 @@ __global__ __launch_bounds__(64 * NW) void attn3_pv_kernel(AttnParams p) {
     // global memory they were 5·16 dependent round trips between the stores (D = 160: +10 us on a 64-row call)
     // likewise the (fake-quantised) value row of the bypassed start-peak key
     float* vtab = reinterpret_cast<float*>(lds8);
-    if (VINT || p.skip > 0) {
-        __syncthreads();                                 // every wave's DMA has landed (its own vmcnt(0) above): the ring is free
-        for (int d = tid; d < G::DV; d += 64 * NW) {
-            if (VINT) {
-                const int idx = (p.fq[2].mode == 0 || d >= D) ? 0 : d;
-                vtab[d] = p.fq[2].delta[idx];
-                vtab[G::DV + d] = p.fq[2].zp[idx] - 0.5f * (p.fq[2].qmax + 1.0f);
-            }
-            if (p.skip > 0)
-                vtab[2 * G::DV + d] = d < D ? fq_apply(p.fq[2], load_any(p.v, p.io_dtype, ((int64_t)(b * p.S) * p.H + hd) * D + d), 0, d) : 0.0f;
+    __syncthreads();                                     // every wave's DMA has landed (its own vmcnt(0) above): the ring is free
+    // three tables of DV entries, always all three (an absent one holds its neutral value): the epilogue below is then free of
+    // per-element conditions
+    for (int d = tid; d < G::DV; d += 64 * NW) {
+        float t0 = 1.0f, t1 = 0.0f, t2 = 0.0f;
+        if (VINT) {
+            const int idx = (p.fq[2].mode == 0 || d >= D) ? 0 : d;
+            t0 = p.fq[2].delta[idx];
+            t1 = p.fq[2].zp[idx] - 0.5f * (p.fq[2].qmax + 1.0f);
         }
-        __syncthreads();
+        if (p.skip > 0 && d < D) t2 = fq_apply(p.fq[2], load_any(p.v, p.io_dtype, ((int64_t)(b * p.S) * p.H + hd) * D + d), 0, d);
+        vtab[d] = t0; vtab[G::DV + d] = t1; vtab[2 * G::DV + d] = t2;
     }
+    __syncthreads();
     DGQ_STAMP(6);
-    if (t < p.T) {
-        const int64_t ob = ((int64_t)(b * p.T + t) * p.H + hd) * D;
+    // The O^T tiles (lane = query, registers = 16 head-dim elements in runs of 4) leave through the idle ring, one 32 x 32 block at a
+    // time: dequantised with the block's table entries (read as 16-byte runs, all of a block's reads issued before its first
+    // use), written as they stand (ds_write_b128 per run of 4), read back row-wise, stored 16 bytes per lane in 128-byte row
+    // segments.  Before: per element two dependent LDS reads, a branch on the start-peak flag and a 4-byte store at a 32-row
+    // stride — 41-57 % of this launch at one wave per SIMD (profiles/r05_attention_timeline.txt).  Same-wave LDS round trip: no
+    // barrier.
+    {
+        constexpr int ELD = 36;
+        float* ep = reinterpret_cast<float*>(lds8) + 3 * G::DV + wid * (32 * ELD);
+        const int tw0 = bx * (32 * NW) + wid * 32;          // first query of this wave
+        const int er = lane >> 3, ec = (lane & 7) * 4;
+        const bool part = blockIdx.z > 0;                   // second key half of a split launch (fp32 o): added by attn3_add_kernel
+        const float pb = p.skip > 0 ? p_bypass : 0.0f;
 #pragma unroll
-        for (int j = 0; j < G::NDT; ++j)
+        for (int j = 0; j < G::NDT; ++j) {
+            DGQ_STAMP_NOW(dg_e0);
+            float4 t0[4], t1[4], t2[4];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int d = j * 32 + key_of(r, h32);
-                if (d < D) {
+            for (int k4 = 0; k4 < 4; ++k4) {
+                const int d = j * 32 + 8 * k4 + 4 * h32;
+                t0[k4] = *reinterpret_cast<const float4*>(vtab + d);
+                t1[k4] = *reinterpret_cast<const float4*>(vtab + G::DV + d);
+                t2[k4] = *reinterpret_cast<const float4*>(vtab + 2 * G::DV + d);
+            }
+#pragma unroll
+            for (int k4 = 0; k4 < 4; ++k4) {
+                const float a0[4] = {t0[k4].x, t0[k4].y, t0[k4].z, t0[k4].w}, a1[4] = {t1[k4].x, t1[k4].y, t1[k4].z, t1[k4].w};
+                const float a2[4] = {t2[k4].x, t2[k4].y, t2[k4].z, t2[k4].w};
+                float o4[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * k4 + e;                 // d = j·32 + key_of(r, h32) = j·32 + 8·k4 + 4·h32 + e
                     float o;
-                    if (VINT) {                              // o = δw·δv(d)·(Σ p̂'·c'v − z'v(d)·Σ p̂')
-                        o = delta * (vtab[d] * (oacc[j][r] - vtab[G::DV + d] * psum));
+                    if (VINT) o = delta * (a0[e] * (oacc[j][r] - a1[e] * psum));     // o = δw·δv(d)·(Σ p̂'·c'v − z'v(d)·Σ p̂')
+                    else o = delta * oacc[j][r];
+                    o4[e] = o + pb * a2[e];                   // start-peak: + p(key 0)·v̂(key 0)   (pb = 0 otherwise)
+                }
+                *reinterpret_cast<float4*>(ep + (lane & 31) * ELD + 8 * k4 + 4 * h32) = make_float4(o4[0], o4[1], o4[2], o4[3]);
+            }
+            DGQ_STAMP_ACC(7, dg_e0);                           // (diagnostic) dequantise + ds_write
+            DGQ_STAMP_NOW(dg_e1);
+            float4 ov[4];
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) ov[ps] = *reinterpret_cast<const float4*>(ep + (er + 8 * ps) * ELD + ec);
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) {
+                const int row = er + 8 * ps, tt = tw0 + row, d0 = j * 32 + ec;
+                const float4 v = ov[ps];
+                if (tt < p.T && d0 < D) {
+                    const int64_t oi = ((int64_t)(b * p.T + tt) * p.H + hd) * D + d0;
+                    if (part) {
+                        *reinterpret_cast<float4*>(p.o_part + oi) = v;
+                    } else if (p.io_dtype == DGQ_F32) {
+                        *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.o) + oi) = v;
+                    } else if (p.io_dtype == DGQ_F16) {
+                        __half hv[4] = {__float2half(v.x), __float2half(v.y), __float2half(v.z), __float2half(v.w)};
+                        *reinterpret_cast<uint2*>(reinterpret_cast<__half*>(p.o) + oi) = *reinterpret_cast<const uint2*>(hv);
                     } else {
-                        o = delta * oacc[j][r];
+                        __hip_bfloat16 hv[4] = {__float2bfloat16(v.x), __float2bfloat16(v.y), __float2bfloat16(v.z), __float2bfloat16(v.w)};
+                        *reinterpret_cast<uint2*>(reinterpret_cast<__hip_bfloat16*>(p.o) + oi) = *reinterpret_cast<const uint2*>(hv);
                     }
-                    if (p.skip > 0) o += p_bypass * vtab[2 * G::DV + d];
-                    if (blockIdx.z > 0) p.o_part[ob + d] = o;      // second key half of a split launch (fp32 o): added by attn3_add_kernel
-                    else store_any(p.o, p.io_dtype, ob + d, o);
                 }
             }
+            DGQ_STAMP_ACC(12, dg_e1);                          // (diagnostic) ds_read + global store issue
+        }
     }
     DGQ_STAMP(9); DGQ_DIAG_DRAIN(); DGQ_STAMP(10); DGQ_STAMP_REAL(11);
     DGQ_DIAG_FLUSH(attn, NW, wid, lane);
@@ -1164,7 +1212,9 @@ static int launch_attn3(AttnParams p, const void* q_raw, unsigned char* planes, 
     p.planes = planes;
     p.img_bytes = G::IMG_BYTES;
     constexpr int stats_lds = G::STATS_STAGES * G::K_PIECES * 1024;
-    constexpr int pv_lds = G::PV_STAGES * G::IMG_BYTES;
+    // (+ the P·V epilogue's scratch in the idle ring: 3·DV floats of V tables, then 32 x 36 floats per wave — 8 waves at most)
+    constexpr int pv_ring = G::PV_STAGES * G::IMG_BYTES, pv_scratch = 3 * G::DV * 4 + 8 * 32 * 36 * 4;
+    constexpr int pv_lds = pv_ring > pv_scratch ? pv_ring : pv_scratch;
     static_assert(stats_lds <= 160 * 1024 && pv_lds <= 160 * 1024, "LDS ring too large");
     // up to 138 KB of dynamic LDS (D = 160): opt in, once per device (the attribute is per device)
     static std::atomic<bool> attr_set[64];

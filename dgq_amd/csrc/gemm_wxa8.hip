@@ -767,6 +767,53 @@ static bool plan_panel_fuse(int M, int N, int Kp, bool per_m, GemmPlan& pl) {
     return true;
 }
 
+// The panel kernel on a code matrix (no quantise-on-load): where it beats the tile family (tools/tile_sweep.py sd and
+// tools/bench_gemm_cold.py with the P<TM>,<NW>,<S>,<KW> candidates, profiles/r05_gemm_tile_sweep_sd_with_panel.txt,
+// r05_gemm_cold_weights_sweep.txt): launches whose K slice fits the LDS panel and whose output is not store-bound —
+//   2048 x 640 x 2560 per-K 18.3 -> 13.6 us, 512 x 1280 x 1280 per-K 10.4 -> 8.7, 8192 x 320 x 2880 per-K 27.4 -> 23.1, 8192 x 320 x 1280
+//   per-K 19.0 -> 16.3, 2048 x 5120 x 640 per-M 21.3 -> 18.2, 512 x 10240 x 1280 per-M 18.8 -> 16.0, 128 x 1280 x 11520 (K split 4-6,
+//   cold weights) 14.7 -> 13.6 / 16.7 -> 15.0; long-K layers at M >= 512 and outputs beyond 20 M elements stay on the tile family.
+// Fewer than 2048 (row block, column tile) waves: two K waves per column tile.
+static bool plan_panel_codes(int M, int N, int Kp, bool per_m, size_t ws_bytes, GemmPlan& pl) {
+    // OFF by default: inside the step (one launch of each layer, every kernel cold) the same launches measure 0.3-0.9 % SLOWER with
+    // the panel kernel than on the tile family, class by class (profiles/r05_panel_plan_in_step_ab.txt) — the replayed-launch tables
+    // above do not carry over.  DGQ_GEMM_PANEL_PLAN=1 enables the rule (sweeps).
+    static const bool on = [] { const char* e = getenv("DGQ_GEMM_PANEL_PLAN"); return e && *e == '1'; }();
+    if (!on || M < 32 || N < 128 || (double)M * N > 2.0e7) return false;
+    const int nk = Kp / BK;
+    int splits = 1;
+    if (nk > 25) {
+        if (M <= 160) splits = (nk + 23) / 24;
+        else if (M <= 512 && nk <= 48) splits = 2;
+        else return false;
+        if ((size_t)splits * M * N * 4 > ws_bytes) return false;
+    }
+    const long waves = (long)((M + 31) / 32) * ((N + 31) / 32) * splits;
+    int kw = waves < 2048 ? 2 : 1;
+    int nw;
+    if (kw == 2) nw = (M > 512 && N % 160 == 0) ? 5 : 4;
+    else nw = (N % 320 == 0 && N <= 640) ? 10 : (N % 256 == 0 ? 8 : (N % 160 == 0 ? 5 : 4));
+    {   // experiment hook: DGQ_GEMM_PANEL_MASK — 1: K-split launches, 2: M <= 512 unsplit, 4: M <= 2048, 8: larger M
+        const char* em = getenv("DGQ_GEMM_PANEL_MASK");
+        if (em) {
+            const int mask = atoi(em);
+            const int cls = splits > 1 ? 1 : (M <= 512 ? 2 : (M <= 2048 ? 4 : 8));
+            if (!(mask & cls)) return false;
+        }
+    }
+    const int tiles = (nk + splits - 1) / splits;
+    {   // experiment hook: DGQ_GEMM_PANEL_ONE="NW,KW" — one panel configuration for every launch the rule admits
+        const char* e1 = getenv("DGQ_GEMM_PANEL_ONE");
+        int a = 0, b = 0;
+        if (e1 && sscanf(e1, "%d,%d", &a, &b) == 2) { nw = a; kw = b; }
+    }
+    if (tiles < 2 * kw) return false;
+    const size_t need = dgq_gemm_panel_lds_bytes(1, nw, kw, per_m, false, tiles);
+    if (need == 0 || need > 150 * 1024) return false;
+    pl.bm = PANEL_BM0 + 1; pl.bn = nw; pl.kw = kw; pl.fuse = false; pl.splits = splits;
+    return true;
+}
+
 extern "C" int dgq_gemm_act_fuses(int M, int N, int K, int Kp, int w_bits, int per_m, int n_problems, int x_dtype, int y_dtype) {
     if (w_bits != 4 || x_dtype != y_dtype || M < 1 || N < 1 || K < 4 || K % 4 != 0 || Kp < K || Kp % BK != 0 || n_problems < 1 || n_problems > DGQ_GEMM_BATCH)
         return 0;
@@ -978,6 +1025,10 @@ extern "C" int dgq_gemm_wxa8(const int8_t* codes, const float* rowsum, int rowsu
         if (forced_plan(f) && f.fuse) pl = f;
         p.splits = 1; p.slab = nullptr; p.tiles_per_split = Kp / BK;
         return dispatch_gemm(bt, w_bits, per_m != 0, pl, y_dtype, (hipStream_t)stream);
+    }
+    if (!p.cv.codes_in && p.wfrag && w_bits == 4) {
+        GemmPlan pp = pl;
+        if (plan_panel_codes(M, N, Kp, per_m != 0, workspace ? workspace_bytes : 0, pp) && !(p.ex.geglu && pp.splits > 1)) pl = pp;
     }
     if (p.cv.codes_in) {
         // implicit im2col: the row sums of the unfolded operand from the per-pixel sums first (a tiny launch), then one of the three

@@ -63,6 +63,8 @@ def run(D, T, S, B=2, H=8, bits=8):
             d = (rr[:, b] - rr[:, a]).astype(np.float64)
             print("    %-56s %8.0f cyc (p10 %6.0f, p90 %6.0f) = %5.2f us %5.1f %%" % (name, np.median(d), np.percentile(d, 10), np.percentile(d, 90),
                                                                                     np.median(d) / clk / 1e3, 100 * np.median(d) / tot))
+        if tag == 3:
+            print("    output stores: dequantise + LDS writes %.0f cyc, LDS reads + global stores %.0f cyc (medians)" % (np.median(rr[:, 7]), np.median(rr[:, 12])))
 
 
 shapes = sys.argv[1:] or ["160,256,256", "160,256,77", "80,1024,1024", "80,1024,77", "40,4096,77", "160,64,64", "40,4096,4096"]

@@ -23,7 +23,7 @@ if len(sys.argv) > 1:
         SHAPES.append((int(f[0]), int(f[1]), int(f[2]), int(f[3]), f[4]))
 TILES = [tuple(int(v) for v in t.split("x")) for t in os.environ.get("TILES", "32x64;64x64;128x64;64x128").split(";")]
 SPLITS = [int(v) for v in os.environ.get("SPLITS", "1;2;3;4;6;8;12;16;24;32").split(";")]
-COLD_BYTES = 320 << 20
+COLD_BYTES = 160 << 20          # per image (row-major + fragment-major copies: 320 MB per cycle)
 
 
 def replay_us(fns):
@@ -64,6 +64,7 @@ for (M, N, C, taps, mode) in SHAPES:
     for r in range(R):
         c = copy.copy(ab)
         c.wpacked = ab.wpacked.clone()
+        c.wfrag = ab.wfrag.clone() if ab.wfrag is not None else None
         abs_.append(c)
     codes = torch.randint(-128, 128, (M, ab.Kp), dtype=torch.int8, device=dev)
     rowsum = torch.randn(M, device=dev)
@@ -80,6 +81,13 @@ for (M, N, C, taps, mode) in SHAPES:
                 continue
             os.environ["DGQ_GEMM_FORCE"] = "%d,%d,%d" % (bm, bn, s)
             res.append((replay_us([(lambda c=c: ops.gemm_wxa8(codes, rowsum, M, c, torch.float32, out)) for c in abs_]), bm, bn, s))
+    for tm, nw, kw in ((1, 5, 1), (1, 10, 1), (1, 4, 1), (1, 8, 1), (2, 4, 1), (2, 8, 1), (1, 4, 2), (1, 4, 4), (1, 5, 2)):
+        for s in SPLITS:
+            tiles = -(-nk // s)
+            if (s > 1 and s * 2 > nk) or tiles * 32 * tm * 128 > 120 * 1024 or s * M * N * 4 > ops.WORKSPACE_BYTES or tiles < 2 * kw:
+                continue
+            os.environ["DGQ_GEMM_FORCE"] = "P%d,%d,%d,%d" % (tm, nw, s, kw)
+            res.append((replay_us([(lambda c=c: ops.gemm_wxa8(codes, rowsum, M, c, torch.float32, out)) for c in abs_]), 1000 + tm, nw * 10 + kw, s))
     os.environ.pop("DGQ_GEMM_FORCE", None)
     best = min(res)
     wbytes = ab.wpacked.numel()
