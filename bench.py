@@ -478,7 +478,7 @@ def measure_gemm_roofline(torch, ops, qnn, run_step, args):
             break
     hbm_gemm = G["hbm_bound"]["ideal_ms"] >= G["compute_bound"]["ideal_ms"]
     out = {"kernel": "dgq_gemm_wxa8 / dgq_gemm_wxa8_batch (gemm_wxa8_kernel<...> tile family, gemm_big_kernel<...>, split-K combine where "
-                     "used); the 23 time_emb_proj layers (2 rows each, 0.1 Gop) run in dgq_linear_smallm_batch and are not counted",
+                     "used); the 22 time_emb_proj layers (2 rows each, 0.1 Gop) run in dgq_linear_smallm_batch and are not counted",
            "layers_covered": layers[0],
            # which roof the family's IDEAL time mostly sits under (per launch: argmin(P_int8, AI·BW)); `achieved` / `frac` stay
            # the int8-MFMA accounting of the north star either way

@@ -87,9 +87,38 @@ def mse(x: torch.Tensor, symmetric: bool = False, level: int = 256, always_zero:
     """The scalar L2.4 range search (quant_layer.py:62-86) = ``channel_mse`` of the tensor taken as ONE channel: all 80 shrink
     candidates are ranked by the same batched evaluation; 0-d (δ, z) like the reference returns."""
     if symmetric or always_zero:
-        raise NotImplementedError("symmetric / always_zero range search is not on the DGQ path (every DGQ quantizer is asymmetric)")
+        return _mse_flagged(x, symmetric, level, always_zero)
     d, z = channel_mse(x.reshape(1, -1), level)
     return d.reshape(()), z.reshape(())
+
+
+def _mse_flagged(x: torch.Tensor, symmetric: bool, level: int, always_zero: bool):
+    """The same search under the quantizer flags (quant_layer.py:72-80): ``always_zero`` (the uniform softmax quantizer aqtizer_w,
+    quant_block.py:145-156: δ = max/(level − 1), z = 0, codes in [0, level − 1]) and ``symmetric`` (δ = 2·max|range|/(level − 2),
+    z = 0, codes in [−level/2, level/2 − 1]).  The 80 shrink candidates are evaluated eight at a time over the flattened tensor;
+    the first candidate with the smallest error wins (the reference's strict ``<``)."""
+    flat = x.detach().reshape(-1).float()
+    x_min, x_max = float(flat.min()), float(flat.max())
+    f = 1.0 - 0.01 * torch.arange(80, dtype=torch.float64)
+    new_min, new_max = x_min * f, x_max * f
+    if always_zero:
+        deltas = (new_max / (level - 1)).float()                     # torch.tensor(python double): rounded to fp32 once
+        nb, pb = 0, level - 1
+    else:
+        m = torch.maximum(new_min.abs(), new_max)
+        deltas = (m + m) / (level - 2)                               # stays a python double in the reference: the division below
+        nb, pb = -level // 2, level // 2 - 1                         # rounds it to fp32 when it meets the fp32 tensor
+    deltas = deltas.to(flat.device)
+    best, best_d = None, None
+    for i0 in range(0, 80, 8):
+        d = deltas[i0:i0 + 8].float()[:, None]
+        x_q = torch.clamp(torch.round(flat[None, :] / d), nb, pb)
+        err = (d * x_q - flat[None, :]).abs().pow(2.4).mean(dim=1)
+        for j in range(err.numel()):
+            if best is None or float(err[j]) < best:
+                best, best_d = float(err[j]), deltas[i0 + j]
+    delta = best_d.float() if always_zero else best_d                # (symmetric: the reference returns the python double)
+    return torch.as_tensor(delta).to(dtype=x.dtype, device=x.device).reshape(()), torch.tensor(0.0, dtype=x.dtype, device=x.device)
 
 
 def _outside_scope(name):

@@ -2,6 +2,7 @@
 /root/reference on CPU through oracle/ref_harness.py).  Development-container only.
 
     python tests/golden/make_golden.py small            # F2 quantizers, F3 layers, F4 blocks  (seconds)
+    python tests/golden/make_golden.py wide             # F3c wide Linear layers (K = 9216: clears of the running totals in the plan)
     python tests/golden/make_golden.py schema           # F1 ckpt schema + F6 loader side effects
     python tests/golden/make_golden.py calib | recon    # F8 DGQ activation calibration, F9 weight PTQ (mini model)
     python tests/golden/make_golden.py qstats           # F8b statistics of the calibration, quantizer by quantizer
@@ -12,6 +13,7 @@
     python tests/golden/make_golden.py pndm | euler     # F7 vendored PNDM / EulerAncestral schedulers on a closed-form ε model
     python tests/golden/make_golden.py pndm_unet [steps] [res]   # F10 the reference QuantModel under the pipeline's PNDM loop
     DIFFUSERS_REWRITE=sdxl python tests/golden/make_golden.py unet xl   # SDXL (separate process)
+    DIFFUSERS_REWRITE=sdxl python tests/golden/make_golden.py unet xl_c5 32   # SDXL W4A6 g=1 (config C5), 32x32 latents; xl_c5b8: 8 prompts
 
 Fixtures are DATA: seeded inputs and the reference's outputs (``.pt`` files of plain tensors +
 JSON).  Full-UNet inputs are not stored — they are regenerated from ``dgq_amd.synth`` (name-keyed).
@@ -107,13 +109,18 @@ def make_quantizers(ref):
 
 
 # --------------------------------------------------------------------------------------- F3
-def make_layers(ref):
+def make_layers_wide(ref):
+    """F3c: the wide Linear cases of recipes.f3_wide_cases() through the reference's QuantLayer (as make_layers)."""
+    make_layers(ref, recipes.f3_wide_cases(), "f3c_layers_wide.pt")
+
+
+def make_layers(ref, cases=None, fname="f3_layers.pt"):
     """QuantLayer Linear & Conv (3x3 s1, 3x3 s2 p1, 1x1) x act-param layout x W{4,8} x A{6,8} x G{1,8,16}.
     Inputs come from tests/golden/recipes.py (name-keyed, regenerated by the tests); only the
     reference's weight-quantizer params and outputs are stored."""
     import torch.nn as nn
     out = {}
-    for case in recipes.f3_cases():
+    for case in (cases or recipes.f3_cases()):
         inp = recipes.f3_inputs(case)
         wq = {"bits": case["wbits"], "channel_wise": True, "scaler": ref.ql.Scaler.MINMAX}
         aq = {"bits": case.get("abits", 8), "channel_wise": False, "scaler": ref.ql.Scaler.MINMAX,
@@ -136,7 +143,7 @@ def make_layers(ref):
             rec["wdelta"], rec["wzp"] = ql.wqtizer.delta.clone(), ql.wqtizer.zero_point.clone()
         rec["y"] = ql(inp["x"]).clone()
         out[case["name"]] = rec
-    save("f3_layers.pt", out)
+    save(fname, out)
 
 
 # --------------------------------------------------------------------------------------- F4
@@ -249,6 +256,12 @@ def make_unet(ref, arch, name, res=None, batch=2):
         c = dict(wbits=4, abits=8, use_aq=True, G=16, log=True, rt=True, sp=True, time_aware=True, steps=4,
                  ts=(999, 249))
         batch = 1
+    elif name.startswith("xl_c5"):
+        # BASELINE.json configs[4] on its own graph: SDXL W4A6 with the G = 1 preset (scripts/quantize_act.sh:19-23: scalar activation
+        # scales -> the native F.conv2d path, quant_layer.py:659; uniform aqtizer_w, quant/quant_block.py:145-156).  "xl_c5b8": 8
+        # prompts, the per-GPU batch of the config (the launch plans of the batch differ from batch 2's)
+        c = dict(wbits=4, abits=6, use_aq=True, G=1, log=False, rt=False, sp=False, time_aware=True, steps=4, ts=(999, 249))
+        batch = 8 if name.endswith("b8") else 2
     res = res or synth.ARCH[arch]["sample_size"]
     need_slots = 1 + max((1000 - t) // (1000 // c["steps"]) for t in c["ts"]) if c["time_aware"] else 1
     t0 = time.time()
@@ -569,7 +582,8 @@ def make_scalers(ref):
         elif sc == "LOGMINMAX":
             d, z = fn(x, False, level, True), torch.tensor(0.0)
         else:
-            d, z = fn(x, False, level, False)
+            sym, az = recipes.scaler_flags(name)
+            d, z = fn(x, sym, level, az)
         out[name] = dict(delta=torch.as_tensor(d).clone().float(), zero_point=torch.as_tensor(z).clone().float())
         print(name, sc, shape, "delta", out[name]["delta"].flatten()[:4].tolist(), "zp", out[name]["zero_point"].flatten()[:4].tolist())
     save("f2b_scale_initialisers.pt", out)
@@ -862,6 +876,8 @@ if __name__ == "__main__":  # noqa: C901
         make_quantizers(ref)
         make_layers(ref)
         make_blocks(ref)
+    elif what == "wide":
+        make_layers_wide(ref)
     elif what == "schema":
         make_schema(ref, arch)
     elif what == "unet":

@@ -37,6 +37,14 @@ def f3_cases():
     return cases
 
 
+def f3_wide_cases():
+    """F3c: one wide Linear layer per activation-scale layout (K = 9216 > the 8704 codes a W4A8 running total may span, so the per-K
+    plan carries clears of the running totals; M = 300 rows, N = 256): the shapes the 256-row GEMM and the K-split launches meet with
+    REAL plan_act tables (non-representable flush coefficients), not the power-of-two scales of the exact-integer tests."""
+    return [dict(name="wide_linear_w4a8g16_%s" % lay, kind="linear", wbits=4, abits=8, G=(1 if lay == "scalar" else 16), layout=lay,
+                 state="wa", dims=dict(B=2, T=150, K=9216, N=256)) for lay in ("perK", "perM", "scalar")]
+
+
 F3_LIN = dict(B=2, T=24, K=96, N=40)
 F3_CONV = dict(B=2, C=32, H=9, W=9, N=24)
 
@@ -46,11 +54,11 @@ def f3_inputs(case):
     ab = case.get("abits", 8)
     G = case.get("G", 1)
     if case["kind"] == "linear":
-        d = F3_LIN
+        d = case.get("dims", F3_LIN)
         out["x"] = nt("f3|lin|x", (d["B"], d["T"], d["K"]), 1.5)
         if case.get("two_d"):
             out["x"] = nt("f3|lin|x2d", (d["B"], d["K"]), 1.5)
-        out["w"] = nt("f3|lin|w", (d["N"], d["K"]), 0.1)
+        out["w"] = nt("f3|lin|w", (d["N"], d["K"]), 0.1 if "dims" not in case else d["K"] ** -0.5)
         out["b"] = nt("f3|lin|b", (d["N"],), 0.1)
         nK, nM = d["K"], d["T"]
         shpK, shpM = (1, 1, -1), (1, -1, 1)
@@ -197,13 +205,23 @@ SCALER_CASES = [
     ("hist_scalar_a8", "HIST", (4, 50, 24), 256, False),
     ("omse_scalar_l16", "OMSE", (3, 40), 16, False),
     ("logminmax_probs", "LOGMINMAX", (2, 4, 16, 16), 256, False),
+    # the flags of the scalar MSE search (quant_layer.py:62-86): always_zero is what the uniform softmax quantizer aqtizer_w is
+    # built with (quant_block.py:145-156) — `quantize_weight --cali --use_aq` initialises it through Scaler.MSE
+    ("mse_always_zero_probs", "MSE", (2, 4, 16, 16), 256, False),
+    ("mse_always_zero_a6", "MSE", (4, 50, 24), 64, False),
+    ("mse_symmetric_a8", "MSE", (4, 50, 24), 256, False),
 ]
+
+
+def scaler_flags(name):
+    """(symmetric, always_zero) of a SCALER_CASES entry (by its name)"""
+    return ("symmetric" in name, "always_zero" in name)
 
 
 def scaler_input(name, shape):
     """Heavy-tailed data (a few outliers per channel) so that the range searches actually shrink the range."""
     x = _synth().named_randn("scaler|" + name, shape, 11)
     x = x * (1.0 + 4.0 * (_synth().named_randn("scaler_tail|" + name, shape, 12).abs() > 2.2).float())
-    if name.startswith("logminmax"):
+    if name.startswith("logminmax") or name.endswith("_probs"):
         x = torch.softmax(x.reshape(shape[0], shape[1], shape[2], shape[3]) * 2.0, dim=-1)
     return x

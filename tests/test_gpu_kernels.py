@@ -184,6 +184,46 @@ def test_gemm_exact_integer_big_kernel(dev, monkeypatch):
         _gemm_exact_case(dev, M, N, Kp, 4, seed=seed)
 
 
+@pytest.mark.parametrize("case", recipes.f3_wide_cases(), ids=lambda c: c["name"])
+def test_f3_wide_layers_every_kernel_vs_reference(case, dev, monkeypatch):
+    """F3c: a wide Linear layer (M = 300, N = 256, K = 9216) with a REAL plan_act table — per-K with 16 DGQ groups
+    (flush coefficients that are not powers of two, a clear of the running totals inside the K range), per-M and scalar — against the
+    reference's own output (tests/golden/f3c_layers_wide.pt), on every member of the GEMM family that takes the shape: the planner's
+    choice, the 256-row kernel (DGQ_GEMM_FORCE=256,256,1), a K-split tile launch, and the panel kernel with K splits and K waves.
+    Each within 2e-5 of the reference; the tile family and the 256-row kernel share their epilogue AND their summation order inside a
+    K tile sequence only up to the order of the group sums, so they are compared at 1e-6 (per-M / scalar: bit for bit)."""
+    from dgq_amd import ops
+    from dgq_amd.plan import plan_act
+    g = gold("f3c_layers_wide.pt")[case["name"]]
+    inp = recipes.f3_inputs(case)
+    w = inp["w"].to(dev)
+    C = w.shape[1]
+    pw = ops.PackedWeight(w, g["wdelta"].to(dev), g["wzp"].to(dev), None, inp["b"].to(dev), 4, C, 1)
+    lay = plan_act(inp["adelta"], inp["azp"], "linear", C, 1, 8)
+    ab = ops.ActBinding(lay, pw, 8)
+    if lay.mode == "perK":
+        assert int((ab.cflush == 2).sum()) >= 1, "the plan of this case must carry a clear of the running totals"
+    x = inp["x"].to(dev)
+    monkeypatch.setattr(ops, "GEMM_FUSE", False)                 # (K = 9216 does not fit the fused form anyway)
+    outs = {}
+    for plan in (None, "256,256,1", "64,64,4", "128,128,1", "P1,4,4,2", "P1,8,3,1"):
+        if plan is None:
+            monkeypatch.delenv("DGQ_GEMM_FORCE", raising=False)
+        else:
+            monkeypatch.setenv("DGQ_GEMM_FORCE", plan)
+        y = ops.quant_linear(x, ab)
+        torch.cuda.synchronize()
+        err = rel_l2(y.cpu(), g["y"])
+        assert err < 2e-5, (plan, err)
+        outs[plan] = y.clone()
+    ref = outs["128,128,1"]
+    for plan, y in outs.items():
+        if lay.mode == "perK":
+            assert rel_l2(y, ref) < 1e-6, plan
+        elif plan is not None and not plan.startswith("P") and plan != "64,64,4":
+            assert torch.equal(y, ref), plan                     # unsplit integer sums: the same numbers through the same epilogue
+
+
 PANEL_PLANS = ["P1,5,1", "P1,10,1", "P2,5,1", "P1,4,1", "P1,8,1", "P2,4,1", "P2,8,1", "P1,5,3", "P2,4,2", "P1,10,4"]
 
 

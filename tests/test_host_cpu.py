@@ -31,6 +31,24 @@ def test_abi_library_loads_and_exports_every_declared_symbol():
     assert rc == -1 and "dgq_pack_w4" in _lib.last_error()
 
 
+def test_shipped_library_is_not_a_diagnostic_build():
+    """In-kernel clock stamps (csrc/diag.h) and the wrong-output timing switches of the 256-row kernel (BIG_STAMP, BIG_ABL) exist only
+    behind -DDGQ_DIAG, which `make` / __graft_entry__.build() never set: the shipped library exports no dgq_diag_* symbol, and the
+    sources refuse BIG_STAMP / BIG_ABL without DGQ_DIAG at compile time."""
+    import ctypes
+    from dgq_amd import _lib
+    lib = _lib.load() if "diag" not in os.path.basename(_lib.LIB_PATH) else ctypes.CDLL(os.path.join(ROOT, "dgq_amd", "csrc", "libdgq_hip.so"))
+    for name in ("dgq_diag_fetch_gemm", "dgq_diag_fetch_quant", "dgq_diag_fetch_panel", "dgq_diag_fetch_attn", "dgq_diag_clear_gemm"):
+        assert not hasattr(lib, name), "the shipped libdgq_hip.so was built with -DDGQ_DIAG (%s)" % name
+    mk = open(os.path.join(ROOT, "dgq_amd", "csrc", "Makefile")).read()
+    all_rule = mk.split("diag:")[0]
+    assert "-DDGQ_DIAG" not in all_rule.split("# Diagnostic build")[0], "the product build rule must not define DGQ_DIAG"
+    big = open(os.path.join(ROOT, "dgq_amd", "csrc", "gemm_wxa8_big.hip")).read()
+    assert "#if !defined(DGQ_DIAG) && (BIG_ABL != 0 || BIG_STAMP != 0)" in big and "#error" in big
+    entry = open(os.path.join(ROOT, "__graft_entry__.py")).read()
+    assert "DGQ_DIAG" not in entry and "make diag" not in entry and '"diag"' not in entry
+
+
 def test_product_has_no_cpu_fallback():
     from dgq_amd.quant import QuantLayer, Scaler
     lin = torch.nn.Linear(32, 16)

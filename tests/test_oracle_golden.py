@@ -270,7 +270,8 @@ def test_f2b_scale_initialisers_vs_reference(case, golden_dir):
             dc, zc = ql.mse(x[c], False, level, False)
             assert float(dc) == float(g["delta"].flatten()[c]) and float(zc) == float(g["zero_point"].flatten()[c]), (name, c)
     else:
-        d, z = ql.mse(x, False, level, False)
+        sym, az = recipes.scaler_flags(name)
+        d, z = ql.mse(x, sym, level, az)
     d, z = torch.as_tensor(d).float(), torch.as_tensor(z).float()
     assert d.shape == g["delta"].shape and torch.equal(d, g["delta"]), (name, (d - g["delta"]).abs().max())
     assert torch.equal(z.reshape(g["zero_point"].shape), g["zero_point"]), name
