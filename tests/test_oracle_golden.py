@@ -235,6 +235,41 @@ def test_f5_oracle_forward_matches_reference_unet_sdxl_32x32(golden_dir):
     assert e == 0.0 or e < 2.5 * self_dev, (t, e, self_dev)
 
 
+def test_f5_oracle_forward_matches_reference_unet_sdxl_c5_32x32(golden_dir):
+    """BASELINE.json configs[4] on ITS OWN graph (VERDICT r4 missing #3): SDXL W4A6 under the G = 1 preset (scripts/quantize_act.sh:19-23 —
+    scalar activation scales, so every convolution takes the reference's native F.conv2d branch, quant_layer.py:659; uniform
+    always-zero aqtizer_w, quant/quant_block.py:145-156), batch 2 at 32x32 latents: OracleModel.forward against the REAL
+    reference's output (tests/golden/f5_unet_sdxl_xl_c5_r32.pt = make_golden.py `unet xl_c5 32` under DIFFUSERS_REWRITE=sdxl).
+    Same thread count as the golden run => expected bit-identical; otherwise bounded by the reference's own 1-thread deviation."""
+    import warnings
+    from oracle import dgq_oracle as orc
+    from dgq_amd import synth
+    g = torch.load(os.path.join(golden_dir, "f5_unet_sdxl_xl_c5_r32.pt"))
+    m = g["meta"]
+    assert m["arch"] == "sdxl" and m["res"] == 32 and m["batch"] == 2 and m["G"] == 1 and m["abits"] == 6 and not m["log"]
+    t = max(g["outputs"].keys())
+    slot = (1000 - t) // (1000 // m["steps"])
+    ck = synth.build_cali_ckpt("sdxl", m["wbits"], m["abits"], m["G"], num_slots=[slot], seed=0, batch=m["batch"], res=m["res"],
+                               start_peak=m["sp"], uniform_softmax=True, with_act=True)
+    cfg = orc.OracleConfig("sdxl", m["wbits"], m["abits"], True, True, m["abits"], m["log"], m["rt"], m["sp"],
+                           m["time_aware"], m["steps"], m["G"] > 1)
+    om = orc.OracleModel(ck, cfg, synth.synth_state_dict("sdxl", 0))
+    inp = synth.synth_inputs("sdxl", m["batch"], m["input_seed"], m["res"])
+    nt = torch.get_num_threads()
+    torch.set_num_threads(m.get("threads", nt))
+    try:
+        y = om.forward(inp["sample"], t, inp["encoder_hidden_states"], text_embeds=inp["text_embeds"], time_ids=inp["time_ids"])
+    finally:
+        torch.set_num_threads(nt)
+    ref = g["outputs"][t]
+    e = ((y.double() - ref.double()).norm() / ref.double().norm()).item()
+    self_dev = ((g["outputs_1thread"][t].double() - ref.double()).norm() / ref.double().norm()).item()
+    if e != 0.0:
+        warnings.warn("SDXL C5 oracle vs reference golden at t=%d: rel-L2 %.3g (not bit-identical on this host; reference "
+                      "self-deviation %.3g)" % (t, e, self_dev))
+    assert e == 0.0 or e < 2.5 * self_dev, (t, e, self_dev)
+
+
 def test_oracle_exact_gemm_mode_is_a_rounding_level_change_per_layer():
     """The float64-GEMM variant of the oracle (the "exact" target of the GPU parity statistics) differs from the
     reference-faithful fp32 one only by the rounding of each contraction: on a single quantized layer the outputs
