@@ -477,8 +477,8 @@ def measure_gemm_roofline(torch, ops, qnn, run_step, args):
                     os.path.basename(tj), tjd.get("measured_at_commit"), csrc_digest())
             break
     hbm_gemm = G["hbm_bound"]["ideal_ms"] >= G["compute_bound"]["ideal_ms"]
-    out = {"kernel": "dgq_gemm_wxa8 / dgq_gemm_wxa8_batch (gemm_wxa8_kernel<...> tile family, gemm_big_kernel<...>, split-K combine where "
-                     "used); the 22 time_emb_proj layers (2 rows each, 0.1 Gop) run in dgq_linear_smallm_batch and are not counted",
+    out = {"kernel": "dgq_gemm_wxa8 / dgq_gemm_wxa8_batch (gemm_wxa8_kernel<...> tile family, gemm_big_kernel<...>, gemm_panel_kernel<...> with quantise-on-load, "
+                     "split-K combine where used); the 22 time_emb_proj layers (2 rows each, 0.1 Gop) run in dgq_linear_smallm_batch and are not counted",
            "layers_covered": layers[0],
            # which roof the family's IDEAL time mostly sits under (per launch: argmin(P_int8, AI·BW)); `achieved` / `frac` stay
            # the int8-MFMA accounting of the north star either way
@@ -515,7 +515,7 @@ def measure_gemm_roofline(torch, ops, qnn, run_step, args):
     return out, extra
 
 
-GEMM_SOURCES = ("gemm_wxa8.hip", "gemm_wxa8_big.hip", "gemm_tile.h")
+GEMM_SOURCES = ("gemm_wxa8.hip", "gemm_wxa8_big.hip", "gemm_panel.hip", "gemm_tile.h")
 
 
 def csrc_digest(names=GEMM_SOURCES):

@@ -1,16 +1,20 @@
 """HBM-side bytes of a kernel family from rocprofv3 --pmc passes (counter_collection CSVs).
-usage: pmc_traffic.py <fetch_pass.csv> <write_pass.csv> <kernel substring> <out.json> [config dtype commit [prompts_per_gpu]]
+usage: pmc_traffic.py <fetch_pass.csv> <write_pass.csv> <kernel substring[|substring...]> <out.json> [config dtype commit [prompts_per_gpu]]
+A family of kernels is named by '|'-separated substrings; bytes are summed over all of them, launches count every dispatch but the
+split-K combine (splitk_epilogue: the second kernel of ONE GEMM launch, as bench.py counts launches).
 FETCH_SIZE / WRITE_SIZE are in KiB (rocprofv3 derived metrics); on gfx950 FETCH_SIZE tallies the 128-byte requests of
 wide (16 B/lane) reads at 64 B, so it is doubled (MI355X_MICROARCH.md, HBM section); WRITE_SIZE is exact for 16-byte stores."""
 import collections, csv, json, sys
 fetch_csv, write_csv, pat, out = sys.argv[1:5]
+pats = pat.split("|")
 
 def total(path, counter):
     tot, n = 0.0, set()
     for r in csv.DictReader(open(path)):
-        if pat in r["Kernel_Name"] and r["Counter_Name"] == counter:
+        if any(q in r["Kernel_Name"] for q in pats) and r["Counter_Name"] == counter:
             tot += float(r["Counter_Value"])
-            n.add(r["Dispatch_Id"])
+            if "splitk_epilogue" not in r["Kernel_Name"] or pats == ["splitk_epilogue"]:
+                n.add(r["Dispatch_Id"])
     return tot, len(n)
 
 f_kib, nf = total(fetch_csv, "FETCH_SIZE")
@@ -24,7 +28,7 @@ res["traffic_bytes_per_launch"] = res["fetch_bytes_per_launch_corrected_x2"] + r
 import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
-files = ("quant_act.hip",) if "quant_act" in pat else bench.GEMM_SOURCES
+files = ("quant_act.hip", "quant_common.h") if "quant_act" in pat else bench.GEMM_SOURCES
 res["digest_files"] = list(files)
 res["csrc_digest"] = bench.csrc_digest(files)
 if len(sys.argv) > 5:
