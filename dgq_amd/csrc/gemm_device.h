@@ -38,6 +38,18 @@ __device__ __forceinline__ float dgq_extra(const dgq_gemm_extra_t& ex, float y, 
 }
 
 
+// Running totals of the per-K W4 kernels as floats without v_cvt_f32_i32: their int32 accumulators start at (and are cleared to)
+// DGQ_ACC_BIAS_I = bits(1.5·2^23); while |T| < 2^22 (dgq_amd/plan.py:seg_limit) the bits of bias + T ARE the float 1.5·2^23 + T, and
+// subtracting 1.5·2^23 is exact: float(T) by one packed add per two totals instead of two conversions.  The K loop of the short
+// per-K launches is VALU-issue bound (cvt + fma per accumulator register and chunk: profiles/r05_small_launch_timeline.txt).
+constexpr int DGQ_ACC_BIAS_I = 0x4B400000;
+constexpr float DGQ_ACC_BIAS_F = 12582912.0f;
+template <bool BIASED>
+__device__ __forceinline__ float dgq_total_to_float(int t) {
+    if constexpr (BIASED) return __int_as_float(t) - DGQ_ACC_BIAS_F;
+    else return (float)t;
+}
+
 // Dequantising epilogue of one output element, shared by every GEMM-family kernel so that their results agree bit for bit:
 //   y = alpha·(R0·acc − zw·R1 + R2·vn) + gamma     per-K: R0 = 1, R1 = Σ_k δ_k s, R2 = 0;  per-M: R0 = δ_m, R1 = δ_m·Σ_k s,
 //   R2 = δ_m·(offset − z_m)

@@ -382,12 +382,14 @@ __global__ __launch_bounds__(64 * NW * KW) void gemm_panel_kernel(GemmBatch bt, 
         }
     v16i acc[ACCS][TM][1];
     v16f accf[TM][1];
+    constexpr bool BIASED = !PER_M;                         // per-K (W4): totals carry DGQ_ACC_BIAS_I (gemm_device.h)
+    constexpr int ACC0 = BIASED ? DGQ_ACC_BIAS_I : 0;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
 #pragma unroll
-            for (int a = 0; a < ACCS; ++a) acc[a][i][0][r] = 0;
+            for (int a = 0; a < ACCS; ++a) acc[a][i][0][r] = ACC0;
             accf[i][0][r] = 0.0f;
         }
     auto flush = [&](const v16i (&ac)[TM][1], float coef) {
@@ -396,7 +398,7 @@ __global__ __launch_bounds__(64 * NW * KW) void gemm_panel_kernel(GemmBatch bt, 
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) accf[i][0][r] = __builtin_fmaf(sc, (float)ac[i][0][r], accf[i][0][r]);
+                for (int r = 0; r < 16; ++r) accf[i][0][r] = __builtin_fmaf(sc, dgq_total_to_float<BIASED>(ac[i][0][r]), accf[i][0][r]);
         }
     };
     float pend = 0.0f;
@@ -445,7 +447,7 @@ __global__ __launch_bounds__(64 * NW * KW) void gemm_panel_kernel(GemmBatch bt, 
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) acc[a][i][0][r] = 0;
+                        for (int r = 0; r < 16; ++r) acc[a][i][0][r] = ACC0;
             }
         }
     };

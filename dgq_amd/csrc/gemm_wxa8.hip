@@ -184,6 +184,8 @@ void gemm_wxa8_kernel(GemmBatch bt) {
 
     v16i acc[ACCS][TM][TN];
     v16f accf[TM][TN];
+    constexpr bool BIASED = !PER_M && WBITS == 4;           // per-K W4: totals carry DGQ_ACC_BIAS_I (gemm_device.h)
+    constexpr int ACC0 = BIASED ? DGQ_ACC_BIAS_I : 0;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -191,7 +193,7 @@ void gemm_wxa8_kernel(GemmBatch bt) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
 #pragma unroll
-                for (int a = 0; a < ACCS; ++a) acc[a][i][j][r] = 0;
+                for (int a = 0; a < ACCS; ++a) acc[a][i][j][r] = ACC0;
                 accf[i][j][r] = 0.0f;
             }
         }
@@ -345,7 +347,7 @@ void gemm_wxa8_kernel(GemmBatch bt) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) accf[i][j][r] = __builtin_fmaf(sc, (float)ac[i][j][r], accf[i][j][r]);
+                    for (int r = 0; r < 16; ++r) accf[i][j][r] = __builtin_fmaf(sc, dgq_total_to_float<BIASED>(ac[i][j][r]), accf[i][j][r]);
                 }
         }
     };
@@ -416,7 +418,7 @@ void gemm_wxa8_kernel(GemmBatch bt) {
 #pragma unroll
                         for (int j = 0; j < TN; ++j)
 #pragma unroll
-                            for (int r = 0; r < 16; ++r) acc[a][i][j][r] = 0;
+                            for (int r = 0; r < 16; ++r) acc[a][i][j][r] = ACC0;
             }
         }
     }

@@ -138,12 +138,14 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_big_kernel(GemmBatch bt) {
 
     v16i acc[TM][TN];
     v16f accf[TM][TN];
+    constexpr bool BIASED = !PER_M;                         // per-K (W4): totals carry DGQ_ACC_BIAS_I (gemm_device.h)
+    constexpr int ACC0 = BIASED ? DGQ_ACC_BIAS_I : 0;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0; accf[i][j][r] = 0.0f; }
+            for (int r = 0; r < 16; ++r) { acc[i][j][r] = ACC0; accf[i][j][r] = 0.0f; }
 
     // fragment addresses inside a stage: lane l holds row / column l & 31 and the 16 k of half l >> 5 of a chunk.  Row tiles are
     // 32 rows apart — 4096 (A) / 2048 (W) bytes — and the swizzle terms do not change with them, so one address per chunk serves
@@ -343,7 +345,7 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_big_kernel(GemmBatch bt) {
 #pragma unroll
                             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                                for (int r = 0; r < 16; ++r) accf[i][j][r] = __builtin_fmaf(sc, (float)acc[i][j][r], accf[i][j][r]);
+                                for (int r = 0; r < 16; ++r) accf[i][j][r] = __builtin_fmaf(sc, dgq_total_to_float<BIASED>(acc[i][j][r]), accf[i][j][r]);
                     }
                 }
             }
@@ -354,7 +356,7 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_big_kernel(GemmBatch bt) {
 #pragma unroll
                         for (int i = 0; i < TM; ++i)
 #pragma unroll
-                            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
+                            for (int r = 0; r < 16; ++r) acc[i][j][r] = ACC0;
                 }
             }
             if (BIG_PRIO == 1) __builtin_amdgcn_s_setprio(0);

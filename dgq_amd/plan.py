@@ -82,9 +82,11 @@ def classify_act_params(delta: torch.Tensor, kind: str):
 
 def seg_limit(abits: int, wbits: int) -> int:
     """Codes (a multiple of KTILE: clears sit behind whole K tiles) a running int32 total may span before it is cleared:
-    |s| <= 2^(abits−1) and |qw'| <= 15 (W4, unsigned nibbles) or 128 (W8, centred), so |T| <= 2^24 and float(T) is exact."""
-    wmax = 15 if wbits == 4 else 128
-    return max(KTILE, (1 << 24) // ((1 << (abits - 1)) * wmax) // KTILE * KTILE)
+    |s| <= 2^(abits−1) and |qw'| <= 15 (W4, unsigned nibbles) or 128 (W8, centred).  W8: |T| <= 2^24, float(T) by conversion is
+    exact.  W4: |T| < 2^22 — the per-K W4 kernels keep their totals biased by bits(1.5·2^23) and read float(T) off the bits
+    (csrc/gemm_device.h:dgq_total_to_float), exact on that range."""
+    wmax, bound = (15, 1 << 22) if wbits == 4 else (128, 1 << 24)
+    return max(KTILE, bound // ((1 << (abits - 1)) * wmax) // KTILE * KTILE)
 
 
 def mark_clears(cflush: torch.Tensor, abits: int, wbits: int) -> torch.Tensor:

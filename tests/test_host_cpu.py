@@ -318,10 +318,18 @@ def test_summation_by_parts_matches_group_sums_on_planned_tables():
                     for s0 in range(0, tiles, per):
                         tot += _abel_total(cd, cf, P, 4 * s0, min(nch, 4 * (s0 + per)), wvk)
                     assert tot == ref, (C, taps, G, splits, wvk)
-    # clear marks: uniform segments of whole K tiles, W4A8 8704 codes, W8A8 1024, never longer than what keeps |T| <= 2^24
-    assert seg_limit(8, 4) == 8704 and seg_limit(8, 8) == 1024 and seg_limit(6, 4) == 34944
-    for ab, wb in ((8, 4), (8, 8), (6, 4)):
-        assert seg_limit(ab, wb) * (1 << (ab - 1)) * (15 if wb == 4 else 128) <= 1 << 24
+    # clear marks: uniform segments of whole K tiles, W4A8 2176 codes, W8A8 1024, never longer than what keeps |T| < 2^22 (W4: the
+    # kernels read float(T) off the bits of a biased total) or <= 2^24 (W8: by conversion)
+    assert seg_limit(8, 4) == 2176 and seg_limit(8, 8) == 1024 and seg_limit(6, 4) == 8704
+    for ab, wb in ((8, 4), (8, 8), (6, 4), (4, 4)):
+        worst = seg_limit(ab, wb) * (1 << (ab - 1)) * (15 if wb == 4 else 128)
+        assert worst < (1 << 22) if wb == 4 else worst <= (1 << 24)
+    # the bit trick itself, on the host: bits(1.5·2^23) + T read as a float, minus 1.5·2^23, is float(T) for every |T| < 2^22
+    import numpy as np
+    T = np.concatenate([np.array([0, 1, -1, (1 << 22) - 1, -(1 << 22) + 1], dtype=np.int64),
+                        np.random.default_rng(0).integers(-(1 << 22) + 1, 1 << 22, 100000)])
+    biased = (np.int64(0x4B400000) + T).astype(np.int32).view(np.float32)
+    assert np.array_equal(biased - np.float32(12582912.0), T.astype(np.float32))
     cf = mark_clears(torch.zeros(100, dtype=torch.uint8), 8, 8)
     assert cf.tolist().count(2) == 3 and int(cf[31]) == 2 and int(cf[63]) == 2 and int(cf[95]) == 2
 
