@@ -437,6 +437,26 @@ void gemm_wxa8_kernel(GemmBatch bt) {
     DGQ_DIAG_FLUSH(gemm, NW, wid, lane);
 }
 
+// Sum of the split-K slabs of one (row, 4 columns) segment, in slab order.  R loads go out per round (a load per iteration of a
+// runtime-bounded loop is waited for before the next is issued: S dependent round trips); the launch picks R >= S where it can (one
+// round: the wide conv splits of the 8x8 / 16x16 levels have 8-16 slabs and spent 3-4 dependent rounds here).
+template <int R>
+__device__ __forceinline__ void splitk_sum_slabs(const float* base, int64_t slab_stride, int splits, float (&a)[4]) {
+    for (int s0 = 0; s0 < splits; s0 += R) {
+        float4 v[R];
+#pragma unroll
+        for (int j = 0; j < R; ++j) v[j] = *reinterpret_cast<const float4*>(base + (int64_t)min(s0 + j, splits - 1) * slab_stride);
+#pragma unroll
+        for (int j = 0; j < R; ++j)
+            if (s0 + j < splits) { a[0] += v[j].x; a[1] += v[j].y; a[2] += v[j].z; a[3] += v[j].w; }
+    }
+}
+__device__ __forceinline__ void splitk_sum(const float* base, int64_t slab_stride, int splits, float (&a)[4]) {
+    if (splits <= 4) splitk_sum_slabs<4>(base, slab_stride, splits, a);          // (uniform branches: splits is a kernel argument)
+    else if (splits <= 8) splitk_sum_slabs<8>(base, slab_stride, splits, a);
+    else splitk_sum_slabs<16>(base, slab_stride, splits, a);
+}
+
 // Deterministic split-K combine + dequantisation epilogue: one thread per 4 consecutive n.
 template <bool PER_M, typename TOut>
 __global__ __launch_bounds__(256) void splitk_epilogue_kernel(GemmParams p) {
@@ -456,17 +476,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(GemmParams p) {
         float a[4] = {0.f, 0.f, 0.f, 0.f};
         const bool full = (nb + 3 < p.N) && ((p.N & 3) == 0);
         if (full) {
-            // four slabs per round: the loads go out together (a load per iteration of a runtime-bounded loop is waited for before
-            // the next one is issued: S dependent round trips), the sums are taken in slab order as before
-            for (int s0 = 0; s0 < p.splits; s0 += 4) {
-                float4 v[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    v[j] = *reinterpret_cast<const float4*>(p.slab + (int64_t)min(s0 + j, p.splits - 1) * slab_stride + (int64_t)m * p.N + nb);
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (s0 + j < p.splits) { a[0] += v[j].x; a[1] += v[j].y; a[2] += v[j].z; a[3] += v[j].w; }
-            }
+            splitk_sum(p.slab + (int64_t)m * p.N + nb, slab_stride, p.splits, a);
         } else {
             for (int s = 0; s < p.splits; ++s) {
                 const float* src = p.slab + s * slab_stride + (int64_t)m * p.N + nb;
@@ -536,15 +546,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(GemmParams p) {
         const int nb = (int)(g - (int64_t)rb * n4) * 4;
         const int m = rb * 16 + qd;
         float a[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int s0 = 0; s0 < p.splits; s0 += 4) {            // four slab loads in flight, sums in slab order (see row4)
-            float4 v[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                v[j] = *reinterpret_cast<const float4*>(p.slab + (int64_t)min(s0 + j, p.splits - 1) * slab_stride + (int64_t)m * p.N + nb);
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (s0 + j < p.splits) { a[0] += v[j].x; a[1] += v[j].y; a[2] += v[j].z; a[3] += v[j].w; }
-        }
+        splitk_sum(p.slab + (int64_t)m * p.N + nb, slab_stride, p.splits, a);
         float mean[4], m2[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
