@@ -477,9 +477,11 @@ class Fork:
     hipGraph is being captured: the concurrency is then baked into the graph (parallel branches of small kernels that
     individually fill a fraction of the 256 CUs); eager execution stays on one stream."""
 
-    #: measured on MI355X / ROCm 7.2: forked branches inside a captured graph gave no speed-up on the SD1.4 step
-    #: (20.7 vs 20.3 ms) — kept for experiments, off by default.
-    ENABLED = False
+    #: Off: since rounds 3 / 4 the branches it used to fork are single shared launches — q / k / v of a self-attention are one
+    #: quantise + one GEMM launch (quant_linear_multi), the 32 ctx-side K / V projections of a forward are computed together by the
+    #: first cross-attention (quant_block.CtxGroup) — so a fork has nothing to overlap (DESIGN.md §0 round 5, item 8).  Kept as
+    #: the mechanism for experiments with other branches (DGQ_FORK=1).
+    ENABLED = os.environ.get("DGQ_FORK", "0") == "1"
 
     def __init__(self, device, n_side):
         self.active = Fork.ENABLED and torch.cuda.is_current_stream_capturing()

@@ -162,8 +162,9 @@ int dgq_conv2d_f32w(const void* x, int x_dtype, int B, int H, int W, int C, int 
  * Every chunk of a DGQ group carries the group's δ in cdelta; the kernel sums by parts, Σ_c (cdelta[c] − cdelta[c+1])·T_c
  * with T_c the running int32 total after chunk c, so a group boundary is wherever cdelta changes.  cflush[c] == 2 on the
  * LAST chunk of a K tile (c % 4 == 3) asks for the running totals to be cleared behind that tile (the coefficient in front
- * of the clear is then the full cdelta): the caller places such marks so that |T| stays below 2^24 and its fp32
- * conversion is exact (dgq_amd/plan.py: every 8704 codes for W4A8, 1024 for W8A8); marks on other chunks are ignored,
+ * of the clear is then the full cdelta): the caller places such marks so that float(T) is exact — W8: |T| <= 2^24 (converted);
+ * W4: |T| < 2^22, REQUIRED: the W4 per-K kernels keep T biased by bits(1.5·2^23) and read the float off the bits
+ * (dgq_amd/plan.py:seg_limit: every 2176 codes for W4A8, 1024 for W8A8); marks on other chunks are ignored,
  * other values (0 inside a group, 1 at a group end) are informative. */
 /* Optional epilogue extras (host struct, passed by pointer; NULL = none), applied in this order to the fp32 result:
  *   fq_mode != 0 : the attention-side quantizer of the projection output, aqtizer_{q,k,v} (sd.py:174-182,199):

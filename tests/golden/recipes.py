@@ -38,7 +38,7 @@ def f3_cases():
 
 
 def f3_wide_cases():
-    """F3c: one wide Linear layer per activation-scale layout (K = 9216 > the 8704 codes a W4A8 running total may span, so the per-K
+    """F3c: one wide Linear layer per activation-scale layout (K = 9216 > the 2176 codes (8704 until round 5) a W4A8 running total may span, so the per-K
     plan carries clears of the running totals; M = 300 rows, N = 256): the shapes the 256-row GEMM and the K-split launches meet with
     REAL plan_act tables (non-representable flush coefficients), not the power-of-two scales of the exact-integer tests."""
     return [dict(name="wide_linear_w4a8g16_%s" % lay, kind="linear", wbits=4, abits=8, G=(1 if lay == "scalar" else 16), layout=lay,
