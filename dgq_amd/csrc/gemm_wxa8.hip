@@ -472,7 +472,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(GemmParams p) {
                       (((reinterpret_cast<uintptr_t>(p.alpha) | reinterpret_cast<uintptr_t>(p.zw) | reinterpret_cast<uintptr_t>(p.gamma) |
                          (PER_M ? reinterpret_cast<uintptr_t>(p.vn) : 0)) & 15) == 0) &&
                       (p.ex.residual == nullptr || (p.ex.res_dtype == DGQ_F32 && (p.ex.ldr & 3) == 0 && (reinterpret_cast<uintptr_t>(p.ex.residual) & 15) == 0));
-    auto row4 = [&](int m, int nb, float (&val)[4]) {
+    auto row4 = [&](int m, int nb, float (&val)[4], bool live) {      // live == false: compute (the values as stored), store nothing
         float a[4] = {0.f, 0.f, 0.f, 0.f};
         const bool full = (nb + 3 < p.N) && ((p.N & 3) == 0);
         if (full) {
@@ -506,12 +506,12 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(GemmParams p) {
             }
             TOut* dst = y + (int64_t)m * p.ldy + nb;
             if (sizeof(TOut) == 4) {
-                *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+                if (live) *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) val[e] = o[e];
             } else {
                 TOut t[4] = {dgq_from_float<TOut>(o[0]), dgq_from_float<TOut>(o[1]), dgq_from_float<TOut>(o[2]), dgq_from_float<TOut>(o[3])};
-                *reinterpret_cast<uint2*>(dst) = *reinterpret_cast<const uint2*>(t);
+                if (live) *reinterpret_cast<uint2*>(dst) = *reinterpret_cast<const uint2*>(t);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) val[e] = dgq_to_float(t[e]);
             }
@@ -522,7 +522,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(GemmParams p) {
             float out = dgq_epilogue<PER_M>(p, a[e], m, n, p.alpha[n], p.zw[n], p.gamma[n], PER_M ? p.vn[n] : 0.0f);
             out = dgq_extra(p.ex, out, m, n);
             const TOut st = dgq_from_float<TOut>(out);
-            y[(int64_t)m * p.ldy + n] = st;
+            if (live) y[(int64_t)m * p.ldy + n] = st;
             val[e] = dgq_to_float(st);
         }
     };
@@ -545,19 +545,11 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(GemmParams p) {
         const int rb = (int)(g / n4);
         const int nb = (int)(g - (int64_t)rb * n4) * 4;
         const int m = rb * 16 + qd;
-        float a[4] = {0.f, 0.f, 0.f, 0.f};
-        splitk_sum(p.slab + (int64_t)m * p.N + nb, slab_stride, p.splits, a);
-        float mean[4], m2[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int n = nb + e;
-            float out = dgq_epilogue<PER_M>(p, a[e], m, n, p.alpha[n], p.zw[n], p.gamma[n], PER_M ? p.vn[n] : 0.0f);
-            out = dgq_extra(p.ex, out, m, n);
-            const TOut st = dgq_from_float<TOut>(out);
-            if (live) y[(int64_t)m * p.ldy + n] = st;
-            mean[e] = dgq_to_float(st);                      // the value as stored
-            m2[e] = 0.0f;
-        }
+        // the segment through row4 — the plain combine's path: column constants and residual as single vector loads, the row constants
+        // formed once, one 16-byte store (this branch used to walk its four elements one by one: per-M launches 12.5-17.5 us against
+        // 6.5-10 for the same slabs without partials)
+        float mean[4], m2[4] = {0.f, 0.f, 0.f, 0.f};
+        row4(m, nb, mean, live);                             // mean[e]: the value as stored
         float cnt = 1.0f;
 #pragma unroll
         for (int off = 4; off < 64; off <<= 1) {             // lanes of a unit: lane & 3 fixed, lane >> 2 = row
@@ -581,7 +573,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(GemmParams p) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int m = (int)(i / n4);
         float val[4];
-        row4(m, (int)(i - (int64_t)m * n4) * 4, val);
+        row4(m, (int)(i - (int64_t)m * n4) * 4, val, true);
     }
 }
 
