@@ -241,6 +241,8 @@ def main(argv=None):
             return ((x + eps * dsg) + noise * sup).to(x.dtype)
         if guidance > 0:
             eps = qnn(torch.cat([x, x], dim=0), t, ctx, **extra)[0]
+            if arch in ("sd", "tiny") and hasattr(sch, "step_guided"):
+                return sch.step_guided(eps, t, x, guidance)        # as dgq_amd/pipeline.py: guidance + DDIM update
             e_u, e_c = eps.chunk(2)
             eps = e_u + guidance * (e_c - e_u)
         else:

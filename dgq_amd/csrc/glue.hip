@@ -1,0 +1,87 @@
+// The elementwise glue of a denoise step as single launches (each replaces a chain of eager / captured torch kernels that cost a
+// dependent launch apiece, profiles/r05_step_dispatch_trace.tsv):
+//   dgq_timestep_embedding : Timesteps.forward (diffusers_rewrite/sd.py get_timestep_embedding with flip_sin_to_cos=True,
+//                            downscale_freq_shift=0): arange, mul, div, exp, mul, cos, sin, cat -> one launch
+//   dgq_cfg_ddim_step      : classifier-free guidance + the DDIM update (pipeline_stable_diffusion.py:1037-1044, scheduling_ddim.py
+//                            step with eta = 0): chunk, sub, mul, add, mul, sub, div, mul, mul, add -> one launch
+// Both follow the operation ORDER of the torch formulation in fp32 (the build has -ffp-contract=off), including torch's division by a
+// host scalar as a multiplication by its fp32 reciprocal, so the results are those of the eager chain bit for bit where the
+// transcendental functions are the same ocml ones (tests/test_gpu_kernels.py).
+#include <math.h>
+#include "dgq_common.h"
+
+template <typename TT, typename TOut>
+__global__ __launch_bounds__(256) void timestep_embedding_kernel(const TT* __restrict__ t, int64_t t_stride, int rows, int half, float coef,
+                                                                 float inv_half, TOut* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * half) return;
+    const int r = i / half, j = i - r * half;
+    // freqs = exp(-ln(10000) * arange(half) / half): (j * coef) * fl(1 / half), as torch evaluates tensor * scalar / scalar
+    const float f = expf(((float)j * coef) * inv_half);
+    const float a = (float)t[(int64_t)r * t_stride] * f;
+    out[(int64_t)r * 2 * half + j] = dgq_from_float<TOut>(cosf(a));
+    out[(int64_t)r * 2 * half + half + j] = dgq_from_float<TOut>(sinf(a));
+}
+
+extern "C" int dgq_timestep_embedding(const void* t, int t_is_float, int64_t t_stride, int rows, int dim, void* out, int out_dtype,
+                                      void* stream) {
+    DGQ_CHECK_ARG(t && out && rows > 0 && dim > 0 && dim % 2 == 0, "dgq_timestep_embedding: null pointer or bad shape (dim even)");
+    const int half = dim / 2;
+    const float coef = (float)(-9.210340371976184);      // -math.log(10000), rounded to fp32 as torch rounds the python scalar
+    const float inv_half = 1.0f / (float)half;
+    const dim3 grid((rows * half + 255) / 256), block(256);
+    hipStream_t st = (hipStream_t)stream;
+#define DGQ_TE(TT, TO) hipLaunchKernelGGL((timestep_embedding_kernel<TT, TO>), grid, block, 0, st, (const TT*)t, t_stride, rows, half, coef, inv_half, (TO*)out)
+    if (t_is_float) {
+        switch (out_dtype) {
+            case DGQ_F32: DGQ_TE(float, float); break;
+            case DGQ_F16: DGQ_TE(float, __half); break;
+            case DGQ_BF16: DGQ_TE(float, __hip_bfloat16); break;
+            default: dgq_set_error("dgq_timestep_embedding: unknown dtype %d", out_dtype); return DGQ_EINVAL;
+        }
+    } else {
+        switch (out_dtype) {
+            case DGQ_F32: DGQ_TE(int64_t, float); break;
+            case DGQ_F16: DGQ_TE(int64_t, __half); break;
+            case DGQ_BF16: DGQ_TE(int64_t, __hip_bfloat16); break;
+            default: dgq_set_error("dgq_timestep_embedding: unknown dtype %d", out_dtype); return DGQ_EINVAL;
+        }
+    }
+#undef DGQ_TE
+    return dgq_launch_status("dgq_timestep_embedding");
+}
+
+// eps = e_u + g·(e_c − e_u);  x' = s3·((x − s1·eps)·inv_s2) + s4·eps   with s1 = √(1−ᾱ_t), inv_s2 = 1/√ᾱ_t, s3 = √ᾱ_prev, s4 = √(1−ᾱ_prev).
+// eps_pair holds the unconditional half followed by the conditional half (n elements each); guidance == 0 with e_c == nullptr: eps = e_u.
+__global__ __launch_bounds__(256) void cfg_ddim_step_kernel(const float* __restrict__ e_u, const float* __restrict__ e_c, const float* __restrict__ x,
+                                                            float* __restrict__ out, int64_t n4, float g, float s1, float inv_s2, float s3, float s4) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const float4 u = reinterpret_cast<const float4*>(e_u)[i], xv = reinterpret_cast<const float4*>(x)[i];
+    float e[4] = {u.x, u.y, u.z, u.w};
+    if (e_c) {
+        const float4 c = reinterpret_cast<const float4*>(e_c)[i];
+        const float cc[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) e[k] = e[k] + g * (cc[k] - e[k]);
+    }
+    const float xx[4] = {xv.x, xv.y, xv.z, xv.w};
+    float o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float p0 = (xx[k] - s1 * e[k]) * inv_s2;
+        o[k] = s3 * p0 + s4 * e[k];
+    }
+    reinterpret_cast<float4*>(out)[i] = make_float4(o[0], o[1], o[2], o[3]);
+}
+
+extern "C" int dgq_cfg_ddim_step(const float* eps_uncond, const float* eps_cond, const float* sample, float* out, int64_t n, float guidance,
+                                 float s1, float inv_s2, float s3, float s4, void* stream) {
+    DGQ_CHECK_ARG(eps_uncond && sample && out && n > 0 && n % 4 == 0, "dgq_cfg_ddim_step: null pointer or n %% 4 != 0");
+    DGQ_CHECK_ARG(((reinterpret_cast<uintptr_t>(eps_uncond) | reinterpret_cast<uintptr_t>(eps_cond) | reinterpret_cast<uintptr_t>(sample) |
+                    reinterpret_cast<uintptr_t>(out)) & 15) == 0, "dgq_cfg_ddim_step: 16-byte alignment");
+    const int64_t n4 = n / 4;
+    hipLaunchKernelGGL(cfg_ddim_step_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, eps_uncond, eps_cond, sample, out,
+                       n4, guidance, s1, inv_s2, s3, s4);
+    return dgq_launch_status("dgq_cfg_ddim_step");
+}

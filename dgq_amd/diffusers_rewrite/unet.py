@@ -82,6 +82,9 @@ class Timesteps(nn.Module):
         self.num_channels = num_channels
 
     def forward(self, timesteps):
+        if timesteps.is_cuda and timesteps.dim() == 1 and timesteps.dtype in (torch.int64, torch.float32) and _glue_on():
+            from .. import ops
+            return ops.timestep_embedding(timesteps, self.num_channels)       # the eight-kernel chain below as one launch
         half = self.num_channels // 2
         freqs = torch.exp(-math.log(10000) * torch.arange(half, dtype=torch.float32, device=timesteps.device)
                           / (half - 0.0))
@@ -97,7 +100,11 @@ class TimestepEmbedding(nn.Module):
         self.linear_2 = nn.Linear(out_features, out_features)
 
     def forward(self, x):
-        return self.linear_2(self.act(self.linear_1(x)))
+        h = self.linear_1(x)
+        fused = getattr(self.linear_2, "forward_fused", None)
+        if fused is not None and _glue_on() and isinstance(self.act, nn.SiLU) and h.is_cuda:
+            return fused(h, pre_act=1)                                         # SiLU in linear_2's load (as the resnets' time_emb_proj)
+        return self.linear_2(self.act(h))
 
 
 class ResnetBlock2D(nn.Module):
@@ -193,6 +200,12 @@ def _residual_fusion_on():
 def _fusion_on():
     from ..quant import quant_block
     return quant_block.FUSION and quant_block.FUSE_NORM
+
+
+def _glue_on():
+    """DGQ_GLUE=0 (A/B runs): timestep embedding and its SiLU as the torch kernels"""
+    import os
+    return _fusion_on() and os.environ.get("DGQ_GLUE", "1") != "0"
 
 
 class Transformer2DModel(nn.Module):

@@ -911,6 +911,28 @@ def fakequant_rows(x2d: torch.Tensor, T, D, mode, delta, zp, skip, bits, out=Non
     return out
 
 
+def timestep_embedding(timesteps: torch.Tensor, dim: int, out_dtype=torch.float32):
+    """Timesteps.forward (diffusers_rewrite/sd.py:19-39) as one launch: ``timesteps`` [rows] int64 or fp32 (any stride: the expanded
+    single timestep has stride 0) -> [rows, dim] = cat(cos, sin)."""
+    assert timesteps.dim() == 1 and timesteps.dtype in (torch.int64, torch.float32) and dim % 2 == 0
+    rows = timesteps.shape[0]
+    out = torch.empty((rows, dim), dtype=out_dtype, device=timesteps.device)
+    _lib_call("dgq_timestep_embedding", _lib.ptr(timesteps), 1 if timesteps.dtype == torch.float32 else 0, int(timesteps.stride(0)), rows, dim,
+              _lib.ptr(out), _lib.DTYPE_CODE[out_dtype], _lib.stream())
+    return out
+
+
+def cfg_ddim_step(eps_uncond, eps_cond, sample, guidance, s1, inv_s2, s3, s4):
+    """eps = e_u + guidance·(e_c − e_u) (``eps_cond`` None: eps = e_u), then the DDIM update s3·((x − s1·eps)·inv_s2) + s4·eps in the
+    order of the eager chain (pipeline_stable_diffusion.py:1037-1044, scheduling_ddim.py); fp32 contiguous tensors."""
+    for t in (eps_uncond, eps_cond, sample):
+        assert t is None or (t.dtype == torch.float32 and t.is_contiguous() and t.numel() == sample.numel())
+    out = torch.empty_like(sample)
+    _lib_call("dgq_cfg_ddim_step", _lib.ptr(eps_uncond), _lib.ptr(eps_cond), _lib.ptr(sample), _lib.ptr(out), sample.numel(),
+              _c.c_float(guidance), _c.c_float(s1), _c.c_float(inv_s2), _c.c_float(s3), _c.c_float(s4), _lib.stream())
+    return out
+
+
 def max_f32(p: torch.Tensor, skip_cols=0):
     assert p.is_contiguous() and p.dtype == torch.float32
     S = p.shape[-1]

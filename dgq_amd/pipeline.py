@@ -34,6 +34,9 @@ def stable_diffusion_denoise(unet, latents, prompt_embeds, num_inference_steps=2
             on_call(i, t)
         noise_pred = unet(latent_model_input, tt, encoder_hidden_states=prompt_embeds, timestep_cond=timestep_cond,
                           cross_attention_kwargs=None, added_cond_kwargs=None, return_dict=False)[0]
+        if do_cfg and hasattr(sch, "step_guided"):
+            latents = sch.step_guided(noise_pred, t, latents, guidance_scale)      # guidance + scheduler step (one launch on the GPU)
+            continue
         if do_cfg:
             noise_uncond, noise_text = noise_pred.chunk(2)
             noise_pred = noise_uncond + guidance_scale * (noise_text - noise_uncond)

@@ -30,6 +30,22 @@ class DDIMScheduler:
         pred_x0 = (sample - (1 - a_t) ** 0.5 * model_output) / a_t ** 0.5
         return a_prev ** 0.5 * pred_x0 + (1 - a_prev) ** 0.5 * model_output
 
+    def step_guided(self, noise_pred, t, sample, guidance_scale):
+        """Classifier-free guidance on the (unconditional ‖ conditional) prediction followed by ``step`` — the two statements of
+        the pipeline loop (pipeline_stable_diffusion.py:1037-1044).  fp32 device tensors take both as ONE launch
+        (dgq_cfg_ddim_step: the same fp32 operations in the same order — bit-identical to the ten eager kernels, including torch's
+        division by a host scalar as a multiplication by its reciprocal); anything else runs the torch statements."""
+        e_u, e_c = noise_pred.chunk(2)
+        import os
+        if (os.environ.get("DGQ_GLUE", "1") != "0" and noise_pred.is_cuda and noise_pred.dtype == torch.float32 and sample.dtype == torch.float32 and noise_pred.is_contiguous()
+                and sample.is_contiguous() and sample.numel() % 4 == 0 and e_u.numel() == sample.numel()):
+            from . import ops
+            a_t, a_prev = self._coef[int(t)]
+            s1, s2 = float((1 - a_t) ** 0.5), (a_t ** 0.5)
+            inv_s2 = float(torch.ones((), dtype=torch.float32) / s2)           # fp32 reciprocal, as the device kernel of `/ scalar` forms it
+            return ops.cfg_ddim_step(e_u, e_c, sample, float(guidance_scale), s1, inv_s2, float(a_prev ** 0.5), float((1 - a_prev) ** 0.5))
+        return self.step(e_u + guidance_scale * (e_c - e_u), t, sample)
+
 
 class PNDMScheduler:
     """PLMS (PNDM with ``skip_prk_steps=True``) — the scheduler the reference actually runs SD with: its pipeline is

@@ -139,6 +139,18 @@ int dgq_groupnorm_scale_shift(const void* x, int x_dtype, int B, int HW, int C, 
 int dgq_groupnorm_from_partials(const float* partial, int C1, const float* partial2, int C2, int B, int HW, int G, float eps,
                                 const float* gamma, const float* beta, float* scale, float* shift, void* stream);
 
+/* ---- elementwise glue of a denoise step as single launches ------------------------------------------------------------------
+ * Timesteps.forward (diffusers_rewrite/sd.py:19-39: flip_sin_to_cos, no frequency shift): out [rows][dim] =
+ * cat(cos(t·f), sin(t·f)), f_j = exp(−ln(10000)·j / (dim/2)).  t: rows values of int64 (t_is_float = 0) or fp32 (1), element
+ * stride t_stride (0 = the one timestep expanded over the batch, sd.py:550).  Same operation order as the torch chain. */
+int dgq_timestep_embedding(const void* t, int t_is_float, int64_t t_stride, int rows, int dim, void* out, int out_dtype, void* stream);
+/* Classifier-free guidance + DDIM update (eta = 0) of the pipeline loop (pipeline_stable_diffusion.py:1037-1044,
+ * schedulers/scheduling_ddim.py step): eps = e_u + guidance·(e_c − e_u) (eps_cond == NULL: eps = e_u),
+ * out = s3·((sample − s1·eps)·inv_s2) + s4·eps with s1 = sqrt(1−a_t), inv_s2 = 1/sqrt(a_t), s3 = sqrt(a_prev), s4 = sqrt(1−a_prev); fp32,
+ * n elements per tensor (n % 4 == 0, 16-byte aligned), evaluated in the order of the eager torch chain. */
+int dgq_cfg_ddim_step(const float* eps_uncond, const float* eps_cond, const float* sample, float* out, int64_t n, float guidance,
+                      float s1, float inv_s2, float s3, float s4, void* stream);
+
 /* ---- weight-only state (use_wq without use_aq: quant_layer.py:642-659 with unquantised activations) -----------------
  * y[m][n] = Σ_k x_unfolded[m][k]·w[n][k] + bias[n] in exact fp32 (V_MFMA_F32_32X32X2_F32), the im2col of a convolution folded
  * into the operand load: x channels-last [B][H][W][C] (x_dtype), w [N][kh·kw·C] fp32 = the dequantised weight δw·(qw − zw) with

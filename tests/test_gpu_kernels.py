@@ -1104,3 +1104,49 @@ def test_implicit_conv_geometries(geom, dev, monkeypatch):
         outs.append(ops.quant_conv2d(x, ab, k, k, stride, pad, norm=norm, residual=res))
     torch.cuda.synchronize()
     assert torch.equal(outs[0], outs[1]), (geom, (outs[0] - outs[1]).abs().max().item())
+
+
+# ------------------------------------------------------------------------------------------ step glue (glue.hip)
+@pytest.mark.parametrize("dim,tdtype", [(320, torch.int64), (256, torch.float32), (320, torch.float32)])
+def test_timestep_embedding_is_the_torch_chain(dim, tdtype, dev):
+    """dgq_timestep_embedding against Timesteps.forward's own torch chain (diffusers_rewrite/sd.py:19-39) on the device: the same
+    operations in the same order — equal bit for bit where the device libm functions coincide, within 2 ulp of an fp32 value in
+    [-1, 1] (2.4e-7) otherwise; and against the float64 formula on the host within fp32 evaluation error of the argument."""
+    import math
+    from dgq_amd import ops
+    for tv in ([981], [1], [999.0, 749.0, 0.0, 512.0, 3.0, 64.0]):
+        t = torch.tensor(tv, dtype=tdtype, device=dev)
+        if len(tv) == 1:
+            t = t.expand(2)                                                   # the expanded single timestep (stride 0)
+        half = dim // 2
+        freqs = torch.exp(-math.log(10000) * torch.arange(half, dtype=torch.float32, device=dev) / (half - 0.0))
+        ang = t[:, None].float() * freqs[None, :]
+        want = torch.cat([torch.cos(ang), torch.sin(ang)], dim=-1)
+        got = ops.timestep_embedding(t, dim)
+        torch.cuda.synchronize()
+        assert got.shape == want.shape
+        assert (got - want).abs().max().item() <= 2.4e-7, (tv, (got - want).abs().max().item())
+        f64 = torch.exp(-math.log(10000) * torch.arange(half, dtype=torch.float64) / half)
+        a64 = t.cpu().double()[:, None] * f64[None, :]
+        w64 = torch.cat([torch.cos(a64), torch.sin(a64)], dim=-1)
+        assert (got.cpu().double() - w64).abs().max().item() <= 1e-3           # |arg| <= 999 carries ~1e-4 of fp32 error
+
+
+def test_cfg_ddim_step_is_the_eager_chain_bit_for_bit(dev):
+    """guidance + DDIM update as one launch == the ten eager torch kernels of the pipeline loop (pipeline_stable_diffusion.py:1037-1044
+    + scheduling_ddim.py step): same fp32 operations, same order, torch's `/ host scalar` as `* (1 / scalar)`."""
+    from dgq_amd.scheduler import DDIMScheduler
+    sch = DDIMScheduler(50)
+    g = torch.Generator().manual_seed(3)
+    for t in (sch.timesteps[0], sch.timesteps[17], sch.timesteps[-1]):
+        eps = torch.randn(2, 4, 64, 64, generator=g).to(dev)
+        x = torch.randn(1, 4, 64, 64, generator=g).to(dev)
+        e_u, e_c = eps.chunk(2)
+        want = sch.step(e_u + 7.5 * (e_c - e_u), t, x)
+        got = sch.step_guided(eps, t, x, 7.5)
+        torch.cuda.synchronize()
+        assert torch.equal(got, want), (t, (got - want).abs().max().item())
+    # host tensors take the torch statements (pipeline glue, no device op involved)
+    eps, x = torch.randn(2, 4, 8, 8, generator=g), torch.randn(1, 4, 8, 8, generator=g)
+    e_u, e_c = eps.chunk(2)
+    assert torch.equal(sch.step_guided(eps, 1, x, 7.5), sch.step(e_u + 7.5 * (e_c - e_u), 1, x))
