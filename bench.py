@@ -178,6 +178,8 @@ def main(argv=None):
 
     C = CONFIGS[args.config]
     arch, res, qcfg, guidance = C["arch"], C["res"], C["cfg"], C["guidance"]
+    if os.environ.get("DGQ_BENCH_GUIDANCE") is not None:      # development: 0 = the conditional half alone (batch 1) — what one half of the CFG pair costs
+        guidance = float(os.environ["DGQ_BENCH_GUIDANCE"])
     if DRY:
         arch, res, guidance = "tiny", 16, 7.5
         args.no_graph = args.no_roofline = args.no_cpu_baseline = True

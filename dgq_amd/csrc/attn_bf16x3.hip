@@ -33,6 +33,12 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 #define KT 32
+#ifndef DGQ_ATTN_TPS_STATS
+#define DGQ_ATTN_TPS_STATS 2   // key tiles per ring stage of the 8-wave statistics launches (see attn3_stats_kernel)
+#endif
+#ifndef DGQ_ATTN_TPS_PV
+#define DGQ_ATTN_TPS_PV 2      // ... of the 8-wave P·V launches (where two stages of that many tile images fit the LDS)
+#endif
 #ifndef DGQ_PV_ST64
 #define DGQ_PV_ST64 2          // P·V ring depth at D = 64 with small (int8 K + one-plane V) images
 #endif
@@ -746,11 +752,14 @@ __device__ __forceinline__ void attn_block_coords(int xcd_remap, int& bx, int& b
 // NW waves of 32 query rows per block.  NW = 8 (256 rows, one block per CU, two waves per SIMD) where the grid still
 // fills the chip (T >= 2048 at B*H = 16): the K/V tile images are then staged once per 256 rows instead of once per
 // 128 — half the LDS-DMA pieces per wave per tile, the largest non-MFMA cost of the loop.
-template <int D, int NW, int QM>
+// TPS: key tiles per ring stage.  The barrier that retires a stage keeps the two waves of a SIMD (same workgroup) in lockstep — both in
+// their MFMA phase, then both in their VALU phase; with TPS = 2 a wave runs two tiles between barriers and its sibling may be a tile apart,
+// so one wave's exponentials overlap the other's products (the long self-attention loops: 128 tiles at T = S = 4096).
+template <int D, int NW, int QM, int TPS = 1>
 __global__ __launch_bounds__(64 * NW) void attn3_stats_kernel(AttnParams p) {
     using G = Geo<D, QM>;
     constexpr bool QI8 = G::QI8, KS = QM == 3;
-    constexpr int ST = G::STATS_STAGES, NP = G::K_PIECES, SB = NP * 1024;
+    constexpr int ST = TPS > 1 ? 3 : G::STATS_STAGES, NP = G::K_PIECES, TB = NP * 1024, SB = TPS * TB;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds8[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, h32 = lane >> 5;
     DGQ_DIAG_DECL
@@ -771,7 +780,9 @@ __global__ __launch_bounds__(64 * NW) void attn3_stats_kernel(AttnParams p) {
     const int nsp = gridDim.z, i0 = (int)((long)p.NT * blockIdx.z / nsp), i1 = (int)((long)p.NT * (blockIdx.z + 1) / nsp);
 #pragma unroll
     for (int i = 0; i < ST - 1; ++i)
-        issue_image<NP, NW>(img_lane + (int64_t)min(i0 + i, i1 - 1) * p.img_bytes, lds_base + i * SB, wid);
+#pragma unroll
+        for (int j = 0; j < TPS; ++j)
+            issue_image<NP, NW>(img_lane + (int64_t)min(i0 + TPS * i + j, i1 - 1) * p.img_bytes, lds_base + i * SB + j * TB, wid);
     bf16x8 qf[3][QI8 ? 1 : G::NKK];
     v4i qc[G::NK32];
     float4 qt = make_float4(1.0f, 0.0f, 0.0f, 0.0f);
@@ -794,17 +805,24 @@ __global__ __launch_bounds__(64 * NW) void attn3_stats_kernel(AttnParams p) {
     const float sl2 = p.scale * LOG2E * qt.x * dk;       // scores in log2 units: p = 2^(s2 − m)/l  (QI8: δq folded in, > 0)
     float mraw = -INFINITY, l = 0.0f, m2raw = -INFINITY; // running maxima of the UNSCALED scores (scale > 0)
     DGQ_STAMP(3);
-    wait_image<NP, ST - 2, NW>(wid);
+    wait_image<NP, TPS * (ST - 2), NW>(wid);
     __builtin_amdgcn_s_barrier();
     DGQ_STAMP(4);
     int stage = 0, istage = ST - 1;
-    for (int i = i0; i < i1; ++i) {
-        issue_image<NP, NW>(img_lane + (int64_t)min(i + ST - 1, i1 - 1) * p.img_bytes, lds_base + istage * SB, wid);
+    // (TPS > 1: the host launches this form only for key ranges of a whole number of stages)
+    for (int ib = i0; ib < i1; ib += TPS) {
+#pragma unroll
+      for (int jt = 0; jt < TPS; ++jt)
+        issue_image<NP, NW>(img_lane + (int64_t)min(ib + TPS * (ST - 1) + jt, i1 - 1) * p.img_bytes, lds_base + istage * SB + jt * TB, wid);
+#pragma unroll
+      for (int jt = 0; jt < TPS; ++jt) {
+        const int i = ib + jt;
+        const unsigned char* tile_lds = lds8 + stage * SB + jt * TB;
         const int s0 = i * KT;
         v16f acc;
-        if constexpr (QI8) acc = score_tile_i8<D, KS>(lds8 + stage * SB, qc, qt, lane, i == 0 && p.kskip > 0, inv_dk, cq);
-        else if constexpr (QM == 2) acc = score_tile_q1<D>(reinterpret_cast<const unsigned short*>(lds8 + stage * SB), qf, qt.y, lane);
-        else acc = score_tile<D>(reinterpret_cast<const unsigned short*>(lds8 + stage * SB), qf, lane);
+        if constexpr (QI8) acc = score_tile_i8<D, KS>(tile_lds, qc, qt, lane, i == 0 && p.kskip > 0, inv_dk, cq);
+        else if constexpr (QM == 2) acc = score_tile_q1<D>(reinterpret_cast<const unsigned short*>(tile_lds), qf, qt.y, lane);
+        else acc = score_tile<D>(reinterpret_cast<const unsigned short*>(tile_lds), qf, lane);
         const bool edge = (s0 + KT > p.S) || (s0 < p.skip);      // block-uniform: only the first / a partial last tile
         float tmax = -INFINITY, tmax2 = -INFINITY;
         if (edge) {
@@ -834,7 +852,8 @@ __global__ __launch_bounds__(64 * NW) void attn3_stats_kernel(AttnParams p) {
         l = l * __builtin_amdgcn_exp2f(fmaf(mraw, sl2, nb)) + (part.x + part.y);
         mraw = mn;
         m2raw = fmaxf(m2raw, tmax2);
-        wait_image<NP, ST - 2, NW>(wid);                      // tile i+1 (this wave's pieces) has landed
+      }
+        wait_image<NP, TPS * (ST - 2), NW>(wid);              // the next stage (this wave's pieces) has landed
         __builtin_amdgcn_s_barrier();                     // ... everyone's; and everyone is done reading `stage`
         stage = (stage + 1 == ST) ? 0 : stage + 1;
         istage = (istage + 1 == ST) ? 0 : istage + 1;
@@ -920,11 +939,13 @@ __global__ __launch_bounds__(256) void attn3_merge_kernel(AttnParams p) {
     }
 }
 
-template <int D, bool UNIFORM, int NW, int QM, bool VINT>
+// TPS: key tiles per ring stage (see attn3_stats_kernel); TPS = 2 runs a two-stage ring — the same prefetch distance in tiles as the
+// three-stage ring of single tiles, half the barriers.
+template <int D, bool UNIFORM, int NW, int QM, bool VINT, int TPS = 1>
 __global__ __launch_bounds__(64 * NW) void attn3_pv_kernel(AttnParams p) {
     using G = Geo<D, QM, VINT>;
     constexpr bool QI8 = G::QI8, KS = QM == 3;
-    constexpr int ST = G::PV_STAGES, NP = G::IMG_PIECES, SB = G::IMG_BYTES;
+    constexpr int ST = TPS > 1 ? 2 : G::PV_STAGES, NP = G::IMG_PIECES, TB = G::IMG_BYTES, SB = TPS * TB;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds8[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, h32 = lane >> 5;
     DGQ_DIAG_DECL
@@ -942,7 +963,9 @@ __global__ __launch_bounds__(64 * NW) void attn3_pv_kernel(AttnParams p) {
     const int nsp = gridDim.z, i0 = (int)((long)p.NT * blockIdx.z / nsp), i1 = (int)((long)p.NT * (blockIdx.z + 1) / nsp);   // key-split launches
 #pragma unroll
     for (int i = 0; i < ST - 1; ++i)
-        issue_image<NP, NW>(img_lane + (int64_t)min(i0 + i, i1 - 1) * G::IMG_BYTES, lds_base + i * SB, wid);
+#pragma unroll
+        for (int j = 0; j < TPS; ++j)
+            issue_image<NP, NW>(img_lane + (int64_t)min(i0 + TPS * i + j, i1 - 1) * G::IMG_BYTES, lds_base + i * SB + j * TB, wid);
     bf16x8 qf[3][QI8 ? 1 : G::NKK];
     v4i qc[G::NK32];
     float4 qt = make_float4(1.0f, 0.0f, 0.0f, 0.0f);
@@ -994,13 +1017,19 @@ __global__ __launch_bounds__(64 * NW) void attn3_pv_kernel(AttnParams p) {
     __builtin_amdgcn_s_barrier();
     DGQ_STAMP(4);
     int stage = 0, istage = ST - 1;
-    for (int i = i0; i < i1; ++i) {
-        issue_image<NP, NW>(img_lane + (int64_t)min(i + ST - 1, i1 - 1) * G::IMG_BYTES, lds_base + istage * SB, wid);
+    // (TPS > 1: the host launches this form only for key ranges of a whole number of stages)
+    for (int ib = i0; ib < i1; ib += TPS) {
+#pragma unroll
+      for (int jt = 0; jt < TPS; ++jt)
+        issue_image<NP, NW>(img_lane + (int64_t)min(ib + TPS * (ST - 1) + jt, i1 - 1) * G::IMG_BYTES, lds_base + istage * SB + jt * TB, wid);
+#pragma unroll
+      for (int jt = 0; jt < TPS; ++jt) {
+        const int i = ib + jt;
         const int s0 = i * KT;
-        const unsigned short* kbc = reinterpret_cast<const unsigned short*>(lds8 + stage * SB);
+        const unsigned short* kbc = reinterpret_cast<const unsigned short*>(lds8 + stage * SB + jt * TB);
         const unsigned short* vtc = kbc + G::K_ELEMS;
         v16f acc;
-        if constexpr (QI8) acc = score_tile_i8<D, KS>(lds8 + stage * SB, qc, qt, lane, i == 0 && p.kskip > 0, inv_dk, cq);
+        if constexpr (QI8) acc = score_tile_i8<D, KS>(lds8 + stage * SB + jt * TB, qc, qt, lane, i == 0 && p.kskip > 0, inv_dk, cq);
         else if constexpr (QM == 2) acc = score_tile_q1<D>(kbc, qf, qt.y, lane);
         else acc = score_tile<D>(kbc, qf, lane);
         // interior tiles carry no per-key conditions; only the first tile (bypassed column) and a partial last tile do
@@ -1101,7 +1130,8 @@ __global__ __launch_bounds__(64 * NW) void attn3_pv_kernel(AttnParams p) {
                 oacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pf[ks], oacc[j], 0, 0, 0);
             }
         }
-        wait_image<NP, ST - 2, NW>(wid);
+      }
+        wait_image<NP, TPS * (ST - 2), NW>(wid);
         __builtin_amdgcn_s_barrier();
         stage = (stage + 1 == ST) ? 0 : stage + 1;
         istage = (istage + 1 == ST) ? 0 : istage + 1;
@@ -1212,10 +1242,14 @@ static int launch_attn3(AttnParams p, const void* q_raw, unsigned char* planes, 
     p.planes = planes;
     p.img_bytes = G::IMG_BYTES;
     constexpr int stats_lds = G::STATS_STAGES * G::K_PIECES * 1024;
+    constexpr int TPS_S = (3 * DGQ_ATTN_TPS_STATS * G::K_PIECES * 1024 <= 160 * 1024) ? DGQ_ATTN_TPS_STATS : 2;                                // key tiles per stage of the wide statistics launches (three stages)
+    constexpr int stats2_lds = D <= 64 ? 3 * TPS_S * G::K_PIECES * 1024 : 0;
     // (+ the P·V epilogue's scratch in the idle ring: 3·DV floats of V tables, then 32 x 36 floats per wave — 8 waves at most)
     constexpr int pv_ring = G::PV_STAGES * G::IMG_BYTES, pv_scratch = 3 * G::DV * 4 + 8 * 32 * 36 * 4;
     constexpr int pv_lds = pv_ring > pv_scratch ? pv_ring : pv_scratch;
-    static_assert(stats_lds <= 160 * 1024 && pv_lds <= 160 * 1024, "LDS ring too large");
+    constexpr int TPS_P = (2 * DGQ_ATTN_TPS_PV * G::IMG_BYTES <= 160 * 1024) ? DGQ_ATTN_TPS_PV : 2;     // ... of the wide P·V launches (two stages)
+    constexpr int pv2_ring = D <= 64 ? 2 * TPS_P * G::IMG_BYTES : 0, pv2_lds = pv2_ring > pv_scratch ? pv2_ring : pv_scratch;
+    static_assert(stats_lds <= 160 * 1024 && pv_lds <= 160 * 1024 && stats2_lds <= 160 * 1024 && pv2_lds <= 160 * 1024, "LDS ring too large");
     // up to 138 KB of dynamic LDS (D = 160): opt in, once per device (the attribute is per device)
     static std::atomic<bool> attr_set[64];
     int dev = 0;
@@ -1226,8 +1260,11 @@ static int launch_attn3(AttnParams p, const void* q_raw, unsigned char* planes, 
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn3_pv_kernel<D, false, 4, QM, VINT>), hipFuncAttributeMaxDynamicSharedMemorySize, pv_lds);
         if constexpr (D <= 64) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn3_stats_kernel<D, 8, QM>), hipFuncAttributeMaxDynamicSharedMemorySize, stats_lds);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn3_stats_kernel<D, 8, QM, TPS_S>), hipFuncAttributeMaxDynamicSharedMemorySize, stats2_lds);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn3_pv_kernel<D, true, 8, QM, VINT>), hipFuncAttributeMaxDynamicSharedMemorySize, pv_lds);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn3_pv_kernel<D, false, 8, QM, VINT>), hipFuncAttributeMaxDynamicSharedMemorySize, pv_lds);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn3_pv_kernel<D, true, 8, QM, VINT, TPS_P>), hipFuncAttributeMaxDynamicSharedMemorySize, pv2_lds);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn3_pv_kernel<D, false, 8, QM, VINT, TPS_P>), hipFuncAttributeMaxDynamicSharedMemorySize, pv2_lds);
         }
         if (dev >= 0 && dev < 64) attr_set[dev].store(true, std::memory_order_release);
     }
@@ -1285,8 +1322,14 @@ static int launch_attn3(AttnParams p, const void* q_raw, unsigned char* planes, 
     if (wide) {
         if constexpr (D <= 64) {
             dim3 grid((p.T + 255) / 256, p.B * p.H), block(512);
-            hipLaunchKernelGGL((attn3_stats_kernel<D, 8, QM>), grid, block, stats_lds, st, p);
-            if (p.mode == 3) hipLaunchKernelGGL((attn3_pv_kernel<D, true, 8, QM, VINT>), grid, block, pv_lds, st, p);
+            const char* te = getenv("DGQ_ATTN_TPS");                        // "1": one key tile per stage everywhere (read per call: tests toggle it)
+            const bool tps_off = te && *te == '1';
+            if (!tps_off && p.NT >= 4 * TPS_S && p.NT % TPS_S == 0) hipLaunchKernelGGL((attn3_stats_kernel<D, 8, QM, TPS_S>), grid, block, stats2_lds, st, p);
+            else hipLaunchKernelGGL((attn3_stats_kernel<D, 8, QM>), grid, block, stats_lds, st, p);
+            if (!tps_off && p.NT >= 4 * TPS_P && p.NT % TPS_P == 0) {
+                if (p.mode == 3) hipLaunchKernelGGL((attn3_pv_kernel<D, true, 8, QM, VINT, TPS_P>), grid, block, pv2_lds, st, p);
+                else hipLaunchKernelGGL((attn3_pv_kernel<D, false, 8, QM, VINT, TPS_P>), grid, block, pv2_lds, st, p);
+            } else if (p.mode == 3) hipLaunchKernelGGL((attn3_pv_kernel<D, true, 8, QM, VINT>), grid, block, pv_lds, st, p);
             else hipLaunchKernelGGL((attn3_pv_kernel<D, false, 8, QM, VINT>), grid, block, pv_lds, st, p);
         }
     } else {
