@@ -262,15 +262,14 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_big_kernel(GemmBatch bt) {
             // are then s_cmp + s_cbranch (not taken); from the LDS table they take a v_readfirstlane each.
             int cqb[CPP];
             int tclr_b = 0;
+            v4i c4 = {0, 0, 0, 0};
             float cq[CPP];
             float tclr = 0.0f;
             if constexpr (!PER_M) {
                 if (__builtin_expect(use_ccoef, 1)) {
                     const float* cp = p.ccoef + (t * NCH + ph * CPP);
                     if constexpr (CPP == 4) {
-                        v4i c4;
-                        asm volatile("s_load_dwordx4 %0, %1, 0x0" : "=s"(c4) : "s"(cp) : "memory");
-                        cqb[0] = c4.x; cqb[1] = c4.y; cqb[2] = c4.z; cqb[3] = c4.w;
+                        asm volatile("s_load_dwordx4 %0, %1, 0x0" : "=s"(c4) : "s"(cp) : "memory");      // (read only behind the wait: see below)
                     } else {
 #pragma unroll
                         for (int cc = 0; cc < CPP; ++cc) asm volatile("s_load_dword %0, %1, 0x0" : "=s"(cqb[cc]) : "s"(cp + cc) : "memory");
@@ -303,6 +302,18 @@ __global__ __launch_bounds__(BIG_NT, 2) void gemm_big_kernel(GemmBatch bt) {
 #pragma unroll
                     for (int cc = 0; cc < CPP; ++cc) cqb[cc] = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, cq[cc]));
                     tclr_b = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, tclr));
+                } else {
+                    // the scalar loads above were issued from inline asm, which the compiler's waitcnt insertion does not track: their
+                    // outputs pass through this (empty, volatile: ordered behind the s_waitcnt lgkmcnt(0) asm above) statement as
+                    // read-write operands, so that every use of them is scheduled behind the wait
+                    if constexpr (CPP == 4) {
+                        asm volatile("" : "+s"(c4), "+s"(tclr_b));
+                        cqb[0] = c4.x; cqb[1] = c4.y; cqb[2] = c4.z; cqb[3] = c4.w;
+                    } else {
+#pragma unroll
+                        for (int cc = 0; cc < CPP; ++cc) asm volatile("" : "+s"(cqb[cc]));
+                        asm volatile("" : "+s"(tclr_b));
+                    }
                 }
             }
             // int4 -> int8 here, not in COMPUTE: the fragments have just arrived, and the MFMA segment then opens with an MFMA
