@@ -50,7 +50,7 @@ __host__ __device__ constexpr int panel_ctab_bytes(bool per_m, int nk) { return 
 template <int TM, int NW, int KW>
 constexpr int panel_lds(bool per_m, bool fuse, int nk) {
     return panel_region0<TM, NW, KW>(nk) + PanelCfg<TM, NW, KW>::VEC_BYTES + panel_ctab_bytes(per_m, nk) +
-           ((fuse && !per_m) ? 2 * nk * NCH * 4 : 0);
+           ((fuse && !per_m) ? nk * NCH * 16 + nk * BK * 4 : 0);      // (δ, z, 1/δ, ·) per chunk | decoded destination per source channel
 }
 
 template <bool PER_M, typename TIO, int TM, int NW, int KW, bool FUSE>
@@ -133,8 +133,10 @@ __global__ __launch_bounds__(64 * NW * KW) void gemm_panel_kernel(GemmBatch bt, 
     float* vtab = reinterpret_cast<float*>(smem + region0);  // [3][BM]: R0 R1 R2 | [4][BN]: alpha zw gamma vn
     float* vcol = vtab + 3 * BM;
     float* ctab = vcol + 4 * BN;                              // [nk·4] flush coefficients | [nk] clear flags
-    float* tdelta = reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(ctab) + panel_ctab_bytes(PER_M, nk));   // FUSE per-K: [nk·4] δ | [nk·4] z
-    float* tzp = tdelta + nk * NCH;
+    // FUSE per-K: [nk·NCH] float4 (δ, z, 1/δ, ·) of the chunks | [<= nk·BK] per source channel: panel offset of its code byte at row 0 with
+    // swizzle 0 (bits 0-19) and its chunk (bits 20-31) — the per-element work of the scatter is then one xor-add and one table read
+    float4* tq = reinterpret_cast<float4*>(reinterpret_cast<uint8_t*>(ctab) + panel_ctab_bytes(PER_M, nk));
+    uint32_t* tdst = reinterpret_cast<uint32_t*>(tq + nk * NCH);
     static_assert(BM <= NT && BN <= NT, "one row / column of the epilogue vectors per thread");
     constexpr int MYCH = NCH;
     const int n_coef = PER_M ? 0 : nk * MYCH, n_tab = PER_M ? 0 : n_coef + nk;
@@ -193,7 +195,14 @@ __global__ __launch_bounds__(64 * NW * KW) void gemm_panel_kernel(GemmBatch bt, 
         const int K = act.K;
         const float qmax = (float)((1 << act.bits) - 1), aoff = (float)(1 << (act.bits - 1));
         if constexpr (!PER_M) {
-            for (int i = tid; i < nk * NCH; i += NT) { tdelta[i] = p.cdelta[kt_begin * NCH + i]; tzp[i] = act.czp[kt_begin * NCH + i]; }
+            for (int i = tid; i < nk * NCH; i += NT) {
+                const float dl = p.cdelta[kt_begin * NCH + i];
+                tq[i] = make_float4(dl, act.czp[kt_begin * NCH + i], dgq_rcp(dl), 0.0f);
+            }
+            for (int c = tid; c < K; c += NT) {
+                const int kp = act.kdst[c];
+                tdst[c] = (uint32_t)((kp >> 7) * (BM * BK) + (kp & 127)) | ((uint32_t)(kp >> 5) << 20);
+            }
             for (int i = tid * 16; i < nk * BM * BK; i += NT * 16) *reinterpret_cast<uint4*>(smem + i) = make_uint4(0, 0, 0, 0);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
@@ -201,7 +210,7 @@ __global__ __launch_bounds__(64 * NW * KW) void gemm_panel_kernel(GemmBatch bt, 
         DGQ_STAMP(14);
         constexpr int QL = (NWT >= 8) ? 16 : 8;              // lanes per row
         constexpr int RPWV = 64 / QL, RP = NWT * RPWV;       // rows per wave / per pass of the workgroup
-        constexpr int SEG = 4;                               // 16-byte loads per lane in flight per round
+        constexpr int SEG = 4;                               // 16-byte loads per lane in flight per round (5 spills: 168 VGPRs + scratch)
         const int sl = lane % QL, rw = lane / QL;
         auto panel_addr = [&](int row, int kp) {
             return (kp >> 7) * (BM * BK) + row * BK + ((((kp & 127) >> 4) ^ ((row >> 1) & 7)) << 4) + (kp & 15);
@@ -252,6 +261,7 @@ __global__ __launch_bounds__(64 * NW * KW) void gemm_panel_kernel(GemmBatch bt, 
             }
             const float bias = 128.0f - aoff;
             float partial = 0.0f;
+            const uint32_t row_base = (uint32_t)(row * BK), row_swz = (uint32_t)(((row >> 1) & 7) << 4);
             const int kend = PER_M ? nk * BK : K;            // per-M also writes the zero codes of the K padding
             for (int c0 = sl * 4; c0 < kend; c0 += 4 * QL * SEG) {
                 float v[SEG][4];
@@ -261,7 +271,7 @@ __global__ __launch_bounds__(64 * NW * KW) void gemm_panel_kernel(GemmBatch bt, 
                 for (int j = 0; j < SEG; ++j) {
                     const int cc = min(c0 + j * 4 * QL, K - 4);
                     load4<TIO>(xr + cc, v[j]);
-                    if constexpr (!PER_M) kd[j] = *reinterpret_cast<const int4*>(act.kdst + cc);
+                    if constexpr (!PER_M) kd[j] = *reinterpret_cast<const int4*>(tdst + cc);
                 }
                 DGQ_STAMP_NOW(dg_q0);
                 if (psc) {
@@ -288,6 +298,8 @@ __global__ __launch_bounds__(64 * NW * KW) void gemm_panel_kernel(GemmBatch bt, 
 #pragma unroll
                 for (int j = 0; j < SEG; ++j) {
                     const int c = c0 + j * 4 * QL;                     // (past K: the clamped load's values, computed and discarded)
+                    // ... unless the whole wave is past the end (K = 320: the second round holds one segment, not four): wave-uniform
+                    if (c - sl * 4 >= kend) break;
                     if (psc) {
                         v[j][0] = v[j][0] * f0[j].x + f1[j].x; v[j][1] = v[j][1] * f0[j].y + f1[j].y;
                         v[j][2] = v[j][2] * f0[j].z + f1[j].z; v[j][3] = v[j][3] * f0[j].w + f1[j].w;
@@ -312,19 +324,20 @@ __global__ __launch_bounds__(64 * NW * KW) void gemm_panel_kernel(GemmBatch bt, 
                         }
                     } else {
                         {
-                            const int dst[4] = {kd[j].x, kd[j].y, kd[j].z, kd[j].w};
+                            const uint32_t dst[4] = {(uint32_t)kd[j].x, (uint32_t)kd[j].y, (uint32_t)kd[j].z, (uint32_t)kd[j].w};
                             float d4[4], i4[4], z4[4], qv[4];
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
-                                const int ch = dst[e] >> 5;
-                                d4[e] = tdelta[ch]; z4[e] = tzp[ch]; i4[e] = dgq_rcp(d4[e]);
+                                const float4 t4 = tq[dst[e] >> 20];
+                                d4[e] = t4.x; z4[e] = t4.y; i4[e] = t4.z;
                             }
                             dgq_affine_code4_fast(v[j], d4, i4, z4, qmax, qv);
                             const bool live = rv && c < K;
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
                                 const float scode = qv[e] - aoff;
-                                if (live) smem[panel_addr(row, dst[e])] = (uint8_t)(int)scode;
+                                // panel_addr(row, kp) = row·BK + (offset at row 0 ^ the row's 16-byte swizzle)
+                                if (live) smem[row_base + ((dst[e] & 0xFFFFFu) ^ row_swz)] = (uint8_t)(int)scode;
                                 partial += (c < K) ? d4[e] * scode : 0.0f;
                             }
                         }

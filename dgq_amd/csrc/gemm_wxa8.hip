@@ -801,6 +801,9 @@ static bool plan_panel_fuse(int M, int N, int Kp, bool per_m, GemmPlan& pl) {
     const char* ea = getenv("DGQ_GEMM_FUSE_ALL");        // (read per call: the test suite switches it)
     const bool all = ea && *ea == '1';
     if (!all && ((N + 32 * nw - 1) / (32 * nw) > 2 || M < 2048)) return false;
+    // (the 16-wave configurations compile with a few scratch dwords at 128 VGPRs — beside hand-counted vmcnt waits that is not something
+    // to ship: they stay test / sweep configurations)
+    if (!all && nw * kw >= 16) return false;
     pl.bm = PANEL_BM0 + 1; pl.bn = nw; pl.kw = kw; pl.fuse = true; pl.splits = 1;
     return true;
 }
