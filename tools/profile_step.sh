@@ -10,6 +10,7 @@ cd $R
 K=$(find $O/trace -name "*kernel_trace.csv" | head -1)
 S=$(find $O/trace -name "*kernel_stats.csv" | head -1)
 python tools/prof_summary.py $K 5 gpurun_out/${TAG}_bench_kernel_stats_per_step.csv "$TAG" > /dev/null
+python tools/step_trace.py $K > gpurun_out/${TAG}_step_dispatch_trace.tsv     # every dispatch of the last step in order (start, duration, gap, grid)
 cp $S gpurun_out/${TAG}_bench_rocprofv3_kernel_stats_whole_process.csv
 rm -rf $O/trace
 head -40 gpurun_out/${TAG}_bench_kernel_stats_per_step.csv | cut -c1-150
