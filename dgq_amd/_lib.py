@@ -47,7 +47,7 @@ SIGNATURES = {
     "dgq_adaround_reg_fwd": [_vp, _i64, _f, _vp, _vp],
     "dgq_adaround_reg_bwd": [_vp, _i64, _f, _vp, _vp, _vp],
     "dgq_timestep_embedding": [_vp, _i, _i64, _i, _i, _vp, _i, _vp],
-    "dgq_cfg_ddim_step": [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _vp],
+    "dgq_cfg_ddim_step": [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, _f, _f, _f, _f, _f, _vp],
 }
 
 

@@ -52,36 +52,28 @@ extern "C" int dgq_timestep_embedding(const void* t, int t_is_float, int64_t t_s
 }
 
 // eps = e_u + g·(e_c − e_u);  x' = s3·((x − s1·eps)·inv_s2) + s4·eps   with s1 = √(1−ᾱ_t), inv_s2 = 1/√ᾱ_t, s3 = √ᾱ_prev, s4 = √(1−ᾱ_prev).
-// eps_pair holds the unconditional half followed by the conditional half (n elements each); guidance == 0 with e_c == nullptr: eps = e_u.
+// sample / out: [n][C][HW] contiguous (the pipeline's latents); the two eps halves: element (n, c, p) at n·C·HW + c·ec + p·ep — ec = HW,
+// ep = 1 for the same layout, ec = 1, ep = C for the channels-last tensor the UNet returns.  e_c == nullptr: eps = e_u (no guidance).
 __global__ __launch_bounds__(256) void cfg_ddim_step_kernel(const float* __restrict__ e_u, const float* __restrict__ e_c, const float* __restrict__ x,
-                                                            float* __restrict__ out, int64_t n4, float g, float s1, float inv_s2, float s3, float s4) {
+                                                            float* __restrict__ out, int64_t n, int C, int HW, int64_t ec, int64_t ep, float g,
+                                                            float s1, float inv_s2, float s3, float s4) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n4) return;
-    const float4 u = reinterpret_cast<const float4*>(e_u)[i], xv = reinterpret_cast<const float4*>(x)[i];
-    float e[4] = {u.x, u.y, u.z, u.w};
-    if (e_c) {
-        const float4 c = reinterpret_cast<const float4*>(e_c)[i];
-        const float cc[4] = {c.x, c.y, c.z, c.w};
-#pragma unroll
-        for (int k = 0; k < 4; ++k) e[k] = e[k] + g * (cc[k] - e[k]);
-    }
-    const float xx[4] = {xv.x, xv.y, xv.z, xv.w};
-    float o[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const float p0 = (xx[k] - s1 * e[k]) * inv_s2;
-        o[k] = s3 * p0 + s4 * e[k];
-    }
-    reinterpret_cast<float4*>(out)[i] = make_float4(o[0], o[1], o[2], o[3]);
+    if (i >= n) return;
+    const int64_t img = i / ((int64_t)C * HW), r = i - img * C * HW;
+    const int c = (int)(r / HW), p = (int)(r - (int64_t)c * HW);
+    const int64_t ei = img * C * HW + c * ec + p * ep;
+    float e = e_u[ei];
+    if (e_c) e = e + g * (e_c[ei] - e);
+    const float p0 = (x[i] - s1 * e) * inv_s2;
+    out[i] = s3 * p0 + s4 * e;
 }
 
-extern "C" int dgq_cfg_ddim_step(const float* eps_uncond, const float* eps_cond, const float* sample, float* out, int64_t n, float guidance,
-                                 float s1, float inv_s2, float s3, float s4, void* stream) {
-    DGQ_CHECK_ARG(eps_uncond && sample && out && n > 0 && n % 4 == 0, "dgq_cfg_ddim_step: null pointer or n %% 4 != 0");
-    DGQ_CHECK_ARG(((reinterpret_cast<uintptr_t>(eps_uncond) | reinterpret_cast<uintptr_t>(eps_cond) | reinterpret_cast<uintptr_t>(sample) |
-                    reinterpret_cast<uintptr_t>(out)) & 15) == 0, "dgq_cfg_ddim_step: 16-byte alignment");
-    const int64_t n4 = n / 4;
-    hipLaunchKernelGGL(cfg_ddim_step_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, eps_uncond, eps_cond, sample, out,
-                       n4, guidance, s1, inv_s2, s3, s4);
+extern "C" int dgq_cfg_ddim_step(const float* eps_uncond, const float* eps_cond, const float* sample, float* out, int64_t n, int C, int HW,
+                                 int eps_channels_last, float guidance, float s1, float inv_s2, float s3, float s4, void* stream) {
+    DGQ_CHECK_ARG(eps_uncond && sample && out && n > 0 && C > 0 && HW > 0 && n % ((int64_t)C * HW) == 0,
+                  "dgq_cfg_ddim_step: null pointer or n not a whole number of [C][HW] images");
+    const int64_t ec = eps_channels_last ? 1 : HW, ep = eps_channels_last ? C : 1;
+    hipLaunchKernelGGL(cfg_ddim_step_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, eps_uncond, eps_cond, sample, out,
+                       n, C, HW, ec, ep, guidance, s1, inv_s2, s3, s4);
     return dgq_launch_status("dgq_cfg_ddim_step");
 }

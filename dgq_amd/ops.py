@@ -922,13 +922,29 @@ def timestep_embedding(timesteps: torch.Tensor, dim: int, out_dtype=torch.float3
     return out
 
 
+def _dense_layout(t):
+    """0: [N,C,H,W] contiguous, 1: channels-last dense, None: neither (4-D tensors; 2-/3-D contiguous counts as 0)"""
+    if t.is_contiguous():
+        return 0
+    if t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last):
+        return 1
+    return None
+
+
 def cfg_ddim_step(eps_uncond, eps_cond, sample, guidance, s1, inv_s2, s3, s4):
     """eps = e_u + guidance·(e_c − e_u) (``eps_cond`` None: eps = e_u), then the DDIM update s3·((x − s1·eps)·inv_s2) + s4·eps in the
-    order of the eager chain (pipeline_stable_diffusion.py:1037-1044, scheduling_ddim.py); fp32 contiguous tensors."""
+    order of the eager chain (pipeline_stable_diffusion.py:1037-1044, scheduling_ddim.py); fp32; ``sample`` contiguous, the eps halves in
+    the same layout or channels-last (what the UNet returns).  Returns None when the layouts are not of that kind."""
+    lay = _dense_layout(eps_uncond)
+    if (lay is None or not sample.is_contiguous() or sample.dim() < 2 or eps_uncond.shape != sample.shape
+            or (eps_cond is not None and (eps_cond.shape != sample.shape or _dense_layout(eps_cond) != lay))):
+        return None
     for t in (eps_uncond, eps_cond, sample):
-        assert t is None or (t.dtype == torch.float32 and t.is_contiguous() and t.numel() == sample.numel())
+        assert t is None or t.dtype == torch.float32
+    C = sample.shape[1]
+    HW = sample.numel() // (sample.shape[0] * C)
     out = torch.empty_like(sample)
-    _lib_call("dgq_cfg_ddim_step", _lib.ptr(eps_uncond), _lib.ptr(eps_cond), _lib.ptr(sample), _lib.ptr(out), sample.numel(),
+    _lib_call("dgq_cfg_ddim_step", _lib.ptr(eps_uncond), _lib.ptr(eps_cond), _lib.ptr(sample), _lib.ptr(out), sample.numel(), C, HW, lay,
               _c.c_float(guidance), _c.c_float(s1), _c.c_float(inv_s2), _c.c_float(s3), _c.c_float(s4), _lib.stream())
     return out
 

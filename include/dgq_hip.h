@@ -147,9 +147,10 @@ int dgq_timestep_embedding(const void* t, int t_is_float, int64_t t_stride, int 
 /* Classifier-free guidance + DDIM update (eta = 0) of the pipeline loop (pipeline_stable_diffusion.py:1037-1044,
  * schedulers/scheduling_ddim.py step): eps = e_u + guidance·(e_c − e_u) (eps_cond == NULL: eps = e_u),
  * out = s3·((sample − s1·eps)·inv_s2) + s4·eps with s1 = sqrt(1−a_t), inv_s2 = 1/sqrt(a_t), s3 = sqrt(a_prev), s4 = sqrt(1−a_prev); fp32,
- * n elements per tensor (n % 4 == 0, 16-byte aligned), evaluated in the order of the eager torch chain. */
-int dgq_cfg_ddim_step(const float* eps_uncond, const float* eps_cond, const float* sample, float* out, int64_t n, float guidance,
-                      float s1, float inv_s2, float s3, float s4, void* stream);
+ * n elements per tensor = whole [C][HW] images; sample / out contiguous [n/(C·HW)][C][HW]; the eps halves in the same layout
+ * (eps_channels_last = 0) or as [.][HW][C] (1: the UNet's channels-last output); evaluated in the order of the eager torch chain. */
+int dgq_cfg_ddim_step(const float* eps_uncond, const float* eps_cond, const float* sample, float* out, int64_t n, int C, int HW,
+                      int eps_channels_last, float guidance, float s1, float inv_s2, float s3, float s4, void* stream);
 
 /* ---- weight-only state (use_wq without use_aq: quant_layer.py:642-659 with unquantised activations) -----------------
  * y[m][n] = Σ_k x_unfolded[m][k]·w[n][k] + bias[n] in exact fp32 (V_MFMA_F32_32X32X2_F32), the im2col of a convolution folded

@@ -1138,14 +1138,26 @@ def test_cfg_ddim_step_is_the_eager_chain_bit_for_bit(dev):
     from dgq_amd.scheduler import DDIMScheduler
     sch = DDIMScheduler(50)
     g = torch.Generator().manual_seed(3)
-    for t in (sch.timesteps[0], sch.timesteps[17], sch.timesteps[-1]):
-        eps = torch.randn(2, 4, 64, 64, generator=g).to(dev)
-        x = torch.randn(1, 4, 64, 64, generator=g).to(dev)
-        e_u, e_c = eps.chunk(2)
-        want = sch.step(e_u + 7.5 * (e_c - e_u), t, x)
-        got = sch.step_guided(eps, t, x, 7.5)
-        torch.cuda.synchronize()
-        assert torch.equal(got, want), (t, (got - want).abs().max().item())
+    from dgq_amd import ops
+    calls = []
+    real = ops.cfg_ddim_step
+    ops.cfg_ddim_step = lambda *a: calls.append(real(*a)) or calls[-1]
+    try:
+        for t in (sch.timesteps[0], sch.timesteps[17], sch.timesteps[-1]):
+            for P, cl in ((1, True), (1, False), (3, True)):          # channels-last: the layout the UNet's output has
+                eps = torch.randn(2 * P, 4, 64, 64, generator=g).to(dev)
+                if cl:
+                    eps = eps.contiguous(memory_format=torch.channels_last)
+                x = torch.randn(P, 4, 64, 64, generator=g).to(dev)
+                e_u, e_c = eps.chunk(2)
+                want = sch.step(e_u + 7.5 * (e_c - e_u), t, x)
+                n0 = len(calls)
+                got = sch.step_guided(eps, t, x, 7.5)
+                torch.cuda.synchronize()
+                assert len(calls) == n0 + 1 and calls[-1] is not None, "the single-launch form was not taken"
+                assert torch.equal(got, want), (t, P, cl, (got - want).abs().max().item())
+    finally:
+        ops.cfg_ddim_step = real
     # host tensors take the torch statements (pipeline glue, no device op involved)
     eps, x = torch.randn(2, 4, 8, 8, generator=g), torch.randn(1, 4, 8, 8, generator=g)
     e_u, e_c = eps.chunk(2)
