@@ -253,7 +253,8 @@ class ActBinding:
         return hit
 
     def conv_zero_code(self):
-        """centred int8 code of the value 0.0 under this scalar quantizer: clamp(rne(0/δ) + z) − offset (set at construction)"""
+        """centred int8 code of the value 0.0 under this scalar quantizer, z − offset (set at construction); None when z is not a
+        code of the b-bit range (no implicit operand for such a layer)"""
         return self._zc
 
     def conv_fill(self):
@@ -289,9 +290,17 @@ class ActBinding:
             self.gamma = pw.bias
             self.vn = pw.vn()
             if layout.mode == "scalar":                    # implicit-im2col convolutions: the code of 0.0 and the DMA fill line
+                # The reference's scalar-δ convolution is the native F.conv2d(aqtizer(x), ŵ, padding) (quant_layer.py:659): it pads with
+                # exact 0.0 BEHIND the quantizer, i.e. with the code z.  That is a code of the b-bit range only while 0 <= z <= 2^b − 1
+                # (always, for the min/max-derived scales of every DGQ recipe; a Scaler.MSE range of a one-signed input could leave it).
+                # Outside it neither this path nor the materialised one can represent the padding value: no implicit operand then
+                # (``conv_zero_code() is None``), the layer takes the materialising pass and its documented pad-then-quantise form.
                 z = float(layout.mzp.reshape(-1)[0])
-                self._zc = float(min(max(round(z), 0.0), 2.0 ** abits - 1.0) - self.offset)
-                self._fill = torch.tensor([int(self._zc)] * 16 + [0] * 16, dtype=torch.int8, device=dev)
+                if 0.0 <= round(z) <= 2.0 ** abits - 1.0:
+                    self._zc = float(round(z) - self.offset)
+                    self._fill = torch.tensor([int(self._zc)] * 16 + [0] * 16, dtype=torch.int8, device=dev)
+                else:
+                    self._zc, self._fill = None, None
 
 
 # ------------------------------------------------------------------------------------------ hot path
@@ -829,7 +838,7 @@ def quant_conv2d(x: torch.Tensor, ab: ActBinding, kh, kw, stride, pad, norm=None
         if part is not None:
             out._dgq_gn = dict(parts=[(part, N)], B=B, HW=Ho * Wo, C=N, ver=out._version)
         return out
-    implicit = CONV_IMPLICIT and ab.mode == "scalar" and kh * kw > 1 and C % 16 == 0 and ab.pw.bits == 4
+    implicit = CONV_IMPLICIT and ab.mode == "scalar" and kh * kw > 1 and C % 16 == 0 and ab.pw.bits == 4 and ab.conv_zero_code() is not None
     conv_desc = None
     if implicit:
         # ONE (δ, z) for the whole operand (the reference's native path F.conv2d(aqtizer(x), ŵ), quant_layer.py:659): every input

@@ -203,7 +203,8 @@ int dgq_conv2d_f32w(const void* x, int x_dtype, int B, int H, int W, int C, int 
  * dgq_gemm_wxa8 then takes the rows of the unfolded operand straight from codes_in: K order kp = tap·C + c (the natural
  * conv order of dgq_pack_w4's kperm == NULL image of the [N][kh][kw][C] weight), row m = (b·Ho + ho)·Wo + wo, tap (dh, dw)
  * reads pixel (ho·stride − pad + dh, wo·stride − pad + dw); a tap outside the image reads `fill` (16 bytes of the code of
- * the value 0.0 — F.unfold pads BEFORE the quantizer, quant_layer.py:634-641 — followed by 16 zero bytes for the K padding).
+ * the value 0.0, i.e. z − offset: the native F.conv2d of quant_layer.py:659 pads with 0.0 BEHIND the quantizer, which is the code
+ * z — the caller offers this operand only while 0 <= z <= 2^b − 1 — followed by 16 zero bytes for the K padding).
  * `codes` / `rowsum` of the call: codes is ignored (pass codes_in), rowsum [M] is an OUTPUT scratch the call fills first
  * (Σ over the taps of pixsum, C·zero_code for a tap outside).  per_m == 1 with L == 1, C % 16 == 0, w_bits == 4. */
 typedef struct dgq_gemm_conv {
