@@ -1377,7 +1377,7 @@ int dgq_attention_bf16x3(const void* q, const void* k, const void* v, void* o, i
                          float scale, int mode, int skip, float qmax, float* stats_ws, float* delta_ws, void* planes,
                          float* qfq, float* o_part, const dgq_attn_fq_t* fq, hipStream_t st) {
     AttnParams p;
-    p.stats_part = stats_ws + (size_t)B * H * T * 2;      // (the statistics area holds 10 floats per row: 2 merged + 2 x 4 partial)
+    p.stats_part = stats_ws + (((size_t)B * H * T * 2 + 3) & ~(size_t)3);      // (the statistics area holds 10 floats per row: 2 merged + 2 x 4 partial, read as float4: 16-byte aligned for an odd row count too)
     p.o_part = o_part;
     for (int i = 0; i < 3; ++i) {
         p.fq[i].mode = -1; p.fq[i].skip = 0; p.fq[i].qmax = 0.0f; p.fq[i].delta = nullptr; p.fq[i].zp = nullptr;
