@@ -82,7 +82,7 @@ class QuantActArgs(ctypes.Structure):
     _fields_ = [("x", _vp), ("x_dtype", _i), ("B", _i), ("H", _i), ("W", _i), ("C", _i), ("kh", _i), ("kw", _i), ("stride", _i),
                 ("pad", _i), ("ksrc", _vp), ("koff", _vp), ("klds", _vp), ("kdst", _vp), ("Kp", _i), ("per_m", _i), ("delta", _vp), ("zp", _vp),
                 ("L", _i), ("bits", _i), ("codes", _vp), ("rowsum", _vp), ("ksplits", _i), ("pre_scale", _vp), ("pre_shift", _vp),
-                ("pre_act", _i), ("ln_gamma", _vp), ("ln_beta", _vp), ("ln_eps", _f), ("kpat", _vp)]
+                ("pre_act", _i), ("ln_gamma", _vp), ("ln_beta", _vp), ("ln_eps", _f), ("kpat", _vp), ("ups", _i)]
 
 
 class GemmArgs(ctypes.Structure):

@@ -34,6 +34,8 @@ struct QuantActParams {
     const float* ln_gamma;    // optional [C]: LayerNorm over the C elements of the row, v = (x − μ)·rstd·γ + β (1x1 only)
     const float* ln_beta;
     float ln_eps;
+    int ups;                  // 1: x holds (H/2) x (W/2) pixels per image and pixel (hi, wi) of the H x W input reads (hi/2, wi/2) — a 2x nearest
+                              // upsample in front of the layer (Upsample2D) folded into the load; scatter and block-staged conv paths only
 };
 
 // Up to DGQ_QA_BATCH problems of ONE kernel variant and the same row count in one launch (blockIdx.z = problem): the
@@ -457,7 +459,8 @@ __global__ __launch_bounds__(64 * NWV) void quant_act_scatter_kernel(QuantActBat
         const int b = row / L, l = row - b * L;
         const int ho = l / p.Wo, wo = l - ho * p.Wo;
         const int hbase = ho * p.stride - p.pad, wbase = wo * p.stride - p.pad;
-        const TIn* img = x + (int64_t)b * p.H * p.W * p.ldc;
+        const int us = p.ups, Ws = p.W >> us;               // source geometry: (H >> ups) x (W >> ups) pixels per image
+        const TIn* img = x + (int64_t)b * (p.H >> us) * Ws * p.ldc;
         const float* pre_sc = p.pre_scale ? p.pre_scale + (int64_t)b * p.C : nullptr;
         const float* pre_sh = p.pre_shift ? p.pre_shift + (int64_t)b * p.C : nullptr;
         const int taps = p.kh * p.kw;
@@ -469,7 +472,7 @@ __global__ __launch_bounds__(64 * NWV) void quant_act_scatter_kernel(QuantActBat
             const int dh = tap / p.kw, dw = tap - dh * p.kw;
             const int hi = hbase + dh, wi = wbase + dw;
             const bool inb = hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;     // wave-uniform
-            const TIn* src = img + ((int64_t)hi * p.W + wi) * p.ldc;
+            const TIn* src = img + ((int64_t)(hi >> us) * Ws + (wi >> us)) * p.ldc;
             const int32_t* kd = p.kdst + tap * p.C;
                 float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
                 if (inb) {
@@ -573,7 +576,8 @@ __global__ __launch_bounds__(64 * NW) void quant_act_conv_kernel(QuantActBatch b
     const int ho0 = th * TH, wo0 = tw * TW;
     const int PH = (TH - 1) * p.stride + p.kh, PW = (TW - 1) * p.stride + p.kw;
     const int hi0 = ho0 * p.stride - p.pad, wi0 = wo0 * p.stride - p.pad;
-    const TIn* img = reinterpret_cast<const TIn*>(p.x) + (int64_t)b * p.H * p.W * p.C;
+    const int us = p.ups, Ws = p.W >> us;                   // source geometry: (H >> ups) x (W >> ups) pixels per image
+    const TIn* img = reinterpret_cast<const TIn*>(p.x) + (int64_t)b * (p.H >> us) * Ws * p.C;
     const float* pre_sc = p.pre_scale ? p.pre_scale + (int64_t)b * p.C : nullptr;
     const float* pre_sh = p.pre_shift ? p.pre_shift + (int64_t)b * p.C : nullptr;
     // ---- stage the patch: wave w takes pixels w, w + NW, ...
@@ -581,7 +585,7 @@ __global__ __launch_bounds__(64 * NW) void quant_act_conv_kernel(QuantActBatch b
         const int ph = pp / PW, pw_ = pp - ph * PW;
         const int hi = hi0 + ph, wi = wi0 + pw_;
         const bool inb = hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;       // wave-uniform
-        const TIn* src = img + ((int64_t)hi * p.W + wi) * p.C;
+        const TIn* src = img + ((int64_t)(hi >> us) * Ws + (wi >> us)) * p.C;      // (ups: the four pixels of a 2 x 2 cell read one source pixel)
         float* dst = patch + pp * p.C;
         for (int c = lane * 4; c < p.C; c += 256) {
             float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -874,6 +878,8 @@ static int fill_quant_act(const dgq_quant_act_args_t& a, QuantActParams& p) {
     p.pre_scale = a.pre_scale; p.pre_shift = a.pre_shift; p.pre_act = a.pre_act;
     p.ln_gamma = a.ln_gamma; p.ln_beta = a.ln_beta; p.ln_eps = a.ln_eps;
     p.ldc = a.pre_act == 2 ? 2 * a.C : a.C;
+    p.ups = a.ups ? 1 : 0;
+    DGQ_CHECK_ARG(!p.ups || (a.H % 2 == 0 && a.W % 2 == 0 && a.kh * a.kw > 1), "dgq_quant_act: ups needs even H, W and a convolution");
     return DGQ_OK;
 }
 
@@ -886,6 +892,8 @@ extern "C" int dgq_quant_act_batch(int n, const dgq_quant_act_args_t* args, void
         if (rc != DGQ_OK) return rc;
         const int v = quant_act_variant(bt.p[i], args[i].ksrc != nullptr);
         if (i == 0) variant = v;
+        DGQ_CHECK_ARG(!bt.p[i].ups || v == 3 || v == 4 || v == 5, "dgq_quant_act_batch: the folded 2x upsample exists on the scatter and block-staged "
+                      "conv paths (dgq_quant_act_variant 3 / 4 / 5), this problem takes variant %d", v);
         DGQ_CHECK_ARG(v == variant && args[i].x_dtype == args[0].x_dtype && (args[i].per_m != 0) == (args[0].per_m != 0) &&
                       bt.p[i].M == bt.p[0].M,
                       "dgq_quant_act_batch: problem %d differs from problem 0 in kernel variant / dtype / scale mode / row count", i);
@@ -925,6 +933,6 @@ extern "C" int dgq_quant_act(const void* x, int x_dtype, int B, int H, int W, in
     a.x = x; a.x_dtype = x_dtype; a.B = B; a.H = H; a.W = W; a.C = C; a.kh = kh; a.kw = kw; a.stride = stride; a.pad = pad;
     a.ksrc = ksrc; a.koff = koff; a.klds = klds; a.kdst = nullptr; a.kpat = nullptr; a.Kp = Kp; a.per_m = per_m; a.delta = delta; a.zp = zp; a.L = L; a.bits = bits;
     a.codes = codes; a.rowsum = rowsum; a.ksplits = ksplits; a.pre_scale = pre_scale; a.pre_shift = pre_shift; a.pre_act = pre_act;
-    a.ln_gamma = ln_gamma; a.ln_beta = ln_beta; a.ln_eps = ln_eps;
+    a.ln_gamma = ln_gamma; a.ln_beta = ln_beta; a.ln_eps = ln_eps; a.ups = 0;
     return dgq_quant_act_batch(1, &a, stream);
 }

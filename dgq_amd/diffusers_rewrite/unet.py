@@ -269,6 +269,9 @@ class Upsample2D(nn.Module):
         self.conv = nn.Conv2d(c, c, 3, 1, 1)
 
     def forward(self, x):
+        folded = getattr(self.conv, "forward_upsampled", None)
+        if folded is not None and _fusion_on():
+            return folded(x)                                   # QuantLayer: the interpolate folded into the conv's quantise-on-load pass
         return self.conv(F.interpolate(x, scale_factor=2.0, mode="nearest"))
 
 

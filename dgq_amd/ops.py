@@ -6,6 +6,7 @@ import os
 from typing import Optional
 
 import torch
+import torch.nn.functional as F
 
 from . import _lib
 from .plan import ActLayout, natural_kperm, round_up, KTILE, act_offset, mark_clears, flush_coefficients
@@ -386,10 +387,12 @@ def groupnorm_from_partials(gn, groups, eps, gamma, beta):
     return scale, shift
 
 
-def quant_act(x_cl: torch.Tensor, B, H, W, C, kh, kw, stride, pad, ab: ActBinding, pre=None, ln=None):
+def quant_act(x_cl: torch.Tensor, B, H, W, C, kh, kw, stride, pad, ab: ActBinding, pre=None, ln=None, ups=False):
     """x_cl: contiguous channels-last storage [B][H][W][C] (any fp dtype). Returns (codes, rowsum[parts][M], M).
     pre = (scale [B][C], shift [B][C], act) folds a GroupNorm (+SiLU when act == 1) into the load;
-    ln = (gamma [C], beta [C], eps) folds a LayerNorm over each row's C elements (Linear inputs)."""
+    ln = (gamma [C], beta [C], eps) folds a LayerNorm over each row's C elements (Linear inputs).
+    ups: x_cl holds [B][H/2][W/2][C] and is read through a 2x nearest upsample (Upsample2D's interpolate folded into the load);
+    returns None when the layer's quantise variant has no such form."""
     Ho = (H + 2 * pad - kh) // stride + 1
     Wo = (W + 2 * pad - kw) // stride + 1
     M = B * Ho * Wo
@@ -408,12 +411,15 @@ def quant_act(x_cl: torch.Tensor, B, H, W, C, kh, kw, stride, pad, ab: ActBindin
     a.pre_act = pre[2] if pre else 0
     lnp = (as_f32(ln[0]), as_f32(ln[1]), float(ln[2])) if ln else None
     a.ln_gamma, a.ln_beta, a.ln_eps = (lnp[0].data_ptr(), lnp[1].data_ptr(), lnp[2]) if lnp else (None, None, 0.0)
+    a.ups = 1 if ups else 0
     # the LDS-scatter path (per-K convs, per-K Linear inputs with short groups) takes the whole row in one wave / block:
     # ask for it with one K split first
     parts = 1
     a.ksplits = 1
     a.codes = a.rowsum = 1                                   # placeholders: dgq_quant_act_variant only validates non-NULL
     if (a.kdst is None and a.kpat is None) or _lib.load().dgq_quant_act_variant(_c.byref(a)) not in (3, 4, 5):
+        if ups:
+            return None                                      # (the folded upsample exists on the scatter / block-staged paths)
         parts = act_ksplits(M, ab.Kp)
         a.ksplits = parts
     codes = torch.empty((M, ab.Kp), dtype=torch.int8, device=x_cl.device)
@@ -425,7 +431,7 @@ def quant_act(x_cl: torch.Tensor, B, H, W, C, kh, kw, stride, pad, ab: ActBindin
     issue()
     if QUANT_LAUNCH_HOOK is not None:
         # algorithmic bytes: the input once (un-unfolded) + the codes + the row sums
-        QUANT_LAUNCH_HOOK(issue, B * H * W * ldc * x_cl.element_size() + M * ab.Kp + 4 * parts * M)
+        QUANT_LAUNCH_HOOK(issue, (B * H * W * ldc * x_cl.element_size() >> (2 if ups else 0)) + M * ab.Kp + 4 * parts * M)
     return codes, rowsum, M
 
 
@@ -804,12 +810,18 @@ def quant_linear_multi(x: torch.Tensor, bindings, ln=None):
     return [o.view(*x.shape[:-1], o.shape[-1]) for o in outs]
 
 
-def quant_conv2d(x: torch.Tensor, ab: ActBinding, kh, kw, stride, pad, norm=None, residual=None, bias_rows=None, gn_out=True):
+def quant_conv2d(x: torch.Tensor, ab: ActBinding, kh, kw, stride, pad, norm=None, residual=None, bias_rows=None, gn_out=True, upsample=False):
     """x logical NCHW (any strides; made channels-last) -> logical NCHW output in channels-last storage.
     norm = (groups, eps, gamma, beta, act): GroupNorm (+SiLU) of x folded into the quantise-on-load pass;
     residual (logical NCHW, same shape as the output) is added in the GEMM epilogue; bias_rows [B][N] likewise, one row
-    per image (conv1(...) + time_emb_proj(...)[:, :, None, None])."""
+    per image (conv1(...) + time_emb_proj(...)[:, :, None, None]).
+    upsample: the layer's input is F.interpolate(x, scale_factor=2, mode="nearest") (Upsample2D.forward); where the quantise
+    variant of the layer can read x through that mapping the 4x tensor is never written, otherwise it is materialised here."""
+    if upsample and (norm is not None or ab.mode == "scalar" or kh * kw == 1):
+        x, upsample = F.interpolate(x, scale_factor=2.0, mode="nearest"), False
     B, C, H, W = x.shape
+    if upsample:
+        H, W = 2 * H, 2 * W                           # the layer's input geometry; x stays the (H/2) x (W/2) source
     xc = x.contiguous(memory_format=torch.channels_last)
     x_store = xc.permute(0, 2, 3, 1)                  # [B,H,W,C] view over the same storage, contiguous
     pre = None
@@ -853,7 +865,11 @@ def quant_conv2d(x: torch.Tensor, ab: ActBinding, kh, kw, stride, pad, norm=None
         cv.zero_code, cv.pixsum_parts = ab.conv_zero_code(), pixsum.shape[0]
         conv_desc = (cv, pixsum)
     else:
-        codes, rowsum, M = quant_act(x_store, B, H, W, C, kh, kw, stride, pad, ab, pre)
+        qa = quant_act(x_store, B, H, W, C, kh, kw, stride, pad, ab, pre, ups=upsample)
+        if qa is None:                                # no folded form for this layer's quantise variant: materialise the upsample
+            return quant_conv2d(F.interpolate(x, scale_factor=2.0, mode="nearest"), ab, kh, kw, stride, pad, norm=norm, residual=residual,
+                                bias_rows=bias_rows, gn_out=gn_out)
+        codes, rowsum, M = qa
     # GroupNorm partials of the output for whoever normalises it next: from the GEMM's own epilogue, or — a K-split launch —
     # from its combine kernel (DGQ_GN_FROM_SPLITK=0: only unsplit launches, the tensor gets a statistics pass otherwise)
     N = ab.pw.N

@@ -613,6 +613,18 @@ class QuantLayer(nn.Module):
             y = y.index_select(-1, self._row_unperm(y.device))
         return _tap(self, y, x=x, prologue=False)
 
+    def forward_upsampled(self, x: torch.Tensor) -> torch.Tensor:
+        """``self(F.interpolate(x, scale_factor=2.0, mode="nearest"))`` — Upsample2D.forward (diffusers_rewrite/sd.py).  On the integer
+        path of a k x k convolution the quantise-on-load pass reads x through the (h/2, w/2) mapping and the upsampled tensor is
+        never written (ops.quant_conv2d(upsample=True)); with a layer tap installed, during calibration or in any other state the
+        interpolate runs as written."""
+        if (LAYER_TAP is None and self.is_conv and self.on_integer_path(x) and x.dtype in ops.FLOAT_DTYPES and not self.aqtizer.calibrating()
+                and not self._forward_hooks and not self._forward_pre_hooks and self.w.shape[2] * self.w.shape[3] > 1
+                and os.environ.get("DGQ_FOLD_UPSAMPLE", "1") != "0"):
+            kh, kw = self.w.shape[2], self.w.shape[3]
+            return ops.quant_conv2d(x, self._binding(), kh, kw, self.fwd_kwargs["stride"][0], self.fwd_kwargs["padding"][0], upsample=True)
+        return self(F.interpolate(x, scale_factor=2.0, mode="nearest"))
+
     def on_integer_path(self, x: torch.Tensor) -> bool:
         """True when forward(x) would run dgq_quant_act + dgq_gemm_wxa8 (weights and activations quantised, GPU)."""
         return (self.use_wq and self.use_aq and not self.disable_aq and x.is_cuda

@@ -117,6 +117,10 @@ typedef struct dgq_quant_act_args {
                                  Enables the block-staged conv path (variant 5): a workgroup stages the input patch of a tile
                                  of output positions once in LDS with the GroupNorm / SiLU prologue applied once per element
                                  (the per-row paths apply it once per tap), then gathers every row's codes from it. */
+    int ups;                  /* 0, or 1: x holds (H/2) x (W/2) pixels per image and input pixel (hi, wi) reads (hi/2, wi/2) — the
+                                 F.interpolate(x, scale_factor=2, mode="nearest") in front of Upsample2D's conv (diffusers_rewrite/sd.py
+                                 Upsample2D.forward) folded into the load.  H, W are the UPSAMPLED dims; convolutions on the scatter /
+                                 block-staged paths only (dgq_quant_act_variant 3 / 4 / 5, asked with ups set), DGQ_EINVAL otherwise. */
 } dgq_quant_act_args_t;
 int dgq_quant_act_batch(int n, const dgq_quant_act_args_t* args, void* stream);
 int dgq_quant_act_variant(const dgq_quant_act_args_t* args);

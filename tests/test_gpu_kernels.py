@@ -1183,3 +1183,39 @@ def test_attention_two_tiles_per_stage_is_bit_identical(D, T, S, mode, skip, qmo
     torch.cuda.synchronize()
     assert torch.isfinite(o2).all()
     assert torch.equal(o1, o2), (o1 - o2).abs().max().item()
+
+
+@pytest.mark.parametrize("B,C,Hs,N,mode", [(2, 64, 8, 64, "perK"), (2, 320, 32, 320, "perK"), (2, 128, 16, 96, "perK"), (2, 320, 32, 64, "perM"),
+                                           (1, 64, 8, 32, "perM"), (2, 64, 16, 64, "scalar")])
+def test_upsample_folded_into_the_conv_quantiser(B, C, Hs, N, mode, dev):
+    """Upsample2D.forward = conv(F.interpolate(x, 2x, nearest)) (diffusers_rewrite/sd.py): ops.quant_conv2d(upsample=True) reads the
+    (H/2) x (W/2) source through the (h/2, w/2) mapping inside the quantise-on-load pass (scatter and block-staged conv kernels,
+    dgq_quant_act_args_t.ups) and materialises the interpolate for layers on other variants — bit-identical either way."""
+    from dgq_amd import ops, synth
+    from dgq_amd.plan import plan_act
+    g = torch.Generator().manual_seed(B * C + Hs + N)
+    K = C * 9
+    w = (torch.randn(N, C, 3, 3, generator=g) * 0.05).to(dev)
+    x = (torch.randn(B, C, Hs, Hs, generator=g) * 1.3 + 0.2).to(dev)
+    wd, wz = synth.channel_minmax(w.cpu(), 4)
+    pw = ops.PackedWeight(w, wd.to(dev), wz.to(dev), None, torch.randn(N, generator=g).to(dev), 4, C, 9)
+    H = 2 * Hs
+    if mode == "perK":
+        d, z = synth._group_params(K, 16, 8, "ups|%d" % K, 0)
+        lay = plan_act(d.view(1, -1, 1), z.view(1, -1, 1), "conv", C, 9, 8)
+    elif mode == "perM":
+        d, z = synth._group_params(H * H, 16, 8, "ups|%d" % K, 0)
+        lay = plan_act(d.view(1, 1, -1), z.view(1, 1, -1), "conv", C, 9, 8)
+    else:
+        lay = plan_act(torch.tensor(0.031), torch.tensor(121.0), "conv", C, 9, 8)
+    ab = ops.ActBinding(lay, pw, 8)
+    res = torch.randn(B, N, H, H, generator=g).to(dev)
+    want = ops.quant_conv2d(torch.nn.functional.interpolate(x, scale_factor=2.0, mode="nearest"), ab, 3, 3, 1, 1, residual=res)
+    got = ops.quant_conv2d(x, ab, 3, 3, 1, 1, residual=res, upsample=True)
+    torch.cuda.synchronize()
+    assert got.shape == want.shape == (B, N, H, H)
+    assert torch.equal(got, want), (got - want).abs().max().item()
+    gw, gg = getattr(want, "_dgq_gn", None), getattr(got, "_dgq_gn", None)
+    assert (gw is None) == (gg is None)
+    if gw is not None:
+        assert torch.equal(gw["parts"][0][0], gg["parts"][0][0])
