@@ -774,11 +774,22 @@ static void launch_quant_act(const QuantActBatch& bt, int n, int variant, bool p
             DGQ_QA_ATTR(true, 4, 8); DGQ_QA_ATTR(false, 4, 8); DGQ_QA_ATTR(true, 4, 4); DGQ_QA_ATTR(false, 4, 4);
             DGQ_QA_ATTR(true, 2, 4); DGQ_QA_ATTR(false, 2, 4);
 #undef DGQ_QA_ATTR
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&quant_act_conv_kernel<TIn, true, 4, 4, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&quant_act_conv_kernel<TIn, false, 4, 4, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
             if (dev >= 0 && dev < 64) attr5[dev].store(true, std::memory_order_release);
         }
 #define DGQ_QA_CONV(PM, TH_, TW_) hipLaunchKernelGGL((quant_act_conv_kernel<TIn, PM, TH_, TW_, 8>), dim3(tiles, 1, n), dim3(512), t.lds, st, bt)
         if (t.id == 1) { if (per_m) DGQ_QA_CONV(true, 4, 8); else DGQ_QA_CONV(false, 4, 8); }
-        else if (t.id == 2) { if (per_m) DGQ_QA_CONV(true, 4, 4); else DGQ_QA_CONV(false, 4, 4); }
+        else if (t.id == 2) {
+            // 16 positions per tile: one wave per output position (16 waves) instead of two positions per wave — the gather / quantise phase is a
+            // chain of dependent LDS reads per 1024 codes, and twice the waves hide twice the latency (same lanes, same order per row:
+            // bit-identical; step +0.3-0.5 % same box).  DGQ_QA_CONV_W16=0: the 8-wave form.
+            static const bool w16 = [] { const char* e = getenv("DGQ_QA_CONV_W16"); return !(e && *e == '0'); }();
+            if (w16) {
+                if (per_m) hipLaunchKernelGGL((quant_act_conv_kernel<TIn, true, 4, 4, 16>), dim3(tiles, 1, n), dim3(1024), t.lds, st, bt);
+                else hipLaunchKernelGGL((quant_act_conv_kernel<TIn, false, 4, 4, 16>), dim3(tiles, 1, n), dim3(1024), t.lds, st, bt);
+            } else if (per_m) DGQ_QA_CONV(true, 4, 4); else DGQ_QA_CONV(false, 4, 4);
+        }
         else { if (per_m) DGQ_QA_CONV(true, 2, 4); else DGQ_QA_CONV(false, 2, 4); }
 #undef DGQ_QA_CONV
         return;
