@@ -617,13 +617,19 @@ __global__ __launch_bounds__(64 * NW) void quant_act_conv_kernel(QuantActBatch b
     if (!PER_M)
         for (int c = tid; c < (p.Kp >> 5); c += 64 * NW) { tdl[c] = p.delta[c]; tzp[c] = p.zp[c]; }
     __syncthreads();
-    // ---- gather + quantise: wave w takes output positions w, w + NW, ... of the tile
+    // ---- gather + quantise: wave w takes output positions w, w + NW, ... of the tile; with more waves than positions (WPR waves per
+    // position) a position's 1024-code steps are dealt round-robin over its waves and the row sum is the sum of their parts in wave order
+    constexpr int WPR = (NW > TH * TW) ? NW / (TH * TW) : 1;
+    static_assert(WPR == 1 || NW == WPR * TH * TW, "waves per position: a whole number");
+    __shared__ float rs_part[WPR > 1 ? TH * TW * WPR : 1];
+    const int part = WPR > 1 ? wv % WPR : 0;
     const float bias = 128.0f - p.offset;
-    for (int r = wv; r < TH * TW; r += NW) {
+    for (int r = wv / WPR; r < TH * TW; r += NW / WPR) {
         const int i = r / TW, j = r - i * TW;
         const int ho = ho0 + i, wo = wo0 + j;
-        if (ho >= p.Ho || wo >= p.Wo) continue;                               // wave-uniform
-        const int row = (b * p.Ho + ho) * p.Wo + wo;
+        if (WPR == 1 && (ho >= p.Ho || wo >= p.Wo)) continue;                 // wave-uniform
+        const bool live = ho < p.Ho && wo < p.Wo;                             // (WPR > 1: every wave reaches the barrier below)
+        const int row = (b * p.Ho + min(ho, p.Ho - 1)) * p.Wo + min(wo, p.Wo - 1);
         const float* pr = patch + ((i * p.stride) * PW + j * p.stride) * p.C;
         float md = 1.0f, mz = 0.0f, minv = 1.0f;
         if (PER_M) {
@@ -634,7 +640,7 @@ __global__ __launch_bounds__(64 * NW) void quant_act_conv_kernel(QuantActBatch b
         }
         float partial = 0.0f;
         uint32_t* out = reinterpret_cast<uint32_t*>(p.codes + (int64_t)row * p.Kp);
-        for (int kb = lane * 4; kb < p.Kp; kb += 1024) {
+        for (int kb = lane * 4 + 1024 * part; kb < (live ? p.Kp : 0); kb += 1024 * WPR) {
             int idx[4][4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -670,7 +676,18 @@ __global__ __launch_bounds__(64 * NW) void quant_act_conv_kernel(QuantActBatch b
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) partial += __shfl_down(partial, o, 64);
-        if (lane == 0) p.rowsum[row] = partial;
+        if constexpr (WPR == 1) {
+            if (lane == 0) p.rowsum[row] = partial;
+        } else {
+            if (lane == 0) rs_part[r * WPR + part] = partial;
+            __syncthreads();                                                  // (one position per wave group: every wave gets here exactly once)
+            if (lane == 0 && part == 0 && live) {
+                float tot = rs_part[r * WPR];
+#pragma unroll
+                for (int q = 1; q < WPR; ++q) tot += rs_part[r * WPR + q];
+                p.rowsum[row] = tot;
+            }
+        }
     }
 }
 
@@ -776,6 +793,8 @@ static void launch_quant_act(const QuantActBatch& bt, int n, int variant, bool p
 #undef DGQ_QA_ATTR
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&quant_act_conv_kernel<TIn, true, 4, 4, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&quant_act_conv_kernel<TIn, false, 4, 4, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&quant_act_conv_kernel<TIn, true, 2, 4, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&quant_act_conv_kernel<TIn, false, 2, 4, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
             if (dev >= 0 && dev < 64) attr5[dev].store(true, std::memory_order_release);
         }
 #define DGQ_QA_CONV(PM, TH_, TW_) hipLaunchKernelGGL((quant_act_conv_kernel<TIn, PM, TH_, TW_, 8>), dim3(tiles, 1, n), dim3(512), t.lds, st, bt)
@@ -790,7 +809,15 @@ static void launch_quant_act(const QuantActBatch& bt, int n, int variant, bool p
                 else hipLaunchKernelGGL((quant_act_conv_kernel<TIn, false, 4, 4, 16>), dim3(tiles, 1, n), dim3(1024), t.lds, st, bt);
             } else if (per_m) DGQ_QA_CONV(true, 4, 4); else DGQ_QA_CONV(false, 4, 4);
         }
-        else { if (per_m) DGQ_QA_CONV(true, 2, 4); else DGQ_QA_CONV(false, 2, 4); }
+        else {
+            // 8 positions per tile, 16 waves: two waves per position (the per-K row sum then adds its two parts: last-bit differences
+            // against the one-wave order; per-M sums are exact integers).  DGQ_QA_CONV_W16=0: 8 waves.
+            static const bool w16b = [] { const char* e = getenv("DGQ_QA_CONV_W16"); return !(e && *e == '0'); }();
+            if (w16b) {
+                if (per_m) hipLaunchKernelGGL((quant_act_conv_kernel<TIn, true, 2, 4, 16>), dim3(tiles, 1, n), dim3(1024), t.lds, st, bt);
+                else hipLaunchKernelGGL((quant_act_conv_kernel<TIn, false, 2, 4, 16>), dim3(tiles, 1, n), dim3(1024), t.lds, st, bt);
+            } else if (per_m) DGQ_QA_CONV(true, 2, 4); else DGQ_QA_CONV(false, 2, 4);
+        }
 #undef DGQ_QA_CONV
         return;
     }
