@@ -428,7 +428,7 @@ __global__ __launch_bounds__(256) void quant_act_staged_kernel(QuantActBatch bt)
 // 128 x 11904 codes against 6.0 us for the per-M form of the same layer); the (tap, 256-channel step) units are dealt round-robin instead.
 template <typename TIn, int RPB, int NWV = 4>
 __global__ __launch_bounds__(64 * NWV) void quant_act_scatter_kernel(QuantActBatch bt) {
-    static_assert(RPB == 1 || NWV == 4, "four rows per block: one wave each");
+    static_assert(RPB == 1 || NWV == 4 || NWV == 8, "four rows per block: one or two waves each");
     const QuantActParams& p = bt.p[blockIdx.z];
     extern __shared__ __attribute__((aligned(16))) uint8_t sc_smem[];
     constexpr int WPR = NWV / RPB;                           // waves per row
@@ -529,7 +529,7 @@ __global__ __launch_bounds__(64 * NWV) void quant_act_scatter_kernel(QuantActBat
     DGQ_STAMP(5);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) partial += __shfl_down(partial, o, 64);
-    if (RPB == 1 && lane == 0) psum[wv] = partial;
+    if ((RPB == 1 || WPR > 1) && lane == 0) psum[wv] = partial;
     __syncthreads();                                        // every wave's bytes of the shared image(s) are in LDS
     DGQ_STAMP(6);
     if (row < p.M) {
@@ -542,6 +542,10 @@ __global__ __launch_bounds__(64 * NWV) void quant_act_scatter_kernel(QuantActBat
                 tot = 0.0f;
 #pragma unroll
                 for (int w = 0; w < NWV; w += 2) tot += psum[w] + psum[w + 1];
+            } else if (WPR > 1) {                            // the row's waves, in wave order
+                tot = psum[rslot * WPR];
+#pragma unroll
+                for (int w = 1; w < WPR; ++w) tot += psum[rslot * WPR + w];
             }
             p.rowsum[row] = tot;
         }
@@ -832,11 +836,17 @@ static void launch_quant_act(const QuantActBatch& bt, int n, int variant, bool p
         (void)hipGetDevice(&dev);
         if (dev < 0 || dev >= 64 || !attr_set[dev].load(std::memory_order_acquire)) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&quant_act_scatter_kernel<TIn, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&quant_act_scatter_kernel<TIn, 4, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&quant_act_scatter_kernel<TIn, 1, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&quant_act_scatter_kernel<TIn, 1, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
             if (dev >= 0 && dev < 64) attr_set[dev].store(true, std::memory_order_release);
         }
-        if (variant == 3) hipLaunchKernelGGL((quant_act_scatter_kernel<TIn, 4>), dim3((p0.M + 3) / 4, 1, n), dim3(256), lds, st, bt);
+        // four rows per block: two waves per row (the (tap, 256-channel) units dealt round-robin; each wave forms the row's LayerNorm
+        // statistics itself) — a 2048-row launch is 2048 waves otherwise, two per SIMD, each a chain of dependent loads.
+        // DGQ_QA_SCATTER_W8=0: one wave per row.
+        static const bool sw8 = [] { const char* e = getenv("DGQ_QA_SCATTER_W8"); return !(e && *e == '0'); }();
+        if (variant == 3 && sw8) hipLaunchKernelGGL((quant_act_scatter_kernel<TIn, 4, 8>), dim3((p0.M + 3) / 4, 1, n), dim3(512), lds, st, bt);
+        else if (variant == 3) hipLaunchKernelGGL((quant_act_scatter_kernel<TIn, 4>), dim3((p0.M + 3) / 4, 1, n), dim3(256), lds, st, bt);
         else if ((long)p0.M * n <= 256) hipLaunchKernelGGL((quant_act_scatter_kernel<TIn, 1, 16>), dim3(p0.M, 1, n), dim3(1024), lds, st, bt);
         else hipLaunchKernelGGL((quant_act_scatter_kernel<TIn, 1, 8>), dim3(p0.M, 1, n), dim3(512), lds, st, bt);
         return;
