@@ -127,29 +127,47 @@ __global__ __launch_bounds__(256) void conv_f32w_smalln_kernel(ConvF32Params p) 
                      (reinterpret_cast<uintptr_t>(p.w) & 15) == 0 &&
                      (!p.pre_scale || (((reinterpret_cast<uintptr_t>(p.pre_scale) | reinterpret_cast<uintptr_t>(p.pre_shift)) & 15) == 0));
     if (vec) {
+        // (tap, four channels) units of the position dealt round-robin over the lanes, four units per lane and round with all their loads
+        // issued before the first use: C = 320 is 720 units = 11.25 per lane in three rounds (N <= 4; two units per round for 5..8 outputs).  (Tap by tap with 256-channel steps the
+        // second step of every tap ran on 16 of the 64 lanes and a wave walked 18 dependent load rounds: 49 us for conv_out of an SD step.)
         const float* xf = reinterpret_cast<const float*>(p.x);
-        for (int tap = 0; tap < p.kh * p.kw; ++tap) {
-            const int dh = tap / p.kw, dw = tap - dh * p.kw;
-            const int hi = ho * p.stride - p.pad + dh, wi = wo * p.stride - p.pad + dw;
-            if (hi < 0 || hi >= p.H || wi < 0 || wi >= p.W) continue;          // wave-uniform
-            const float* xs = xf + (((int64_t)b * p.H + hi) * p.W + wi) * p.C;
-            const float* wt = p.w + (int64_t)tap * p.C;
-            for (int c = lane * 4; c < p.C; c += 256) {
-                float4 v = *reinterpret_cast<const float4*>(xs + c);
+        const int c4n = p.C >> 2, units = p.kh * p.kw * c4n;
+        constexpr int UB = NMAX <= 4 ? 4 : 2;                      // (registers: UB x NMAX float4 of weights in flight)
+        for (int u0 = lane; u0 < units; u0 += 64 * UB) {
+            float4 v[UB], sc[UB], sh[UB], w4[UB][NMAX];
+            bool inb[UB];
+#pragma unroll
+            for (int j = 0; j < UB; ++j) {
+                const int u = min(u0 + 64 * j, units - 1);
+                const int tap = u / c4n, c = (u - tap * c4n) << 2;
+                const int dh = tap / p.kw, dw = tap - dh * p.kw;
+                const int hi = ho * p.stride - p.pad + dh, wi = wo * p.stride - p.pad + dw;
+                inb[j] = (u0 + 64 * j < units) && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
+                const int hc = min(max(hi, 0), p.H - 1), wc = min(max(wi, 0), p.W - 1);       // clamped: the load is unconditional
+                v[j] = *reinterpret_cast<const float4*>(xf + (((int64_t)b * p.H + hc) * p.W + wc) * p.C + c);
                 if (p.pre_scale) {
-                    const float4 sc = *reinterpret_cast<const float4*>(p.pre_scale + (int64_t)b * p.C + c);
-                    const float4 sh = *reinterpret_cast<const float4*>(p.pre_shift + (int64_t)b * p.C + c);
-                    v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+                    sc[j] = *reinterpret_cast<const float4*>(p.pre_scale + (int64_t)b * p.C + c);
+                    sh[j] = *reinterpret_cast<const float4*>(p.pre_shift + (int64_t)b * p.C + c);
                 }
-                if (p.pre_act == 1) { v.x = dgq_silu(v.x); v.y = dgq_silu(v.y); v.z = dgq_silu(v.z); v.w = dgq_silu(v.w); }
+#pragma unroll
+                for (int n = 0; n < NMAX; ++n)
+                    if (n < p.N) w4[j][n] = *reinterpret_cast<const float4*>(p.w + (int64_t)n * p.K + (int64_t)tap * p.C + c);
+            }
+#pragma unroll
+            for (int j = 0; j < UB; ++j) {
+                float4 t = v[j];
+                if (p.pre_scale) {
+                    t.x = t.x * sc[j].x + sh[j].x; t.y = t.y * sc[j].y + sh[j].y; t.z = t.z * sc[j].z + sh[j].z; t.w = t.w * sc[j].w + sh[j].w;
+                }
+                if (p.pre_act == 1) { t.x = dgq_silu(t.x); t.y = dgq_silu(t.y); t.z = dgq_silu(t.z); t.w = dgq_silu(t.w); }
+                if (!inb[j]) t = make_float4(0.0f, 0.0f, 0.0f, 0.0f);                       // a tap outside the image / past the last unit adds nothing
 #pragma unroll
                 for (int n = 0; n < NMAX; ++n)
                     if (n < p.N) {
-                        const float4 w4 = *reinterpret_cast<const float4*>(wt + (int64_t)n * p.K + c);
-                        acc[n] = __builtin_fmaf(v.x, w4.x, acc[n]);
-                        acc[n] = __builtin_fmaf(v.y, w4.y, acc[n]);
-                        acc[n] = __builtin_fmaf(v.z, w4.z, acc[n]);
-                        acc[n] = __builtin_fmaf(v.w, w4.w, acc[n]);
+                        acc[n] = __builtin_fmaf(t.x, w4[j][n].x, acc[n]);
+                        acc[n] = __builtin_fmaf(t.y, w4[j][n].y, acc[n]);
+                        acc[n] = __builtin_fmaf(t.z, w4[j][n].z, acc[n]);
+                        acc[n] = __builtin_fmaf(t.w, w4[j][n].w, acc[n]);
                     }
             }
         }
@@ -196,7 +214,8 @@ extern "C" int dgq_conv2d_f32w(const void* x, int x_dtype, int B, int H, int W, 
     p.N = N; p.K = kh * kw * C; p.M = B * p.Ho * p.Wo; p.ldy = ldy;
     DGQ_CHECK_ARG(ldy >= N, "dgq_conv2d_f32w: ldy < N");
     if (N <= 8) {
-        hipLaunchKernelGGL(conv_f32w_smalln_kernel<8>, dim3((p.M + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
+        if (N <= 4) hipLaunchKernelGGL(conv_f32w_smalln_kernel<4>, dim3((p.M + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL(conv_f32w_smalln_kernel<8>, dim3((p.M + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
         return dgq_launch_status("dgq_conv2d_f32w");
     }
     dim3 grid((N + CF_BN - 1) / CF_BN, (p.M + CF_BM - 1) / CF_BM);
