@@ -845,9 +845,10 @@ static void launch_quant_act(const QuantActBatch& bt, int n, int variant, bool p
         // statistics itself) — a 2048-row launch is 2048 waves otherwise, two per SIMD, each a chain of dependent loads.
         // DGQ_QA_SCATTER_W8=0: one wave per row.
         static const bool sw8 = [] { const char* e = getenv("DGQ_QA_SCATTER_W8"); return !(e && *e == '0'); }();
+        static const long s16_max = [] { const char* e = getenv("DGQ_QA_SCATTER16_MAXM"); return e && *e ? atol(e) : 2048L; }();  // rows (x problems) up to which a row gets 16 waves instead of 8: 256 -> 2048 measured +0.5 % on the SD step (same box)
         if (variant == 3 && sw8) hipLaunchKernelGGL((quant_act_scatter_kernel<TIn, 4, 8>), dim3((p0.M + 3) / 4, 1, n), dim3(512), lds, st, bt);
         else if (variant == 3) hipLaunchKernelGGL((quant_act_scatter_kernel<TIn, 4>), dim3((p0.M + 3) / 4, 1, n), dim3(256), lds, st, bt);
-        else if ((long)p0.M * n <= 256) hipLaunchKernelGGL((quant_act_scatter_kernel<TIn, 1, 16>), dim3(p0.M, 1, n), dim3(1024), lds, st, bt);
+        else if ((long)p0.M * n <= s16_max) hipLaunchKernelGGL((quant_act_scatter_kernel<TIn, 1, 16>), dim3(p0.M, 1, n), dim3(1024), lds, st, bt);
         else hipLaunchKernelGGL((quant_act_scatter_kernel<TIn, 1, 8>), dim3(p0.M, 1, n), dim3(512), lds, st, bt);
         return;
     }
