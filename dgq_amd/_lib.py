@@ -9,6 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DGQ_HIP_LIB") or os.path.join(_HERE, "csrc", "libdgq_hip.so")   # override: A/B builds of the kernels
 
 _vp, _i, _f, _i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64
+ABI_VERSION = 120          # DGQ_ABI_VERSION of include/dgq_hip.h: the struct layouts below are that revision's
 
 # name -> argtypes; every function returns int except dgq_last_error
 SIGNATURES = {
@@ -35,6 +36,7 @@ SIGNATURES = {
     "dgq_conv2d_f32w": [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _i, _vp, _vp, _i, _vp],
     "dgq_attention_fuses_fakequant": [_i, _i],
     "dgq_attention_workspace_bytes": [_i, _i, _i, _i, _i],
+    "dgq_attention_sync_timeouts": [],
     "dgq_minmax_rows_cols": [_vp, _i, _i, _i, _i64, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "dgq_linear_smallm_batch": [_vp, _i, _i, _i, _i64, _i, _i, _vp, _i, _vp],
     "dgq_quant_act_batch": [_i, _vp, _vp],
@@ -114,6 +116,9 @@ def load():
             fn = getattr(lib, name)
             fn.argtypes = args
             fn.restype = ctypes.c_size_t if name.endswith("_workspace_bytes") else ctypes.c_int
+        if lib.dgq_version() != ABI_VERSION:
+            raise RuntimeError("dgq_amd: %s is ABI revision %d, this binding was written against %d (include/dgq_hip.h: "
+                               "DGQ_ABI_VERSION) — rebuild with `make -C dgq_amd/csrc`" % (LIB_PATH, lib.dgq_version(), ABI_VERSION))
         lib.dgq_last_error.argtypes = []
         lib.dgq_last_error.restype = ctypes.c_char_p
         _lib = lib

@@ -12,5 +12,5 @@ void dgq_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-extern "C" int dgq_version(void) { return 100; }   /* 0.1.0 */
+extern "C" int dgq_version(void) { return DGQ_ABI_VERSION; }
 extern "C" const char* dgq_last_error(void) { return g_err; }

@@ -221,8 +221,8 @@ size_t dgq_attention_qi8_bytes(int B, int H, int T, int D);
 
 // workspace layout: [0,256) δ scalar | stats B·H·T·10 floats (2 merged + 2 x 4 per key half of a split launch; 256-byte aligned) | tile images of the bf16 split planes of
 // K and V | fake-quantised copy of q (used when aqtizer_q is fused) | the second key half's part of o (split launches)
-static size_t attn_stats_off() { return 256; }
-static size_t attn_planes_off(int B, int H, int T) { return 256 + ((((size_t)B * H * T * 10 + 4) * sizeof(float) + 255) / 256) * 256; }   // (+ 4: the partial area starts 16-byte aligned)
+static size_t attn_stats_off() { return 8704; }   // (δ slots at 0, the single-launch form's 1024 exchange granules at 512: DELTA_AREA_BYTES of attn_bf16x3_dev.h)
+static size_t attn_planes_off(int B, int H, int T) { return 8704 + ((((size_t)B * H * T * 10 + 4) * sizeof(float) + 255) / 256) * 256; }   // (+ 4: the partial area starts 16-byte aligned)
 
 // query scratch: an fp32 (fake-quantised) copy of q, or the int8 codes + per-query table of the QI8 path
 static size_t attn_q_scratch(int B, int H, int T, int D) {

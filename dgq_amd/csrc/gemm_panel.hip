@@ -1,22 +1,23 @@
-// gemm_panel.hip — the SHORT-K member of the W4A8 GEMM family (round 5): the launches of a UNet step whose K extent (or K slice) is a
-// few K tiles — every Linear / 1x1 layer of SD1.4 (K = 320 ... 1280, after DGQ padding Kp = 384 ... 1664), and the weight-streaming
-// low-M layers through a K split.  Same operands, tables, epilogue (gemm_tile.h) and results as gemm_wxa8_kernel; a different loop,
-// and — FUSE — the activation quantiser of the layer inside the same launch.
+// gemm_panel.hip — the quantise-on-load member of the W4A8 GEMM family (round 5): Linear / 1x1 layers whose whole padded K fits an LDS
+// panel (SD1.4: K = 320 ... 1280, after DGQ padding Kp = 384 ... 1664) run their activation quantiser (UniformAffineQuantizer.forward on
+// the layer input, quant/quant_layer.py:295-299, with the LayerNorm / GroupNorm / SiLU in front of it folded in) INSIDE the GEMM launch:
+// no int8 code matrix, no row-sum vector, no second launch (QuantLayer.forward, quant_layer.py:626-661, as one kernel).  Same tables,
+// epilogue (gemm_tile.h) and results as dgq_quant_act + gemm_wxa8_kernel.
 //
 // Why (profiles/r05_small_launch_timeline.txt, s_memtime stamps of the 32x64 tile kernel on 8192 x 320 x 320 per-K): the K loop was
 // 62 % of a workgroup's life at 1681 cycles per K tile for TWO MFMAs per wave — five co-resident waves per SIMD, each paying per K
 // tile two LDS-DMA pieces (60-100 issue cycles each), a barrier, a counted wait, fragment reads for both operands and the ring
 // bookkeeping; and in front of every such launch sits a quantise-on-load launch of about the same length that exists only to turn
 // the fp32 rows into int8 codes in HBM.  The weights of a 32-row tile are read by ONE wave (no reuse), so LDS staging buys nothing.
-//   * A (activation codes): the workgroup's BM = 32·TM rows x the WHOLE K slice sit in LDS (the "panel"): filled up front — by
-//     LDS-DMA from the code matrix, every piece issued at once, or (FUSE) by the workgroup quantising its rows itself —, ONE
-//     barrier, no ring.  Image per K tile as in gemm_wxa8_kernel (128-byte rows, 16-byte pieces XOR-swizzled).
+//   * A (activation codes): the workgroup's 32 rows x the WHOLE K sit in LDS (the "panel"), written by the workgroup quantising its
+//     rows itself; ONE barrier, no ring.  Image per K tile as in gemm_wxa8_kernel (128-byte rows, 16-byte pieces XOR-swizzled).
 //   * W (int4): never touches LDS.  dgq_pack_w4 layout 2 stores the weights FRAGMENT-MAJOR: for every 32-column tile and every pair
 //     of 32-wide K chunks one 1-KiB block in which lane l finds, at l·16, the 8 bytes of its column (l & 31) and K half (l >> 5) of
 //     both chunks — one perfectly coalesced global_load_dwordx4 per two MFMA B operands, prefetched DT K tiles ahead in registers.
-//   * a wave owns a (32·TM) x 32 output tile; NW waves side by side (BN = 32·NW columns) x KW waves along K (each a contiguous
-//     range of the slice's K tiles; their partial tiles meet in LDS behind the loop, in a fixed order).
-// Grid = column blocks x row blocks x (problems | K splits).
+//   * a wave owns a 32 x 32 output tile; NW waves side by side (BN = 32·NW columns) x KW waves along K (each a contiguous
+//     range of the K tiles; their partial tiles meet in LDS behind the loop, in a fixed order).
+// Grid = column blocks x row blocks x problems.  (The round-5 form that took a materialised code matrix lost to the tile family inside
+// the step — profiles/r05_panel_plan_in_step_ab.txt — and was removed in round 6.)
 #include "gemm_tile.h"
 #include "quant_common.h"
 
@@ -38,8 +39,8 @@ struct PanelCfg {
 };
 
 __host__ __device__ constexpr int align16(int v) { return (v + 15) & ~15; }
-// LDS map: region 0 (the A panel; once it is idle the epilogue's scratch + the K waves' partial tiles) | vtab | vcol | ctab | (FUSE,
-// per-K) the chunks' δ and z
+// LDS map: region 0 (the A panel; once it is idle the epilogue's scratch + the K waves' partial tiles) | vtab | vcol | ctab |
+// (per-K) the chunks' δ and z
 template <int TM, int NW, int KW>
 __host__ __device__ constexpr int panel_region0(int nk) {
     using C = PanelCfg<TM, NW, KW>;
@@ -48,19 +49,19 @@ __host__ __device__ constexpr int panel_region0(int nk) {
 }
 __host__ __device__ constexpr int panel_ctab_bytes(bool per_m, int nk) { return per_m ? 0 : align16((NCH + 1) * nk * 4); }
 template <int TM, int NW, int KW>
-constexpr int panel_lds(bool per_m, bool fuse, int nk) {
+constexpr int panel_lds(bool per_m, int nk) {
     return panel_region0<TM, NW, KW>(nk) + PanelCfg<TM, NW, KW>::VEC_BYTES + panel_ctab_bytes(per_m, nk) +
-           ((fuse && !per_m) ? nk * NCH * 16 + nk * BK * 4 : 0);      // (δ, z, 1/δ, ·) per chunk | decoded destination per source channel
+           (!per_m ? nk * NCH * 16 + nk * BK * 4 : 0);      // (δ, z, 1/δ, ·) per chunk | decoded destination per source channel
 }
 
-template <bool PER_M, typename TIO, int TM, int NW, int KW, bool FUSE>
+template <bool PER_M, typename TIO, int TM, int NW, int KW>
 __global__ __launch_bounds__(64 * NW * KW) void gemm_panel_kernel(GemmBatch bt, int n_major) {
     using Cfg = PanelCfg<TM, NW, KW>;
     constexpr int BM = Cfg::BM, BN = Cfg::BN, NT = Cfg::NT, NWT = Cfg::NWT;
     constexpr int ACCS = (!PER_M && TM == 1) ? 2 : 1;        // two accumulator sets: a chunk's flush issues behind the next chunk's MFMA
     constexpr int DT = 4;                                    // W prefetch depth in K tiles (two 16-byte loads per lane each)
     static_assert(DT == 4, "the wait ladder of the K loop is written for DT = 4");
-    static_assert(!FUSE || TM == 1, "quantise-on-load: one 32-row tile per workgroup");
+    static_assert(TM == 1, "quantise-on-load: one 32-row tile per workgroup");
     const GemmParams& p = bt.p[bt.n > 1 ? blockIdx.z : 0];
     const int zsplit = bt.n > 1 ? 0 : blockIdx.z;
     gemm_prefetch_params(p);
@@ -113,27 +114,15 @@ __global__ __launch_bounds__(64 * NW * KW) void gemm_panel_kernel(GemmBatch bt, 
 #pragma unroll
     for (int j = 0; j < 2; ++j) wr[DT][j] = (v4i){0, 0, 0, 0};
 
-    // ---- A panel (not FUSE): every LDS-DMA piece (8 rows x 128 B) of the slice, dealt round-robin over the waves, issued now
     const uint32_t lds_base = (uint32_t)(uintptr_t)(lptr_t)smem;
-    if constexpr (!FUSE) {
-        constexpr int PPT = BM / 8;                          // pieces per K tile
-        const int npieces = nk * PPT;
-        for (int q = wid; q < npieces; q += NWT) {
-            const int t = q / PPT, blk = q - t * PPT;
-            const int row = blk * 8 + (lane >> 3);
-            const int c = (lane & 7) ^ ((row >> 1) & 7);
-            const int m = min(m0 + row, p.M - 1);
-            glds16(p.codes + (int64_t)m * p.Kp + (int64_t)(kt_begin + t) * BK + 16 * c,
-                   __builtin_amdgcn_readfirstlane(lds_base + t * (BM * BK) + blk * 1024));
-        }
-    }
+    (void)lds_base;
 
     // ---- tables (as gemm_wxa8_kernel: asm loads at clamped indices, retired by one wait)
     const int region0 = panel_region0<TM, NW, KW>(nk);
     float* vtab = reinterpret_cast<float*>(smem + region0);  // [3][BM]: R0 R1 R2 | [4][BN]: alpha zw gamma vn
     float* vcol = vtab + 3 * BM;
     float* ctab = vcol + 4 * BN;                              // [nk·4] flush coefficients | [nk] clear flags
-    // FUSE per-K: [nk·NCH] float4 (δ, z, 1/δ, ·) of the chunks | [<= nk·BK] per source channel: panel offset of its code byte at row 0 with
+    // per-K: [nk·NCH] float4 (δ, z, 1/δ, ·) of the chunks | [<= nk·BK] per source channel: panel offset of its code byte at row 0 with
     // swizzle 0 (bits 0-19) and its chunk (bits 20-31) — the per-element work of the scatter is then one xor-add and one table read
     float4* tq = reinterpret_cast<float4*>(reinterpret_cast<uint8_t*>(ctab) + panel_ctab_bytes(PER_M, nk));
     uint32_t* tdst = reinterpret_cast<uint32_t*>(tq + nk * NCH);
@@ -166,15 +155,9 @@ __global__ __launch_bounds__(64 * NW * KW) void gemm_panel_kernel(GemmBatch bt, 
         return x.is_coef ? coef : flag;
     };
     const bool final_ep = (p.splits == 1);
-    const bool has_row = final_ep && tid < BM, has_col = final_ep && tid < BN;
-    float rs = 0.0f, md = 1.0f, mz = 0.0f, c_vn = 0.0f, c_d = 0.0f, c_dn = 0.0f;
+    const bool has_col = final_ep && tid < BN;
+    float c_vn = 0.0f, c_d = 0.0f, c_dn = 0.0f;
     uint32_t c_cf = 0;
-    if constexpr (!FUSE) {
-        const int m = min(m0 + tid, p.M - 1);
-        const int li = PER_M ? m % p.L : 0;
-        rs = gload_f32(p.rowsum + m);
-        if constexpr (PER_M) { md = gload_f32(p.mdelta + li); mz = gload_f32(p.mzp + li); }
-    }
     const int ncol = min(n0 + tid, p.N - 1);
     float c_al = gload_f32(p.alpha + ncol), c_zw = gload_f32(p.zw + ncol), c_ga = gload_f32(p.gamma + ncol);
     if constexpr (PER_M) c_vn = gload_f32(p.vn + ncol);
@@ -185,11 +168,11 @@ __global__ __launch_bounds__(64 * NW * KW) void gemm_panel_kernel(GemmBatch bt, 
     }
     DGQ_STAMP(3);
 
-    // ---- FUSE: the activation quantiser of the layer (dgq_quant_act's arithmetic) on this workgroup's BM rows, written into the
+    // ---- the activation quantiser of the layer (dgq_quant_act's arithmetic) on this workgroup's BM rows, written into the
     // panel image.  QL lanes share a row (64 / QL rows per wave at a time); per-M / scalar scales: natural K order, four codes per
     // dword store; per-K: each source channel's code byte goes to its packed position kdst[c] (padding stays zero).
     // (every load below is an ordinary one: the asm loads above are all OLDER, so hipcc's counted waits for these stay correct)
-    if constexpr (FUSE) {
+    {
         const dgq_gemm_act_t& act = p.act;
         const TIO* x = reinterpret_cast<const TIO*>(act.x);
         const int K = act.K;
@@ -223,32 +206,52 @@ __global__ __launch_bounds__(64 * NW * KW) void gemm_panel_kernel(GemmBatch bt, 
             float mu = 0.0f, rstd = 1.0f;
             // (every load of a round goes out unconditionally at a clamped address — a load under `if (c < K)` makes hipcc branch around
             // it and wait for each one before the next is issued: five dependent round trips per pass of a 320-wide row)
-            if (act.ln_gamma) {                              // LayerNorm statistics of the row in one pass, shifted by its first element
-                float x0[4];
-                load4<TIO>(xr, x0);
-                const float sh0 = x0[0];
-                float s1 = 0.0f, s2 = 0.0f;
-                for (int c0 = sl * 4; c0 < K; c0 += 4 * QL * SEG) {
-                    float v[SEG][4];
+            if (act.ln_gamma) {
+                // LayerNorm statistics of the row: two passes (mean, then Σ(x − mean)²) in the summation order of quant_act.hip's
+                // row_layernorm_stats — that kernel gives a row to 64 lanes, lane v owning columns 4v + 256i; here a row's QL lanes
+                // each stand for the 64/QL lanes v = sl + QL·u of it and merge them in the order of its xor-shuffle tree (offsets 32,
+                // 16, (8)), then finish the tree among themselves: mean and rstd — and with them the codes — equal the two-launch
+                // form's bit for bit (the second pass re-reads the row from L1)
+                constexpr int NU = 64 / QL;
+                float sv[NU];
 #pragma unroll
-                    for (int j = 0; j < SEG; ++j) load4<TIO>(xr + min(c0 + j * 4 * QL, K - 4), v[j]);
+                for (int u = 0; u < NU; ++u) sv[u] = 0.0f;
+                for (int i0 = 0; i0 < K; i0 += 256) {
+                    float v[NU][4];
 #pragma unroll
-                    for (int j = 0; j < SEG; ++j) {
-                        const float keep = (c0 + j * 4 * QL < K) ? 1.0f : 0.0f;
+                    for (int u = 0; u < NU; ++u) load4<TIO>(xr + min(i0 + (sl + QL * u) * 4, K - 4), v[u]);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float dv = (v[j][e] - sh0) * keep;
-                            s1 += dv;
-                            s2 = __builtin_fmaf(dv, dv, s2);
-                        }
+                    for (int u = 0; u < NU; ++u) {
+                        const float t4 = (v[u][0] + v[u][1]) + (v[u][2] + v[u][3]);
+                        sv[u] += (i0 + (sl + QL * u) * 4 < K) ? t4 : 0.0f;
                     }
                 }
+                auto tree = [&](float (&a)[NU]) {
 #pragma unroll
-                for (int o = QL / 2; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
-                const float md_ = s1 / (float)K;                 // mean − shift
-                mu = sh0 + md_;
-                const float var = fmaxf(s2 / (float)K - md_ * md_, 0.0f);
-                rstd = 1.0f / sqrtf(var + act.ln_eps);
+                    for (int h = NU / 2; h > 0; h >>= 1)
+#pragma unroll
+                        for (int u = 0; u < h; ++u) a[u] += a[u + h];
+                    float r = a[0];
+#pragma unroll
+                    for (int o = QL / 2; o > 0; o >>= 1) r += __shfl_xor(r, o, 64);
+                    return r;
+                };
+                mu = tree(sv) / (float)K;
+#pragma unroll
+                for (int u = 0; u < NU; ++u) sv[u] = 0.0f;
+                for (int i0 = 0; i0 < K; i0 += 256) {
+                    float v[NU][4];
+#pragma unroll
+                    for (int u = 0; u < NU; ++u) load4<TIO>(xr + min(i0 + (sl + QL * u) * 4, K - 4), v[u]);
+#pragma unroll
+                    for (int u = 0; u < NU; ++u) {
+                        float q4 = sv[u];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) q4 += (v[u][e] - mu) * (v[u][e] - mu);
+                        sv[u] = (i0 + (sl + QL * u) * 4 < K) ? q4 : sv[u];
+                    }
+                }
+                rstd = 1.0f / sqrtf(tree(sv) / (float)K + act.ln_eps);
             }
             DGQ_STAMP(15);
             const int img = act.pre_scale ? m / act.rows_per_image : 0;
@@ -357,18 +360,9 @@ __global__ __launch_bounds__(64 * NW * KW) void gemm_panel_kernel(GemmBatch bt, 
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the panel (DMA), the first W tiles and the tables
     DGQ_STAMP(4);
-    if (PER_M) asm volatile("" : "+v"(rs), "+v"(md), "+v"(mz), "+v"(c_al), "+v"(c_zw), "+v"(c_ga), "+v"(c_vn));
-    else asm volatile("" : "+v"(rs), "+v"(c_al), "+v"(c_zw), "+v"(c_ga), "+v"(c_d), "+v"(c_dn), "+v"(c_cf));
+    if (PER_M) asm volatile("" : "+v"(c_al), "+v"(c_zw), "+v"(c_ga), "+v"(c_vn));
+    else asm volatile("" : "+v"(c_al), "+v"(c_zw), "+v"(c_ga), "+v"(c_d), "+v"(c_dn), "+v"(c_cf));
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (!FUSE) {
-        if (has_row) {
-            const int m = min(m0 + tid, p.M - 1);
-            for (int j = 1; j < p.rowsum_parts; ++j) rs += p.rowsum[(int64_t)j * p.M + m];     // K-split quantise passes only
-            float r0 = 1.0f, r1 = rs, r2 = 0.0f;
-            if (PER_M) { r0 = md; r1 = md * rs; r2 = md * (p.offset - mz); }
-            vtab[tid] = r0; vtab[BM + tid] = r1; vtab[2 * BM + tid] = r2;
-        }
-    }
     if (has_col) {
         vcol[tid] = c_al; vcol[BN + tid] = c_zw; vcol[2 * BN + tid] = c_ga; vcol[3 * BN + tid] = c_vn;
     }
@@ -542,7 +536,7 @@ __global__ __launch_bounds__(64 * NW * KW) void gemm_panel_kernel(GemmBatch bt, 
     DGQ_DIAG_FLUSH(panel, NWT, wid, lane);
 }
 
-template <bool PER_M, typename TIO, int TM, int NW, int KW, bool FUSE>
+template <bool PER_M, typename TIO, int TM, int NW, int KW>
 void launch_panel(const GemmBatch& bt, hipStream_t st) {
     using Cfg = PanelCfg<TM, NW, KW>;
     const GemmParams& p = bt.p[0];
@@ -555,33 +549,33 @@ void launch_panel(const GemmBatch& bt, hipStream_t st) {
         a_bytes += (size_t)bt.p[i].M * bt.p[i].Kp;
         w_bytes += (size_t)bt.p[i].N * bt.p[i].Kp / 2;
     }
-    const int lds = panel_lds<TM, NW, KW>(PER_M, FUSE, max_tps);
+    const int lds = panel_lds<TM, NW, KW>(PER_M, max_tps);
     static std::atomic<bool> attr_set[64];
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= 64 || !attr_set[dev].load(std::memory_order_acquire)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_panel_kernel<PER_M, TIO, TM, NW, KW, FUSE>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_panel_kernel<PER_M, TIO, TM, NW, KW>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (dev >= 0 && dev < 64) attr_set[dev].store(true, std::memory_order_release);
     }
     dim3 grid((maxN + Cfg::BN - 1) / Cfg::BN, (maxM + Cfg::BM - 1) / Cfg::BM, bt.n > 1 ? bt.n : p.splits), block(Cfg::NT);
-    hipLaunchKernelGGL((gemm_panel_kernel<PER_M, TIO, TM, NW, KW, FUSE>), grid, block, lds, st, bt, w_bytes > a_bytes ? 1 : 0);
+    hipLaunchKernelGGL((gemm_panel_kernel<PER_M, TIO, TM, NW, KW>), grid, block, lds, st, bt, w_bytes > a_bytes ? 1 : 0);
 }
 
-// configurations (TM, NW, KW, FUSE): key = fuse·10000 + TM·1000 + NW·10 + KW
-#define DGQ_PANEL_CONFIGS(X) \
-    X(1, 5, 1, false) X(1, 10, 1, false) X(1, 4, 1, false) X(1, 8, 1, false) X(2, 5, 1, false) X(2, 4, 1, false) X(2, 8, 1, false) \
-    X(1, 4, 2, false) X(1, 4, 4, false) X(1, 5, 2, false) \
-    X(1, 10, 1, true) X(1, 5, 1, true) X(1, 5, 2, true) X(1, 4, 4, true) X(1, 8, 2, true) X(1, 4, 2, true)
+// configurations (TM, NW, KW): key = TM·1000 + NW·10 + KW.  (Round 5 also carried ten configurations that took a materialised code
+// matrix — measured slower inside the step than the tile family, profiles/r05_panel_plan_in_step_ab.txt — and two 16-wave
+// quantise-on-load ones that compiled with scratch beside the hand-counted W-stream waits: removed in round 6; the Makefile's
+// `check-panel-spills` fails the build if any kernel of this file needs scratch.)
+#define DGQ_PANEL_CONFIGS(X) X(1, 10, 1) X(1, 5, 1) X(1, 5, 2) X(1, 4, 2)
 
 template <bool PER_M, typename TIO>
-int launch_panel_cfg(const GemmBatch& bt, int tm, int nw, int kw, bool fuse, hipStream_t st) {
-    const int key = (fuse ? 10000 : 0) + tm * 1000 + nw * 10 + kw;
+int launch_panel_cfg(const GemmBatch& bt, int tm, int nw, int kw, hipStream_t st) {
+    const int key = tm * 1000 + nw * 10 + kw;
     switch (key) {
-#define X(TM_, NW_, KW_, F_) case ((F_) ? 10000 : 0) + (TM_) * 1000 + (NW_) * 10 + (KW_): launch_panel<PER_M, TIO, TM_, NW_, KW_, F_>(bt, st); break;
+#define X(TM_, NW_, KW_) case (TM_) * 1000 + (NW_) * 10 + (KW_): launch_panel<PER_M, TIO, TM_, NW_, KW_>(bt, st); break;
         DGQ_PANEL_CONFIGS(X)
 #undef X
-        default: dgq_set_error("dgq_gemm_wxa8: no panel configuration TM=%d NW=%d KW=%d fuse=%d", tm, nw, kw, (int)fuse); return DGQ_EINVAL;
+        default: dgq_set_error("dgq_gemm_wxa8: no panel configuration TM=%d NW=%d KW=%d", tm, nw, kw); return DGQ_EINVAL;
     }
     return DGQ_OK;
 }
@@ -589,21 +583,21 @@ int launch_panel_cfg(const GemmBatch& bt, int tm, int nw, int kw, bool fuse, hip
 }  // namespace
 
 // does the configuration exist, and how much LDS does a launch with K slices of `tiles` K tiles need (0: no such configuration)
-size_t dgq_gemm_panel_lds_bytes(int tm, int nw, int kw, bool per_m, bool fuse, int tiles) {
-    const int key = (fuse ? 10000 : 0) + tm * 1000 + nw * 10 + kw;
+size_t dgq_gemm_panel_lds_bytes(int tm, int nw, int kw, bool per_m, int tiles) {
+    const int key = tm * 1000 + nw * 10 + kw;
     switch (key) {
-#define X(TM_, NW_, KW_, F_) case ((F_) ? 10000 : 0) + (TM_) * 1000 + (NW_) * 10 + (KW_): return (size_t)panel_lds<TM_, NW_, KW_>(per_m, F_, tiles);
+#define X(TM_, NW_, KW_) case (TM_) * 1000 + (NW_) * 10 + (KW_): return (size_t)panel_lds<TM_, NW_, KW_>(per_m, tiles);
         DGQ_PANEL_CONFIGS(X)
 #undef X
         default: return 0;
     }
 }
 
-int dgq_launch_gemm_panel(const GemmBatch& bt, bool per_m, int y_dtype, int tm, int nw, int kw, bool fuse, hipStream_t st) {
+int dgq_launch_gemm_panel(const GemmBatch& bt, bool per_m, int y_dtype, int tm, int nw, int kw, hipStream_t st) {
     switch (y_dtype) {
-        case DGQ_F32: return per_m ? launch_panel_cfg<true, float>(bt, tm, nw, kw, fuse, st) : launch_panel_cfg<false, float>(bt, tm, nw, kw, fuse, st);
-        case DGQ_F16: return per_m ? launch_panel_cfg<true, __half>(bt, tm, nw, kw, fuse, st) : launch_panel_cfg<false, __half>(bt, tm, nw, kw, fuse, st);
-        case DGQ_BF16: return per_m ? launch_panel_cfg<true, __hip_bfloat16>(bt, tm, nw, kw, fuse, st) : launch_panel_cfg<false, __hip_bfloat16>(bt, tm, nw, kw, fuse, st);
+        case DGQ_F32: return per_m ? launch_panel_cfg<true, float>(bt, tm, nw, kw, st) : launch_panel_cfg<false, float>(bt, tm, nw, kw, st);
+        case DGQ_F16: return per_m ? launch_panel_cfg<true, __half>(bt, tm, nw, kw, st) : launch_panel_cfg<false, __half>(bt, tm, nw, kw, st);
+        case DGQ_BF16: return per_m ? launch_panel_cfg<true, __hip_bfloat16>(bt, tm, nw, kw, st) : launch_panel_cfg<false, __hip_bfloat16>(bt, tm, nw, kw, st);
         default: dgq_set_error("dgq_gemm_wxa8: unknown y dtype %d", y_dtype); return DGQ_EINVAL;
     }
 }

@@ -580,11 +580,11 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(GemmParams p) {
 // gemm_wxa8_big.hip: the 256-row ping-pong kernel (W4, one problem, no K split); the plan names it by bm == 256
 int dgq_launch_gemm_big(const GemmBatch& bt, bool per_m, int y_dtype, hipStream_t st);
 size_t dgq_gemm_big_lds_bytes(bool per_m, int Kp);
-// gemm_panel.hip: the short-K kernel (whole K slice of the activations in LDS, weights streamed fragment-major into registers); the
-// plan names it by bm = PANEL_BM0 + TM (wave tile rows / 32), bn = waves per workgroup
+// gemm_panel.hip: the quantise-on-load kernel (the workgroup's 32 rows x the whole K quantised into an LDS panel, weights streamed
+// fragment-major into registers); the plan names it by bm = PANEL_BM0 + TM (wave tile rows / 32), bn = column waves per workgroup
 #define PANEL_BM0 1000
-int dgq_launch_gemm_panel(const GemmBatch& bt, bool per_m, int y_dtype, int tm, int nw, int kw, bool fuse, hipStream_t st);
-size_t dgq_gemm_panel_lds_bytes(int tm, int nw, int kw, bool per_m, bool fuse, int tiles);
+int dgq_launch_gemm_panel(const GemmBatch& bt, bool per_m, int y_dtype, int tm, int nw, int kw, hipStream_t st);
+size_t dgq_gemm_panel_lds_bytes(int tm, int nw, int kw, bool per_m, int tiles);
 
 template <bool PER_M, typename TOut>
 static void launch_combine(const GemmParams& p, hipStream_t st);
@@ -693,24 +693,16 @@ static int launch_gemm(const GemmBatch& p, const GemmPlan& pl, int y_dtype, hipS
     }
     if (bm > PANEL_BM0) {
         const int tm = bm - PANEL_BM0, nw = bn;
-        DGQ_CHECK_ARG(WBITS == 4, "dgq_gemm_wxa8: the panel kernel takes W4 weights");
+        DGQ_CHECK_ARG(WBITS == 4 && pl.fuse, "dgq_gemm_wxa8: the panel kernel is the quantise-on-load form of W4 layers");
         for (int i = 0; i < p.n; ++i) {
-            DGQ_CHECK_ARG(p.p[i].wfrag && !p.p[i].cv.codes_in, "dgq_gemm_wxa8: the panel kernel needs the fragment-major weights (extra.wfrag) and a materialised operand");
-            const size_t need = dgq_gemm_panel_lds_bytes(tm, nw, pl.kw, PER_M, pl.fuse, p.p[i].tiles_per_split);
-            DGQ_CHECK_ARG(need > 0 && need <= 160 * 1024, "dgq_gemm_wxa8: no panel configuration TM=%d NW=%d KW=%d fuse=%d for K slices of %d tiles",
-                          tm, nw, pl.kw, (int)pl.fuse, p.p[i].tiles_per_split);
-            DGQ_CHECK_ARG(pl.fuse == (p.p[i].act.x != nullptr), "dgq_gemm_wxa8: quantise-on-load (extra.act) and the launch plan disagree");
-            DGQ_CHECK_ARG(!pl.fuse || p.p[i].splits == 1, "dgq_gemm_wxa8: quantise-on-load takes the whole K extent in one workgroup");
+            DGQ_CHECK_ARG(p.p[i].wfrag && !p.p[i].cv.codes_in && p.p[i].act.x, "dgq_gemm_wxa8: quantise-on-load needs the fragment-major weights (extra.wfrag) and the activation descriptor (extra.act)");
+            const size_t need = dgq_gemm_panel_lds_bytes(tm, nw, pl.kw, PER_M, p.p[i].tiles_per_split);
+            DGQ_CHECK_ARG(need > 0 && need <= 160 * 1024, "dgq_gemm_wxa8: no panel configuration TM=%d NW=%d KW=%d for a K extent of %d tiles",
+                          tm, nw, pl.kw, p.p[i].tiles_per_split);
+            DGQ_CHECK_ARG(p.p[i].splits == 1, "dgq_gemm_wxa8: quantise-on-load takes the whole K extent in one workgroup");
         }
-        rc = dgq_launch_gemm_panel(p, PER_M, y_dtype, tm, nw, pl.kw, pl.fuse, st);
+        rc = dgq_launch_gemm_panel(p, PER_M, y_dtype, tm, nw, pl.kw, st);
         if (rc != DGQ_OK) return rc;
-        if (p.n == 1 && p.p[0].splits > 1) {
-            switch (y_dtype) {
-                case DGQ_F32: launch_combine<PER_M, float>(p.p[0], st); break;
-                case DGQ_F16: launch_combine<PER_M, __half>(p.p[0], st); break;
-                default: launch_combine<PER_M, __hip_bfloat16>(p.p[0], st); break;
-            }
-        }
         return dgq_launch_status("dgq_gemm_wxa8");
     }
     switch (y_dtype) {
@@ -788,70 +780,18 @@ static bool plan_panel_fuse(int M, int N, int Kp, bool per_m, GemmPlan& pl) {
     if (!on) return false;
     const int nk = Kp / BK;
     const long mb = (M + 31) / 32, nt = (N + 31) / 32;
-    int kw = 1;
-    while (kw < 4 && mb * nt * kw < 2048 && nk >= 4 * kw) kw *= 2;
+    const int kw = (mb * nt < 2048 && nk >= 4) ? 2 : 1;
     int nw;
     if (kw == 1) nw = (N % 320 == 0) ? 10 : 5;
-    else if (kw == 2) nw = (N % 160 == 0) ? 5 : ((N % 256 == 0) ? 8 : 4);
-    else nw = 4;
-    const size_t need = dgq_gemm_panel_lds_bytes(1, nw, kw, per_m, true, nk);
+    else nw = (N % 160 == 0) ? 5 : 4;
+    const size_t need = dgq_gemm_panel_lds_bytes(1, nw, kw, per_m, nk);
     if (need == 0 || need > 150 * 1024) return false;
     // every column block of a row block quantises the rows again: the fused form pays while that redundancy is small and the row
     // blocks alone fill the chip (tools/bench_fused.py, profiles/r05_fused_linear_shapes.txt); DGQ_GEMM_FUSE_ALL=1: wherever it fits
     const char* ea = getenv("DGQ_GEMM_FUSE_ALL");        // (read per call: the test suite switches it)
     const bool all = ea && *ea == '1';
     if (!all && ((N + 32 * nw - 1) / (32 * nw) > 2 || M < 2048)) return false;
-    // (the 16-wave configurations compile with a few scratch dwords at 128 VGPRs — beside hand-counted vmcnt waits that is not something
-    // to ship: they stay test / sweep configurations)
-    if (!all && nw * kw >= 16) return false;
     pl.bm = PANEL_BM0 + 1; pl.bn = nw; pl.kw = kw; pl.fuse = true; pl.splits = 1;
-    return true;
-}
-
-// The panel kernel on a code matrix (no quantise-on-load): where it beats the tile family (tools/tile_sweep.py sd and
-// tools/bench_gemm_cold.py with the P<TM>,<NW>,<S>,<KW> candidates, profiles/r05_gemm_tile_sweep_sd_with_panel.txt,
-// r05_gemm_cold_weights_sweep.txt): launches whose K slice fits the LDS panel and whose output is not store-bound —
-//   2048 x 640 x 2560 per-K 18.3 -> 13.6 us, 512 x 1280 x 1280 per-K 10.4 -> 8.7, 8192 x 320 x 2880 per-K 27.4 -> 23.1, 8192 x 320 x 1280
-//   per-K 19.0 -> 16.3, 2048 x 5120 x 640 per-M 21.3 -> 18.2, 512 x 10240 x 1280 per-M 18.8 -> 16.0, 128 x 1280 x 11520 (K split 4-6,
-//   cold weights) 14.7 -> 13.6 / 16.7 -> 15.0; long-K layers at M >= 512 and outputs beyond 20 M elements stay on the tile family.
-// Fewer than 2048 (row block, column tile) waves: two K waves per column tile.
-static bool plan_panel_codes(int M, int N, int Kp, bool per_m, size_t ws_bytes, GemmPlan& pl) {
-    // OFF by default: inside the step (one launch of each layer, every kernel cold) the same launches measure 0.3-0.9 % SLOWER with
-    // the panel kernel than on the tile family, class by class (profiles/r05_panel_plan_in_step_ab.txt) — the replayed-launch tables
-    // above do not carry over.  DGQ_GEMM_PANEL_PLAN=1 enables the rule (sweeps).
-    static const bool on = [] { const char* e = getenv("DGQ_GEMM_PANEL_PLAN"); return e && *e == '1'; }();
-    if (!on || M < 32 || N < 128 || (double)M * N > 2.0e7) return false;
-    const int nk = Kp / BK;
-    int splits = 1;
-    if (nk > 25) {
-        if (M <= 160) splits = (nk + 23) / 24;
-        else if (M <= 512 && nk <= 48) splits = 2;
-        else return false;
-        if ((size_t)splits * M * N * 4 > ws_bytes) return false;
-    }
-    const long waves = (long)((M + 31) / 32) * ((N + 31) / 32) * splits;
-    int kw = waves < 2048 ? 2 : 1;
-    int nw;
-    if (kw == 2) nw = (M > 512 && N % 160 == 0) ? 5 : 4;
-    else nw = (N % 320 == 0 && N <= 640) ? 10 : (N % 256 == 0 ? 8 : (N % 160 == 0 ? 5 : 4));
-    {   // experiment hook: DGQ_GEMM_PANEL_MASK — 1: K-split launches, 2: M <= 512 unsplit, 4: M <= 2048, 8: larger M
-        const char* em = getenv("DGQ_GEMM_PANEL_MASK");
-        if (em) {
-            const int mask = atoi(em);
-            const int cls = splits > 1 ? 1 : (M <= 512 ? 2 : (M <= 2048 ? 4 : 8));
-            if (!(mask & cls)) return false;
-        }
-    }
-    const int tiles = (nk + splits - 1) / splits;
-    {   // experiment hook: DGQ_GEMM_PANEL_ONE="NW,KW" — one panel configuration for every launch the rule admits
-        const char* e1 = getenv("DGQ_GEMM_PANEL_ONE");
-        int a = 0, b = 0;
-        if (e1 && sscanf(e1, "%d,%d", &a, &b) == 2) { nw = a; kw = b; }
-    }
-    if (tiles < 2 * kw) return false;
-    const size_t need = dgq_gemm_panel_lds_bytes(1, nw, kw, per_m, false, tiles);
-    if (need == 0 || need > 150 * 1024) return false;
-    pl.bm = PANEL_BM0 + 1; pl.bn = nw; pl.kw = kw; pl.fuse = false; pl.splits = splits;
     return true;
 }
 
@@ -898,19 +838,21 @@ __global__ __launch_bounds__(256) void conv_rowsum_kernel(dgq_gemm_conv_t c, int
 }
 
 // Development hook: DGQ_GEMM_FORCE="BM,BN,S" overrides the plan (tile sweeps, tools/bench_gemm_sweep.py); read per call.
-// "P<TM>,<NW>,S[,KW]" names the panel kernel (gemm_panel.hip): wave tile of 32·TM rows, NW x KW waves per workgroup.
+// "F<TM>,<NW>,1,<KW>" names a quantise-on-load configuration (gemm_panel.hip; honoured only for calls that carry extra.act).
 static bool forced_plan(GemmPlan& pl) {
     const char* e = getenv("DGQ_GEMM_FORCE");
     if (!e || !*e) return false;
     int bm = 0, bn = 0, s = 0;
-    if (*e == 'P' || *e == 'F') {                          // F: with quantise-on-load (honoured only for calls that carry extra.act)
+    if (*e == 'F') {
         int kw = 1;
         if (sscanf(e + 1, "%d,%d,%d,%d", &bm, &bn, &s, &kw) < 3) return false;
         bm += PANEL_BM0;
         pl.kw = kw < 1 ? 1 : kw;
-        pl.fuse = (*e == 'F');
+        pl.fuse = true;
     } else if (sscanf(e, "%d,%d,%d", &bm, &bn, &s) != 3) {
         return false;
+    } else {
+        pl.fuse = false;
     }
     pl.bm = bm; pl.bn = bn; pl.splits = s < 1 ? 1 : s;
     return true;
@@ -1066,10 +1008,6 @@ extern "C" int dgq_gemm_wxa8(const int8_t* codes, const float* rowsum, int rowsu
         if (forced_plan(f) && f.fuse) pl = f;
         p.splits = 1; p.slab = nullptr; p.tiles_per_split = Kp / BK;
         return dispatch_gemm(bt, w_bits, per_m != 0, pl, y_dtype, (hipStream_t)stream);
-    }
-    if (!p.cv.codes_in && p.wfrag && w_bits == 4) {
-        GemmPlan pp = pl;
-        if (plan_panel_codes(M, N, Kp, per_m != 0, workspace ? workspace_bytes : 0, pp) && !(p.ex.geglu && pp.splits > 1)) pl = pp;
     }
     if (p.cv.codes_in) {
         // implicit im2col: the row sums of the unfolded operand from the per-pixel sums first (a tiny launch), then one of the three

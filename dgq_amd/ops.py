@@ -1101,3 +1101,12 @@ def attention(q, k, v, H, D, scale, mode, skip, delta, bits, fq=None):
 
 
 attention_f32 = attention
+
+
+def attention_sync_timeouts():
+    """Workgroups of single-launch attention calls (csrc/attn_one.hip) that ever gave up the wait for the real-time δ exchange
+    in this process; synchronises.  0 unless a grid was not resident as a whole."""
+    n = _lib.load().dgq_attention_sync_timeouts()
+    if n < 0:
+        raise RuntimeError("dgq_attention_sync_timeouts failed")
+    return n

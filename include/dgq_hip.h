@@ -32,6 +32,13 @@ extern "C" {
 #define DGQ_KCHUNK 32     /* K granularity of one MFMA_I32_32x32x32_I8 slice = DGQ group padding */
 #define DGQ_KTILE 128     /* Kp (padded, permuted K) must be a multiple of this */
 
+/* ABI revision, major·100 + minor.  A host binding must refuse a library whose revision differs from the header it was written
+ * against (dgq_amd/_lib.py does): the argument structs are passed by pointer and have grown between revisions.
+ *   100  rounds 1-4
+ *   110  round 5: dgq_gemm_extra_t += wfrag, act; dgq_quant_act_args_t += ups; W4 per-K clear marks (cflush == 2) at least every
+ *        2176 codes (the kernels read float(T) off a biased int32 total: |T| < 2^22), plan.seg_limit
+ *   120  round 6: dgq_attention_sync_timeouts; the attention workspace's δ area is 512 bytes */
+#define DGQ_ABI_VERSION 120
 int dgq_version(void);
 const char* dgq_last_error(void);
 
@@ -340,6 +347,13 @@ int dgq_attention(const void* q, const void* k, const void* v, void* o, int dtyp
                   void* workspace, size_t workspace_bytes, void* stream);
 int dgq_attention_fuses_fakequant(int D, int mode);
 size_t dgq_attention_workspace_bytes(int B, int H, int T, int S, int D);
+/* Calls whose key range is at most 8 tiles (S <= 256: every cross-attention over the text tokens, the 16x16 / 8x8 self-attentions)
+ * run statistics, the real-time δ maximum and P·V in ONE launch (csrc/attn_one.hip; results equal to the three-launch form bit for
+ * bit).  Under mode 1 the workgroups of that launch exchange their maxima through the workspace and wait for each other with a
+ * bounded poll; the form is taken only for grids that are resident as a whole.  dgq_attention_sync_timeouts: how many workgroups ever
+ * gave up that poll in this process (device counter, read with a synchronous copy; 0 unless a grid was not resident — then the
+ * affected call's output is invalid); < 0 on a runtime error.  DGQ_ATTN_ONE=0 in the environment keeps every call on three launches. */
+int dgq_attention_sync_timeouts(void);
 
 /* ---- batched small-M Linear ------------------------------------------------------------------------
  * dgq_linear_smallm_batch: y_l = W_l·aqtizer_l(act(x)) + b_l for up to 24 quantized Linear layers that share one input

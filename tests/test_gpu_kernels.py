@@ -189,7 +189,7 @@ def test_f3_wide_layers_every_kernel_vs_reference(case, dev, monkeypatch):
     """F3c: a wide Linear layer (M = 300, N = 256, K = 9216) with a REAL plan_act table — per-K with 16 DGQ groups
     (flush coefficients that are not powers of two, a clear of the running totals inside the K range), per-M and scalar — against the
     reference's own output (tests/golden/f3c_layers_wide.pt), on every member of the GEMM family that takes the shape: the planner's
-    choice, the 256-row kernel (DGQ_GEMM_FORCE=256,256,1), a K-split tile launch, and the panel kernel with K splits and K waves.
+    choice, the 256-row kernel (DGQ_GEMM_FORCE=256,256,1) and a K-split tile launch.
     Each within 2e-5 of the reference; the tile family and the 256-row kernel share their epilogue AND their summation order inside a
     K tile sequence only up to the order of the group sums, so they are compared at 1e-6 (per-M / scalar: bit for bit)."""
     from dgq_amd import ops
@@ -206,7 +206,7 @@ def test_f3_wide_layers_every_kernel_vs_reference(case, dev, monkeypatch):
     x = inp["x"].to(dev)
     monkeypatch.setattr(ops, "GEMM_FUSE", False)                 # (K = 9216 does not fit the fused form anyway)
     outs = {}
-    for plan in (None, "256,256,1", "64,64,4", "128,128,1", "P1,4,4,2", "P1,8,3,1"):
+    for plan in (None, "256,256,1", "64,64,4", "128,128,1"):
         if plan is None:
             monkeypatch.delenv("DGQ_GEMM_FORCE", raising=False)
         else:
@@ -220,27 +220,11 @@ def test_f3_wide_layers_every_kernel_vs_reference(case, dev, monkeypatch):
     for plan, y in outs.items():
         if lay.mode == "perK":
             assert rel_l2(y, ref) < 1e-6, plan
-        elif plan is not None and not plan.startswith("P") and plan != "64,64,4":
+        elif plan is not None and plan != "64,64,4":
             assert torch.equal(y, ref), plan                     # unsplit integer sums: the same numbers through the same epilogue
 
 
-PANEL_PLANS = ["P1,5,1", "P1,10,1", "P2,5,1", "P1,4,1", "P1,8,1", "P2,4,1", "P2,8,1", "P1,5,3", "P2,4,2", "P1,10,4"]
-
-
-@pytest.mark.parametrize("plan", PANEL_PLANS)
-def test_gemm_exact_integer_panel_kernel(plan, dev, monkeypatch):
-    """the short-K panel kernel (gemm_panel.hip; DGQ_GEMM_FORCE = P<TM>,<NW>,<splits>): exact integers on ragged M / N edges, a
-    single K tile, more K tiles than the weight ring is deep (clears of the running totals inside), K split over workgroups with
-    the slab combine; per-K and per-M epilogues"""
-    monkeypatch.setenv("DGQ_GEMM_FORCE", plan)
-    splits = int(plan.split(",")[2])
-    for (M, N, Kp, seed) in ((203, 332, 640, 3), (64, 320, 128, 5), (300, 136, 1024, 6), (100, 200, 2048, 7), (33, 1290, 384, 8)):
-        if splits > 1 and Kp // 128 < 2 * splits:
-            continue
-        _gemm_exact_case(dev, M, N, Kp, 4, seed=seed, frag=True)
-
-
-FUSED_PLANS = ["F1,10,1,1", "F1,5,1,1", "F1,5,1,2", "F1,4,1,4", "F1,8,1,2", "F1,4,1,2"]
+FUSED_PLANS = ["F1,10,1,1", "F1,5,1,1", "F1,5,1,2", "F1,4,1,2"]
 
 
 @pytest.mark.parametrize("plan", FUSED_PLANS)
@@ -1183,6 +1167,78 @@ def test_attention_two_tiles_per_stage_is_bit_identical(D, T, S, mode, skip, qmo
     torch.cuda.synchronize()
     assert torch.isfinite(o2).all()
     assert torch.equal(o1, o2), (o1 - o2).abs().max().item()
+
+
+ONE_LAUNCH_CASES = [
+    # D, T, S, mode, skip, qmode, kmode, vmode, dtype      (qmode / kmode / vmode: 0 scalar, 1 per token, 2 per head-dim)
+    (40, 4096, 77, 1, 1, 1, 1, 2, torch.float32),    # SD 64x64 cross-attention: 512 workgroups, int8 scores, start-peak, real-time δ
+    (40, 4096, 77, 1, 1, 2, 1, 1, torch.float32),    # ... one Q plane x three K planes, three V planes
+    (80, 1024, 77, 1, 1, 1, 1, 2, torch.float32),
+    (80, 1024, 77, 1, 1, 2, 2, 1, torch.float32),
+    (160, 256, 77, 1, 1, 1, 0, 0, torch.float32),    # scalar aqtizer_k (δk folded into the per-query constants)
+    (160, 256, 256, 1, 0, 1, 1, 2, torch.float32),   # SD 16x16 self-attention: eight key tiles kept in registers
+    (160, 256, 256, 1, 0, 2, 1, 1, torch.float32),
+    (160, 64, 64, 1, 0, 1, 1, 2, torch.float32),
+    (160, 64, 77, 1, 1, 2, 1, 2, torch.float32),
+    (160, 200, 250, 1, 0, 1, 1, 2, torch.float32),   # ragged rows and keys
+    (64, 1024, 77, 3, 0, 0, 0, 0, torch.float32),    # SDXL C5: uniform softmax quantiser, scalar tables
+    (64, 4096, 77, 2, 0, 1, 1, 2, torch.float32),    # static log2 δ (no exchange)
+    (64, 1024, 256, 3, 0, 1, 1, 2, torch.float16),
+    (40, 4096, 77, 1, 1, 1, 1, 2, torch.bfloat16),
+    (80, 1024, 200, 1, 0, 1, 1, 1, torch.float16),
+]
+
+
+@pytest.mark.parametrize("D,T,S,mode,skip,qmode,kmode,vmode,dtype", ONE_LAUNCH_CASES)
+def test_attention_one_launch_is_bit_identical(D, T, S, mode, skip, qmode, kmode, vmode, dtype, dev, monkeypatch):
+    """Key ranges of at most 8 tiles run statistics, the real-time δ maximum (exchanged between the resident workgroups inside the
+    launch) and P·V as ONE kernel (csrc/attn_one.hip).  Scores, row statistics, the δ maximum and the P·V arithmetic are those of the
+    three launches without a key split, so the output is equal bit for bit (DGQ_ATTN_ONE=0 DGQ_ATTN_SPLIT=0 select that form); no
+    workgroup gives up the exchange."""
+    from dgq_amd import ops
+    B, H, bits = 2, 8, 8
+    g = torch.Generator().manual_seed(D + T + S + mode + 7 * qmode + 3 * vmode)
+    q, k, v = ((torch.randn(B, n, H * D, generator=g) * 1.1).to(dev).to(dtype) for n in (T, S, S))
+    delta = None if mode == 1 else torch.tensor([1.0 / 255.0 if mode == 3 else 0.8], device=dev)
+    tab = lambda n: (torch.rand(n, generator=g).to(dev) * 0.02 + 0.02, torch.randint(100, 156, (n,), generator=g).float().to(dev))
+    ntab = lambda m, ntok: 1 if m == 0 else (ntok if m == 1 else D)
+    fq = ((qmode,) + tab(ntab(qmode, T)) + (0, 8), (kmode,) + tab(ntab(kmode, S - skip)) + (skip, 8), (vmode,) + tab(ntab(vmode, S)) + (0, 8))
+    before = ops.attention_sync_timeouts()
+    monkeypatch.setenv("DGQ_ATTN_ONE", "0")
+    monkeypatch.setenv("DGQ_ATTN_SPLIT", "0")
+    o3 = ops.attention(q, k, v, H, D, D ** -0.5, mode, skip, delta, bits, fq=fq).clone()
+    monkeypatch.delenv("DGQ_ATTN_ONE")
+    monkeypatch.delenv("DGQ_ATTN_SPLIT")
+    o1 = ops.attention(q, k, v, H, D, D ** -0.5, mode, skip, delta, bits, fq=fq).clone()
+    torch.cuda.synchronize()
+    assert torch.isfinite(o1.float()).all()
+    assert torch.equal(o1, o3), (o1.float() - o3.float()).abs().max().item()
+    assert ops.attention_sync_timeouts() == before
+
+
+def test_attention_one_launch_delta_exchange_under_load(dev, monkeypatch):
+    """The δ exchange of the single-launch form repeated back to back on changing inputs, between other launches that keep the caches
+    warm with the previous call's words: every call still equals the three-launch form bit for bit (a stale δ slot or counter would
+    show as a different quantisation grid), and no workgroup gives up."""
+    from dgq_amd import ops
+    B, H, D, T, S, bits = 2, 8, 40, 4096, 77, 8
+    g = torch.Generator().manual_seed(11)
+    tab = lambda n: (torch.rand(n, generator=g).to(dev) * 0.02 + 0.02, torch.randint(100, 156, (n,), generator=g).float().to(dev))
+    fq = ((1,) + tab(T) + (0, 8), (1,) + tab(S - 1) + (1, 8), (2,) + tab(D) + (0, 8))
+    before = ops.attention_sync_timeouts()
+    scratch = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
+    for it in range(24):
+        q, k, v = ((torch.randn(B, n, H * D, generator=g) * (0.5 + 0.1 * it)).to(dev) for n in (T, S, S))
+        o1 = ops.attention(q, k, v, H, D, D ** -0.5, 1, 1, None, bits, fq=fq).clone()
+        if it % 3 == 0:
+            scratch.fill_(it)                               # other traffic between the calls
+        monkeypatch.setenv("DGQ_ATTN_ONE", "0")
+        monkeypatch.setenv("DGQ_ATTN_SPLIT", "0")
+        o3 = ops.attention(q, k, v, H, D, D ** -0.5, 1, 1, None, bits, fq=fq).clone()
+        monkeypatch.delenv("DGQ_ATTN_ONE")
+        monkeypatch.delenv("DGQ_ATTN_SPLIT")
+        assert torch.equal(o1, o3), (it, (o1 - o3).abs().max().item())
+    assert ops.attention_sync_timeouts() == before
 
 
 @pytest.mark.parametrize("B,C,Hs,N,mode", [(2, 64, 8, 64, "perK"), (2, 320, 32, 320, "perK"), (2, 128, 16, 96, "perK"), (2, 320, 32, 64, "perM"),

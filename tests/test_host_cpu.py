@@ -24,7 +24,7 @@ def test_abi_library_loads_and_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), "libdgq_hip.so does not export %s" % name
     assert set(_lib.SIGNATURES) | {"dgq_last_error"} == declared
-    assert lib.dgq_version() >= 100
+    assert lib.dgq_version() == _lib.ABI_VERSION
     assert isinstance(_lib.last_error(), str)
     # argument validation happens before any launch: bad arguments -> DGQ_EINVAL and a message
     rc = lib.dgq_pack_w4(None, 0, 0, None, 0, 0, None, None)
