@@ -151,181 +151,13 @@ __global__ __launch_bounds__(256) void attn3_prep_kernel(const TIn* __restrict__
     // real-time δ: the maxima start at 0 — and with them the granules of the single-launch form's exchange (attn_one.hip) behind the slots
     if (delta_reset && blockIdx.x == 0 && bh == 0)
         for (int i = threadIdx.x; i < n_reset; i += 256) delta_reset[i] = 0.0f;
-    const TIn* kbase = k + ((int64_t)(b * S) * H + hd) * D;
-    const TIn* vbase = v + ((int64_t)(b * S) * H + hd) * D;
+    const int64_t kbase = ((int64_t)(b * S) * H + hd) * D, vbase = kbase;     // element index of key 0 of this (batch, head)
     const int64_t HD = (int64_t)H * D;
     unsigned short* kimg = reinterpret_cast<unsigned short*>(planes + ((int64_t)bh * NT + tile) * G::IMG_BYTES);
     unsigned short* vimg = kimg + G::K_ELEMS;
-    if (QI8 && do_k) {
-        // int8 K codes + per-key table; 8 threads per key row like the Q rows above
-        int8_t* k8 = reinterpret_cast<int8_t*>(kimg);
-        float* ktab = reinterpret_cast<float*>(k8 + G::K8_BYTES);
-        const int r = threadIdx.x >> 3, part = threadIdx.x & 7;
-        const int sidx = s0 + r;
-        const bool quant = sidx < S && sidx >= fk.skip;          // key 0 under start-peak: zero row, scale 0 (rank-1 path)
-        float dl = 0.0f, z = 0.0f, inv = 0.0f;
-        if (quant) {
-            const int idx = fk.mode == 0 ? 0 : sidx - fk.skip;
-            dl = fk.delta[idx]; z = fk.zp[idx]; inv = dgq_rcp(dl);
-        }
-        const float off = 0.5f * (fk.qmax + 1.0f);
-        float csum = 0.0f;
-        for (int c8 = part; c8 < G::K8_LD / 8; c8 += 8) {
-            unsigned w0 = 0, w1 = 0;
-            if (quant && 8 * c8 < D) {
-                float x[8];
-                load8<TIn>(kbase + sidx * HD + 8 * c8, x);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float c = fq_code(x[j], dl, inv, z, fk.qmax, off);
-                    csum += c;
-                    const unsigned byte = ((unsigned)(int)c) & 0xFFu;
-                    if (j < 4) w0 |= byte << (8 * j); else w1 |= byte << (8 * (j - 4));
-                }
-            }
-            *reinterpret_cast<uint2*>(k8 + r * G::K8_LD + 8 * c8) = make_uint2(w0, w1);
-        }
-#pragma unroll
-        for (int o = 4; o > 0; o >>= 1) csum += __shfl_xor(csum, o, 64);
-        if (part == 0) {
-            ktab[r] = dl;                                        // 0 for padding keys and the bypassed key
-            ktab[KT + r] = quant ? -(z - off) : 0.0f;
-            ktab[2 * KT + r] = -csum;
-        }
-    }
-    constexpr int KC = G::KLD / 8;                       // 16-byte chunks per K row (padding chunks are zero)
-    if (QM == 2 && do_k) {
-        // Q1K3: three planes of K̃[s][d] = aqtizer_k(k)[s][d]·(δq(d) for a per-head-dim aqtizer_q) and, per key,
-        // Σ_d w(d)·K̃[s][d] with w = z'q(d) (per-head-dim) or 1; 8 threads per key row, deterministic shuffle reduction
-        const int r = threadIdx.x >> 3, part = threadIdx.x & 7;
-        const int sidx = s0 + r;
-        const float offq = 0.5f * (fqq.qmax + 1.0f);
-        float corr = 0.0f;
-        constexpr int KIT = (KC + 7) / 8;
-        float x[KIT][8];
-#pragma unroll
-        for (int it = 0; it < KIT; ++it)                     // all loads of the thread in flight together
-            if (sidx < S && 8 * (part + 8 * it) < D) load8<TIn>(kbase + sidx * HD + 8 * (part + 8 * it), x[it]);
-#pragma unroll
-        for (int it = 0; it < KIT; ++it) {
-            const int c8 = part + 8 * it;
-            if (c8 >= KC) continue;
-            unsigned wh[4] = {0, 0, 0, 0}, wm[4] = {0, 0, 0, 0}, wl[4] = {0, 0, 0, 0};
-            if (sidx < S && 8 * c8 < D) {
-                fq_apply8(fk, x[it], sidx, 8 * c8);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    if (fqq.mode == 2) {
-                        x[it][j] *= fqq.delta[8 * c8 + j];
-                        corr += (fqq.zp[8 * c8 + j] - offq) * x[it][j];
-                    } else {
-                        corr += x[it][j];
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    unsigned short h0, m0, l0, h1, m1, l1;
-                    split3(x[it][2 * j], h0, m0, l0);
-                    split3(x[it][2 * j + 1], h1, m1, l1);
-                    wh[j] = (unsigned)h0 | ((unsigned)h1 << 16);
-                    wm[j] = (unsigned)m0 | ((unsigned)m1 << 16);
-                    wl[j] = (unsigned)l0 | ((unsigned)l1 << 16);
-                }
-            }
-            unsigned short* dst = kimg + r * G::KLD + 8 * c8;
-            *reinterpret_cast<uint4*>(dst) = make_uint4(wh[0], wh[1], wh[2], wh[3]);
-            *reinterpret_cast<uint4*>(dst + KT * G::KLD) = make_uint4(wm[0], wm[1], wm[2], wm[3]);
-            *reinterpret_cast<uint4*>(dst + 2 * KT * G::KLD) = make_uint4(wl[0], wl[1], wl[2], wl[3]);
-        }
-#pragma unroll
-        for (int o = 4; o > 0; o >>= 1) corr += __shfl_xor(corr, o, 64);
-        if (part == 0) reinterpret_cast<float*>(kimg + 3 * KT * G::KLD)[r] = corr;
-        if (G::FOLDZ && part == (D / 8) % 8) {               // (this thread wrote the zero chunk D/8 above: same-thread order)
-            unsigned short th, tm, tl;
-            split3(corr, th, tm, tl);
-            unsigned short* dst = kimg + r * G::KLD + D;     // slots D, D+1, D+2 all hold tv[s] = th + tm + tl
-            *reinterpret_cast<uint2*>(dst) = make_uint2((unsigned)th | ((unsigned)th << 16), (unsigned)th);
-            *reinterpret_cast<uint2*>(dst + KT * G::KLD) = make_uint2((unsigned)tm | ((unsigned)tm << 16), (unsigned)tm);
-            *reinterpret_cast<uint2*>(dst + 2 * KT * G::KLD) = make_uint2((unsigned)tl | ((unsigned)tl << 16), (unsigned)tl);
-        }
-    }
-    for (int i = threadIdx.x; QM == 0 && do_k && i < KT * KC; i += 256) {
-        const int r = i / KC, c8 = i - r * KC;
-        const int sidx = s0 + r;
-        unsigned wh[4], wm[4], wl[4];
-        const bool live = sidx < S && 8 * c8 < D;
-        float x[8];
-        if (live) {
-            load8<TIn>(kbase + sidx * HD + 8 * c8, x);
-            fq_apply8(fk, x, sidx, 8 * c8);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            unsigned short h0 = 0, m0 = 0, l0 = 0, h1 = 0, m1 = 0, l1 = 0;
-            if (live) {
-                split3(x[2 * j], h0, m0, l0);
-                split3(x[2 * j + 1], h1, m1, l1);
-            }
-            wh[j] = (unsigned)h0 | ((unsigned)h1 << 16);
-            wm[j] = (unsigned)m0 | ((unsigned)m1 << 16);
-            wl[j] = (unsigned)l0 | ((unsigned)l1 << 16);
-        }
-        unsigned short* dst = kimg + r * G::KLD + 8 * c8;
-        *reinterpret_cast<uint4*>(dst) = make_uint4(wh[0], wh[1], wh[2], wh[3]);
-        *reinterpret_cast<uint4*>(dst + KT * G::KLD) = make_uint4(wm[0], wm[1], wm[2], wm[3]);
-        *reinterpret_cast<uint4*>(dst + 2 * KT * G::KLD) = make_uint4(wl[0], wl[1], wl[2], wl[3]);
-    }
-    constexpr int VC = G::VLD / 8;                       // 4 chunks of 8 key slots + 1 padding chunk per V^T row
-    constexpr int VIT = (G::DV * VC + 255) / 256;
-    if (!do_k) {
-        float xv[VIT][8];
-#pragma unroll
-        for (int it = 0; it < VIT; ++it) {                   // all loads of the thread in flight together
-            const int i = threadIdx.x + 256 * it;
-            const int c8 = i / G::DV, d = i - c8 * G::DV;    // lanes run over d: coalesced reads of every key row
-#pragma unroll
-            for (int s8 = 0; s8 < 8; ++s8) {                 // slot within the chunk = 4a + b
-                const int sidx = s0 + 16 * (c8 >> 1) + 8 * (s8 >> 2) + 4 * (c8 & 1) + (s8 & 3);
-                xv[it][s8] = (c8 < 4 && sidx < S && d < D) ? dgq_to_float(vbase[sidx * HD + d]) : 0.0f;
-            }
-        }
-#pragma unroll
-        for (int it = 0; it < VIT; ++it) {
-            const int i = threadIdx.x + 256 * it;
-            if (i >= G::DV * VC) continue;
-            const int c8 = i / G::DV, d = i - c8 * G::DV;
-            unsigned wh[4], wm[4], wl[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                unsigned short hh[2] = {0, 0}, mm[2] = {0, 0}, ll[2] = {0, 0};
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const int slot8 = 2 * j + e;
-                    const int sidx = s0 + 16 * (c8 >> 1) + 8 * (slot8 >> 2) + 4 * (c8 & 1) + (slot8 & 3);
-                    if (G::VONES && c8 < 4 && d == D) hh[e] = 0x3F80;          // the ones row (every slot: padding keys carry p̂ = 0)
-                    if (c8 < 4 && sidx < S && d < D) {
-                        const float x1 = xv[it][slot8];
-                        if (VINT) {                                            // centred code (|c'| <= 128: exact in bf16)
-                            const int idx = fv.mode == 0 ? 0 : d;
-                            const float dl = fv.delta[idx];
-                            hh[e] = bf16_bits(fq_code(x1, dl, dgq_rcp(dl), fv.zp[idx], fv.qmax, 0.5f * (fv.qmax + 1.0f)));
-                        } else {
-                            split3(fq_apply(fv, x1, sidx, d), hh[e], mm[e], ll[e]);
-                        }
-                    }
-                }
-                wh[j] = (unsigned)hh[0] | ((unsigned)hh[1] << 16);
-                wm[j] = (unsigned)mm[0] | ((unsigned)mm[1] << 16);
-                wl[j] = (unsigned)ll[0] | ((unsigned)ll[1] << 16);
-            }
-            unsigned short* dst = vimg + d * G::VLD + 8 * c8;
-            *reinterpret_cast<uint4*>(dst) = make_uint4(wh[0], wh[1], wh[2], wh[3]);
-            if (!VINT) {
-                *reinterpret_cast<uint4*>(dst + G::DV * G::VLD) = make_uint4(wm[0], wm[1], wm[2], wm[3]);
-                *reinterpret_cast<uint4*>(dst + 2 * G::DV * G::VLD) = make_uint4(wl[0], wl[1], wl[2], wl[3]);
-            }
-        }
-    }
+    const TypedLd<TIn> ld{};
+    if (do_k) prep_k_tile<D, QM, VINT>(ld, k, kbase, HD, S, s0, fk, fqq, kimg, threadIdx.x);
+    else prep_v_tile<D, QM, VINT>(ld, v, vbase, HD, S, s0, fv, vimg, threadIdx.x);
     DGQ_ATTN_PREP_DONE();
 }
 

@@ -1192,9 +1192,9 @@ ONE_LAUNCH_CASES = [
 @pytest.mark.parametrize("D,T,S,mode,skip,qmode,kmode,vmode,dtype", ONE_LAUNCH_CASES)
 def test_attention_one_launch_is_bit_identical(D, T, S, mode, skip, qmode, kmode, vmode, dtype, dev, monkeypatch):
     """Key ranges of at most 8 tiles run statistics, the real-time δ maximum (exchanged between the resident workgroups inside the
-    launch) and P·V as ONE kernel (csrc/attn_one.hip).  Scores, row statistics, the δ maximum and the P·V arithmetic are those of the
-    three launches without a key split, so the output is equal bit for bit (DGQ_ATTN_ONE=0 DGQ_ATTN_SPLIT=0 select that form); no
-    workgroup gives up the exchange."""
+    launch) and P·V as ONE kernel behind the pre-pass (csrc/attn_one.hip).  Scores, row statistics, the δ maximum and the P·V
+    arithmetic are those of the three launches without a key split, so the output is equal bit for bit (DGQ_ATTN_ONE=0
+    DGQ_ATTN_SPLIT=0 select that form); no workgroup gives up the exchange."""
     from dgq_amd import ops
     B, H, bits = 2, 8, 8
     g = torch.Generator().manual_seed(D + T + S + mode + 7 * qmode + 3 * vmode)

@@ -39,6 +39,6 @@ for D, T, S in shapes:
                 os.environ["DGQ_ATTN_ONE"] = one
                 res.append(timed(lambda: ops.attention(q, k, v, H, D, D ** -0.5, mode, skip, delta, 8, fq=fq)))
         os.environ.pop("DGQ_ATTN_ONE")
-        print("D=%3d T=%5d S=%4d %s  real-time δ: three launches %6.1f us, one %6.1f | static δ: three %6.1f, one %6.1f"
+        print("D=%3d T=%5d S=%4d %s  real-time δ: pre-pass + statistics + P·V launches %6.1f us, pre-pass + one launch %6.1f | static δ: %6.1f, %6.1f"
               % (D, T, S, name, res[0], res[1], res[2], res[3]), flush=True)
 print("sync timeouts:", ops.attention_sync_timeouts())
