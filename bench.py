@@ -50,6 +50,13 @@ CONFIGS = {
                metric="UNet denoise steps/sec @ SD1.4 512^2 W4A8 g16",
                workload="SD v1.4 UNet W4A8 g=16 (time-aware, log2 softmax real-time δ, start-peak), DDIM 50-step schedule, "
                         "512x512 (64x64 latents), CFG pair per step per GPU"),
+    # SD v1.4 W4A6 g=8, the reference's preset for G > 1 (scripts/quantize_act.sh:16-19: log2 softmax quantiser, real-time δ, start-peak,
+    # time-aware) — BASELINE.json configs[2]
+    "c3": dict(arch="sd", res=64, cfg=dict(wbits=4, abits=6, use_aq=True, G=8, log=True, rt=True, sp=True, time_aware=True, steps=50),
+               guidance=7.5, prompts=1,
+               metric="UNet denoise steps/sec @ SD1.4 512^2 W4A6 g8",
+               workload="SD v1.4 UNet W4A6 g=8 + t2i_log_quant (real-time δ, start-peak) + time_aware_aqtizer, DDIM 50-step schedule, "
+                        "512x512 (64x64 latents), CFG pair per step per GPU"),
     # SDXL-turbo W4A8 g=16, 4 steps, 1024x1024, batch 1, no CFG
     "c4": dict(arch="sdxl", res=128, cfg=dict(wbits=4, abits=8, use_aq=True, G=16, log=True, rt=True, sp=True, time_aware=True, steps=4),
                guidance=0.0, prompts=1,
@@ -78,6 +85,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-launch GEMM replay pass (profiling runs)")
     ap.add_argument("--prompts-per-gpu", type=int, default=0,
                     help="prompts denoised together on each GPU (default: the config's own: c2/c4 1, c5 8)")
+    ap.add_argument("--dev-no-guidance", action="store_true",
+                    help="development: run the SD configs without the CFG pair (batch 1 per prompt) — the line says so in "
+                         "config.workload / config.dev_override and is never the headline")
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "fp16", "bf16"],
                     help="inter-layer activation dtype (fp32 = the reference's default .float() mode)")
     return ap.parse_args(argv)
@@ -178,8 +188,8 @@ def main(argv=None):
 
     C = CONFIGS[args.config]
     arch, res, qcfg, guidance = C["arch"], C["res"], C["cfg"], C["guidance"]
-    if os.environ.get("DGQ_BENCH_GUIDANCE") is not None:      # development: 0 = the conditional half alone (batch 1) — what one half of the CFG pair costs
-        guidance = float(os.environ["DGQ_BENCH_GUIDANCE"])
+    if args.dev_no_guidance:                                 # development: the conditional half alone (batch 1); labelled in the line below
+        guidance = 0.0
     if DRY:
         arch, res, guidance = "tiny", 16, 7.5
         args.no_graph = args.no_roofline = args.no_cpu_baseline = True
@@ -354,6 +364,15 @@ def main(argv=None):
                 glue = gd
                 break
         import resource
+        # anything that departs from the configuration's own definition is said in the line itself: the workload string
+        # and a dev_override list
+        workload_label, overrides = C["workload"], []
+        if P != C["prompts"]:
+            overrides.append("--prompts-per-gpu %d (the configuration runs %d): batch %d per GPU" % (P, C["prompts"], batch))
+            workload_label = workload_label.replace("CFG pair per step per GPU", "%d prompts x CFG pair per step per GPU (NOT the headline batch)" % P)
+        if args.dev_no_guidance and C["guidance"] > 0:
+            overrides.append("--dev-no-guidance: conditional half only, batch %d" % batch)
+            workload_label = workload_label.replace("CFG pair per step per GPU", "NO CFG pair: conditional half only (development run)")
         load = dict(getattr(qnn, "_build_laps", {}))
         load.update({"prepare_slots (plan + pack %d slots)" % len(slots): round(t_prep, 2),
                      "model_ready_s": round(sum(v for k, v in load.items() if k != "write cali_ckpt") + t_prep, 1),
@@ -369,7 +388,7 @@ def main(argv=None):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int8 (W%dA%d MFMA, int32 accumulate; %s between layers)" % (qcfg["wbits"], qcfg["abits"], args.dtype),
             "data": "synthetic",
-            "config": {"workload": C["workload"], "config_id": args.config,
+            "config": {"workload": workload_label, "config_id": args.config,
                        "prompts_per_gpu": P, "batch_per_gpu": batch, "parallelism": "replicas x%d (no collectives)" % n},
             "windows": {"n": len(windows), "steps_each": K, "value_from": "median",
                         "ms_per_step_min": round(1e3 * min(windows) / (K * P), 3),
@@ -377,6 +396,8 @@ def main(argv=None):
             "roofline": roofline, "cpu_baseline": cpu_baseline, "load": load,
             "non_hip_kernels": glue,
         }
+        if overrides:
+            out["config"]["dev_override"] = overrides        # (a line that carries this key is not the configuration BASELINE.json names)
         out.update(roofline_extra)                       # roofline_quant_act, roofline_attention, roofline_step
         if DRY:
             out["dry_run"] = "DGQ_BENCH_BACKEND=gloo: launcher rehearsal on CPU ranks with the FP tiny UNet — NOT a measurement"
@@ -419,13 +440,15 @@ def measure_gemm_roofline(torch, ops, qnn, run_step, args):
     def gemm_hook(issue, problems):
         ms = timed(issue)
         layers[0] += len(problems)
-        # un-unfolded input counted once at 1 B/code, int4 weights, output at its dtype
-        o = sum(2.0 * M * ab.pw.N * ab.pw.K for M, ab, _ in problems)
-        by = sum(M * ab.pw.K / max(1, ab.pw.taps) + ab.pw.N * ab.pw.K * ab.pw.bits / 8 + M * ab.pw.N * es for M, ab, es in problems)
+        # a layer's bytes = its input once (un-unfolded, at its dtype) + int4 weights + output at its dtype.  The input
+        # belongs to the launch that READS it: this one when it quantises its own operand (xb > 0), else the dgq_quant_act launch in front
+        # of it (quant hook below) — the int8 code matrix between the two is overhead, not algorithmic traffic
+        o = sum(2.0 * M * ab.pw.N * ab.pw.K for M, ab, _, _ in problems)
+        by = sum(xb + ab.pw.N * ab.pw.K * ab.pw.bits / 8 + M * ab.pw.N * es for M, ab, es, xb in problems)
         rec["gemm"].append((ms, o, by))
         if os.environ.get("DGQ_BENCH_GEMM_DUMP"):            # per-launch table for tools (shape, scale mode, time)
             with open(os.environ["DGQ_BENCH_GEMM_DUMP"], "a") as f:
-                f.write("%s %.2f\n" % (";".join("%d,%d,%d,%d,%s,%d" % (M, ab.pw.N, ab.pw.K, ab.Kp, ab.mode, es) for M, ab, es in problems), 1e3 * ms))
+                f.write("%s %.2f\n" % (";".join("%d,%d,%d,%d,%s,%d" % (M, ab.pw.N, ab.pw.K, ab.Kp, ab.mode, es) for M, ab, es, _ in problems), 1e3 * ms))
 
     ops.GEMM_LAUNCH_HOOK = gemm_hook
     def dump(kind, ms, work):                                # per-launch tables for tools: DGQ_BENCH_QUANT_DUMP / _ATTN_DUMP=<file>
@@ -435,7 +458,13 @@ def measure_gemm_roofline(torch, ops, qnn, run_step, args):
                 f.write("%.0f %.2f\n" % (work, 1e3 * ms))
         return ms
 
-    ops.QUANT_LAUNCH_HOOK = lambda issue, by: rec["quant"].append((dump("QUANT", timed(issue), by), 0.0, float(by)))
+    overhead = [0.0]
+
+    def quant_hook(issue, by, over):
+        overhead[0] += over
+        rec["quant"].append((dump("QUANT", timed(issue), by + over), 0.0, float(by)))
+
+    ops.QUANT_LAUNCH_HOOK = quant_hook
     ops.ATTN_LAUNCH_HOOK = lambda issue, fl, by: rec["attn"].append((dump("ATTN", timed(issue), fl), float(fl), float(by)))
     graphs_were = qnn._graphs
     qnn._graphs = None
@@ -501,7 +530,11 @@ def measure_gemm_roofline(torch, ops, qnn, run_step, args):
                                        "bound": "hbm", "achieved": round(Q["bytes"] / (q_ms * 1e-3) / 1e12, 3), "peak": HBM_PEAK_TBS,
                                        "unit": "TB/s", "frac": round(Q["bytes"] / (q_ms * 1e-3) / 1e12 / HBM_PEAK_TBS, 4),
                                        "launches_per_step": Q["launches"], "kernel_ms_per_step": q_ms, "ideal_ms_per_step": Q["ideal_ms_per_step"],
-                                       "algorithmic_MB_per_launch": round(Q["bytes"] / Q["launches"] / 1e6, 3)}
+                                       "algorithmic_MB_per_launch": round(Q["bytes"] / Q["launches"] / 1e6, 3),
+                                       "algorithmic": "the layer input read once, un-unfolded (SURVEY.md §8(d)); the layer's weights and output are the GEMM launch's",
+                                       "overhead_MB_per_launch": round(overhead[0] / Q["launches"] / 1e6, 3),
+                                       "overhead": "int8 code matrix [M][Kp] + row sums written for the GEMM launch behind: traffic the algorithm does not need",
+                                       "moved_TBs": round((Q["bytes"] + overhead[0]) / (q_ms * 1e-3) / 1e12, 3)}
     if A["launches"]:
         a_ms = A["ms_per_step"]
         extra["roofline_attention"] = {"kernel": "dgq_attention (attn3_prep + attn3_stats + attn3_pv): aqtizer_q/k/v, QK^T, softmax, log2 / uniform aqtizer_w, P·V",

@@ -719,7 +719,6 @@ static int launch_attn3(AttnParams p, const void* q_raw, unsigned char* planes, 
         if (one <= 0) return one;
     }
     // 8-wave blocks (256 query rows) when they still give one block per CU; register budgets allow it for D <= 64
-    static const bool force4 = getenv("DGQ_ATTN_NW4") != nullptr;
     // ... unless the 8-wave grid ends in a mostly empty round: two 8-wave workgroups share a CU (512 resident), and e.g. 640 of
     // them (T = 1024, B·H = 160) run as 1.25 rounds in the time of 2 — the 4-wave grid's last round costs a fraction of that
     // (its lone workgroups have their SIMDs to themselves): 165 -> 152 us for that call, while 4096 rows at B·H = 80 (2.5
@@ -727,7 +726,7 @@ static int launch_attn3(AttnParams p, const void* q_raw, unsigned char* planes, 
     const long nblk8 = (long)((p.T + 255) / 256) * p.B * p.H;
     const long rounds8 = (nblk8 + 511) / 512;
     const bool tail_ok = nblk8 <= 512 || 10 * nblk8 >= 8 * 512 * rounds8;
-    const bool wide = D <= 64 && !force4 && nblk8 >= 256 && tail_ok;
+    const bool wide = D <= 64 && nblk8 >= 256 && tail_ok;
     // Key split: a grid that leaves the chip under-filled (fewer 128-row workgroups than ~0.9 per CU) runs each (query block,
     // batch·head) as TWO workgroups over the two halves of the key tiles.  The statistics halves are merged by attn3_merge_kernel
     // ; the P·V halves use the merged (m, l, δ), so their parts simply add (the second half's part goes to a scratch tensor,
@@ -742,11 +741,9 @@ static int launch_attn3(AttnParams p, const void* q_raw, unsigned char* planes, 
     if (wide) {
         if constexpr (D <= 64) {
             dim3 grid((p.T + 255) / 256, p.B * p.H), block(512);
-            const char* te = getenv("DGQ_ATTN_TPS");                        // "1": one key tile per stage everywhere (read per call: tests toggle it)
-            const bool tps_off = te && *te == '1';
-            if (!tps_off && p.NT >= 4 * TPS_S && p.NT % TPS_S == 0) hipLaunchKernelGGL((attn3_stats_kernel<D, 8, QM, TPS_S>), grid, block, stats2_lds, st, p);
+            if (p.NT >= 4 * TPS_S && p.NT % TPS_S == 0) hipLaunchKernelGGL((attn3_stats_kernel<D, 8, QM, TPS_S>), grid, block, stats2_lds, st, p);
             else hipLaunchKernelGGL((attn3_stats_kernel<D, 8, QM>), grid, block, stats_lds, st, p);
-            if (!tps_off && p.NT >= 4 * TPS_P && p.NT % TPS_P == 0) {
+            if (p.NT >= 4 * TPS_P && p.NT % TPS_P == 0) {
                 if (p.mode == 3) hipLaunchKernelGGL((attn3_pv_kernel<D, true, 8, QM, VINT, TPS_P>), grid, block, pv2_lds, st, p);
                 else hipLaunchKernelGGL((attn3_pv_kernel<D, false, 8, QM, VINT, TPS_P>), grid, block, pv2_lds, st, p);
             } else if (p.mode == 3) hipLaunchKernelGGL((attn3_pv_kernel<D, true, 8, QM, VINT>), grid, block, pv_lds, st, p);

@@ -755,12 +755,11 @@ static GemmPlan plan_gemm(int M, int N, int Kp, int w_bits, size_t ws_bytes, boo
     // epilogues, profiles/r04_c5_gemm_big_vs_tiles.txt): 8192x10240x1280 -12 %, 32768x1280x11520 -2 %; 8192x1280x{1280,5120}
     // (160 tiles) and 32768x640x2560 (2.5 column tiles) lose 35-100 % and stay on the tile family.  Per-K it pays on long K
     // only (8192^3 34 -> 39 %): at K = 1280 with 16 groups the flushes bound either kernel.
-    static const bool big_on = [] { const char* e = getenv("DGQ_GEMM_BIG"); return !(e && *e == '0'); }();   // A/B hook
     {
         const int bn_big = per_m ? 256 : 128;
         const long tiles = (long)((M + 255) / 256) * ((N + bn_big - 1) / bn_big);
-        static const long min_tiles = [] { const char* e = getenv("DGQ_GEMM_BIG_TILES"); return e && *e ? atol(e) : 256L; }();   // sweep hook
-        if (big_on && allow_big && w_bits == 4 && pl.splits == 1 && M >= 2048 && N % bn_big == 0 && tiles >= min_tiles &&
+        constexpr long min_tiles = 256;
+        if (allow_big && w_bits == 4 && pl.splits == 1 && M >= 2048 && N % bn_big == 0 && tiles >= min_tiles &&
             (nk >= 32 || (per_m && nk >= 8 && N >= 4096)) && dgq_gemm_big_lds_bytes(per_m, Kp) <= 160 * 1024)
             pl = {256, 256, 1, 0.0};
     }

@@ -740,18 +740,16 @@ static int quant_act_variant(const QuantActParams& p, bool table) {
     // per-K Linear inputs whose groups are short (K = 320 with 16 groups: Kp = 512, 38 % padding): the staged gather
     // evaluates the quantiser for every PACKED position, padding included; the scatter path evaluates it once per SOURCE
     // element (K instead of Kp codes, 16-byte coalesced reads with the LayerNorm / GEGLU prologue applied on the way) and
-    // drops the byte into the row image in LDS.  One wave per row (RPB = 4).  DGQ_QA_LINEAR_SCATTER = 0 off, 2 always.
+    // drops the byte into the row image in LDS.  Taken where the padding is at least a quarter of K.
     {
-        static const int mode = [] { const char* e = getenv("DGQ_QA_LINEAR_SCATTER"); return e && *e ? atoi(e) : 1; }();
         const size_t tab_b = (((size_t)3 * (p.Kp >> 5) + 16) * 4 + 15) & ~(size_t)15;
-        if (mode && table && p.kdst && taps_ == 1 && p.C % 4 == 0 && ks == 1 && (!p.ln_gamma || p.C <= DGQ_LN_MAX_C) &&
-            tab_b + 4 * (size_t)p.Kp <= 150 * 1024 && (mode == 2 || 4 * p.Kp >= 5 * p.K))
+        if (table && p.kdst && taps_ == 1 && p.C % 4 == 0 && ks == 1 && (!p.ln_gamma || p.C <= DGQ_LN_MAX_C) &&
+            tab_b + 4 * (size_t)p.Kp <= 150 * 1024 && 4 * p.Kp >= 5 * p.K)
             return 3;
     }
-    // convolutions whose input patch fits the LDS: the block-staged path (DGQ_QA_CONV_BLOCK=0: A/B hook)
+    // convolutions whose input patch fits the LDS: the block-staged path
     {
-        static const bool conv_block = [] { const char* e = getenv("DGQ_QA_CONV_BLOCK"); return !(e && *e == '0'); }();
-        if (conv_block && p.kpat && taps_ > 1 && p.C % 4 == 0 && ks == 1 && p.pre_act != 2 && !p.ln_gamma &&
+        if (p.kpat && taps_ > 1 && p.C % 4 == 0 && ks == 1 && p.pre_act != 2 && !p.ln_gamma &&
             conv_block_pays(p, conv_tile(p.C, p.kh, p.kw, p.stride, p.Kp)))
             return 5;
     }
@@ -792,8 +790,7 @@ static void launch_quant_act(const QuantActBatch& bt, int n, int variant, bool p
         if (dev < 0 || dev >= 64 || !attr5[dev].load(std::memory_order_acquire)) {          // all six instantiations of this dtype, once
 #define DGQ_QA_ATTR(PM, TH_, TW_) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&quant_act_conv_kernel<TIn, PM, TH_, TW_, 8>), \
                                                             hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024)
-            DGQ_QA_ATTR(true, 4, 8); DGQ_QA_ATTR(false, 4, 8); DGQ_QA_ATTR(true, 4, 4); DGQ_QA_ATTR(false, 4, 4);
-            DGQ_QA_ATTR(true, 2, 4); DGQ_QA_ATTR(false, 2, 4);
+            DGQ_QA_ATTR(true, 4, 8); DGQ_QA_ATTR(false, 4, 8);
 #undef DGQ_QA_ATTR
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&quant_act_conv_kernel<TIn, true, 4, 4, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&quant_act_conv_kernel<TIn, false, 4, 4, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
@@ -806,21 +803,15 @@ static void launch_quant_act(const QuantActBatch& bt, int n, int variant, bool p
         else if (t.id == 2) {
             // 16 positions per tile: one wave per output position (16 waves) instead of two positions per wave — the gather / quantise phase is a
             // chain of dependent LDS reads per 1024 codes, and twice the waves hide twice the latency (same lanes, same order per row:
-            // bit-identical; step +0.3-0.5 % same box).  DGQ_QA_CONV_W16=0: the 8-wave form.
-            static const bool w16 = [] { const char* e = getenv("DGQ_QA_CONV_W16"); return !(e && *e == '0'); }();
-            if (w16) {
-                if (per_m) hipLaunchKernelGGL((quant_act_conv_kernel<TIn, true, 4, 4, 16>), dim3(tiles, 1, n), dim3(1024), t.lds, st, bt);
-                else hipLaunchKernelGGL((quant_act_conv_kernel<TIn, false, 4, 4, 16>), dim3(tiles, 1, n), dim3(1024), t.lds, st, bt);
-            } else if (per_m) DGQ_QA_CONV(true, 4, 4); else DGQ_QA_CONV(false, 4, 4);
+            // bit-identical; step +0.3-0.5 % same box)
+            if (per_m) hipLaunchKernelGGL((quant_act_conv_kernel<TIn, true, 4, 4, 16>), dim3(tiles, 1, n), dim3(1024), t.lds, st, bt);
+            else hipLaunchKernelGGL((quant_act_conv_kernel<TIn, false, 4, 4, 16>), dim3(tiles, 1, n), dim3(1024), t.lds, st, bt);
         }
         else {
             // 8 positions per tile, 16 waves: two waves per position (the per-K row sum then adds its two parts: last-bit differences
-            // against the one-wave order; per-M sums are exact integers).  DGQ_QA_CONV_W16=0: 8 waves.
-            static const bool w16b = [] { const char* e = getenv("DGQ_QA_CONV_W16"); return !(e && *e == '0'); }();
-            if (w16b) {
-                if (per_m) hipLaunchKernelGGL((quant_act_conv_kernel<TIn, true, 2, 4, 16>), dim3(tiles, 1, n), dim3(1024), t.lds, st, bt);
-                else hipLaunchKernelGGL((quant_act_conv_kernel<TIn, false, 2, 4, 16>), dim3(tiles, 1, n), dim3(1024), t.lds, st, bt);
-            } else if (per_m) DGQ_QA_CONV(true, 2, 4); else DGQ_QA_CONV(false, 2, 4);
+            // against the one-wave order; per-M sums are exact integers)
+            if (per_m) hipLaunchKernelGGL((quant_act_conv_kernel<TIn, true, 2, 4, 16>), dim3(tiles, 1, n), dim3(1024), t.lds, st, bt);
+            else hipLaunchKernelGGL((quant_act_conv_kernel<TIn, false, 2, 4, 16>), dim3(tiles, 1, n), dim3(1024), t.lds, st, bt);
         }
 #undef DGQ_QA_CONV
         return;
@@ -835,7 +826,6 @@ static void launch_quant_act(const QuantActBatch& bt, int n, int variant, bool p
         int dev = 0;
         (void)hipGetDevice(&dev);
         if (dev < 0 || dev >= 64 || !attr_set[dev].load(std::memory_order_acquire)) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&quant_act_scatter_kernel<TIn, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&quant_act_scatter_kernel<TIn, 4, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&quant_act_scatter_kernel<TIn, 1, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&quant_act_scatter_kernel<TIn, 1, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
@@ -843,12 +833,9 @@ static void launch_quant_act(const QuantActBatch& bt, int n, int variant, bool p
         }
         // four rows per block: two waves per row (the (tap, 256-channel) units dealt round-robin; each wave forms the row's LayerNorm
         // statistics itself) — a 2048-row launch is 2048 waves otherwise, two per SIMD, each a chain of dependent loads.
-        // DGQ_QA_SCATTER_W8=0: one wave per row.
-        static const bool sw8 = [] { const char* e = getenv("DGQ_QA_SCATTER_W8"); return !(e && *e == '0'); }();
-        static const long s16_max = [] { const char* e = getenv("DGQ_QA_SCATTER16_MAXM"); return e && *e ? atol(e) : 2048L; }();  // rows (x problems) up to which a row gets 16 waves instead of 8: 256 -> 2048 measured +0.5 % on the SD step (same box)
-        if (variant == 3 && sw8) hipLaunchKernelGGL((quant_act_scatter_kernel<TIn, 4, 8>), dim3((p0.M + 3) / 4, 1, n), dim3(512), lds, st, bt);
-        else if (variant == 3) hipLaunchKernelGGL((quant_act_scatter_kernel<TIn, 4>), dim3((p0.M + 3) / 4, 1, n), dim3(256), lds, st, bt);
-        else if ((long)p0.M * n <= s16_max) hipLaunchKernelGGL((quant_act_scatter_kernel<TIn, 1, 16>), dim3(p0.M, 1, n), dim3(1024), lds, st, bt);
+        // Rows (x problems) up to 2048 get 16 waves each instead of 8 (256 -> 2048 measured +0.5 % on the SD step, same box).
+        if (variant == 3) hipLaunchKernelGGL((quant_act_scatter_kernel<TIn, 4, 8>), dim3((p0.M + 3) / 4, 1, n), dim3(512), lds, st, bt);
+        else if ((long)p0.M * n <= 2048L) hipLaunchKernelGGL((quant_act_scatter_kernel<TIn, 1, 16>), dim3(p0.M, 1, n), dim3(1024), lds, st, bt);
         else hipLaunchKernelGGL((quant_act_scatter_kernel<TIn, 1, 8>), dim3(p0.M, 1, n), dim3(512), lds, st, bt);
         return;
     }

@@ -205,7 +205,7 @@ def _fusion_on():
 def _glue_on():
     """DGQ_GLUE=0 (A/B runs): timestep embedding and its SiLU as the torch kernels"""
     import os
-    return _fusion_on() and os.environ.get("DGQ_GLUE", "1") != "0"
+    return _fusion_on()
 
 
 class Transformer2DModel(nn.Module):

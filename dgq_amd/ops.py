@@ -113,7 +113,7 @@ W4_LAYOUT = 1
 W4_FRAG_LAYOUT = 2
 #: keep a fragment-major copy of every W4 weight beside the row-major one, so that dgq_gemm_wxa8 may take its short-K kernel
 #: (DGQ_GEMM_PANEL=0: never — the tile family alone, as in round 4)
-GEMM_PANEL = os.environ.get("DGQ_GEMM_PANEL", "1") == "1"
+GEMM_PANEL = True
 
 
 def pack_weight(codes: torch.Tensor, kperm: Optional[torch.Tensor], Kp: int, bits: int, layout: int = W4_LAYOUT):
@@ -346,15 +346,15 @@ def groupnorm_scale_shift(x_cl: torch.Tensor, B, HW, C, groups, eps, gamma, beta
 #: of a pass over the tensor.  A conv output carries its partials as a tensor attribute (``_dgq_gn``); a GroupNorm folded
 #: into the next layer's load uses them when the very same tensor object (or a channel concat of two such tensors,
 #: ``cat_channels``) reaches it.  DGQ_GN_FROM_GEMM=0 restores the standalone statistics kernels.
-GN_FROM_GEMM = os.environ.get("DGQ_GN_FROM_GEMM", "1") == "1"
+GN_FROM_GEMM = True
 #: ... also where the producing GEMM is K-split: its combine kernel writes the partials (=0: statistics pass for those tensors)
-GN_FROM_SPLITK = os.environ.get("DGQ_GN_FROM_SPLITK", "1") == "1"
+GN_FROM_SPLITK = True
 
 
 #: convolutions whose activation quantizer is one (δ, z) pair (config C5 / C2U; the reference's native conv path) take the
 #: implicit-im2col GEMM (dgq_gemm_conv_t): the input is quantised once per pixel and the unfolded operand never exists.
 #: DGQ_CONV_IMPLICIT=0: the materialising pass of every other conv layer.
-CONV_IMPLICIT = os.environ.get("DGQ_CONV_IMPLICIT", "1") == "1"
+CONV_IMPLICIT = True
 
 
 def cat_channels(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
@@ -430,8 +430,7 @@ def quant_act(x_cl: torch.Tensor, B, H, W, C, kh, kw, stride, pad, ab: ActBindin
         _lib_call("dgq_quant_act_batch", 1, _c.byref(a), _lib.stream())
     issue()
     if QUANT_LAUNCH_HOOK is not None:
-        # algorithmic bytes: the input once (un-unfolded) + the codes + the row sums
-        QUANT_LAUNCH_HOOK(issue, (B * H * W * ldc * x_cl.element_size() >> (2 if ups else 0)) + M * ab.Kp + 4 * parts * M)
+        QUANT_LAUNCH_HOOK(issue, B * H * W * ldc * x_cl.element_size() >> (2 if ups else 0), M * ab.Kp + 4 * parts * M)
     return codes, rowsum, M
 
 
@@ -440,32 +439,25 @@ def _dp(t):
 
 
 _WORKSPACE = {}
-_SIDE_STREAMS = {}
 WORKSPACE_BYTES = 128 << 20
-#: slabs kept for user streams (other than the default / capture stream and the registered side streams): least recently
+#: slabs kept for user streams (other than the default / capture stream): least recently
 #: used first out, so a program that keeps creating streams does not leak 128 MB per handle
 _STREAM_SLABS_MAX = 4
 
 
 def workspace(device):
     """Persistent split-K scratch (caller-owned; one per device AND stream, so that layers running concurrently on
-    forked streams never share it): the library never allocates."""
+    different streams never share it): the library never allocates."""
     cur = torch.cuda.current_stream(device).cuda_stream
-    branch = None
-    for i, st in enumerate(_SIDE_STREAMS.get(str(device), [])):
-        if st.cuda_stream == cur:
-            branch = i
-    if branch is None:
-        # the default stream and torch's graph-capture stream of a device are one serial chain (a capture runs while the
-        # default stream is idle) and share the "main" slab; any OTHER user stream gets a slab of its own, keyed by handle,
-        # so two user streams can never race on one split-K workspace
-        is_main = cur == torch.cuda.default_stream(device).cuda_stream or torch.cuda.is_current_stream_capturing()
-        branch = "main" if is_main else ("stream", cur)
+    # the default stream and torch's graph-capture stream of a device are one serial chain (a capture runs while the
+    # default stream is idle) and share the "main" slab; any OTHER user stream gets a slab of its own, keyed by handle,
+    # so two user streams can never race on one split-K workspace
+    is_main = cur == torch.cuda.default_stream(device).cuda_stream or torch.cuda.is_current_stream_capturing()
+    branch = "main" if is_main else ("stream", cur)
     key = (str(device), branch)
     if key not in _WORKSPACE:
         if torch.cuda.is_current_stream_capturing():
-            raise RuntimeError("dgq_amd: split-K workspace of a forked stream must exist before graph capture "
-                               "(ops.prepare_side_streams)")
+            raise RuntimeError("dgq_amd: the split-K workspace must exist before graph capture (run the model once eagerly)")
         if isinstance(branch, tuple):                       # a user stream: bounded, least recently used first out
             old = [k for k in _WORKSPACE if k[0] == str(device) and isinstance(k[1], tuple)]
             while len(old) >= _STREAM_SLABS_MAX:
@@ -474,62 +466,6 @@ def workspace(device):
     elif isinstance(branch, tuple):
         _WORKSPACE[key] = _WORKSPACE.pop(key)               # most recently used last
     return _WORKSPACE[key]
-
-
-def prepare_side_streams(device, n=2):
-    """Create the forked streams used under graph capture and their split-K workspaces (outside any capture)."""
-    pool = _SIDE_STREAMS.setdefault(str(device), [])
-    while len(pool) < n:
-        pool.append(torch.cuda.Stream(device))
-    for st in pool[:n]:
-        with torch.cuda.stream(st):
-            workspace(device)
-    workspace(device)
-
-
-class Fork:
-    """Run independent branches of the layer graph on forked HIP streams (joined before use).  Only active while a
-    hipGraph is being captured: the concurrency is then baked into the graph (parallel branches of small kernels that
-    individually fill a fraction of the 256 CUs); eager execution stays on one stream."""
-
-    #: Off: since rounds 3 / 4 the branches it used to fork are single shared launches — q / k / v of a self-attention are one
-    #: quantise + one GEMM launch (quant_linear_multi), the 32 ctx-side K / V projections of a forward are computed together by the
-    #: first cross-attention (quant_block.CtxGroup) — so a fork has nothing to overlap (DESIGN.md §0 round 5, item 8).  Kept as
-    #: the mechanism for experiments with other branches (DGQ_FORK=1).
-    ENABLED = os.environ.get("DGQ_FORK", "0") == "1"
-
-    def __init__(self, device, n_side):
-        self.active = Fork.ENABLED and torch.cuda.is_current_stream_capturing()
-        self.main = torch.cuda.current_stream(device)
-        self.side = []
-        self.used = []
-        if self.active:
-            pool = _SIDE_STREAMS.setdefault(str(device), [])
-            while len(pool) < n_side:
-                pool.append(torch.cuda.Stream(device))
-            self.side = pool[:n_side]
-
-    def run(self, i, fn, *inputs):
-        """Branch 0 runs on the main stream, branch i>0 on side stream i-1."""
-        if not self.active or i == 0:
-            return fn()
-        st = self.side[i - 1]
-        st.wait_stream(self.main)
-        for t in inputs:
-            t.record_stream(st)
-        with torch.cuda.stream(st):
-            out = fn()
-        self.used.append(st)
-        outs = out if isinstance(out, (tuple, list)) else (out,)
-        for t in outs:
-            if torch.is_tensor(t):
-                t.record_stream(self.main)
-        return out
-
-    def join(self):
-        for st in self.used:
-            self.main.wait_stream(st)
-        self.used = []
 
 
 def make_extra(residual=None, fq=None, res_div=1, geglu=False, gn_partial=None, conv=None):
@@ -566,13 +502,15 @@ def make_extra(residual=None, fq=None, res_div=1, geglu=False, gn_partial=None, 
     return ex
 
 
-#: measurement hooks (bench.py's roofline leg), None in production.  QUANT_LAUNCH_HOOK(issue, algorithmic_bytes): every
-#: dgq_quant_act_batch launch; ATTN_LAUNCH_HOOK(issue, flops, bytes): every dgq_attention call (its two or three kernels).
+#: measurement hooks (bench.py's roofline leg), None in production.  QUANT_LAUNCH_HOOK(issue, algorithmic_bytes, overhead_bytes): every
+#: dgq_quant_act_batch launch — algorithmic = the layer input read once, un-unfolded; overhead = the int8 code matrix
+#: and the row sums it writes, which the algorithm does not need; ATTN_LAUNCH_HOOK(issue, flops, bytes): every dgq_attention call (its two or three kernels).
 QUANT_LAUNCH_HOOK = None
 ATTN_LAUNCH_HOOK = None
 #: when set, every GEMM launch of the dgq_gemm_wxa8 family is issued through
 #: ``GEMM_LAUNCH_HOOK(issue, problems)`` — ``issue()`` launches it (again) on the current stream, ``problems`` lists the
-#: (M, ActBinding, out_element_size) of the layers the launch computes.  None in production.
+#: (M, ActBinding, out_element_size, input_bytes) of the layers the launch computes — input_bytes > 0 where the launch quantises its own
+#: operand (the fp input it reads), 0 where it reads a code matrix a dgq_quant_act launch wrote.  None in production.
 GEMM_LAUNCH_HOOK = None
 
 
@@ -595,15 +533,42 @@ def with_layer_tables(extra, ab: "ActBinding", M):
 
 #: Linear / 1x1 layers whose whole padded K fits the short-K kernel's LDS panel run as ONE launch: the GEMM quantises its own rows
 #: (dgq_gemm_act_t) instead of reading the codes a dgq_quant_act launch wrote.  DGQ_GEMM_FUSE=0: the two-launch form everywhere.
-GEMM_FUSE = os.environ.get("DGQ_GEMM_FUSE", "1") == "1"
+GEMM_FUSE = True
 
 
-def act_fuses(ab: "ActBinding", M, K, dtype, n_problems=1):
-    """True where quant_linear / quant_conv2d (1x1) may hand the layer to dgq_gemm_wxa8 with quantise-on-load"""
+def _act_operand_ok(x2):
+    """what dgq_gemm_wxa8 requires of a quantise-on-load operand (fill_gemm): 16-byte aligned base, row pitch a multiple of 8 bytes"""
+    return x2 is None or (x2.data_ptr() % 16 == 0 and (x2.stride(0) * x2.element_size()) % 8 == 0 and x2.stride(-1) == 1)
+
+
+def act_fuses(ab: "ActBinding", M, K, dtype, n_problems=1, x2=None, N=None, Kp=None):
+    """True where quant_linear / quant_conv2d (1x1) may hand the layer to dgq_gemm_wxa8 with quantise-on-load.  x2: the [M][K] operand
+    view the launch would read — a view the kernel cannot address (an unaligned slice) keeps the layer on the two-launch form instead
+    of failing the call.  N / Kp: what the library plans a shared launch with (problem 0's N, the widest Kp of the launch)."""
     if not (GEMM_FUSE and GEMM_PANEL) or getattr(ab, "wfrag", None) is None or ab.pw.taps != 1 or K % 4 != 0 or dtype not in _lib.DTYPE_CODE:
         return False
+    if not _act_operand_ok(x2):
+        return False
     dt = _lib.DTYPE_CODE[dtype]
-    return bool(_lib.load().dgq_gemm_act_fuses(M, ab.pw.N, K, ab.Kp, ab.pw.bits, 0 if ab.mode == "perK" else 1, n_problems, dt, dt))
+    return bool(_lib.load().dgq_gemm_act_fuses(M, ab.pw.N if N is None else N, K, ab.Kp if Kp is None else Kp, ab.pw.bits,
+                                               0 if ab.mode == "perK" else 1, n_problems, dt, dt))
+
+
+def _multi_fuses(bindings, M, Kin, dtype, x2):
+    """quant_linear_multi: every shared launch of _quant_linear_multi_fused (one per scale mode and 8 layers) must take quantise-on-load
+    with the shape the library plans it by — problem 0's N and the launch's widest Kp (dgq_gemm_wxa8_batch)"""
+    groups = {}
+    for i, ab in enumerate(bindings):
+        if ab.pw.K != Kin:
+            return False
+        groups.setdefault(0 if ab.mode == "perK" else 1, []).append(ab)
+    for abs_ in groups.values():
+        for j0 in range(0, len(abs_), 8):
+            chunk = abs_[j0:j0 + 8]
+            kp = max(ab.Kp for ab in chunk)
+            if not all(act_fuses(ab, M, Kin, dtype, len(chunk), x2, N=chunk[0].pw.N, Kp=kp) for ab in chunk):
+                return False
+    return True
 
 
 def make_act(x2: torch.Tensor, ab: "ActBinding", pre=None, ln=None, rows_per_image=1):
@@ -661,7 +626,7 @@ def gemm_wxa8(codes, rowsum, M, ab: ActBinding, out_dtype, out: Optional[torch.T
                   _c.byref(extra) if extra is not None else None, _lib.stream())
     issue()
     if GEMM_LAUNCH_HOOK is not None:
-        GEMM_LAUNCH_HOOK(issue, [(M, ab, out.element_size())])
+        GEMM_LAUNCH_HOOK(issue, [(M, ab, out.element_size(), _fused_bytes)])
     return out
 
 
@@ -681,7 +646,7 @@ def quant_linear(x: torch.Tensor, ab: ActBinding, pre_act=0, residual=None, fq=N
         res2 = residual.reshape(-1, ab.pw.N)
         if not res2.is_contiguous():
             res2 = res2.contiguous()
-    if pre_act != 2 and act_fuses(ab, rows, K, x.dtype):
+    if pre_act != 2 and act_fuses(ab, rows, K, x.dtype, x2=x2):
         y = gemm_act(x2, rows, ab, x.dtype, extra=make_extra(res2, fq, geglu=geglu), pre=pre, ln=ln)
         return y.view(*x.shape[:-1], y.shape[-1])
     codes, rowsum, M = quant_act(x2, rows, 1, 1, K, 1, 1, 1, 0, ab, pre, ln)
@@ -721,7 +686,8 @@ def _quant_linear_multi_fused(x, x2, M, bindings, ln):
                 _lib_call("dgq_gemm_wxa8_batch", n_chunk, _c.cast(arr, _c.c_void_p), _lib.stream())
             issue()
             if GEMM_LAUNCH_HOOK is not None:
-                GEMM_LAUNCH_HOOK(issue, [(M, bindings[i], outs[i].element_size()) for i in chunk])
+                GEMM_LAUNCH_HOOK(issue, [(M, bindings[i], outs[i].element_size(), (M * bindings[i].pw.K * x2.element_size()) if j == 0 else 0)
+                                         for j, i in enumerate(chunk)])      # (one shared input: counted once)
     return [o.view(*x.shape[:-1], o.shape[-1]) for o in outs]
 
 
@@ -737,7 +703,7 @@ def quant_linear_multi(x: torch.Tensor, bindings, ln=None):
     M = x2.shape[0]
     dev = x2.device
     lib = _lib.load()
-    if all(ab.pw.K == Kin and act_fuses(ab, M, Kin, x.dtype, min(len(bindings), 8)) for ab in bindings):
+    if _multi_fuses(bindings, M, Kin, x.dtype, x2):
         return _quant_linear_multi_fused(x, x2, M, bindings, ln)
     lnp = (as_f32(ln[0]), as_f32(ln[1]), float(ln[2])) if ln else None
     qa, keep = [], []
@@ -776,7 +742,7 @@ def quant_linear_multi(x: torch.Tensor, bindings, ln=None):
                 _lib_call("dgq_quant_act_batch", n_chunk, _c.cast(arr, _c.c_void_p), _lib.stream())
             issue_q()
             if QUANT_LAUNCH_HOOK is not None:          # one shared input, one code matrix + row sums per problem
-                QUANT_LAUNCH_HOOK(issue_q, M * Kin * x2.element_size() + sum(M * bindings[i].Kp + 4 * qa[i][5] * M for i in chunk))
+                QUANT_LAUNCH_HOOK(issue_q, M * Kin * x2.element_size(), sum(M * bindings[i].Kp + 4 * qa[i][5] * M for i in chunk))
     outs = [torch.empty((M, ab.pw.N), dtype=x.dtype, device=dev) for ab in bindings]
     ggroups = {}
     for i, ab in enumerate(bindings):
@@ -805,7 +771,7 @@ def quant_linear_multi(x: torch.Tensor, bindings, ln=None):
                 _lib_call("dgq_gemm_wxa8_batch", n_chunk, _c.cast(arr, _c.c_void_p), _lib.stream())
             issue()
             if GEMM_LAUNCH_HOOK is not None:
-                GEMM_LAUNCH_HOOK(issue, [(M, bindings[i], outs[i].element_size()) for i in chunk])
+                GEMM_LAUNCH_HOOK(issue, [(M, bindings[i], outs[i].element_size(), 0) for i in chunk])
     keep.append(qa)
     return [o.view(*x.shape[:-1], o.shape[-1]) for o in outs]
 
@@ -842,7 +808,7 @@ def quant_conv2d(x: torch.Tensor, ab: ActBinding, kh, kw, stride, pad, norm=None
     elif bias_rows is not None:                       # [B][N]: one row per image, broadcast over its Ho*Wo positions
         res2, res_div = bias_rows.contiguous(), M // B
     N = ab.pw.N
-    if kh == 1 and kw == 1 and stride == 1 and pad == 0 and act_fuses(ab, M, C, x.dtype):
+    if kh == 1 and kw == 1 and stride == 1 and pad == 0 and act_fuses(ab, M, C, x.dtype, x2=x_store.reshape(M, C)):
         # a 1x1 convolution is a Linear layer over the pixels: one launch, the GEMM quantises its own rows (dgq_gemm_act_t)
         part = torch.empty((M // 16, N, 2), dtype=torch.float32, device=x.device) if (GN_FROM_GEMM and gn_out and (Ho * Wo) % 16 == 0 and N % 4 == 0) else None
         y = gemm_act(x_store.reshape(M, C), M, ab, x.dtype, extra=make_extra(res2, res_div=res_div, gn_partial=part), pre=pre, rows_per_image=H * W)

@@ -31,23 +31,23 @@ FUSE_NORM = True
 #   SiLU(temb), GroupNorm(+SiLU), LayerNorm folded into the load pass                                 (see FUSE_NORM)
 #   aqtizer_{q,k,v} in the attention pre-pass                                                         +0.3 %
 #   aqtizer_{q,k,v} in the projection GEMM's epilogue (exact division per output inside under-filled grids)  slower: off
-_F_RES = _os.environ.get("DGQ_FUSE_RESIDUAL", "1") == "1"
-_F_FQ = _os.environ.get("DGQ_FUSE_FQ", "0") == "1"
-_F_GEGLU = _os.environ.get("DGQ_FUSE_GEGLU", "1") == "1"
+_F_RES = True
+_F_FQ = False
+_F_GEGLU = True
 # ... or (round 3) in ff.net.0's GEMM epilogue: half the stores of the widest layer, no GEGLU pass in front of ff.net.2
-_F_GEGLU_EPI = _os.environ.get("DGQ_FUSE_GEGLU_EPILOGUE", "1") == "1"
-_F_SILU = _os.environ.get("DGQ_FUSE_SILU", "1") == "1"
+_F_GEGLU_EPI = True
+_F_SILU = True
 # norm1/2/3 of the transformer block folded into the quantise-on-load pass of the layers that consume them
-_F_LN = _os.environ.get("DGQ_FUSE_LN", "1") == "1"
+_F_LN = True
 # layers that consume the same tensor share their launches (dgq_quant_act_batch / dgq_gemm_wxa8_batch): to_q/to_k/to_v of a
 # self-attention (one input, three quantizer tables) and the to_k/to_v of EVERY cross-attention (one text context)
-_F_QKV_BATCH = _os.environ.get("DGQ_QKV_BATCH", "1") == "1"
-_F_CTX_BATCH = _os.environ.get("DGQ_CTX_BATCH", "1") == "1"
+_F_QKV_BATCH = True
+_F_CTX_BATCH = True
 # the time_emb_proj(SiLU(temb)) projections of ALL resnet blocks in one launch (they depend on temb only): 46 launches -> 1
-_F_TEMB_BATCH = _os.environ.get("DGQ_TEMB_BATCH", "1") == "1"
+_F_TEMB_BATCH = True
 # aqtizer_{q,k,v} applied inside the attention pre-pass (K/V while they are split into bf16 planes, Q into a scratch
 # copy by extra blocks of the same launch): three launches per attention saved, nothing added to a GEMM grid
-_F_ATTN_FQ = _os.environ.get("DGQ_FUSE_ATTN_FQ", "1") == "1"
+_F_ATTN_FQ = True
 
 
 class BaseQuantBlock(nn.Module):
@@ -361,18 +361,9 @@ def quant_attention_forward(attn, hidden_states, encoder_hidden_states=None, res
             ops.fakequant_rows(ten.view(bb * ntok, cc), ntok, D, mode, dd, zz, skip, qz.bits)
         return ten
 
-    # the three projection chains are independent: forked streams under graph capture
-    fork = ops.Fork(hidden_states.device, 2) if hidden_states.is_cuda else None
-    if fork is not None and fork.active:
-        q = fork.run(0, lambda: project(attn.to_q, "aqtizer_q", hidden_states, 0))
-        src_t = src.x if isinstance(src, PreLN) else src
-        k = fork.run(1, lambda: project(attn.to_k, "aqtizer_k", src, 1 if start_peak else 0), src_t)
-        v = fork.run(2, lambda: project(attn.to_v, "aqtizer_v", src, 0), src_t)
-        fork.join()
-    else:
-        q = project(attn.to_q, "aqtizer_q", hidden_states, 0)
-        k = project(attn.to_k, "aqtizer_k", src, 1 if start_peak else 0)
-        v = project(attn.to_v, "aqtizer_v", src, 0)
+    q = project(attn.to_q, "aqtizer_q", hidden_states, 0)
+    k = project(attn.to_k, "aqtizer_k", src, 1 if start_peak else 0)
+    v = project(attn.to_v, "aqtizer_v", src, 0)
     b, t, c = q.shape
     s = k.shape[1]
     # weight reconstruction (reconstruction.py) differentiates through the block: the fused kernels have no backward, so a

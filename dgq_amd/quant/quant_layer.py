@@ -376,9 +376,9 @@ class UniformAffineQuantizer(nn.Module):
 #: so a test can compare every operator of the FUSED graph with the oracle and teacher-force it.  None in production.
 LAYER_TAP = None
 #: weight-only state on the library's own exact-fp32 kernel (dgq_conv2d_f32w); =0: F.linear / F.conv2d on the dequantised weight
-WEIGHT_ONLY_HIP = os.environ.get("DGQ_WEIGHT_ONLY_HIP", "1") == "1"
+WEIGHT_ONLY_HIP = True
 #: ... and the FP state (unquantised layers: conv_in / conv_out of a quantized model) too, outside autograd; =0: MIOpen / rocBLAS
-FP_STATE_HIP = os.environ.get("DGQ_FP_STATE_HIP", "1") == "1"
+FP_STATE_HIP = True
 
 
 def _tap(layer, y, **info):
@@ -619,8 +619,7 @@ class QuantLayer(nn.Module):
         never written (ops.quant_conv2d(upsample=True)); with a layer tap installed, during calibration or in any other state the
         interpolate runs as written."""
         if (LAYER_TAP is None and self.is_conv and self.on_integer_path(x) and x.dtype in ops.FLOAT_DTYPES and not self.aqtizer.calibrating()
-                and not self._forward_hooks and not self._forward_pre_hooks and self.w.shape[2] * self.w.shape[3] > 1
-                and os.environ.get("DGQ_FOLD_UPSAMPLE", "1") != "0"):
+                and not self._forward_hooks and not self._forward_pre_hooks and self.w.shape[2] * self.w.shape[3] > 1):
             kh, kw = self.w.shape[2], self.w.shape[3]
             return ops.quant_conv2d(x, self._binding(), kh, kw, self.fwd_kwargs["stride"][0], self.fwd_kwargs["padding"][0], upsample=True)
         return self(F.interpolate(x, scale_factor=2.0, mode="nearest"))

@@ -179,8 +179,6 @@ class QuantModel(nn.Module):
             kw = dict(extra)
             if st["ack"] is not None:
                 kw["added_cond_kwargs"] = st["ack"]
-            from .. import ops
-            ops.prepare_side_streams(dev, 2)
             with torch.no_grad():
                 self._run_model(st["sample"], st["t"], st["ehs"], **kw)     # eager warm-up: lazy inits, caches
                 torch.cuda.synchronize()

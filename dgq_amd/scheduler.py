@@ -36,8 +36,7 @@ class DDIMScheduler:
         (dgq_cfg_ddim_step: the same fp32 operations in the same order — bit-identical to the ten eager kernels, including torch's
         division by a host scalar as a multiplication by its reciprocal); anything else runs the torch statements."""
         e_u, e_c = noise_pred.chunk(2)
-        import os
-        if (os.environ.get("DGQ_GLUE", "1") != "0" and noise_pred.is_cuda and noise_pred.dtype == torch.float32 and sample.dtype == torch.float32
+        if (noise_pred.is_cuda and noise_pred.dtype == torch.float32 and sample.dtype == torch.float32
                 and e_u.shape == sample.shape):
             from . import ops
             a_t, a_prev = self._coef[int(t)]

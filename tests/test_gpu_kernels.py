@@ -1148,22 +1148,23 @@ def test_cfg_ddim_step_is_the_eager_chain_bit_for_bit(dev):
     assert torch.equal(sch.step_guided(eps, 1, x, 7.5), sch.step(e_u + 7.5 * (e_c - e_u), 1, x))
 
 
-@pytest.mark.parametrize("D,T,S,mode,skip,qmode", [(40, 4096, 1024, 1, 0, 2), (40, 4096, 512, 1, 0, 1), (64, 4096, 320 - 64, 3, 0, 1), (40, 4096, 77, 1, 1, 2)])
-def test_attention_two_tiles_per_stage_is_bit_identical(D, T, S, mode, skip, qmode, dev, monkeypatch):
+@pytest.mark.parametrize("D,T,S,mode,qmode", [(40, 4096, 1024, 2, 2), (40, 4096, 512, 2, 1), (64, 4096, 320 - 64, 3, 1), (64, 4096, 1024, 2, 2)])
+def test_attention_two_tiles_per_stage_is_bit_identical(D, T, S, mode, qmode, dev, monkeypatch):
     """The wide (8-wave) self-attention launches walk their key tiles two per ring stage (attn_bf16x3.hip, TPS = 2: one barrier per
-    64 keys) where the tile count is even and >= 8; tile order and per-row arithmetic are those of the one-tile form, so the output is
-    equal bit for bit (DGQ_ATTN_TPS=1 selects the one-tile form).  S = 77 (3 tiles) stays on the one-tile form either way."""
+    64 keys) where the tile count is even and >= 8; tile order and per-row arithmetic are those of the 4-wave, one-tile-per-stage
+    kernels, so with a static softmax δ (nothing exchanged between batch items) the batch-2 call on the wide form equals the two
+    batch-1 calls, which the planner puts on the 4-wave form (too few workgroups for the wide one; key split off), bit for bit."""
     from dgq_amd import ops
     B, H, bits = 2, 8, 8
     g = torch.Generator().manual_seed(D + T + S + mode)
     q, k, v = (torch.randn(B, n, H * D, generator=g).to(dev) for n in (T, S, S))
-    delta = None if mode == 1 else torch.tensor([1.0 / 255.0], device=dev)
+    delta = torch.tensor([1.0 / 255.0 if mode == 3 else 0.7], device=dev)
     tab = lambda n: (torch.rand(n, generator=g).to(dev) * 0.02 + 0.02, torch.randint(100, 156, (n,), generator=g).float().to(dev))
-    fq = ((qmode,) + tab(T if qmode == 1 else D) + (0, 8), (1,) + tab(S - skip) + (skip, 8), (2,) + tab(D) + (0, 8))
-    monkeypatch.setenv("DGQ_ATTN_TPS", "1")
-    o1 = ops.attention(q, k, v, H, D, D ** -0.5, mode, skip, delta, bits, fq=fq).clone()
-    monkeypatch.delenv("DGQ_ATTN_TPS")
-    o2 = ops.attention(q, k, v, H, D, D ** -0.5, mode, skip, delta, bits, fq=fq).clone()
+    fq = ((qmode,) + tab(T if qmode == 1 else D) + (0, 8), (1,) + tab(S) + (0, 8), (2,) + tab(D) + (0, 8))
+    monkeypatch.setenv("DGQ_ATTN_SPLIT", "0")
+    o2 = ops.attention(q, k, v, H, D, D ** -0.5, mode, 0, delta, bits, fq=fq).clone()
+    o1 = torch.cat([ops.attention(q[b:b + 1].contiguous(), k[b:b + 1].contiguous(), v[b:b + 1].contiguous(), H, D, D ** -0.5, mode, 0, delta, bits, fq=fq)
+                    for b in range(B)])
     torch.cuda.synchronize()
     assert torch.isfinite(o2).all()
     assert torch.equal(o1, o2), (o1 - o2).abs().max().item()

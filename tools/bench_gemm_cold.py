@@ -81,13 +81,6 @@ for (M, N, C, taps, mode) in SHAPES:
                 continue
             os.environ["DGQ_GEMM_FORCE"] = "%d,%d,%d" % (bm, bn, s)
             res.append((replay_us([(lambda c=c: ops.gemm_wxa8(codes, rowsum, M, c, torch.float32, out)) for c in abs_]), bm, bn, s))
-    for tm, nw, kw in ((1, 5, 1), (1, 10, 1), (1, 4, 1), (1, 8, 1), (2, 4, 1), (2, 8, 1), (1, 4, 2), (1, 4, 4), (1, 5, 2)):
-        for s in SPLITS:
-            tiles = -(-nk // s)
-            if (s > 1 and s * 2 > nk) or tiles * 32 * tm * 128 > 120 * 1024 or s * M * N * 4 > ops.WORKSPACE_BYTES or tiles < 2 * kw:
-                continue
-            os.environ["DGQ_GEMM_FORCE"] = "P%d,%d,%d,%d" % (tm, nw, s, kw)
-            res.append((replay_us([(lambda c=c: ops.gemm_wxa8(codes, rowsum, M, c, torch.float32, out)) for c in abs_]), 1000 + tm, nw * 10 + kw, s))
     os.environ.pop("DGQ_GEMM_FORCE", None)
     best = min(res)
     wbytes = ab.wpacked.numel()

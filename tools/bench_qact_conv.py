@@ -1,5 +1,5 @@
 """dgq_quant_act on the conv3x3 shapes of the SD1.4 step (GroupNorm + SiLU prologue folded in), hipGraph replay.
-Run once per path: DGQ_QA_CONV_BLOCK=1 (block-staged, default) / 0 (per-row paths).  usage: python tools/bench_qact_conv.py"""
+The library picks the path (block-staged patch kernel where conv_block_pays, else the row-wise scatter).  usage: python tools/bench_qact_conv.py"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -27,7 +27,6 @@ def replay_us(fn):
     return best
 
 
-print("path: DGQ_QA_CONV_BLOCK=%s" % os.environ.get("DGQ_QA_CONV_BLOCK", "1"))
 tot = 0.0
 for (H, C, stride, cnt) in ((64, 320, 1, 7), (64, 640, 1, 2), (64, 960, 1, 1), (64, 320, 2, 1), (32, 640, 1, 6), (32, 320, 1, 1), (32, 1280, 1, 2),
                             (32, 960, 1, 1), (32, 1920, 1, 1), (32, 640, 2, 1), (16, 1280, 1, 8), (16, 640, 1, 1), (16, 2560, 1, 2), (16, 1920, 1, 1),

@@ -28,7 +28,6 @@ XL = [(1024, 10240, 1280, 1, "perK", 1), (1024, 1280, 5120, 1, "perK", 1), (1024
 which = sys.argv[1] if len(sys.argv) > 1 else "sd"
 shapes = SD if which == "sd" else XL if which == "xl" else SD + XL
 TILES = [(128, 128), (128, 64), (64, 128), (64, 64), (32, 128), (32, 64)]
-PANELS = [(1, 5, 1), (1, 10, 1), (2, 5, 1), (1, 4, 1), (1, 8, 1), (2, 4, 1), (2, 8, 1), (1, 4, 2), (1, 4, 4), (1, 5, 2)]
 
 
 def replay_us(fn):
@@ -80,14 +79,6 @@ for (M, N, C, taps, mode, cnt) in shapes:
         for s in cands:
             os.environ["DGQ_GEMM_FORCE"] = "%d,%d,%d" % (bm, bn, s)
             res.append((replay_us(lambda: ops.gemm_wxa8(codes, rowsum, M, ab, torch.float32, out)), bm, bn, s))
-    # the short-K panel kernel (gemm_panel.hip): P<TM>,<NW>,<S>; the A panel (32·TM rows x the K slice) must fit the LDS
-    for tm, nw, kw in PANELS:
-        for s in (1, 2, 3, 4, 6, 8, 12, 16, 24):
-            tiles = -(-nk // s)
-            if (s > 1 and s * 2 > nk) or tiles * 32 * tm * 128 > 120 * 1024 or s * M * N * 4 > ops.WORKSPACE_BYTES or tiles < 2 * kw:
-                continue
-            os.environ["DGQ_GEMM_FORCE"] = "P%d,%d,%d,%d" % (tm, nw, s, kw)
-            res.append((replay_us(lambda: ops.gemm_wxa8(codes, rowsum, M, ab, torch.float32, out)), 1000 + tm, nw * 10 + kw, s))
     os.environ.pop("DGQ_GEMM_FORCE", None)
     res.sort()
     b = res[0]
