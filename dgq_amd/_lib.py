@@ -27,6 +27,7 @@ SIGNATURES = {
     "dgq_gemm_workspace_bytes": [_i, _i, _i],
     "dgq_gemm_plan_splits": [_i, _i, _i, _i, _i, ctypes.c_size_t],
     "dgq_gemm_act_fuses": [_i, _i, _i, _i, _i, _i, _i, _i, _i],
+    "dgq_gemm_conv_act_fuses": [_i] * 14,
     "dgq_groupnorm_from_partials": [_vp, _i, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp],
     "dgq_fakequant_rows": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp],
     "dgq_max_f32": [_vp, _i64, _i, _i, _vp, _vp],
@@ -64,7 +65,8 @@ class GemmAct(ctypes.Structure):
     """dgq_gemm_act_t of include/dgq_hip.h"""
     _fields_ = [("x", _vp), ("x_dtype", _i), ("ldx", _i), ("K", _i), ("kdst", _vp), ("czp", _vp), ("bits", _i),
                 ("pre_scale", _vp), ("pre_shift", _vp), ("rows_per_image", _i), ("pre_act", _i),
-                ("ln_gamma", _vp), ("ln_beta", _vp), ("ln_eps", _f)]
+                ("ln_gamma", _vp), ("ln_beta", _vp), ("ln_eps", _f),
+                ("kpat", _vp), ("B", _i), ("H", _i), ("W", _i), ("kh", _i), ("kw", _i), ("stride", _i), ("pad", _i)]
 
 
 class GemmConv(ctypes.Structure):

@@ -122,10 +122,15 @@ __device__ __forceinline__ void wait_ring(int tiles) {
 // layout; vtab [3][BM] = R0 R1 R2 per row and vcol [4][BN] = alpha zw gamma vn per column were staged into LDS by the prologue;
 // smem .. smem + LDS_CAP is free for the transposition (the operand ring, idle by now: the CALLER has made sure — a barrier —
 // that no wave still reads it).  Variants: split-K slab, GEGLU pairs, residual / fused quantizer, GroupNorm partials.
-template <bool PER_M, typename TOut, int BM, int BN, int WVM, int WVN, int WVK, int LDS_CAP, int TM, int TN>
+// TILED (gemm_convq.hip: the workgroup's 32 rows are a 4 x 8 tile of output positions of one image, not 32 consecutive rows): tile row r
+// is output row m0 + (r >> 3)·tiled_w + (r & 7) (m0 = the tile's first position, tiled_w = Wo), and its two 16-row halves write the
+// GroupNorm partial slots tiled_gn0, tiled_gn0 + 1 (any partition of an image's rows into 16-row blocks merges to the same statistics).
+template <bool PER_M, typename TOut, int BM, int BN, int WVM, int WVN, int WVK, int LDS_CAP, int TM, int TN, bool TILED = false>
 __device__ __forceinline__ void gemm_store_tile(const GemmParams& p, int zsplit, uint8_t* smem, const float* vtab, const float* vcol,
                                                 int wid, int lane, int wave_m, int wave_n, int wave_k, int m0, int n0,
-                                                const v16i (&acc0)[TM][TN], const v16f (&accf)[TM][TN] DGQ_DIAG_PARAM) {
+                                                const v16i (&acc0)[TM][TN], const v16f (&accf)[TM][TN] DGQ_DIAG_PARAM,
+                                                int tiled_w = 0, int tiled_gn0 = 0) {
+    static_assert(!TILED || (BM == 32 && WVM == 1 && WVK == 1), "tiled rows: one 32-row tile per workgroup");
     constexpr int NW = WVM * WVN * WVK;
     constexpr int WM = BM / WVM, WN = BN / WVN;
     static_assert(TM == WM / 32 && TN == WN / 32, "wave tile");
@@ -180,6 +185,7 @@ __device__ __forceinline__ void gemm_store_tile(const GemmParams& p, int zsplit,
     // the wave's rr-th pass: the two K halves of a WVK = 2 tile take the upper / lower half of the rows (contiguous row sets per
     // wave: the GroupNorm partials below are per 16-row block)
     auto tile_row = [&](int rr) { return wave_k * (WM / WVK) + rr * RPP + lrow; };
+    auto row_m = [&](int row) { return TILED ? m0 + (row >> 3) * tiled_w + (row & 7) : m0 + wave_m * WM + row; };
     auto tile_val = [&](int row) {
         const int sr = (EPH == 2) ? (row & (HROWS - 1)) : row;                         // row inside the staged half
         float4 v = *reinterpret_cast<const float4*>(ep0 + sr * EP_LD + c4);
@@ -196,7 +202,7 @@ __device__ __forceinline__ void gemm_store_tile(const GemmParams& p, int zsplit,
         for (int rr = 0; rr < PASSES; ++rr) {
             next_half(rr);
             const int row = tile_row(rr);
-            const int m = m0 + wave_m * WM + row;
+            const int m = row_m(row);
             if (m >= p.M || nb >= p.N) continue;
             const float4 v = tile_val(row);
             float* dst = slab + (int64_t)m * p.N + nb;
@@ -225,7 +231,7 @@ __device__ __forceinline__ void gemm_store_tile(const GemmParams& p, int zsplit,
         for (int rr = 0; rr < PASSES; ++rr) {
             next_half(rr);
             const int row = tile_row(rr);
-            const int m = m0 + wave_m * WM + row;
+            const int m = row_m(row);
             if (m >= p.M || nb >= p.N) continue;
             const float4 v = tile_val(row);
             const float* vr = vtab + wave_m * WM + row;
@@ -265,7 +271,7 @@ __device__ __forceinline__ void gemm_store_tile(const GemmParams& p, int zsplit,
         if (!res_vec) return;
 #pragma unroll
         for (int q = 0; q < HP; ++q) {
-            const int m = min(m0 + wave_m * WM + tile_row(h * HP + q), p.M - 1);
+            const int m = min(row_m(tile_row(h * HP + q)), p.M - 1);
             const int64_t i = (int64_t)(m / p.ex.res_div) * p.ex.ldr + nb;
             if (p.ex.res_dtype == DGQ_F32) {
                 res[q] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.ex.residual) + i);
@@ -300,7 +306,7 @@ __device__ __forceinline__ void gemm_store_tile(const GemmParams& p, int zsplit,
         next_half(rr);
         if (EPH == 2 && rr == HP) load_res(1);
         const int row = tile_row(rr);
-        const int m = m0 + wave_m * WM + row;
+        const int m = row_m(row);
         if (m >= p.M || nb >= p.N) continue;
         const float4 v = tile_val(row);
         const float* vr = vtab + wave_m * WM + row;
@@ -359,7 +365,7 @@ __device__ __forceinline__ void gemm_store_tile(const GemmParams& p, int zsplit,
                     cnt *= 2.0f;
                 }
                 if (lrow == 0) {
-                    float* q = p.ex.gn_partial + ((int64_t)(m >> 4) * p.N + nb) * 2;
+                    float* q = p.ex.gn_partial + ((int64_t)(TILED ? tiled_gn0 + (row >> 4) : (m >> 4)) * p.N + nb) * 2;
                     *reinterpret_cast<float4*>(q) = make_float4(mean[0], m2[0], mean[1], m2[1]);
                     *reinterpret_cast<float4*>(q + 4) = make_float4(mean[2], m2[2], mean[3], m2[3]);
                 }

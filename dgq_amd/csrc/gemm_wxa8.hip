@@ -585,6 +585,9 @@ size_t dgq_gemm_big_lds_bytes(bool per_m, int Kp);
 #define PANEL_BM0 1000
 int dgq_launch_gemm_panel(const GemmBatch& bt, bool per_m, int y_dtype, int tm, int nw, int kw, hipStream_t st);
 size_t dgq_gemm_panel_lds_bytes(int tm, int nw, int kw, bool per_m, int tiles);
+// gemm_convq.hip: a 3x3 convolution with its activation quantiser inside the launch (act.kh > 1): slab length / LDS bytes, 0 = not taken
+int dgq_gemm_convq_plan(int B, int H, int W, int C, int kh, int kw, int stride, int pad, int N, int Kp, int w_bits, bool per_m, int* lds_bytes);
+int dgq_launch_gemm_convq(const GemmBatch& bt, bool per_m, int y_dtype, int slab_tiles, int lds, hipStream_t st);
 
 template <bool PER_M, typename TOut>
 static void launch_combine(const GemmParams& p, hipStream_t st);
@@ -801,6 +804,13 @@ extern "C" int dgq_gemm_act_fuses(int M, int N, int K, int Kp, int w_bits, int p
     return plan_panel_fuse(M, N, Kp, per_m != 0, pl) ? 1 : 0;
 }
 
+extern "C" int dgq_gemm_conv_act_fuses(int B, int H, int W, int C, int kh, int kw, int stride, int pad, int N, int Kp, int w_bits, int per_m,
+                                       int x_dtype, int y_dtype) {
+    static const bool on = [] { const char* e = getenv("DGQ_GEMM_FUSE"); return !(e && *e == '0'); }();      // A/B hook (as dgq_gemm_act_fuses)
+    if (!on || x_dtype != y_dtype) return 0;
+    return dgq_gemm_convq_plan(B, H, W, C, kh, kw, stride, pad, N, Kp, w_bits, per_m != 0, nullptr) > 0 ? 1 : 0;
+}
+
 // implicit-conv launches: four tile shapes carry the CONV addressing.  Measured on the C5 shapes (tools/bench_conv_implicit.py,
 // profiles/r04_conv_implicit_shapes.txt): 64x128 is the best or within 3 % of it on every one of them — the address arithmetic is
 // per DMA piece, and the 64x64 tile the materialised operand prefers at M = 8192 has half the MFMAs per piece.
@@ -914,7 +924,8 @@ static int fill_gemm(const dgq_gemm_args_t& a, GemmParams& p) {
         if (p.ex.act) {
             const dgq_gemm_act_t& q = *p.ex.act;
             DGQ_CHECK_ARG(q.x && p.ex.wfrag && q.K > 0 && q.K % 4 == 0 && q.K <= a.Kp && q.ldx >= q.K && q.bits >= 2 && q.bits <= 8 &&
-                          q.x_dtype == a.y_dtype && (a.per_m || (q.kdst && q.czp)) && (q.pre_scale == nullptr) == (q.pre_shift == nullptr) &&
+                          q.x_dtype == a.y_dtype && (a.per_m || (q.czp && (q.kh > 1 || q.kdst))) && (q.pre_scale == nullptr) == (q.pre_shift == nullptr) &&
+                          (q.kh <= 1 || (q.kpat && !q.ln_gamma && q.B >= 1 && q.H >= 1 && q.W >= 1 && q.kw >= 1 && q.stride >= 1 && q.pad >= 0)) &&
                           (!q.pre_scale || q.rows_per_image >= 1) && (q.pre_act == 0 || q.pre_act == 1) &&
                           (q.ln_gamma == nullptr) == (q.ln_beta == nullptr) && (!q.ln_gamma || (q.ln_eps > 0.0f && !q.pre_scale && q.pre_act == 0)) &&
                           (reinterpret_cast<uintptr_t>(q.x) & 15) == 0 && (q.ldx * (q.x_dtype == DGQ_F32 ? 4 : 2)) % 8 == 0,
@@ -1001,6 +1012,18 @@ extern "C" int dgq_gemm_wxa8(const int8_t* codes, const float* rowsum, int rowsu
     const int rc = fill_gemm(a, p);
     if (rc != DGQ_OK) return rc;
     GemmPlan pl = plan_gemm(M, N, Kp, w_bits, workspace ? workspace_bytes : 0, per_m != 0, /*allow_big=*/!p.cv.codes_in);
+    if (p.act.x && p.act.kh > 1) {                       // a k x k convolution with its quantiser inside the launch (gemm_convq.hip)
+        const dgq_gemm_act_t& q = p.act;
+        int lds = 0;
+        const int slab = dgq_gemm_convq_plan(q.B, q.H, q.W, q.K, q.kh, q.kw, q.stride, q.pad, N, Kp, w_bits, per_m != 0, &lds);
+        const int Ho = (q.H + 2 * q.pad - q.kh) / q.stride + 1, Wo = (q.W + 2 * q.pad - q.kw) / q.stride + 1;
+        DGQ_CHECK_ARG(slab > 0 && !p.cv.codes_in && M == q.B * Ho * Wo && !p.ex.geglu && p.ex.fq_mode == 0 && q.rows_per_image == q.H * q.W,
+                      "dgq_gemm_wxa8: this convolution does not take quantise-on-load (dgq_gemm_conv_act_fuses)");
+        p.splits = 1; p.slab = nullptr; p.tiles_per_split = Kp / BK;
+        const int rc2 = dgq_launch_gemm_convq(bt, per_m != 0, y_dtype, slab, lds, (hipStream_t)stream);
+        if (rc2 != DGQ_OK) return rc2;
+        return dgq_launch_status("dgq_gemm_wxa8");
+    }
     if (p.act.x) {                                       // quantise-on-load: the panel kernel, whole K in one workgroup
         DGQ_CHECK_ARG(!p.cv.codes_in && plan_panel_fuse(M, N, Kp, per_m != 0, pl), "dgq_gemm_wxa8: this shape does not take quantise-on-load (dgq_gemm_act_fuses)");
         GemmPlan f = pl;

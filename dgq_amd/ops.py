@@ -241,6 +241,22 @@ class ActBinding:
                 self._koff[key] = torch.where(kp < kh * kw * C, idx, torch.full_like(idx, -1)).to(torch.int32).contiguous()
         return self._koff[key]
 
+    def kpat_for(self, kh, kw, C, pw):
+        """``kpat`` for a patch PW = pw pixels wide (dgq_gemm_act_t.kpat of the conv form of quantise-on-load, csrc/gemm_convq.hip:
+        4 x 8 output positions per workgroup, pw = 8 + kw − 1).  Cached."""
+        key = ("patw", kh, kw, C, pw)
+        if key not in self._koff:
+            if self.ksrc is not None:
+                e = self.ksrc
+                idx = (((e >> 24) & 0x7F) * pw + ((e >> 16) & 0xFF)) * C + (e & 0xFFFF)
+                self._koff[key] = torch.where(e >= 0, idx, torch.full_like(idx, -1)).to(torch.int32).contiguous()
+            else:                                                   # natural order kp = tap·C + c, padded to Kp
+                kp = torch.arange(self.Kp, device=self.pw.codes.device)
+                tap, c = kp // C, kp % C
+                idx = ((tap // kw) * pw + (tap % kw)) * C + c
+                self._koff[key] = torch.where(kp < kh * kw * C, idx, torch.full_like(idx, -1)).to(torch.int32).contiguous()
+        return self._koff[key]
+
     def input_binding(self, C):
         """This (scalar) quantizer applied to the conv's INPUT tensor as a 1x1 layer in natural order: what dgq_quant_act needs to
         write the int8 NHWC code tensor of the implicit-im2col path (cached)."""
@@ -534,6 +550,8 @@ def with_layer_tables(extra, ab: "ActBinding", M):
 #: Linear / 1x1 layers whose whole padded K fits the short-K kernel's LDS panel run as ONE launch: the GEMM quantises its own rows
 #: (dgq_gemm_act_t) instead of reading the codes a dgq_quant_act launch wrote.  DGQ_GEMM_FUSE=0: the two-launch form everywhere.
 GEMM_FUSE = True
+#: ... also for the 3x3 convolutions whose input patch fits the LDS (csrc/gemm_convq.hip); False: quantise launch + GEMM launch
+CONV_FUSE = os.environ.get("DGQ_CONV_FUSE", "1") != "0"         # (this round's A/B switch: DGQ_CONV_FUSE=0)
 
 
 def _act_operand_ok(x2):
@@ -569,6 +587,18 @@ def _multi_fuses(bindings, M, Kin, dtype, x2):
             if not all(act_fuses(ab, M, Kin, dtype, len(chunk), x2, N=chunk[0].pw.N, Kp=kp) for ab in chunk):
                 return False
     return True
+
+
+def conv_act_fuses(ab: "ActBinding", B, H, W, C, kh, kw, stride, pad, dtype, x_store=None):
+    """True where quant_conv2d may hand a k x k convolution to dgq_gemm_wxa8 with its activation quantiser inside the launch
+    (csrc/gemm_convq.hip: no int8 code matrix in HBM)."""
+    if not (GEMM_FUSE and CONV_FUSE) or getattr(ab, "wfrag", None) is None or ab.mode == "scalar" or dtype not in _lib.DTYPE_CODE:
+        return False
+    if x_store is not None and not (x_store.is_contiguous() and x_store.data_ptr() % 16 == 0 and (C * x_store.element_size()) % 8 == 0):
+        return False
+    dt = _lib.DTYPE_CODE[dtype]
+    return bool(_lib.load().dgq_gemm_conv_act_fuses(B, H, W, C, kh, kw, stride, pad, ab.pw.N, ab.Kp, ab.pw.bits,
+                                                    0 if ab.mode == "perK" else 1, dt, dt))
 
 
 def make_act(x2: torch.Tensor, ab: "ActBinding", pre=None, ln=None, rows_per_image=1):
@@ -812,6 +842,31 @@ def quant_conv2d(x: torch.Tensor, ab: ActBinding, kh, kw, stride, pad, norm=None
         # a 1x1 convolution is a Linear layer over the pixels: one launch, the GEMM quantises its own rows (dgq_gemm_act_t)
         part = torch.empty((M // 16, N, 2), dtype=torch.float32, device=x.device) if (GN_FROM_GEMM and gn_out and (Ho * Wo) % 16 == 0 and N % 4 == 0) else None
         y = gemm_act(x_store.reshape(M, C), M, ab, x.dtype, extra=make_extra(res2, res_div=res_div, gn_partial=part), pre=pre, rows_per_image=H * W)
+        out = y.view(B, Ho, Wo, N).permute(0, 3, 1, 2)
+        if part is not None:
+            out._dgq_gn = dict(parts=[(part, N)], B=B, HW=Ho * Wo, C=N, ver=out._version)
+        return out
+    if kh * kw > 1 and not upsample and conv_act_fuses(ab, B, H, W, C, kh, kw, stride, pad, x.dtype, x_store):
+        # the unfolded operand is quantised INSIDE the GEMM launch from a staged input patch (dgq_gemm_act_t with kh > 1): one launch,
+        # no code matrix (QuantLayer.forward, quant_layer.py:626-661, as one kernel)
+        part = torch.empty((M // 16, N, 2), dtype=torch.float32, device=x.device) if (GN_FROM_GEMM and gn_out and (Ho * Wo) % 16 == 0 and N % 4 == 0) else None
+        act = _lib.GemmAct()
+        kp_ = ab.kpat_for(kh, kw, C, 8 + kw - 1)
+        act.x, act.x_dtype, act.ldx, act.K = x_store.data_ptr(), _lib.DTYPE_CODE[x_store.dtype], C, C
+        act.kpat, act.bits, act.rows_per_image, act.pre_act = kp_.data_ptr(), ab.abits, H * W, 0
+        act.B, act.H, act.W, act.kh, act.kw, act.stride, act.pad = B, H, W, kh, kw, stride, pad
+        act._keep = [x_store, kp_]
+        if ab.mode == "perK":
+            act.czp = ab.czp.data_ptr()
+        if pre is not None:
+            if pre[0] is not None:
+                act.pre_scale, act.pre_shift = pre[0].data_ptr(), pre[1].data_ptr()
+                act._keep += [pre[0], pre[1]]
+            act.pre_act = pre[2]
+        extra = with_layer_tables(make_extra(res2, res_div=res_div, gn_partial=part), ab, M)
+        extra.act = _c.cast(_c.pointer(act), _c.c_void_p)
+        extra._act_keep = act
+        y = gemm_wxa8(ab.wfrag, ab.wfrag, M, ab, x.dtype, extra=extra, _fused_bytes=x.element_size() * B * H * W * C)
         out = y.view(B, Ho, Wo, N).permute(0, 3, 1, 2)
         if part is not None:
             out._dgq_gn = dict(parts=[(part, N)], B=B, HW=Ho * Wo, C=N, ver=out._version)

@@ -242,6 +242,11 @@ typedef struct dgq_gemm_act {
     const int32_t* kdst; const float* czp; int bits;
     const float* pre_scale; const float* pre_shift; int rows_per_image; int pre_act;
     const float* ln_gamma; const float* ln_beta; float ln_eps;
+    /* round 6 (revision 120): a k x k convolution in this form (csrc/gemm_convq.hip) — kh > 1: x is the NHWC input [B][H][W][ldx] of K = C
+     * channels, the call's M = B·Ho·Wo and Kp covers C·kh·kw; kpat [Kp] = for every packed position the index (dh·PW + dw)·C + c into a
+     * workgroup's staged (4 + kh − 1) x PW x C input patch, PW = 8 + kw − 1, −1 for padding (ops.ActBinding.kpat_for); per_m == 0: czp as
+     * above (kdst unused); pre_scale / pre_shift per image ([B][C]); no LayerNorm.  Zero-initialised (kh == 0): a Linear / 1x1 layer. */
+    const int32_t* kpat; int B, H, W, kh, kw, stride, pad;
 } dgq_gemm_act_t;
 
 typedef struct dgq_gemm_extra {
@@ -279,6 +284,10 @@ int dgq_gemm_wxa8(const int8_t* codes, const float* rowsum, int rowsum_parts, in
 /* 1 where dgq_gemm_wxa8 / _batch accept dgq_gemm_extra_t.act for a layer of this shape (n_problems of one launch, all alike): the
  * whole padded K must fit the short-K kernel's LDS panel and the launch must be one it would give that kernel anyway. */
 int dgq_gemm_act_fuses(int M, int N, int K, int Kp, int w_bits, int per_m, int n_problems, int x_dtype, int y_dtype);
+/* ... and whether a dgq_gemm_wxa8 call with extra.act describing a kh x kw convolution (act.kh > 1) is accepted: 3x3, stride 1, pad 1,
+ * W4, N = 160 or 320, H % 4 == 0, W % 8 == 0, the 6 x 10 x C fp32 input patch + a 10-tile operand slab within the LDS (C <= 340). */
+int dgq_gemm_conv_act_fuses(int B, int H, int W, int C, int kh, int kw, int stride, int pad, int N, int Kp, int w_bits, int per_m,
+                            int x_dtype, int y_dtype);
 /* The same with the arguments in a struct, for 1..8 problems in ONE launch (dgq_gemm_wxa8_batch): problems that share
  * weight bits, scale mode (per_m) and output dtype, e.g. the q / k / v projections of one attention or the to_k / to_v of
  * every cross-attention (same text context).  The launch plan (tile shape) of problem 0 serves all; no K split. */
