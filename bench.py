@@ -510,7 +510,7 @@ def measure_gemm_roofline(torch, ops, qnn, run_step, args):
                     os.path.basename(tj), tjd.get("measured_at_commit"), csrc_digest())
             break
     hbm_gemm = G["hbm_bound"]["ideal_ms"] >= G["compute_bound"]["ideal_ms"]
-    out = {"kernel": "dgq_gemm_wxa8 / dgq_gemm_wxa8_batch (gemm_wxa8_kernel<...> tile family, gemm_big_kernel<...>, gemm_panel_kernel<...> with quantise-on-load, "
+    out = {"kernel": "dgq_gemm_wxa8 / dgq_gemm_wxa8_batch (gemm_wxa8_kernel<...> tile family, gemm_big_kernel<...>, gemm_panel_kernel<...> / gemm_convq_kernel<...> with the quantiser inside, "
                      "split-K combine where used); the 22 time_emb_proj layers (2 rows each, 0.1 Gop) run in dgq_linear_smallm_batch and are not counted",
            "layers_covered": layers[0],
            # which roof the family's IDEAL time mostly sits under (per launch: argmin(P_int8, AI·BW)); `achieved` / `frac` stay

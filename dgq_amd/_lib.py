@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DGQ_HIP_LIB") or os.path.join(_HERE, "csrc", "libdgq_hip.so")   # override: A/B builds of the kernels
 
 _vp, _i, _f, _i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64
-ABI_VERSION = 120          # DGQ_ABI_VERSION of include/dgq_hip.h: the struct layouts below are that revision's
+ABI_VERSION = 121          # DGQ_ABI_VERSION of include/dgq_hip.h: the struct layouts below are that revision's
 
 # name -> argtypes; every function returns int except dgq_last_error
 SIGNATURES = {
@@ -50,7 +50,7 @@ SIGNATURES = {
     "dgq_adaround_reg_fwd": [_vp, _i64, _f, _vp, _vp],
     "dgq_adaround_reg_bwd": [_vp, _i64, _f, _vp, _vp, _vp],
     "dgq_timestep_embedding": [_vp, _i, _i64, _i, _i, _vp, _i, _vp],
-    "dgq_cfg_ddim_step": [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, _f, _f, _f, _f, _f, _vp],
+    "dgq_cfg_ddim_step": [_vp, _vp, _vp, _vp, _i, _i64, _i, _i, _i, _f, _f, _f, _f, _f, _vp],
 }
 
 

@@ -313,6 +313,17 @@ __global__ __launch_bounds__(64 * NW) void attn3_stats_kernel(AttnParams p) {
     DGQ_DIAG_FLUSH(attn, NW, wid + 16384, lane);
 }
 
+// 16-bit tensors: both key halves leave as fp32 parts; o = round(part0 + part1) — the fp32 call's sum, rounded once to the tensor's type
+template <typename T>
+__global__ __launch_bounds__(256) void attn3_add16_kernel(T* __restrict__ o, const float* __restrict__ part0, const float* __restrict__ part1, int64_t n4) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n4) {
+        const float4 a = reinterpret_cast<const float4*>(part0)[i], c = reinterpret_cast<const float4*>(part1)[i];
+        T t[4] = {dgq_from_float<T>(a.x + c.x), dgq_from_float<T>(a.y + c.y), dgq_from_float<T>(a.z + c.z), dgq_from_float<T>(a.w + c.w)};
+        reinterpret_cast<uint2*>(o)[i] = *reinterpret_cast<const uint2*>(t);
+    }
+}
+
 __global__ __launch_bounds__(256) void attn3_add_kernel(float* __restrict__ o, const float* __restrict__ part, int64_t n4) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n4) {
@@ -587,7 +598,9 @@ __global__ __launch_bounds__(64 * NW) void attn3_pv_kernel(AttnParams p) {
         float* ep = reinterpret_cast<float*>(lds8) + 3 * G::DV + wid * (32 * ELD);
         const int tw0 = bx * (32 * NW) + wid * 32;          // first query of this wave
         const int er = lane >> 3, ec = (lane & 7) * 4;
-        const bool part = blockIdx.z > 0;                   // second key half of a split launch (fp32 o): added by attn3_add_kernel
+        // a split launch: the second key half's part goes to fp32 scratch (attn3_add_kernel adds it to an fp32 o); for 16-bit tensors so
+        // does the first (attn3_add16_kernel rounds their sum into o)
+        float* const fpart = blockIdx.z > 0 ? p.o_part : ((gridDim.z > 1 && p.io_dtype != DGQ_F32) ? p.o_part0 : nullptr);
         const float pb = p.skip > 0 ? p_bypass : 0.0f;
 #pragma unroll
         for (int j = 0; j < G::NDT; ++j) {
@@ -626,8 +639,8 @@ __global__ __launch_bounds__(64 * NW) void attn3_pv_kernel(AttnParams p) {
                 const float4 v = ov[ps];
                 if (tt < p.T && d0 < D) {
                     const int64_t oi = ((int64_t)(b * p.T + tt) * p.H + hd) * D + d0;
-                    if (part) {
-                        *reinterpret_cast<float4*>(p.o_part + oi) = v;
+                    if (fpart) {
+                        *reinterpret_cast<float4*>(fpart + oi) = v;
                     } else if (p.io_dtype == DGQ_F32) {
                         *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.o) + oi) = v;
                     } else if (p.io_dtype == DGQ_F16) {
@@ -730,14 +743,14 @@ static int launch_attn3(AttnParams p, const void* q_raw, unsigned char* planes, 
     // Key split: a grid that leaves the chip under-filled (fewer 128-row workgroups than ~0.9 per CU) runs each (query block,
     // batch·head) as TWO workgroups over the two halves of the key tiles.  The statistics halves are merged by attn3_merge_kernel
     // ; the P·V halves use the merged (m, l, δ), so their parts simply add (the second half's part goes to a scratch tensor,
-    // attn3_add_kernel adds it — float atomics into o were 2x slower than the unsplit call).  fp32 o only,
-    // >= 4 key tiles per half, D % 4 == 0.
+    // attn3_add_kernel adds it — float atomics into o were 2x slower than the unsplit call; 16-bit tensors: both parts to scratch,
+    // attn3_add16_kernel rounds the sum).  >= 4 key tiles per half, D % 4 == 0.
     // Measured: 1024 x 1024, D = 80, B·H = 16: 86 -> 65 us; SDXL 4096 x 4096 at B·H = 10 (320 workgroups): 333 -> 282 us; 8-wave
     // grids (one workgroup per CU already) gain nothing and stay unsplit.
     const char* se = getenv("DGQ_ATTN_SPLIT");                 // grids below this many 4-wave workgroups split (0: never); read per call: tests toggle it
     const long split_below = se ? atol(se) : 448L;
     const long nblk4 = (long)((p.T + 127) / 128) * p.B * p.H;
-    const int nsp = (!wide && nblk4 < split_below && p.NT >= 8 && p.io_dtype == DGQ_F32) ? 2 : 1;
+    const int nsp = (!wide && nblk4 < split_below && p.NT >= 8 && D % 4 == 0) ? 2 : 1;
     if (wide) {
         if constexpr (D <= 64) {
             dim3 grid((p.T + 255) / 256, p.B * p.H), block(512);
@@ -758,7 +771,10 @@ static int launch_attn3(AttnParams p, const void* q_raw, unsigned char* planes, 
     }
     if (nsp > 1) {
         const int64_t n4 = (int64_t)p.B * p.T * p.H * D / 4;
-        hipLaunchKernelGGL(attn3_add_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, reinterpret_cast<float*>(p.o), p.o_part, n4);
+        const dim3 ag((unsigned)((n4 + 255) / 256));
+        if (p.io_dtype == DGQ_F32) hipLaunchKernelGGL(attn3_add_kernel, ag, dim3(256), 0, st, reinterpret_cast<float*>(p.o), p.o_part, n4);
+        else if (p.io_dtype == DGQ_BF16) hipLaunchKernelGGL(attn3_add16_kernel<__hip_bfloat16>, ag, dim3(256), 0, st, reinterpret_cast<__hip_bfloat16*>(p.o), p.o_part0, p.o_part, n4);
+        else hipLaunchKernelGGL(attn3_add16_kernel<__half>, ag, dim3(256), 0, st, reinterpret_cast<__half*>(p.o), p.o_part0, p.o_part, n4);
     }
     return dgq_launch_status("dgq_attention_f32(bf16x3)");
 }
@@ -796,6 +812,7 @@ int dgq_attention_bf16x3(const void* q, const void* k, const void* v, void* o, i
     AttnParams p;
     p.stats_part = stats_ws + (((size_t)B * H * T * 2 + 3) & ~(size_t)3);      // (the statistics area holds 10 floats per row: 2 merged + 2 x 4 partial, read as float4: 16-byte aligned for an odd row count too)
     p.o_part = o_part;
+    p.o_part0 = o_part + (((size_t)B * T * H * D * sizeof(float) + 255) / 256 * 256) / sizeof(float);
     for (int i = 0; i < 3; ++i) {
         p.fq[i].mode = -1; p.fq[i].skip = 0; p.fq[i].qmax = 0.0f; p.fq[i].delta = nullptr; p.fq[i].zp = nullptr;
         if (fq && fq[i].mode >= 0) {

@@ -94,6 +94,7 @@ struct AttnParams {
     float* stats;          // [B*H][T][2] : m (log2 units), l
     float* stats_part;     // key-split launches (gridDim.z = 2): [2][B*H][T][4] = m, l, m2 (maximum without the bypassed keys) per key half
     float* o_part;         // key-split launches: the second key half's part of o ([B][T][H][D] fp32; attn3_add_kernel adds it to o)
+    float* o_part0;        // key-split launches on 16-bit tensors: the FIRST half's part, fp32 like the second (attn3_add16_kernel stores o = round(part0 + part))
     float* delta;
     const unsigned char* planes;   // [B*H][NT] tile images of the bf16 split planes (Geo<D>::IMG_BYTES each)
     int NT;                        // 32-key tiles per (batch, head)

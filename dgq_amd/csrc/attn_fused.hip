@@ -220,7 +220,7 @@ size_t dgq_attention_bf16x3_bytes(int B, int H, int S, int D);
 size_t dgq_attention_qi8_bytes(int B, int H, int T, int D);
 
 // workspace layout: [0,256) δ scalar | stats B·H·T·10 floats (2 merged + 2 x 4 per key half of a split launch; 256-byte aligned) | tile images of the bf16 split planes of
-// K and V | fake-quantised copy of q (used when aqtizer_q is fused) | the second key half's part of o (split launches)
+// K and V | fake-quantised copy of q (used when aqtizer_q is fused) | the second key half's part of o (split launches) | the first half's (16-bit tensors)
 static size_t attn_stats_off() { return 8704; }   // (δ slots at 0, the single-launch form's 1024 exchange granules at 512: DELTA_AREA_BYTES of attn_bf16x3_dev.h)
 static size_t attn_planes_off(int B, int H, int T) { return 8704 + ((((size_t)B * H * T * 10 + 4) * sizeof(float) + 255) / 256) * 256; }   // (+ 4: the partial area starts 16-byte aligned)
 
@@ -232,7 +232,7 @@ static size_t attn_q_scratch(int B, int H, int T, int D) {
 
 extern "C" size_t dgq_attention_workspace_bytes(int B, int H, int T, int S, int D) {
     return attn_planes_off(B, H, T) + dgq_attention_bf16x3_bytes(B, H, S, D) + attn_q_scratch(B, H, T, D) +
-           ((size_t)B * T * H * D * sizeof(float) + 255) / 256 * 256;
+           2 * (((size_t)B * T * H * D * sizeof(float) + 255) / 256 * 256);       // (16-bit tensors: both halves' parts are fp32 scratch)
 }
 
 extern "C" int dgq_attention_fuses_fakequant(int D, int mode) {

@@ -5,7 +5,7 @@
 // load: rows = output positions, K = tap·C + c (natural order), out-of-image taps read 0 like F.conv2d's zero padding.
 // Plumbing-grade tiling (64x64 block tile, 16-deep K tiles through LDS, no ring): this state is not on the timed path; it
 // exists so that no state of a quantized model leaves this library on the GPU.
-#include "dgq_common.h"
+#include "quant_common.h"
 
 typedef float v16f __attribute__((ext_vector_type(16)));
 
@@ -123,14 +123,15 @@ __global__ __launch_bounds__(256) void conv_f32w_smalln_kernel(ConvF32Params p) 
     // 16-byte loads of four channels, of their folded-GroupNorm scale / shift and of the N weight rows: conv_out of an SD step (8192
     // positions x 2880 -> 4, statistics pass included) 90 -> 67 us, at the 131072 positions of config C5 1.03 -> 0.66 ms; fetching all 18
     // (tap, step) inputs of a position before the first use measured slower (84 us): the unrolled predicates cost more than the overlap
-    const bool vec = p.x_dtype == DGQ_F32 && (p.C & 3) == 0 && (reinterpret_cast<uintptr_t>(p.x) & 15) == 0 &&
+    // (16-bit tensors: the same units from 8-byte loads — the element-by-element form below cost 140 us against 36 for conv_out of a
+    // bf16 SD step)
+    const bool vec = (p.C & 3) == 0 && (reinterpret_cast<uintptr_t>(p.x) & 15) == 0 &&
                      (reinterpret_cast<uintptr_t>(p.w) & 15) == 0 &&
                      (!p.pre_scale || (((reinterpret_cast<uintptr_t>(p.pre_scale) | reinterpret_cast<uintptr_t>(p.pre_shift)) & 15) == 0));
     if (vec) {
         // (tap, four channels) units of the position dealt round-robin over the lanes, four units per lane and round with all their loads
         // issued before the first use: C = 320 is 720 units = 11.25 per lane in three rounds (N <= 4; two units per round for 5..8 outputs).  (Tap by tap with 256-channel steps the
         // second step of every tap ran on 16 of the 64 lanes and a wave walked 18 dependent load rounds: 49 us for conv_out of an SD step.)
-        const float* xf = reinterpret_cast<const float*>(p.x);
         const int c4n = p.C >> 2, units = p.kh * p.kw * c4n;
         constexpr int UB = NMAX <= 4 ? 4 : 2;                      // (registers: UB x NMAX float4 of weights in flight)
         for (int u0 = lane; u0 < units; u0 += 64 * UB) {
@@ -144,7 +145,12 @@ __global__ __launch_bounds__(256) void conv_f32w_smalln_kernel(ConvF32Params p) 
                 const int hi = ho * p.stride - p.pad + dh, wi = wo * p.stride - p.pad + dw;
                 inb[j] = (u0 + 64 * j < units) && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
                 const int hc = min(max(hi, 0), p.H - 1), wc = min(max(wi, 0), p.W - 1);       // clamped: the load is unconditional
-                v[j] = *reinterpret_cast<const float4*>(xf + (((int64_t)b * p.H + hc) * p.W + wc) * p.C + c);
+                const int64_t xi = (((int64_t)b * p.H + hc) * p.W + wc) * p.C + c;
+                float t4[4];
+                if (p.x_dtype == DGQ_F32) load4<float>(reinterpret_cast<const float*>(p.x) + xi, t4);              // (kernel-uniform)
+                else if (p.x_dtype == DGQ_BF16) load4<__hip_bfloat16>(reinterpret_cast<const __hip_bfloat16*>(p.x) + xi, t4);
+                else load4<__half>(reinterpret_cast<const __half*>(p.x) + xi, t4);
+                v[j] = make_float4(t4[0], t4[1], t4[2], t4[3]);
                 if (p.pre_scale) {
                     sc[j] = *reinterpret_cast<const float4*>(p.pre_scale + (int64_t)b * p.C + c);
                     sh[j] = *reinterpret_cast<const float4*>(p.pre_shift + (int64_t)b * p.C + c);

@@ -32,6 +32,7 @@
 // caller-provided workspace; splitk_epilogue_kernel sums them in a fixed order and applies the dequantisation epilogue
 // (no float atomics: results are bit-reproducible).
 #include "gemm_tile.h"
+#include "quant_common.h"
 
 DGQ_DIAG_BUFFER(gemm)
 
@@ -471,7 +472,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(GemmParams p) {
                       p.ex.fq_mode == 0 && !p.ex.geglu &&
                       (((reinterpret_cast<uintptr_t>(p.alpha) | reinterpret_cast<uintptr_t>(p.zw) | reinterpret_cast<uintptr_t>(p.gamma) |
                          (PER_M ? reinterpret_cast<uintptr_t>(p.vn) : 0)) & 15) == 0) &&
-                      (p.ex.residual == nullptr || (p.ex.res_dtype == DGQ_F32 && (p.ex.ldr & 3) == 0 && (reinterpret_cast<uintptr_t>(p.ex.residual) & 15) == 0));
+                      (p.ex.residual == nullptr || ((p.ex.ldr & 3) == 0 && (reinterpret_cast<uintptr_t>(p.ex.residual) & (p.ex.res_dtype == DGQ_F32 ? 15 : 7)) == 0));
     auto row4 = [&](int m, int nb, float (&val)[4], bool live) {      // live == false: compute (the values as stored), store nothing
         float a[4] = {0.f, 0.f, 0.f, 0.f};
         const bool full = (nb + 3 < p.N) && ((p.N & 3) == 0);
@@ -501,8 +502,14 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(GemmParams p) {
             o[2] = dgq_dequant<PER_M>(a[2], r0, r1, r2, al.z, zw.z, ga.z, vn.z);
             o[3] = dgq_dequant<PER_M>(a[3], r0, r1, r2, al.w, zw.w, ga.w, vn.w);
             if (p.ex.residual) {
-                const float4 r = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.ex.residual) + (int64_t)(m / p.ex.res_div) * p.ex.ldr + nb);
-                o[0] += r.x; o[1] += r.y; o[2] += r.z; o[3] += r.w;
+                // (16-bit residuals — the bf16 / fp16 states — as one 8-byte load: they used to drop the whole segment onto the
+                // element-by-element path below, 14 us per combine launch against 10)
+                const int64_t ri = (int64_t)(m / p.ex.res_div) * p.ex.ldr + nb;
+                float r[4];
+                if (p.ex.res_dtype == DGQ_F32) load4<float>(reinterpret_cast<const float*>(p.ex.residual) + ri, r);      // (kernel-uniform)
+                else if (p.ex.res_dtype == DGQ_BF16) load4<__hip_bfloat16>(reinterpret_cast<const __hip_bfloat16*>(p.ex.residual) + ri, r);
+                else load4<__half>(reinterpret_cast<const __half*>(p.ex.residual) + ri, r);
+                o[0] += r[0]; o[1] += r[1]; o[2] += r[2]; o[3] += r[3];
             }
             TOut* dst = y + (int64_t)m * p.ldy + nb;
             if (sizeof(TOut) == 4) {

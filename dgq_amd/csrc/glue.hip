@@ -54,26 +54,45 @@ extern "C" int dgq_timestep_embedding(const void* t, int t_is_float, int64_t t_s
 // eps = e_u + g·(e_c − e_u);  x' = s3·((x − s1·eps)·inv_s2) + s4·eps   with s1 = √(1−ᾱ_t), inv_s2 = 1/√ᾱ_t, s3 = √ᾱ_prev, s4 = √(1−ᾱ_prev).
 // sample / out: [n][C][HW] contiguous (the pipeline's latents); the two eps halves: element (n, c, p) at n·C·HW + c·ec + p·ep — ec = HW,
 // ep = 1 for the same layout, ec = 1, ep = C for the channels-last tensor the UNet returns.  e_c == nullptr: eps = e_u (no guidance).
-__global__ __launch_bounds__(256) void cfg_ddim_step_kernel(const float* __restrict__ e_u, const float* __restrict__ e_c, const float* __restrict__ x,
-                                                            float* __restrict__ out, int64_t n, int C, int HW, int64_t ec, int64_t ep, float g,
+// 16-bit tensors: every statement of the eager chain rounds its result to the tensor's type (torch evaluates each in fp32 and stores
+// bf16 / fp16) — RT(x) below; fp32: the identity.
+template <typename T>
+__global__ __launch_bounds__(256) void cfg_ddim_step_kernel(const T* __restrict__ e_u, const T* __restrict__ e_c, const T* __restrict__ x,
+                                                            T* __restrict__ out, int64_t n, int C, int HW, int64_t ec, int64_t ep, float g,
                                                             float s1, float inv_s2, float s3, float s4) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const int64_t img = i / ((int64_t)C * HW), r = i - img * C * HW;
     const int c = (int)(r / HW), p = (int)(r - (int64_t)c * HW);
     const int64_t ei = img * C * HW + c * ec + p * ep;
-    float e = e_u[ei];
-    if (e_c) e = e + g * (e_c[ei] - e);
-    const float p0 = (x[i] - s1 * e) * inv_s2;
-    out[i] = s3 * p0 + s4 * e;
+    // (the empty asm keeps each fp32 result in a register before its conversion: for fp16 the compiler otherwise folds
+    // fptrunc(fmul) into v_fma_mixlo_f16, whose result differed from the fp32-then-fp16 rounding of the eager kernels in ~1e-3 of the elements)
+    auto RT = [](float v) {
+        if (sizeof(T) == 4) return v;
+        asm volatile("" : "+v"(v));
+        return dgq_to_float(dgq_from_float<T>(v));
+    };
+    float e = dgq_to_float(e_u[ei]);
+    if (e_c) e = RT(e + RT(g * RT(dgq_to_float(e_c[ei]) - e)));
+    const float p0 = RT(RT(dgq_to_float(x[i]) - RT(s1 * e)) * inv_s2);
+    float o = RT(s3 * p0) + RT(s4 * e);
+    if (sizeof(T) != 4) asm volatile("" : "+v"(o));
+    out[i] = dgq_from_float<T>(o);
 }
 
-extern "C" int dgq_cfg_ddim_step(const float* eps_uncond, const float* eps_cond, const float* sample, float* out, int64_t n, int C, int HW,
+extern "C" int dgq_cfg_ddim_step(const void* eps_uncond, const void* eps_cond, const void* sample, void* out, int dtype, int64_t n, int C, int HW,
                                  int eps_channels_last, float guidance, float s1, float inv_s2, float s3, float s4, void* stream) {
     DGQ_CHECK_ARG(eps_uncond && sample && out && n > 0 && C > 0 && HW > 0 && n % ((int64_t)C * HW) == 0,
                   "dgq_cfg_ddim_step: null pointer or n not a whole number of [C][HW] images");
     const int64_t ec = eps_channels_last ? 1 : HW, ep = eps_channels_last ? C : 1;
-    hipLaunchKernelGGL(cfg_ddim_step_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, eps_uncond, eps_cond, sample, out,
-                       n, C, HW, ec, ep, guidance, s1, inv_s2, s3, s4);
+#define DGQ_CFG(TT) hipLaunchKernelGGL(cfg_ddim_step_kernel<TT>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const TT*)eps_uncond, \
+                                       (const TT*)eps_cond, (const TT*)sample, (TT*)out, n, C, HW, ec, ep, guidance, s1, inv_s2, s3, s4)
+    switch (dtype) {
+        case DGQ_F32: DGQ_CFG(float); break;
+        case DGQ_F16: DGQ_CFG(__half); break;
+        case DGQ_BF16: DGQ_CFG(__hip_bfloat16); break;
+        default: dgq_set_error("dgq_cfg_ddim_step: unknown dtype %d", dtype); return DGQ_EINVAL;
+    }
+#undef DGQ_CFG
     return dgq_launch_status("dgq_cfg_ddim_step");
 }

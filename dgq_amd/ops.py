@@ -979,18 +979,19 @@ def _dense_layout(t):
 
 def cfg_ddim_step(eps_uncond, eps_cond, sample, guidance, s1, inv_s2, s3, s4):
     """eps = e_u + guidance·(e_c − e_u) (``eps_cond`` None: eps = e_u), then the DDIM update s3·((x − s1·eps)·inv_s2) + s4·eps in the
-    order of the eager chain (pipeline_stable_diffusion.py:1037-1044, scheduling_ddim.py); fp32; ``sample`` contiguous, the eps halves in
+    order of the eager chain (pipeline_stable_diffusion.py:1037-1044, scheduling_ddim.py); fp32 / fp16 / bf16 tensors (one dtype; a 16-bit
+    chain rounds after every statement as the eager one does); ``sample`` contiguous, the eps halves in
     the same layout or channels-last (what the UNet returns).  Returns None when the layouts are not of that kind."""
     lay = _dense_layout(eps_uncond)
     if (lay is None or not sample.is_contiguous() or sample.dim() < 2 or eps_uncond.shape != sample.shape
             or (eps_cond is not None and (eps_cond.shape != sample.shape or _dense_layout(eps_cond) != lay))):
         return None
-    for t in (eps_uncond, eps_cond, sample):
-        assert t is None or t.dtype == torch.float32
+    for t in (eps_uncond, eps_cond):
+        assert t is None or t.dtype == sample.dtype
     C = sample.shape[1]
     HW = sample.numel() // (sample.shape[0] * C)
     out = torch.empty_like(sample)
-    _lib_call("dgq_cfg_ddim_step", _lib.ptr(eps_uncond), _lib.ptr(eps_cond), _lib.ptr(sample), _lib.ptr(out), sample.numel(), C, HW, lay,
+    _lib_call("dgq_cfg_ddim_step", _lib.ptr(eps_uncond), _lib.ptr(eps_cond), _lib.ptr(sample), _lib.ptr(out), _lib.DTYPE_CODE[sample.dtype], sample.numel(), C, HW, lay,
               _c.c_float(guidance), _c.c_float(s1), _c.c_float(inv_s2), _c.c_float(s3), _c.c_float(s4), _lib.stream())
     return out
 

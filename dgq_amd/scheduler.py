@@ -32,11 +32,12 @@ class DDIMScheduler:
 
     def step_guided(self, noise_pred, t, sample, guidance_scale):
         """Classifier-free guidance on the (unconditional ‖ conditional) prediction followed by ``step`` — the two statements of
-        the pipeline loop (pipeline_stable_diffusion.py:1037-1044).  fp32 device tensors take both as ONE launch
-        (dgq_cfg_ddim_step: the same fp32 operations in the same order — bit-identical to the ten eager kernels, including torch's
-        division by a host scalar as a multiplication by its reciprocal); anything else runs the torch statements."""
+        the pipeline loop (pipeline_stable_diffusion.py:1037-1044).  Device tensors take both as ONE launch
+        (dgq_cfg_ddim_step: the same fp32 operations in the same order, each rounded to the tensors' type where that is 16-bit —
+        bit-identical to the ten eager kernels, including torch's division by a host scalar as a multiplication by its reciprocal);
+        anything else runs the torch statements."""
         e_u, e_c = noise_pred.chunk(2)
-        if (noise_pred.is_cuda and noise_pred.dtype == torch.float32 and sample.dtype == torch.float32
+        if (noise_pred.is_cuda and noise_pred.dtype in (torch.float32, torch.float16, torch.bfloat16) and sample.dtype == noise_pred.dtype
                 and e_u.shape == sample.shape):
             from . import ops
             a_t, a_prev = self._coef[int(t)]

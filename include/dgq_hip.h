@@ -37,8 +37,11 @@ extern "C" {
  *   100  rounds 1-4
  *   110  round 5: dgq_gemm_extra_t += wfrag, act; dgq_quant_act_args_t += ups; W4 per-K clear marks (cflush == 2) at least every
  *        2176 codes (the kernels read float(T) off a biased int32 total: |T| < 2^22), plan.seg_limit
- *   120  round 6: dgq_attention_sync_timeouts; the attention workspace's δ area is 512 bytes */
-#define DGQ_ABI_VERSION 120
+ *   120  round 6: dgq_attention_sync_timeouts; the attention workspace's δ area is 512 bytes; dgq_gemm_act_t += kpat, B, H, W, kh, kw,
+ *        stride, pad; dgq_gemm_conv_act_fuses
+ *   121  round 6: dgq_cfg_ddim_step takes the tensors' dtype (void pointers + `dtype`); dgq_attention_workspace_bytes grew by one fp32
+ *        part area (key-split launches on 16-bit tensors) */
+#define DGQ_ABI_VERSION 121
 int dgq_version(void);
 const char* dgq_last_error(void);
 
@@ -157,10 +160,11 @@ int dgq_groupnorm_from_partials(const float* partial, int C1, const float* parti
 int dgq_timestep_embedding(const void* t, int t_is_float, int64_t t_stride, int rows, int dim, void* out, int out_dtype, void* stream);
 /* Classifier-free guidance + DDIM update (eta = 0) of the pipeline loop (pipeline_stable_diffusion.py:1037-1044,
  * schedulers/scheduling_ddim.py step): eps = e_u + guidance·(e_c − e_u) (eps_cond == NULL: eps = e_u),
- * out = s3·((sample − s1·eps)·inv_s2) + s4·eps with s1 = sqrt(1−a_t), inv_s2 = 1/sqrt(a_t), s3 = sqrt(a_prev), s4 = sqrt(1−a_prev); fp32,
+ * out = s3·((sample − s1·eps)·inv_s2) + s4·eps with s1 = sqrt(1−a_t), inv_s2 = 1/sqrt(a_t), s3 = sqrt(a_prev), s4 = sqrt(1−a_prev); the four
+ * tensors of one dtype (DGQ_F32 / F16 / BF16: a 16-bit chain rounds after every statement, as the eager one does),
  * n elements per tensor = whole [C][HW] images; sample / out contiguous [n/(C·HW)][C][HW]; the eps halves in the same layout
  * (eps_channels_last = 0) or as [.][HW][C] (1: the UNet's channels-last output); evaluated in the order of the eager torch chain. */
-int dgq_cfg_ddim_step(const float* eps_uncond, const float* eps_cond, const float* sample, float* out, int64_t n, int C, int HW,
+int dgq_cfg_ddim_step(const void* eps_uncond, const void* eps_cond, const void* sample, void* out, int dtype, int64_t n, int C, int HW,
                       int eps_channels_last, float guidance, float s1, float inv_s2, float s3, float s4, void* stream);
 
 /* ---- weight-only state (use_wq without use_aq: quant_layer.py:642-659 with unquantised activations) -----------------

@@ -11,7 +11,7 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch --
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 $R/bench.py --steps 2 --warmup 1 --no-graph --no-cpu-baseline --no-roofline --windows 1 > $O/pmc_write.log 2>&1
 cd $R
 F=$(find $O/pmc_fetch -name "*counter_collection.csv" | head -1); W=$(find $O/pmc_write -name "*counter_collection.csv" | head -1)
-python tools/pmc_traffic.py $F $W "gemm_wxa8_kernel|gemm_big_kernel|gemm_panel_kernel|splitk_epilogue" $O/gemm_hbm_traffic.json c2 fp32 $COMMIT | tail -3
+python tools/pmc_traffic.py $F $W "gemm_wxa8_kernel|gemm_big_kernel|gemm_panel_kernel|gemm_convq_kernel|splitk_epilogue" $O/gemm_hbm_traffic.json c2 fp32 $COMMIT | tail -3
 python tools/pmc_traffic.py $F $W splitk_epilogue $O/splitk_hbm_traffic.json | tail -2
 python tools/pmc_traffic.py $F $W quant_act $O/quant_act_hbm_traffic.json c2 fp32 $COMMIT | tail -2
 rm -rf $O/pmc_fetch $O/pmc_write

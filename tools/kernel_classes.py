@@ -6,7 +6,7 @@ import csv, json, subprocess, sys
 src, out = sys.argv[1], sys.argv[2]
 config = sys.argv[3] if len(sys.argv) > 3 else "c2"
 dtype = sys.argv[4] if len(sys.argv) > 4 else "fp32"
-CLASSES = (("dgq_gemm", ("gemm_wxa8_kernel", "gemm_big_kernel", "gemm_panel_kernel", "conv_rowsum_kernel", "splitk_epilogue_kernel", "linear_smallm_kernel")),
+CLASSES = (("dgq_gemm", ("gemm_wxa8_kernel", "gemm_big_kernel", "gemm_panel_kernel", "gemm_convq_kernel", "conv_rowsum_kernel", "splitk_epilogue_kernel", "linear_smallm_kernel")),
            ("dgq_quantise_on_load", ("quant_act_",)),
            ("dgq_attention", ("attn3_", "attn_stats", "attn_pv", "fakequant_rows", "logquant", "max_f32")),
            ("dgq_groupnorm_statistics", ("gn_partial", "gn_finalize", "gn_from_partials")),
