@@ -367,6 +367,64 @@ def test_quant_linear_fused_equals_two_launches(M, K, N, mode, fold, dtype, dev,
         assert rel_l2(y1, y0) < tol, rel_l2(y1, y0)
 
 
+@pytest.mark.parametrize("case", ["linear_perK_ln_res", "linear_perM_res", "linear_perK_small", "linear_perK_geglu", "conv1x1_gn_silu", "conv3x3_perK_gn_res",
+                                  "conv3x3_perM_small", "linear_perK_splitk"])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_quant_layers_half_io_equal_the_fp32_path_rounded_once(case, dtype, dev):
+    """What "bf16 / fp16 between the layers" means here, as an operator-level identity (a stated bound instead of a
+    measured one): a quantized layer on 16-bit tensors == the SAME layer on those values as fp32 tensors, its fp32 result rounded ONCE
+    to the tensor type.  Loads convert exactly, statistics / quantiser / integer contraction / epilogue (residual, GEGLU, GroupNorm
+    prologue) are the fp32 path's, only the store rounds — so the whole cost of the 16-bit modes is the tensors' own 2^-9 / 2^-12.
+    Asserted bit for bit for bf16; fp16 within one ulp on <= 2e-3 of the elements (the compiler folds the epilogue's last fp32
+    operation and the fp16 conversion into v_fma_mixlo_f16, which rounds once where fp32-then-fp16 rounds twice)."""
+    from dgq_amd import ops, synth
+    from dgq_amd.plan import plan_act
+    g = torch.Generator().manual_seed(len(case))
+
+    def binding(N, C, taps, mode, L):
+        w = torch.randn(N, C * taps, generator=g) * 0.05
+        wd, wz = synth.channel_minmax(w, 4)
+        wq = w.view(N, C, 3, 3) if taps == 9 else w
+        pw = ops.PackedWeight(wq.to(dev), wd.to(dev), wz.to(dev), None, torch.randn(N, generator=g).to(dev), 4, C, taps)
+        kind = "linear" if taps == 1 and not case.startswith("conv") else "conv"
+        if mode == "perK":
+            d, z = synth._group_params(C * taps, 16, 8, "half|%s" % case, 0)
+            lay = plan_act(d.view(1, 1, -1) if kind == "linear" else d.view(1, -1, 1), z.view(1, 1, -1) if kind == "linear" else z.view(1, -1, 1), kind, C, taps, 8)
+        else:
+            d, z = synth._group_params(L, 16, 8, "half|%s" % case, 0)
+            lay = plan_act(d.view(1, -1, 1) if kind == "linear" else d.view(1, 1, -1), z.view(1, -1, 1) if kind == "linear" else z.view(1, 1, -1), kind, C, taps, 8)
+        return ops.ActBinding(lay, pw, 8)
+
+    if case.startswith("linear"):
+        M, K, N, mode = {"linear_perK_ln_res": (2048, 640, 640, "perK"), "linear_perM_res": (8192, 320, 320, "perM"), "linear_perK_small": (154, 768, 320, "perK"),
+                         "linear_perK_geglu": (512, 320, 2560, "perK"), "linear_perK_splitk": (128, 5120, 1280, "perK")}[case]
+        ab = binding(N, K, 1, mode, 64)
+        x = torch.randn(M, K, generator=g).to(dev).to(dtype)
+        res = torch.randn(M, N, generator=g).to(dev).to(dtype) if "res" in case else None
+        ln = (torch.linspace(0.5, 1.5, K, device=dev), torch.linspace(-0.1, 0.1, K, device=dev), 1e-5) if "ln" in case else None
+        run = lambda xx, rr: ops.quant_linear(xx, ab, geglu=True) if "geglu" in case else ops.quant_linear(xx, ab, residual=rr, ln=ln)
+    else:
+        B, C, H, N, k, mode = {"conv1x1_gn_silu": (2, 320, 32, 320, 1, "perK"), "conv3x3_perK_gn_res": (2, 320, 16, 320, 3, "perK"),
+                               "conv3x3_perM_small": (1, 64, 8, 160, 3, "perM")}[case]
+        ab = binding(N, C, k * k, mode, H * H)
+        x = (torch.randn(B, C, H, H, generator=g) * 1.3 + 0.2).to(dev).to(dtype).contiguous(memory_format=torch.channels_last)
+        res = torch.randn(B, N, H, H, generator=g).to(dev).to(dtype).contiguous(memory_format=torch.channels_last) if "res" in case else None
+        norm = (32, 1e-5, torch.randn(C, generator=g).to(dev), torch.randn(C, generator=g).to(dev), 1) if "gn" in case else None
+        run = lambda xx, rr: ops.quant_conv2d(xx, ab, k, k, 1, k // 2, norm=norm, residual=rr)
+    y16 = run(x, res)
+    y32 = run(x.float(), None if res is None else res.float())
+    torch.cuda.synchronize()
+    assert y16.dtype == dtype and y32.dtype == torch.float32 and y16.shape == y32.shape
+    want = y32.to(dtype)
+    if dtype == torch.bfloat16:
+        assert torch.equal(y16, want), (case, (y16.float() - want.float()).abs().max().item(), float((y16 != want).float().mean()))
+    else:
+        ne = y16 != want
+        assert float(ne.float().mean()) <= 2e-3, float(ne.float().mean())
+        ulp = torch.maximum(want.float().abs(), torch.tensor(6.2e-5, device=dev)) * 2.0 ** -10
+        assert bool(((y16.float() - want.float()).abs() <= ulp).all())
+
+
 def test_int4_fragment_major_layout(dev):
     """dgq_pack_w4 layout 2 (the panel kernel's weight image): unpacks to the same codes; block (j, p), lane (h << 5) | (n & 31) holds
     the two words of K half h of chunk 2p, then of chunk 2p + 1, of column 32j + (n & 31); columns past N are zero"""
