@@ -194,14 +194,6 @@ __global__ __launch_bounds__(64 * NW) void gemm_convq_kernel(GemmBatch bt, int s
         }
     }
     DGQ_STAMP(3);                                          // (diagnostic) patch staged
-#ifdef CQ_PHASE
-    if (CQ_PHASE == 1) {                                   // (timing builds only, tools/bench_convq.py)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int d = 0; d < NS; ++d) asm volatile("" : "+v"(wr[d][0]), "+v"(wr[d][1]));        // the W registers stay allocated until the loads have landed
-        return;
-    }
-#endif
     // the gather table, the chunks' (δ, z) and the rows' (δ, z, 1/δ) into LDS
     uint16_t* tab = reinterpret_cast<uint16_t*>(smem + L.tab);
     float* tdl = reinterpret_cast<float*>(smem + L.tdl);
@@ -395,9 +387,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_convq_kernel(GemmBatch bt, int s
                 else cq_wait_vmcnt<0>();
                 asm volatile("" : "+v"(wr[sl][0]), "+v"(wr[sl][1]));       // the slot's registers are defined HERE for the compiler
                 __builtin_amdgcn_sched_barrier(0);
-#if !defined(CQ_PHASE) || CQ_PHASE != 2
                 tile_fn(t, ts0 + sl, wr[sl][0], wr[sl][1]);
-#endif
             }
         }
     }
@@ -418,9 +408,6 @@ __global__ __launch_bounds__(64 * NW) void gemm_convq_kernel(GemmBatch bt, int s
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // this wave's slab reads are complete, its vtab rows written ...
     __builtin_amdgcn_s_barrier();                            // ... everyone's: the patch region becomes the epilogue's scratch
-#if defined(CQ_PHASE) && CQ_PHASE >= 2
-    if (acc[0][0][0][0] != 12345) return;
-#endif
     gemm_store_tile<PER_M, TIO, BM, BN, 1, NW, 1, NW * 32 * (32 + 4) * 4, 1, 1, true>(p, 0, smem + L.patch, vtab, vcol, wid, lane, 0, wid, 0, m0, 0,
                                                                                       acc[0], accf DGQ_DIAG_ARG, Wo, tile * 2);
     DGQ_STAMP(9);

@@ -1,6 +1,6 @@
 """3x3 convolution layers of the 64 x 64 level (C = 320): dgq_quant_act + dgq_gemm_wxa8 (two launches, the int8 code matrix through HBM)
 against the quantiser inside the GEMM launch (csrc/gemm_convq.hip), per scale mode; hipGraph replay of 20 calls -> us per layer.
-With a timing build of the library (tools/build_variants.sh UNIT=gemm_convq.hip p1:-DCQ_PHASE=1 ...) the fused column is that phase prefix.
+Where the fused launch spends its time: tools/convq_timeline.py (in-kernel stamps of the diagnostic build).
 usage: python tools/bench_convq.py ["B,C,H,W,N" ...]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
