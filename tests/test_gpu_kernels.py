@@ -1207,6 +1207,45 @@ def test_implicit_conv_geometries(geom, dev, monkeypatch):
     assert torch.equal(outs[0], outs[1]), (geom, (outs[0] - outs[1]).abs().max().item())
 
 
+@pytest.mark.parametrize("case", ["conv_128x128_b8_c320", "conv_64x64_b8_c640", "linear_m32768_geglu_in", "linear_m8192_k5120"])
+def test_c5_full_size_launch_plans_equal_the_small_tile_forms(case, dev, monkeypatch):
+    """the launch plans config C5 takes at its FULL size (8 prompts, 128 x 128 latents: M = 131 072 / 32 768 / 8 192 rows —
+    the implicit-im2col operand, the 256-row kernel, the wide tiles) checked at those sizes, not only on small geometries: the planner's
+    launch against the same layer forced onto the materialising pass / the 64 x 64 tile.  Scalar-δ layers (C5: one (δ, z) per layer):
+    integer sums and one epilogue — bit for bit."""
+    from dgq_amd import ops, synth, _lib
+    from dgq_amd.plan import plan_act
+    gen = torch.Generator().manual_seed(len(case))
+    if case.startswith("conv"):
+        B, C, H, N = (8, 320, 128, 320) if "c320" in case else (8, 640, 64, 640)
+        w = (torch.randn(N, C, 3, 3, generator=gen) * 0.05).to(dev)
+        x = (torch.randn(B, C, H, H, generator=gen) * 1.5 + 0.3).to(dev).contiguous(memory_format=torch.channels_last)
+        wd, wz = synth.channel_minmax(w.cpu(), 4)
+        pw = ops.PackedWeight(w, wd.to(dev), wz.to(dev), None, torch.randn(N, generator=gen).to(dev), 4, C, 9)
+        ab = ops.ActBinding(plan_act(torch.tensor(0.045), torch.tensor(29.0), "conv", C, 9, 6), pw, 6)
+        assert ab.mode == "scalar"
+        res = torch.randn(B, N, H, H, generator=gen).to(dev).contiguous(memory_format=torch.channels_last)
+        norm = (32, 1e-5, torch.randn(C, generator=gen).to(dev), torch.randn(C, generator=gen).to(dev), 1)
+        y1 = ops.quant_conv2d(x, ab, 3, 3, 1, 1, norm=norm, residual=res)                       # the planner's form (implicit operand)
+        monkeypatch.setattr(ops, "CONV_IMPLICIT", False)
+        monkeypatch.setenv("DGQ_GEMM_FORCE", "64,64,1")
+        y0 = ops.quant_conv2d(x, ab, 3, 3, 1, 1, norm=norm, residual=res)                       # int8 im2col matrix + 64 x 64 tiles
+    else:
+        M, K, N = (32768, 640, 5120) if "geglu" in case else (8192, 5120, 1280)
+        w = torch.randn(N, K, generator=gen) * 0.05
+        wd, wz = synth.channel_minmax(w, 4)
+        pw = ops.PackedWeight(w.to(dev), wd.to(dev), wz.to(dev), None, torch.randn(N, generator=gen).to(dev), 4, K, 1)
+        ab = ops.ActBinding(plan_act(torch.tensor(0.045), torch.tensor(29.0), "linear", K, 1, 6), pw, 6)
+        x = torch.randn(M, K, generator=gen).to(dev)
+        res = torch.randn(M, N, generator=gen).to(dev)
+        y1 = ops.quant_linear(x, ab, residual=res)
+        monkeypatch.setattr(ops, "GEMM_FUSE", False)
+        monkeypatch.setenv("DGQ_GEMM_FORCE", "64,64,1")
+        y0 = ops.quant_linear(x, ab, residual=res)
+    torch.cuda.synchronize()
+    assert torch.isfinite(y1).all() and torch.equal(y0, y1), (case, (y0 - y1).abs().max().item())
+
+
 # ------------------------------------------------------------------------------------------ step glue (glue.hip)
 @pytest.mark.parametrize("dim,tdtype", [(320, torch.int64), (256, torch.float32), (320, torch.float32)])
 def test_timestep_embedding_is_the_torch_chain(dim, tdtype, dev):
