@@ -552,7 +552,7 @@ def measure_gemm_roofline(torch, ops, qnn, run_step, args):
     return out, extra
 
 
-GEMM_SOURCES = ("gemm_wxa8.hip", "gemm_wxa8_big.hip", "gemm_panel.hip", "gemm_tile.h")
+GEMM_SOURCES = ("gemm_wxa8.hip", "gemm_wxa8_big.hip", "gemm_panel.hip", "gemm_convq.hip", "gemm_tile.h", "gemm_device.h", "quant_common.h")
 
 
 def csrc_digest(names=GEMM_SOURCES):
