@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DGQ_HIP_LIB") or os.path.join(_HERE, "csrc", "libdgq_hip.so")   # override: A/B builds of the kernels
 
 _vp, _i, _f, _i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64
-ABI_VERSION = 121          # DGQ_ABI_VERSION of include/dgq_hip.h: the struct layouts below are that revision's
+ABI_VERSION = 122          # DGQ_ABI_VERSION of include/dgq_hip.h: the struct layouts below are that revision's
 
 # name -> argtypes; every function returns int except dgq_last_error
 SIGNATURES = {
@@ -34,7 +34,7 @@ SIGNATURES = {
     "dgq_logquant_f32": [_vp, _vp, _i64, _i, _i, _vp, _i, _vp],
     "dgq_attention_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _vp, _i, _vp, _vp, ctypes.c_size_t, _vp],
     "dgq_attention": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _i, _vp, _i, _vp, _vp, ctypes.c_size_t, _vp],
-    "dgq_conv2d_f32w": [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _i, _vp, _vp, _i, _vp],
+    "dgq_conv2d_f32w": [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _i, _vp, _vp, _i, _vp, _i, _vp],
     "dgq_attention_fuses_fakequant": [_i, _i],
     "dgq_attention_workspace_bytes": [_i, _i, _i, _i, _i],
     "dgq_attention_sync_timeouts": [],
@@ -58,7 +58,7 @@ SIGNATURES = {
 class GemmExtra(ctypes.Structure):
     """dgq_gemm_extra_t of include/dgq_hip.h"""
     _fields_ = [("residual", _vp), ("ldr", _i), ("res_div", _i), ("res_dtype", _i), ("fq_mode", _i), ("fq_delta", _vp), ("fq_zp", _vp),
-                ("fq_T", _i), ("fq_D", _i), ("fq_skip", _i), ("fq_qmax", _f), ("geglu", _i), ("gn_partial", _vp), ("conv", _vp), ("flush_coef", _vp), ("wfrag", _vp), ("act", _vp)]
+                ("fq_T", _i), ("fq_D", _i), ("fq_skip", _i), ("fq_qmax", _f), ("geglu", _i), ("gn_partial", _vp), ("conv", _vp), ("flush_coef", _vp), ("wfrag", _vp), ("act", _vp), ("y2", _vp), ("ldy2", _i)]
 
 
 class GemmAct(ctypes.Structure):

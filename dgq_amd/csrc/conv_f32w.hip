@@ -17,6 +17,8 @@ struct ConvF32Params {
     const float* pre_shift;
     int pre_act;              // ... followed by SiLU when 1; out-of-image taps stay 0 (the conv pads AFTER norm + activation)
     void* y;             // [M][ldy], y_dtype
+    void* y2;            // (or nullptr) a second copy of the rows at pitch ldy2 (the output's slot in a concatenation buffer)
+    int ldy2;
     int x_dtype, y_dtype;
     int B, H, W, C, kh, kw, stride, pad, Ho, Wo, N, K, M, ldy;
 };
@@ -30,6 +32,11 @@ __device__ __forceinline__ float ld_pre(const ConvF32Params& p, int b, int64_t p
     return v;
 }
 
+__device__ __forceinline__ void store_any(void* p, int dtype, int64_t i, float v) {
+    if (dtype == DGQ_F16) reinterpret_cast<__half*>(p)[i] = __float2half(v);
+    else if (dtype == DGQ_BF16) reinterpret_cast<__hip_bfloat16*>(p)[i] = __float2bfloat16(v);
+    else reinterpret_cast<float*>(p)[i] = v;
+}
 __device__ __forceinline__ float ld_any(const void* p, int dtype, int64_t i) {
     if (dtype == DGQ_F16) return __half2float(reinterpret_cast<const __half*>(p)[i]);
     if (dtype == DGQ_BF16) return __bfloat162float(reinterpret_cast<const __hip_bfloat16*>(p)[i]);
@@ -98,10 +105,8 @@ __global__ __launch_bounds__(256) void conv_f32w_kernel(ConvF32Params p) {
         const int m = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (m >= p.M) continue;
         const float v = acc[r] + bias;
-        const int64_t i = (int64_t)m * p.ldy + n;
-        if (p.y_dtype == DGQ_F16) reinterpret_cast<__half*>(p.y)[i] = __float2half(v);
-        else if (p.y_dtype == DGQ_BF16) reinterpret_cast<__hip_bfloat16*>(p.y)[i] = __float2bfloat16(v);
-        else reinterpret_cast<float*>(p.y)[i] = v;
+        store_any(p.y, p.y_dtype, (int64_t)m * p.ldy + n, v);
+        if (p.y2) store_any(p.y2, p.y_dtype, (int64_t)m * p.ldy2 + n, v);
     }
 }
 
@@ -195,17 +200,15 @@ __global__ __launch_bounds__(256) void conv_f32w_smalln_kernel(ConvF32Params p) 
         for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
         if (lane == 0 && n < p.N) {
             v += p.bias ? p.bias[n] : 0.0f;
-            const int64_t i = (int64_t)m * p.ldy + n;
-            if (p.y_dtype == DGQ_F16) reinterpret_cast<__half*>(p.y)[i] = __float2half(v);
-            else if (p.y_dtype == DGQ_BF16) reinterpret_cast<__hip_bfloat16*>(p.y)[i] = __float2bfloat16(v);
-            else reinterpret_cast<float*>(p.y)[i] = v;
+            store_any(p.y, p.y_dtype, (int64_t)m * p.ldy + n, v);
+            if (p.y2) store_any(p.y2, p.y_dtype, (int64_t)m * p.ldy2 + n, v);
         }
     }
 }
 
 extern "C" int dgq_conv2d_f32w(const void* x, int x_dtype, int B, int H, int W, int C, int kh, int kw, int stride, int pad,
                                const float* w, const float* bias, int N, void* y, int y_dtype, int ldy,
-                               const float* pre_scale, const float* pre_shift, int pre_act, void* stream) {
+                               const float* pre_scale, const float* pre_shift, int pre_act, void* y2, int ldy2, void* stream) {
     DGQ_CHECK_ARG(x && w && y, "dgq_conv2d_f32w: null pointer");
     DGQ_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && kh > 0 && kw > 0 && stride > 0 && pad >= 0 && N > 0, "dgq_conv2d_f32w: bad geometry");
     DGQ_CHECK_ARG((x_dtype == DGQ_F32 || x_dtype == DGQ_F16 || x_dtype == DGQ_BF16) && (y_dtype == DGQ_F32 || y_dtype == DGQ_F16 || y_dtype == DGQ_BF16),
@@ -218,7 +221,8 @@ extern "C" int dgq_conv2d_f32w(const void* x, int x_dtype, int B, int H, int W, 
     p.Ho = (H + 2 * pad - kh) / stride + 1; p.Wo = (W + 2 * pad - kw) / stride + 1;
     DGQ_CHECK_ARG(p.Ho > 0 && p.Wo > 0, "dgq_conv2d_f32w: empty output");
     p.N = N; p.K = kh * kw * C; p.M = B * p.Ho * p.Wo; p.ldy = ldy;
-    DGQ_CHECK_ARG(ldy >= N, "dgq_conv2d_f32w: ldy < N");
+    DGQ_CHECK_ARG(ldy >= N && (!y2 || ldy2 >= N), "dgq_conv2d_f32w: ldy < N");
+    p.y2 = y2; p.ldy2 = ldy2;
     if (N <= 8) {
         if (N <= 4) hipLaunchKernelGGL(conv_f32w_smalln_kernel<4>, dim3((p.M + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
         else hipLaunchKernelGGL(conv_f32w_smalln_kernel<8>, dim3((p.M + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);

@@ -60,7 +60,7 @@ __device__ __forceinline__ void gemm_prefetch_params(const GemmParams& p) {
     asm volatile("" ::"s"(p.M), "s"(p.N), "s"(p.Kp), "s"(p.tiles_per_split), "s"(p.splits), "s"(p.codes), "s"(p.wpacked), "s"(p.rowsum),
                  "s"(p.rowsum_parts), "s"(p.alpha), "s"(p.zw), "s"(p.gamma), "s"(p.vn), "s"(p.cdelta), "s"(p.cflush), "s"(p.mdelta),
                  "s"(p.mzp), "s"(p.L), "s"(p.offset), "s"(p.y), "s"(p.ldy), "s"(p.slab), "s"(p.ex.residual), "s"(p.ex.ldr),
-                 "s"(p.ex.res_div), "s"(p.ex.res_dtype), "s"(p.ex.fq_mode), "s"(p.ex.geglu), "s"(p.ex.gn_partial), "s"(p.wfrag));
+                 "s"(p.ex.res_div), "s"(p.ex.res_dtype), "s"(p.ex.fq_mode), "s"(p.ex.geglu), "s"(p.ex.gn_partial), "s"(p.wfrag), "s"(p.ex.y2));
 }
 
 template <bool PER_M>
@@ -258,6 +258,8 @@ __device__ __forceinline__ void gemm_store_tile(const GemmParams& p, int zsplit,
     }
     const bool st_vec = vec_ok && ((p.ldy * (int)sizeof(TOut)) % 16 == 0) &&
                         ((reinterpret_cast<uintptr_t>(p.y) & 15) == 0) && (sizeof(TOut) == 4 || (p.ldy & 3) == 0);
+    const bool st_vec2 = vec_ok && ((p.ex.ldy2 * (int)sizeof(TOut)) % 16 == 0) &&
+                         ((reinterpret_cast<uintptr_t>(p.ex.y2) & 15) == 0) && (sizeof(TOut) == 4 || (p.ex.ldy2 & 3) == 0);
     // residual tile: all rows of this lane fetched up front as 16-byte loads, so the epilogue pays one memory latency
     // (fetched row by row inside the store loop, the dependent loads made the fused add slower than a separate kernel)
     const int res_es = p.ex.res_dtype == DGQ_F32 ? 4 : 2;
@@ -325,17 +327,23 @@ __device__ __forceinline__ void gemm_store_tile(const GemmParams& p, int zsplit,
         if (res_vec) {
             o[0] += res[rr % HP].x; o[1] += res[rr % HP].y; o[2] += res[rr % HP].z; o[3] += res[rr % HP].w;
         }
-        TOut* dst = y + (int64_t)m * p.ldy + nb;
-        if (st_vec) {
-            if (sizeof(TOut) == 4) {
-                *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+        // ex.y2: a second copy of the rows (the skip tensor's slot in the concatenation buffer of the up path, sd.py:558-613): the same
+        // values, its own row pitch — no torch.cat launch later
+#pragma unroll
+        for (int cp = 0; cp < 2; ++cp) {
+            if (cp == 1 && p.ex.y2 == nullptr) break;                                  // (kernel-uniform)
+            TOut* dst = cp == 0 ? y + (int64_t)m * p.ldy + nb : reinterpret_cast<TOut*>(p.ex.y2) + (int64_t)m * p.ex.ldy2 + nb;
+            if (cp == 0 ? st_vec : st_vec2) {
+                if (sizeof(TOut) == 4) {
+                    *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+                } else {
+                    TOut t[4] = {dgq_from_float<TOut>(o[0]), dgq_from_float<TOut>(o[1]), dgq_from_float<TOut>(o[2]),
+                                 dgq_from_float<TOut>(o[3])};
+                    *reinterpret_cast<uint2*>(dst) = *reinterpret_cast<const uint2*>(t);
+                }
             } else {
-                TOut t[4] = {dgq_from_float<TOut>(o[0]), dgq_from_float<TOut>(o[1]), dgq_from_float<TOut>(o[2]),
-                             dgq_from_float<TOut>(o[3])};
-                *reinterpret_cast<uint2*>(dst) = *reinterpret_cast<const uint2*>(t);
+                for (int k = 0; k < 4 && nb + k < p.N; ++k) dst[k] = dgq_from_float<TOut>(o[k]);
             }
-        } else {
-            for (int k = 0; k < 4 && nb + k < p.N; ++k) dst[k] = dgq_from_float<TOut>(o[k]);
         }
         if (gn) {                                        // wave-uniform; rows of a 16-row block are all valid or all past M
 #pragma unroll

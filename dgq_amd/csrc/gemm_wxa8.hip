@@ -469,6 +469,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(GemmParams p) {
     // form the row constants once and leave as one 16-byte store; before, each of the four elements re-read the row sums and its
     // own column constants and left as a 4-byte store (8-14 us per combine launch for 3 us of slab traffic).
     const bool vec4 = ((p.N & 3) == 0) && ((p.ldy * (int)sizeof(TOut)) % 16 == 0) && ((reinterpret_cast<uintptr_t>(p.y) & 15) == 0) &&
+                      (p.ex.y2 == nullptr || (((p.ex.ldy2 * (int)sizeof(TOut)) % 16 == 0) && (reinterpret_cast<uintptr_t>(p.ex.y2) & 15) == 0)) &&
                       p.ex.fq_mode == 0 && !p.ex.geglu &&
                       (((reinterpret_cast<uintptr_t>(p.alpha) | reinterpret_cast<uintptr_t>(p.zw) | reinterpret_cast<uintptr_t>(p.gamma) |
                          (PER_M ? reinterpret_cast<uintptr_t>(p.vn) : 0)) & 15) == 0) &&
@@ -512,13 +513,16 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(GemmParams p) {
                 o[0] += r[0]; o[1] += r[1]; o[2] += r[2]; o[3] += r[3];
             }
             TOut* dst = y + (int64_t)m * p.ldy + nb;
+            TOut* dst2 = p.ex.y2 ? reinterpret_cast<TOut*>(p.ex.y2) + (int64_t)m * p.ex.ldy2 + nb : nullptr;     // (ex.y2: a second copy of the rows)
             if (sizeof(TOut) == 4) {
                 if (live) *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+                if (live && dst2) *reinterpret_cast<float4*>(dst2) = make_float4(o[0], o[1], o[2], o[3]);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) val[e] = o[e];
             } else {
                 TOut t[4] = {dgq_from_float<TOut>(o[0]), dgq_from_float<TOut>(o[1]), dgq_from_float<TOut>(o[2]), dgq_from_float<TOut>(o[3])};
                 if (live) *reinterpret_cast<uint2*>(dst) = *reinterpret_cast<const uint2*>(t);
+                if (live && dst2) *reinterpret_cast<uint2*>(dst2) = *reinterpret_cast<const uint2*>(t);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) val[e] = dgq_to_float(t[e]);
             }
@@ -530,6 +534,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(GemmParams p) {
             out = dgq_extra(p.ex, out, m, n);
             const TOut st = dgq_from_float<TOut>(out);
             if (live) y[(int64_t)m * p.ldy + n] = st;
+            if (live && p.ex.y2) reinterpret_cast<TOut*>(p.ex.y2)[(int64_t)m * p.ex.ldy2 + n] = st;
             val[e] = dgq_to_float(st);
         }
     };
@@ -952,12 +957,14 @@ static int fill_gemm(const dgq_gemm_args_t& a, GemmParams& p) {
                           "dgq_gemm_wxa8: bad implicit-conv descriptor (needs per_m with L = 1, W4, C %% 16 == 0, M = B*Ho*Wo, 16-byte aligned codes_in / fill)");
             p.cv = c;
         }
+        DGQ_CHECK_ARG(!p.ex.y2 || (p.ex.ldy2 >= a.N && !p.ex.geglu), "dgq_gemm_wxa8: y2 (second copy of the output rows) needs ldy2 >= N and no GEGLU epilogue");
         DGQ_CHECK_ARG(!p.ex.gn_partial || (a.M % 16 == 0 && a.N % 4 == 0 && !p.ex.geglu && p.ex.fq_mode == 0 &&
                                            (reinterpret_cast<uintptr_t>(p.ex.gn_partial) & 15) == 0),
                       "dgq_gemm_wxa8: GroupNorm partials need M %% 16 == 0, N %% 4 == 0, a 16-byte aligned buffer and no GEGLU / fused quantizer");
     } else {
         p.ex.residual = nullptr; p.ex.ldr = 0; p.ex.res_div = 1; p.ex.res_dtype = DGQ_F32; p.ex.fq_mode = 0; p.ex.fq_delta = nullptr; p.ex.fq_zp = nullptr;
         p.ex.fq_T = 1; p.ex.fq_D = 1; p.ex.fq_skip = 0; p.ex.fq_qmax = 255.0f; p.ex.geglu = 0; p.ex.gn_partial = nullptr; p.ex.conv = nullptr; p.ex.flush_coef = nullptr; p.ex.wfrag = nullptr; p.ex.act = nullptr;
+        p.ex.y2 = nullptr; p.ex.ldy2 = 0;
     }
     p.splits = 1; p.slab = nullptr;
     p.tiles_per_split = a.Kp / BK;

@@ -32,6 +32,86 @@ def _cat_channels(a, b):
     return torch.cat([a, b], dim=1)
 
 
+class _SkipEntry:
+    __slots__ = ("tensor", "ver", "buf", "c1", "h_inplace")
+
+
+class _CatInPlace:
+    """The skip concatenations of the up path (sd.py:558-613: ``torch.cat([hidden_states, res_hidden_states], dim=1)`` in front of every
+    up resnet) without a concatenation launch: for each skip tensor a channels-last buffer [B][H][W][C1 + C2] exists from the moment the
+    skip is produced; the skip's producing layer stores its rows into [..., C1:] AS WELL (dgq_gemm_extra_t.y2 / dgq_conv2d_f32w's y2),
+    the layer that produces the up path's hidden state stores INTO [..., :C1] (its ``y`` with the buffer's row pitch) — both through
+    ``ops.OutputRedirect``, taken by the modules' final layer calls.  Whatever is not placed that way (a module without such a call, a
+    layer tap, an eager FP block) is concatenated as before: ``join`` checks where the tensors actually are."""
+
+    def __init__(self, unet, dtype, device):
+        from .. import ops
+        self.ops = ops
+        self.dtype, self.device = dtype, device
+        tot = [r.norm1.num_channels for blk in unet.up_blocks for r in blk.resnets]     # up resnets in execution order
+        self.ctot = tot[::-1]                                                           # by skip index (skips are popped last-first)
+        self.entries = []
+
+    def _views(self, buf, c1):
+        b2 = buf.view(-1, buf.shape[-1])
+        return b2[:, :c1], b2[:, c1:]
+
+    def produce_skip(self, fn, shape):
+        """run fn() (the module call that produces the next skip tensor, of logical NCHW ``shape``) with its second copy redirected"""
+        i = len(self.entries)
+        e = _SkipEntry()
+        e.buf, e.c1, e.h_inplace = None, 0, False
+        B, C2, H, W = shape
+        ok = i < len(self.ctot) and self.ctot[i] > C2
+        if ok:
+            e.c1 = self.ctot[i] - C2
+            buf = torch.empty((B, H, W, self.ctot[i]), dtype=self.dtype, device=self.device)
+            rd = self.ops.OutputRedirect(out2=self._views(buf, e.c1)[1])
+            self.ops.REDIRECT = rd
+            try:
+                y = fn()
+            finally:
+                self.ops.REDIRECT = None
+            if rd.taken and tuple(y.shape) == tuple(shape):
+                e.buf = buf
+        else:
+            y = fn()
+        e.tensor, e.ver = y, y._version
+        self.entries.append(e)
+        return y
+
+    def produce_h(self, fn):
+        """run fn() (the module call whose result is the hidden state of the NEXT concatenation) with its output redirected INTO the
+        buffer of the skip that concatenation pops"""
+        e = self.entries[-1] if self.entries else None
+        if e is None or e.buf is None:
+            return fn()
+        rd = self.ops.OutputRedirect(out=self._views(e.buf, e.c1)[0])
+        self.ops.REDIRECT = rd
+        try:
+            y = fn()
+        finally:
+            self.ops.REDIRECT = None
+        e.h_inplace = bool(rd.taken and y.data_ptr() == e.buf.data_ptr() and y.shape[1] == e.c1 and y.shape[2:] == e.tensor.shape[2:])
+        return y
+
+    def join(self, h):
+        """torch.cat([h, skip], dim=1) for the skip popped now — the buffer itself where both halves already sit in it"""
+        e = self.entries.pop()
+        if e.buf is not None and e.h_inplace and e.tensor._version == e.ver and h.data_ptr() == e.buf.data_ptr():
+            y = e.buf.permute(0, 3, 1, 2)
+            ga, gb = self.ops._gn_of(h), self.ops._gn_of(e.tensor)
+            if ga is not None and gb is not None and len(ga["parts"]) == 1 and len(gb["parts"]) == 1 and ga["B"] == gb["B"] and ga["HW"] == gb["HW"]:
+                y._dgq_gn = dict(parts=ga["parts"] + gb["parts"], B=ga["B"], HW=ga["HW"], C=ga["C"] + gb["C"], ver=y._version)
+            return y
+        return _cat_channels(h, e.tensor)
+
+
+def _out_channels(conv):
+    w = getattr(conv, "w", None)
+    return int(w.shape[0]) if w is not None else int(conv.out_channels)
+
+
 ARCH = {
     # name: dict(block_out, down=(kind, n_tf_layers, has_down), up=(kind, n_tf_layers, has_up), ...)
     "sd": dict(
@@ -249,7 +329,7 @@ class Transformer2DModel(nn.Module):
         if self.proj_kind == "conv":
             fr = getattr(self.proj_out, "forward_residual", None)
             if fr is not None and _residual_fusion_on():
-                return fr(h, res)                                  # h + res in proj_out's GEMM epilogue
+                return fr(h, res, final=True)                      # h + res in proj_out's GEMM epilogue (the module's own result)
             h = self.proj_out(h)
         return h + res
 
@@ -260,7 +340,8 @@ class Downsample2D(nn.Module):
         self.conv = nn.Conv2d(c, c, 3, 2, 1)
 
     def forward(self, x):
-        return self.conv(x)
+        ff = getattr(self.conv, "forward_final", None)
+        return ff(x) if (ff is not None and _fusion_on()) else self.conv(x)
 
 
 class Upsample2D(nn.Module):
@@ -271,7 +352,7 @@ class Upsample2D(nn.Module):
     def forward(self, x):
         folded = getattr(self.conv, "forward_upsampled", None)
         if folded is not None and _fusion_on():
-            return folded(x)                                   # QuantLayer: the interpolate folded into the conv's quantise-on-load pass
+            return folded(x, final=True)                       # QuantLayer: the interpolate folded into the conv's quantise-on-load pass
         return self.conv(F.interpolate(x, scale_factor=2.0, mode="nearest"))
 
 
@@ -304,26 +385,60 @@ class _Stage(nn.Module):
         att = getattr(self, "attentions", None)
         return att[j](h, encoder_hidden_states=ctx) if att is not None else h
 
-    def run_down(self, h, temb, ctx, skips):
+    def run_down(self, h, temb, ctx, skips, cat=None):
+        """cat (a _CatInPlace, or None): every skip's producer also stores into the skip's slot of its concatenation buffer"""
+        has_att = hasattr(self, "attentions")
         for j, r in enumerate(self.resnets):
-            h = self._att(j, r(h, temb), ctx)
+            if cat is None:
+                h = self._att(j, r(h, temb), ctx)
+            else:
+                shape = (h.shape[0], _out_channels(r.conv2), h.shape[2], h.shape[3])
+                if has_att:
+                    hr = r(h, temb)
+                    h = cat.produce_skip(lambda: self._att(j, hr, ctx), shape)
+                else:
+                    hp = h
+                    h = cat.produce_skip(lambda: r(hp, temb), shape)
             skips.append(h)
         if hasattr(self, "downsamplers"):
-            h = self.downsamplers[0](h)
+            if cat is None:
+                h = self.downsamplers[0](h)
+            else:
+                hp = h
+                shape = (h.shape[0], h.shape[1], (h.shape[2] - 1) // 2 + 1, (h.shape[3] - 1) // 2 + 1)
+                h = cat.produce_skip(lambda: self.downsamplers[0](hp), shape)
             skips.append(h)
         return h
 
-    def run_mid(self, h, temb, ctx):
+    def run_mid(self, h, temb, ctx, cat=None):
         h = self.resnets[0](h, temb)
-        for j, r in enumerate(self.resnets[1:]):
-            h = r(self._att(j, h, ctx), temb)
+        rest = list(self.resnets[1:])
+        for j, r in enumerate(rest):
+            ha = self._att(j, h, ctx)
+            if cat is not None and j == len(rest) - 1:
+                h = cat.produce_h(lambda: r(ha, temb))             # the hidden state of the first up concatenation
+            else:
+                h = r(ha, temb)
         return h
 
-    def run_up(self, h, temb, ctx, skips):
+    def run_up(self, h, temb, ctx, skips, cat=None):
+        has_att, has_up = hasattr(self, "attentions"), hasattr(self, "upsamplers")
+        n = len(self.resnets)
         for j, r in enumerate(self.resnets):
-            h = self._att(j, r(_cat_channels(h, skips.pop()), temb), ctx)
-        if hasattr(self, "upsamplers"):
-            h = self.upsamplers[0](h)
+            if cat is None:
+                h = self._att(j, r(_cat_channels(h, skips.pop()), temb), ctx)
+                continue
+            skips.pop()
+            x = cat.join(h)
+            feeds_cat = not (j == n - 1 and has_up)                # the last hidden state of a stage goes through its upsampler first
+            if has_att:
+                hr = r(x, temb)
+                h = cat.produce_h(lambda: self._att(j, hr, ctx)) if feeds_cat else self._att(j, hr, ctx)
+            else:
+                h = cat.produce_h(lambda: r(x, temb)) if feeds_cat else r(x, temb)
+        if has_up:
+            hp = h
+            h = cat.produce_h(lambda: self.upsamplers[0](hp)) if cat is not None else self.upsamplers[0](h)
         return h
 
 
@@ -389,13 +504,24 @@ class UNet2DConditionModel(nn.Module):
             te = self.add_time_proj(time_ids.flatten()).reshape((text_embeds.shape[0], -1))
             emb = emb + self.add_embedding(torch.cat([text_embeds, te], dim=-1).to(emb.dtype))
         ctx = encoder_hidden_states
-        h = self.conv_in(_cl(sample))
+        cat = None
+        if _fusion_on() and sample.is_cuda and not torch.is_grad_enabled():
+            from .. import ops
+            if ops.CAT_INPLACE:
+                cat = _CatInPlace(self, sample.dtype, sample.device)
+        x0 = _cl(sample)
+        ff = getattr(self.conv_in, "forward_final", None)
+        if cat is not None and ff is not None:
+            h = cat.produce_skip(lambda: ff(x0), (x0.shape[0], _out_channels(self.conv_in), x0.shape[2], x0.shape[3]))
+        else:
+            cat = None
+            h = self.conv_in(x0)
         skips = [h]
         for blk in self.down_blocks:
-            h = blk.run_down(h, emb, ctx, skips)
-        h = self.mid_block.run_mid(h, emb, ctx)
+            h = blk.run_down(h, emb, ctx, skips, cat)
+        h = self.mid_block.run_mid(h, emb, ctx, cat)
         for blk in self.up_blocks:
-            h = blk.run_up(h, emb, ctx, skips)
+            h = blk.run_up(h, emb, ctx, skips, cat)
         fuse = getattr(self.conv_out, "can_fuse_prenorm", None)
         if fuse is not None and _fusion_on() and isinstance(self.conv_act, nn.SiLU) and fuse(h):
             return [self.conv_out.forward_prenorm(h, self.conv_norm_out, silu=True)]

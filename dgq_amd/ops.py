@@ -373,6 +373,34 @@ GN_FROM_SPLITK = True
 CONV_IMPLICIT = True
 
 
+class OutputRedirect:
+    """Where the NEXT "final" layer call of a module may put its output: ``out`` — an [M][N] row view it stores INTO (its result tensor is
+    then a view of that memory), ``out2`` — one it stores into AS WELL.  The UNet sets ``ops.REDIRECT`` around the call of a module whose
+    output is one half of an up-path concatenation (diffusers_rewrite/sd.py:558-613), both halves being row slices [:, :C1] / [:, C1:] of
+    one [M][C1 + C2] buffer; a layer call made with ``final=True`` (the call whose result IS the module's result, residual included)
+    takes it.  Nobody taking it is fine: the caller then finds its tensors elsewhere and concatenates as before."""
+
+    def __init__(self, out=None, out2=None):
+        self.out, self.out2, self.taken = out, out2, False
+
+
+REDIRECT = None
+#: DGQ_CAT_INPLACE=0 (A/B runs): torch.cat for every skip concatenation
+CAT_INPLACE = os.environ.get("DGQ_CAT_INPLACE", "1") != "0"
+
+
+def take_redirect(M, N, dtype):
+    """the pending OutputRedirect's (out, out2) if its views have this layer's output shape and dtype, else (None, None)"""
+    rd = REDIRECT
+    if rd is None or rd.taken:
+        return None, None
+    for v in (rd.out, rd.out2):
+        if v is not None and (tuple(v.shape) != (M, N) or v.dtype != dtype or v.stride(1) != 1):
+            return None, None
+    rd.taken = True
+    return rd.out, rd.out2
+
+
 def cat_channels(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     """torch.cat([a, b], dim=1) of two NCHW tensors that keeps the GroupNorm partials of both sources (the skip concatenation in
     front of an up block's norm1): dgq_groupnorm_from_partials takes the two partial buffers as one channel range."""
@@ -484,14 +512,18 @@ def workspace(device):
     return _WORKSPACE[key]
 
 
-def make_extra(residual=None, fq=None, res_div=1, geglu=False, gn_partial=None, conv=None):
+def make_extra(residual=None, fq=None, res_div=1, geglu=False, gn_partial=None, conv=None, y2=None):
     """dgq_gemm_extra_t: residual [M / res_div][N] fp32 (row stride = its stride(0); res_div > 1 broadcasts each row
     over res_div consecutive output rows); fq = (mode, delta, zp, T, D, skip, bits) with mode 1 scalar / 2 per token /
     3 per head-dim; geglu = the pair epilogue of a row-interleaved ff.net.0.  Keeps the tensors alive on the returned object."""
-    if residual is None and fq is None and not geglu and gn_partial is None and conv is None:
+    if residual is None and fq is None and not geglu and gn_partial is None and conv is None and y2 is None:
         return None
     ex = _lib.GemmExtra()
     ex.res_div = 1
+    if y2 is not None:                                      # a second copy of the output rows ([M][N] view, its own row pitch)
+        assert y2.dim() == 2 and y2.stride(1) == 1
+        ex.y2, ex.ldy2 = y2.data_ptr(), y2.stride(0)
+        ex._y2_keep = y2
     ex.conv = None
     ex.flush_coef = None
     if conv is not None:                                    # (dgq_gemm_conv_t, tensors it points to)
@@ -806,13 +838,16 @@ def quant_linear_multi(x: torch.Tensor, bindings, ln=None):
     return [o.view(*x.shape[:-1], o.shape[-1]) for o in outs]
 
 
-def quant_conv2d(x: torch.Tensor, ab: ActBinding, kh, kw, stride, pad, norm=None, residual=None, bias_rows=None, gn_out=True, upsample=False):
+def quant_conv2d(x: torch.Tensor, ab: ActBinding, kh, kw, stride, pad, norm=None, residual=None, bias_rows=None, gn_out=True, upsample=False,
+                 out=None, out2=None):
     """x logical NCHW (any strides; made channels-last) -> logical NCHW output in channels-last storage.
     norm = (groups, eps, gamma, beta, act): GroupNorm (+SiLU) of x folded into the quantise-on-load pass;
     residual (logical NCHW, same shape as the output) is added in the GEMM epilogue; bias_rows [B][N] likewise, one row
     per image (conv1(...) + time_emb_proj(...)[:, :, None, None]).
     upsample: the layer's input is F.interpolate(x, scale_factor=2, mode="nearest") (Upsample2D.forward); where the quantise
-    variant of the layer can read x through that mapping the 4x tensor is never written, otherwise it is materialised here."""
+    variant of the layer can read x through that mapping the 4x tensor is never written, otherwise it is materialised here.
+    out / out2: [M][N] row views (own row pitch) the output is stored into / stored into AS WELL (OutputRedirect: the halves of a
+    channel-concatenation buffer); the returned tensor is a view of ``out`` then."""
     if upsample and (norm is not None or ab.mode == "scalar" or kh * kw == 1):
         x, upsample = F.interpolate(x, scale_factor=2.0, mode="nearest"), False
     B, C, H, W = x.shape
@@ -841,7 +876,8 @@ def quant_conv2d(x: torch.Tensor, ab: ActBinding, kh, kw, stride, pad, norm=None
     if kh == 1 and kw == 1 and stride == 1 and pad == 0 and act_fuses(ab, M, C, x.dtype, x2=x_store.reshape(M, C)):
         # a 1x1 convolution is a Linear layer over the pixels: one launch, the GEMM quantises its own rows (dgq_gemm_act_t)
         part = torch.empty((M // 16, N, 2), dtype=torch.float32, device=x.device) if (GN_FROM_GEMM and gn_out and (Ho * Wo) % 16 == 0 and N % 4 == 0) else None
-        y = gemm_act(x_store.reshape(M, C), M, ab, x.dtype, extra=make_extra(res2, res_div=res_div, gn_partial=part), pre=pre, rows_per_image=H * W)
+        y = gemm_act(x_store.reshape(M, C), M, ab, x.dtype, extra=make_extra(res2, res_div=res_div, gn_partial=part, y2=out2), pre=pre, rows_per_image=H * W,
+                     out=out)
         out = y.view(B, Ho, Wo, N).permute(0, 3, 1, 2)
         if part is not None:
             out._dgq_gn = dict(parts=[(part, N)], B=B, HW=Ho * Wo, C=N, ver=out._version)
@@ -863,10 +899,10 @@ def quant_conv2d(x: torch.Tensor, ab: ActBinding, kh, kw, stride, pad, norm=None
                 act.pre_scale, act.pre_shift = pre[0].data_ptr(), pre[1].data_ptr()
                 act._keep += [pre[0], pre[1]]
             act.pre_act = pre[2]
-        extra = with_layer_tables(make_extra(res2, res_div=res_div, gn_partial=part), ab, M)
+        extra = with_layer_tables(make_extra(res2, res_div=res_div, gn_partial=part, y2=out2), ab, M)
         extra.act = _c.cast(_c.pointer(act), _c.c_void_p)
         extra._act_keep = act
-        y = gemm_wxa8(ab.wfrag, ab.wfrag, M, ab, x.dtype, extra=extra, _fused_bytes=x.element_size() * B * H * W * C)
+        y = gemm_wxa8(ab.wfrag, ab.wfrag, M, ab, x.dtype, out=out, extra=extra, _fused_bytes=x.element_size() * B * H * W * C)
         out = y.view(B, Ho, Wo, N).permute(0, 3, 1, 2)
         if part is not None:
             out._dgq_gn = dict(parts=[(part, N)], B=B, HW=Ho * Wo, C=N, ver=out._version)
@@ -889,7 +925,7 @@ def quant_conv2d(x: torch.Tensor, ab: ActBinding, kh, kw, stride, pad, norm=None
         qa = quant_act(x_store, B, H, W, C, kh, kw, stride, pad, ab, pre, ups=upsample)
         if qa is None:                                # no folded form for this layer's quantise variant: materialise the upsample
             return quant_conv2d(F.interpolate(x, scale_factor=2.0, mode="nearest"), ab, kh, kw, stride, pad, norm=norm, residual=residual,
-                                bias_rows=bias_rows, gn_out=gn_out)
+                                bias_rows=bias_rows, gn_out=gn_out, out=out, out2=out2)
         codes, rowsum, M = qa
     # GroupNorm partials of the output for whoever normalises it next: from the GEMM's own epilogue, or — a K-split launch —
     # from its combine kernel (DGQ_GN_FROM_SPLITK=0: only unsplit launches, the tensor gets a statistics pass otherwise)
@@ -898,14 +934,14 @@ def quant_conv2d(x: torch.Tensor, ab: ActBinding, kh, kw, stride, pad, norm=None
     if (GN_FROM_GEMM and gn_out and (Ho * Wo) % 16 == 0 and N % 4 == 0 and
             (GN_FROM_SPLITK or _lib.load().dgq_gemm_plan_splits(M, N, ab.Kp, ab.pw.bits, 0 if ab.mode == "perK" else 1, WORKSPACE_BYTES) == 1)):
         part = torch.empty((M // 16, N, 2), dtype=torch.float32, device=x.device)
-    y = gemm_wxa8(codes, rowsum, M, ab, x.dtype, extra=make_extra(res2, res_div=res_div, gn_partial=part, conv=conv_desc))
+    y = gemm_wxa8(codes, rowsum, M, ab, x.dtype, out=out, extra=make_extra(res2, res_div=res_div, gn_partial=part, conv=conv_desc, y2=out2))
     out = y.view(B, Ho, Wo, N).permute(0, 3, 1, 2)
     if part is not None:
         out._dgq_gn = dict(parts=[(part, N)], B=B, HW=Ho * Wo, C=N, ver=out._version)
     return out
 
 
-def conv2d_f32w(x: torch.Tensor, w_nat: torch.Tensor, bias, kh, kw, stride, pad, norm=None):
+def conv2d_f32w(x: torch.Tensor, w_nat: torch.Tensor, bias, kh, kw, stride, pad, norm=None, out2=None):
     """Weight-only state: conv2d / linear of UNQUANTISED activations with the dequantised weight, exact fp32 MFMA with the
     im2col folded into the load (dgq_conv2d_f32w).  x logical NCHW (made channels-last) or [..., K] for a Linear layer
     (kh = kw = 1); w_nat [N][kh·kw·C] fp32 with K in (tap, c) order; bias [N] fp32 or None.
@@ -932,7 +968,7 @@ def conv2d_f32w(x: torch.Tensor, w_nat: torch.Tensor, bias, kh, kw, stride, pad,
         y = torch.empty((B * Ho * Wo, N), dtype=x.dtype, device=x.device)
         _lib_call("dgq_conv2d_f32w", _lib.ptr(xs), _lib.DTYPE_CODE[x.dtype], B, H, W, C, kh, kw, stride, pad,
                   _lib.ptr(w_nat), _lib.ptr(bias), N, _lib.ptr(y), _lib.DTYPE_CODE[y.dtype], N,
-                  _lib.ptr(sc), _lib.ptr(sh), int(act), _lib.stream())
+                  _lib.ptr(sc), _lib.ptr(sh), int(act), _lib.ptr(out2), out2.stride(0) if out2 is not None else 0, _lib.stream())
         return y.view(B, Ho, Wo, N).permute(0, 3, 1, 2)
     K = x.shape[-1]
     assert w_nat.shape[1] == K and kh == kw == 1, "dgq conv2d_f32w: weight [N][%d] does not match input %s" % (w_nat.shape[1], tuple(x.shape))
@@ -942,7 +978,7 @@ def conv2d_f32w(x: torch.Tensor, w_nat: torch.Tensor, bias, kh, kw, stride, pad,
     y = torch.empty((x2.shape[0], N), dtype=x.dtype, device=x.device)
     assert norm is None
     _lib_call("dgq_conv2d_f32w", _lib.ptr(x2), _lib.DTYPE_CODE[x.dtype], x2.shape[0], 1, 1, K, 1, 1, 1, 0,
-              _lib.ptr(w_nat), _lib.ptr(bias), N, _lib.ptr(y), _lib.DTYPE_CODE[y.dtype], N, None, None, 0, _lib.stream())
+              _lib.ptr(w_nat), _lib.ptr(bias), N, _lib.ptr(y), _lib.DTYPE_CODE[y.dtype], N, None, None, 0, None, 0, _lib.stream())
     return y.view(*x.shape[:-1], N)
 
 

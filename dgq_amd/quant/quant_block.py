@@ -129,11 +129,11 @@ class QuantResnetBlock2D(BaseQuantBlock):
         self.nonlinearity = resnet.nonlinearity
         self.conv_shortcut = resnet.conv_shortcut
 
-    def _norm_act_conv(self, norm, conv, x, residual=None, bias_rows=None):
-        """conv(SiLU(norm(x))) + residual (same shape) or + bias_rows[:, :, None, None] ([B, C_out])"""
+    def _norm_act_conv(self, norm, conv, x, residual=None, bias_rows=None, final=False):
+        """conv(SiLU(norm(x))) + residual (same shape) or + bias_rows[:, :, None, None] ([B, C_out]); final: the block's own result"""
         if FUSION and FUSE_NORM and isinstance(conv, QuantLayer) and isinstance(norm, nn.GroupNorm) and conv.can_fuse_prenorm(x):
             if _F_RES:
-                return conv.forward_prenorm(x, norm, silu=True, residual=residual, bias_rows=bias_rows)
+                return conv.forward_prenorm(x, norm, silu=True, residual=residual, bias_rows=bias_rows, final=final)
             y = conv.forward_prenorm(x, norm, silu=True)
         else:
             h = F.silu(norm(x))
@@ -160,7 +160,7 @@ class QuantResnetBlock2D(BaseQuantBlock):
             te = self.time_emb_proj(F.silu(temb))
         h = self._norm_act_conv(self.norm1, self.conv1, input_tensor, bias_rows=te)   # + temb in conv1's epilogue
         sc = self.conv_shortcut(input_tensor) if self.conv_shortcut is not None else input_tensor
-        return self._norm_act_conv(self.norm2, self.conv2, h, residual=sc)     # shortcut + conv2(...) in the epilogue
+        return self._norm_act_conv(self.norm2, self.conv2, h, residual=sc, final=True)     # shortcut + conv2(...) in the epilogue
 
 
 def _qparams(q: UniformAffineQuantizer, dev):

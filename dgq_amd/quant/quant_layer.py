@@ -613,7 +613,37 @@ class QuantLayer(nn.Module):
             y = y.index_select(-1, self._row_unperm(y.device))
         return _tap(self, y, x=x, prologue=False)
 
-    def forward_upsampled(self, x: torch.Tensor) -> torch.Tensor:
+    def _take_redirect(self, x: torch.Tensor, scale: int = 1):
+        """(out, out2) of a pending ops.OutputRedirect for this convolution's output on input x (spatially scaled by ``scale``), or
+        (None, None): asked only by the calls whose result IS their module's result (``final=True``)."""
+        if ops.REDIRECT is None or not self.is_conv or x.dim() != 4:
+            return None, None
+        kh, kw = self.w.shape[2], self.w.shape[3]
+        st, pd = self.fwd_kwargs["stride"][0], self.fwd_kwargs["padding"][0]
+        Ho = (x.shape[2] * scale + 2 * pd - kh) // st + 1
+        Wo = (x.shape[3] * scale + 2 * pd - kw) // st + 1
+        return ops.take_redirect(x.shape[0] * Ho * Wo, self.w.shape[0], x.dtype)
+
+    def forward_final(self, x: torch.Tensor) -> torch.Tensor:
+        """``self(x)`` where the result is the calling module's own result (Downsample2D.conv, the UNet's conv_in): the one place a
+        pending ops.OutputRedirect is honoured on the plain path — integer path or FP state of a convolution, no tap, no hooks."""
+        if (ops.REDIRECT is not None and self.is_conv and x.is_cuda and x.dtype in ops.FLOAT_DTYPES and LAYER_TAP is None and not self.aqtizer.calibrating()
+                and not self._forward_hooks and not self._forward_pre_hooks and not torch.is_grad_enabled()):
+            kh, kw = self.w.shape[2], self.w.shape[3]
+            st, pd = self.fwd_kwargs["stride"][0], self.fwd_kwargs["padding"][0]
+            if self.on_integer_path(x):
+                out, out2 = self._take_redirect(x)
+                return ops.quant_conv2d(x, self._binding(), kh, kw, st, pd, out=out, out2=out2)
+            if (not self.use_wq and not (self.use_aq and not self.disable_aq) and FP_STATE_HIP
+                    and tuple(self.fwd_kwargs.get("dilation", (1, 1)))[0] == 1 and self.fwd_kwargs.get("groups", 1) == 1):
+                out, out2 = self._take_redirect(x)
+                if out is None:                                   # (the FP kernel takes the second copy only)
+                    self._fp_natural(x.device)
+                    return ops.conv2d_f32w(x, self._wnat_fp[1], self._wnat_fp[2], kh, kw, st, pd, out2=out2)
+                ops.REDIRECT.taken = False
+        return self(x)
+
+    def forward_upsampled(self, x: torch.Tensor, final: bool = False) -> torch.Tensor:
         """``self(F.interpolate(x, scale_factor=2.0, mode="nearest"))`` — Upsample2D.forward (diffusers_rewrite/sd.py).  On the integer
         path of a k x k convolution the quantise-on-load pass reads x through the (h/2, w/2) mapping and the upsampled tensor is
         never written (ops.quant_conv2d(upsample=True)); with a layer tap installed, during calibration or in any other state the
@@ -621,7 +651,9 @@ class QuantLayer(nn.Module):
         if (LAYER_TAP is None and self.is_conv and self.on_integer_path(x) and x.dtype in ops.FLOAT_DTYPES and not self.aqtizer.calibrating()
                 and not self._forward_hooks and not self._forward_pre_hooks and self.w.shape[2] * self.w.shape[3] > 1):
             kh, kw = self.w.shape[2], self.w.shape[3]
-            return ops.quant_conv2d(x, self._binding(), kh, kw, self.fwd_kwargs["stride"][0], self.fwd_kwargs["padding"][0], upsample=True)
+            out, out2 = self._take_redirect(x, 2) if final else (None, None)
+            return ops.quant_conv2d(x, self._binding(), kh, kw, self.fwd_kwargs["stride"][0], self.fwd_kwargs["padding"][0], upsample=True,
+                                    out=out, out2=out2)
         return self(F.interpolate(x, scale_factor=2.0, mode="nearest"))
 
     def on_integer_path(self, x: torch.Tensor) -> bool:
@@ -671,13 +703,15 @@ class QuantLayer(nn.Module):
                 and x.dtype in ops.FLOAT_DTYPES
                 and (self.aqtizer.init or (self._slot_ref is not None and self._slot_ref.slot in self._act_tables)))
 
-    def forward_prenorm(self, x: torch.Tensor, norm: nn.GroupNorm, silu: bool = True, residual=None, bias_rows=None) -> torch.Tensor:
-        """conv(act(GroupNorm(x))) [+ residual | + bias_rows[b, :, None, None]] without materialising the normalised tensor."""
+    def forward_prenorm(self, x: torch.Tensor, norm: nn.GroupNorm, silu: bool = True, residual=None, bias_rows=None, final: bool = False) -> torch.Tensor:
+        """conv(act(GroupNorm(x))) [+ residual | + bias_rows[b, :, None, None]] without materialising the normalised tensor.
+        final: the result is the calling module's own result (a pending ops.OutputRedirect may place it)."""
         ab = self._binding()
         kh, kw = self.w.shape[2], self.w.shape[3]
+        out, out2 = self._take_redirect(x) if (final and LAYER_TAP is None) else (None, None)
         return _tap(self, ops.quant_conv2d(x, ab, kh, kw, self.fwd_kwargs["stride"][0], self.fwd_kwargs["padding"][0],
                                            norm=(norm.num_groups, norm.eps, norm.weight, norm.bias, 1 if silu else 0),
-                                           residual=residual, bias_rows=bias_rows),
+                                           residual=residual, bias_rows=bias_rows, out=out, out2=out2),
                     x=x, prologue=True, residual=residual, bias_rows=bias_rows)
 
     # -- Linear projections of a Transformer2D with use_linear_projection (SDXL, sdxl.py: proj_in / proj_out are nn.Linear over the
@@ -730,12 +764,14 @@ class QuantLayer(nn.Module):
             self._wnat_fp = (key, wf.reshape(wf.shape[0], -1).contiguous(), bf)
         return self._wnat_fp[1], self._wnat_fp[2]
 
-    def forward_residual(self, x: torch.Tensor, residual) -> torch.Tensor:
-        """conv(x) + residual with the add in the GEMM epilogue (integer path), else unfused."""
+    def forward_residual(self, x: torch.Tensor, residual, final: bool = False) -> torch.Tensor:
+        """conv(x) + residual with the add in the GEMM epilogue (integer path), else unfused.
+        final: the result is the calling module's own result (a pending ops.OutputRedirect may place it)."""
         if self.is_conv and self.on_integer_path(x) and x.dtype in ops.FLOAT_DTYPES:
             kh, kw = self.w.shape[2], self.w.shape[3]
+            out, out2 = self._take_redirect(x) if (final and LAYER_TAP is None) else (None, None)
             return _tap(self, ops.quant_conv2d(x, self._binding(), kh, kw, self.fwd_kwargs["stride"][0],
-                                               self.fwd_kwargs["padding"][0], residual=residual),
+                                               self.fwd_kwargs["padding"][0], residual=residual, out=out, out2=out2),
                         x=x, prologue=False, residual=residual)
         return self(x) + residual
 

@@ -40,8 +40,9 @@ extern "C" {
  *   120  round 6: dgq_attention_sync_timeouts; the attention workspace's δ area is 512 bytes; dgq_gemm_act_t += kpat, B, H, W, kh, kw,
  *        stride, pad; dgq_gemm_conv_act_fuses
  *   121  round 6: dgq_cfg_ddim_step takes the tensors' dtype (void pointers + `dtype`); dgq_attention_workspace_bytes grew by one fp32
- *        part area (key-split launches on 16-bit tensors) */
-#define DGQ_ABI_VERSION 121
+ *        part area (key-split launches on 16-bit tensors)
+ *   122  round 6: dgq_gemm_extra_t += y2, ldy2; dgq_conv2d_f32w takes y2 / ldy2 */
+#define DGQ_ABI_VERSION 122
 int dgq_version(void);
 const char* dgq_last_error(void);
 
@@ -173,10 +174,11 @@ int dgq_cfg_ddim_step(const void* eps_uncond, const void* eps_cond, const void* 
  * K in (tap, c) order, y [B·Ho·Wo][ldy] (y_dtype).  A Linear layer is B = rows, H = W = kh = kw = stride = 1, pad = 0.
  * Optional prologue as in dgq_quant_act: pre_scale / pre_shift [B][C] (a GroupNorm folded into the load: x·scale + shift) and
  * pre_act = 1 (SiLU) — conv_out(SiLU(conv_norm_out(x))) of the UNets in one launch.
- * Replaces F.linear / F.conv2d on the dequantised (or, for the FP conv_in / conv_out, the original) weight. */
+ * Replaces F.linear / F.conv2d on the dequantised (or, for the FP conv_in / conv_out, the original) weight. 
+ * y2 (or NULL), ldy2: a second copy of the output rows, as dgq_gemm_extra_t.y2. */
 int dgq_conv2d_f32w(const void* x, int x_dtype, int B, int H, int W, int C, int kh, int kw, int stride, int pad,
                     const float* w, const float* bias, int N, void* y, int y_dtype, int ldy,
-                    const float* pre_scale, const float* pre_shift, int pre_act, void* stream);
+                    const float* pre_scale, const float* pre_shift, int pre_act, void* y2, int ldy2, void* stream);
 
 /* ---- the hot kernel: W4A8 / W8A8 MFMA GEMM with fused dequantisation ------------------------------
  * Replaces F.linear / `w.view(N,-1) @ unfolded` / F.conv2d on fake-quantised operands
@@ -276,6 +278,12 @@ typedef struct dgq_gemm_extra {
                                       * (gemm_panel.hip: the activations' whole K slice in LDS, weights streamed straight into MFMA
                                       * B fragments) for the launches it is faster on; results are those of the other kernels. */
     const dgq_gemm_act_t* act;       /* (or NULL) quantise-on-load inside the GEMM, see dgq_gemm_act_t; needs wfrag */
+    void* y2;                        /* (or NULL) a SECOND copy of the output rows, y_dtype, row pitch ldy2 >= N elements: the layer's output
+                                      * stored as well into its slot of a channel-concatenation buffer (the skip connections of the
+                                      * up path, diffusers_rewrite/sd.py:558-613: torch.cat([h, skip], 1) of channels-last tensors is
+                                      * [M][C1 + C2] rows) — with `y` / ldy pointing into such a buffer for the other half, no
+                                      * concatenation launch is needed.  Not with the GEGLU epilogue. */
+    int ldy2;
 } dgq_gemm_extra_t;
 
 int dgq_gemm_wxa8(const int8_t* codes, const float* rowsum, int rowsum_parts, int M, int Kp,

@@ -1246,6 +1246,56 @@ def test_c5_full_size_launch_plans_equal_the_small_tile_forms(case, dev, monkeyp
     assert torch.isfinite(y1).all() and torch.equal(y0, y1), (case, (y0 - y1).abs().max().item())
 
 
+@pytest.mark.parametrize("case", ["conv3x3_perK_tile", "conv3x3_perM_convq", "conv1x1_fused", "conv3x3_splitk", "fp_conv_in"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_output_redirect_into_a_concatenation_buffer(case, dtype, dev):
+    """dgq_gemm_extra_t.y2 / a strided y (ops.OutputRedirect): a layer's output stored INTO rows [:, :C1] of a [M][C1 + C2] buffer, or
+    stored there AS WELL as into its own tensor ([:, C1:]) — the two halves of torch.cat([h, skip], 1) of channels-last tensors
+    (sd.py:558-613) — equals the plain call bit for bit, the rest of the buffer untouched; through the tile family, the conv kernel with
+    its quantiser inside, the fused 1x1 form, a K-split launch with its combine, and the FP conv_in kernel."""
+    from dgq_amd import ops, synth
+    from dgq_amd.plan import plan_act
+    gen = torch.Generator().manual_seed(len(case))
+    B, C, H, N, k, mode = {"conv3x3_perK_tile": (2, 64, 16, 96, 3, "perK"), "conv3x3_perM_convq": (1, 320, 32, 320, 3, "perM"),
+                           "conv1x1_fused": (2, 320, 32, 320, 1, "perK"), "conv3x3_splitk": (2, 1280, 8, 1280, 3, "perK"),
+                           "fp_conv_in": (2, 4, 16, 320, 3, None)}[case]
+    x = (torch.randn(B, C, H, H, generator=gen) * 1.3 + 0.2).to(dev).to(dtype).contiguous(memory_format=torch.channels_last)
+    res = torch.randn(B, N, H, H, generator=gen).to(dev).to(dtype).contiguous(memory_format=torch.channels_last)
+    M, C1 = B * H * H, 64
+    if mode is None:
+        w = torch.randn(N, C * 9, generator=gen).to(dev) * 0.1
+        b = torch.randn(N, generator=gen).to(dev)
+        run = lambda **kw: ops.conv2d_f32w(x, w, b, 3, 3, 1, 1, out2=kw.get("out2"))
+    else:
+        w = (torch.randn(N, C, k, k, generator=gen) * 0.05).to(dev)
+        wd, wz = synth.channel_minmax(w.cpu(), 4)
+        pw = ops.PackedWeight(w, wd.to(dev), wz.to(dev), None, torch.randn(N, generator=gen).to(dev), 4, C, k * k)
+        if mode == "perK":
+            d, z = synth._group_params(C * k * k, 16, 8, "rd|%s" % case, 0)
+            lay = plan_act(d.view(1, -1, 1), z.view(1, -1, 1), "conv", C, k * k, 8)
+        else:
+            d, z = synth._group_params(H * H, 16, 8, "rd|%s" % case, 0)
+            lay = plan_act(d.view(1, 1, -1), z.view(1, 1, -1), "conv", C, k * k, 8)
+        ab = ops.ActBinding(lay, pw, 8)
+        run = lambda **kw: ops.quant_conv2d(x, ab, k, k, 1, k // 2, residual=res, **kw)
+    y0 = run()
+    buf = torch.full((M, C1 + N + 32), 7.0, dtype=dtype, device=dev)
+    y1 = run(out2=buf[:, C1:C1 + N])                                   # second copy
+    torch.cuda.synchronize()
+    assert torch.equal(y0, y1) and torch.equal(buf[:, C1:C1 + N].view(B, H, H, N).permute(0, 3, 1, 2), y0)
+    assert bool((buf[:, :C1] == 7.0).all()) and bool((buf[:, C1 + N:] == 7.0).all())
+    if mode is not None:
+        buf.fill_(7.0)
+        y2 = run(out=buf[:, C1:C1 + N])                                # the output itself lives in the buffer
+        torch.cuda.synchronize()
+        assert y2.data_ptr() == buf[:, C1:].data_ptr() and torch.equal(y2, y0)
+        assert bool((buf[:, :C1] == 7.0).all()) and bool((buf[:, C1 + N:] == 7.0).all())
+        g0, g2 = ops._gn_of(y0), ops._gn_of(y2)
+        assert (g0 is None) == (g2 is None)
+        if g0 is not None:
+            assert torch.equal(g0["parts"][0][0], g2["parts"][0][0])
+
+
 # ------------------------------------------------------------------------------------------ step glue (glue.hip)
 @pytest.mark.parametrize("dim,tdtype", [(320, torch.int64), (256, torch.float32), (320, torch.float32)])
 def test_timestep_embedding_is_the_torch_chain(dim, tdtype, dev):
