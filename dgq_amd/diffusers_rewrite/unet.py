@@ -67,11 +67,11 @@ class _CatInPlace:
             e.c1 = self.ctot[i] - C2
             buf = torch.empty((B, H, W, self.ctot[i]), dtype=self.dtype, device=self.device)
             rd = self.ops.OutputRedirect(out2=self._views(buf, e.c1)[1])
-            self.ops.REDIRECT = rd
+            self.ops.set_redirect(rd)
             try:
                 y = fn()
             finally:
-                self.ops.REDIRECT = None
+                self.ops.set_redirect(None)
             if rd.taken and tuple(y.shape) == tuple(shape):
                 e.buf = buf
         else:
@@ -87,11 +87,11 @@ class _CatInPlace:
         if e is None or e.buf is None:
             return fn()
         rd = self.ops.OutputRedirect(out=self._views(e.buf, e.c1)[0])
-        self.ops.REDIRECT = rd
+        self.ops.set_redirect(rd)
         try:
             y = fn()
         finally:
-            self.ops.REDIRECT = None
+            self.ops.set_redirect(None)
         e.h_inplace = bool(rd.taken and y.data_ptr() == e.buf.data_ptr() and y.shape[1] == e.c1 and y.shape[2:] == e.tensor.shape[2:])
         return y
 

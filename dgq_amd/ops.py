@@ -3,6 +3,7 @@
 hot path: a quantized layer call is `dgq_quant_act` + `dgq_gemm_wxa8`."""
 import ctypes
 import os
+import threading
 from typing import Optional
 
 import torch
@@ -375,7 +376,7 @@ CONV_IMPLICIT = True
 
 class OutputRedirect:
     """Where the NEXT "final" layer call of a module may put its output: ``out`` — an [M][N] row view it stores INTO (its result tensor is
-    then a view of that memory), ``out2`` — one it stores into AS WELL.  The UNet sets ``ops.REDIRECT`` around the call of a module whose
+    then a view of that memory), ``out2`` — one it stores into AS WELL.  The UNet sets it (``ops.set_redirect``) around the call of a module whose
     output is one half of an up-path concatenation (diffusers_rewrite/sd.py:558-613), both halves being row slices [:, :C1] / [:, C1:] of
     one [M][C1 + C2] buffer; a layer call made with ``final=True`` (the call whose result IS the module's result, residual included)
     takes it.  Nobody taking it is fine: the caller then finds its tensors elsewhere and concatenates as before."""
@@ -384,14 +385,24 @@ class OutputRedirect:
         self.out, self.out2, self.taken = out, out2, False
 
 
-REDIRECT = None
+_REDIRECT_TLS = threading.local()                      # per thread: two threads running a model each never see the other's redirect
+
+
+def set_redirect(rd):
+    _REDIRECT_TLS.rd = rd
+
+
+def pending_redirect():
+    return getattr(_REDIRECT_TLS, "rd", None)
+
+
 #: DGQ_CAT_INPLACE=0 (A/B runs): torch.cat for every skip concatenation
 CAT_INPLACE = os.environ.get("DGQ_CAT_INPLACE", "1") != "0"
 
 
 def take_redirect(M, N, dtype):
     """the pending OutputRedirect's (out, out2) if its views have this layer's output shape and dtype, else (None, None)"""
-    rd = REDIRECT
+    rd = pending_redirect()
     if rd is None or rd.taken:
         return None, None
     for v in (rd.out, rd.out2):

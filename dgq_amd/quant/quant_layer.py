@@ -616,7 +616,7 @@ class QuantLayer(nn.Module):
     def _take_redirect(self, x: torch.Tensor, scale: int = 1):
         """(out, out2) of a pending ops.OutputRedirect for this convolution's output on input x (spatially scaled by ``scale``), or
         (None, None): asked only by the calls whose result IS their module's result (``final=True``)."""
-        if ops.REDIRECT is None or not self.is_conv or x.dim() != 4:
+        if ops.pending_redirect() is None or not self.is_conv or x.dim() != 4:
             return None, None
         kh, kw = self.w.shape[2], self.w.shape[3]
         st, pd = self.fwd_kwargs["stride"][0], self.fwd_kwargs["padding"][0]
@@ -627,7 +627,7 @@ class QuantLayer(nn.Module):
     def forward_final(self, x: torch.Tensor) -> torch.Tensor:
         """``self(x)`` where the result is the calling module's own result (Downsample2D.conv, the UNet's conv_in): the one place a
         pending ops.OutputRedirect is honoured on the plain path — integer path or FP state of a convolution, no tap, no hooks."""
-        if (ops.REDIRECT is not None and self.is_conv and x.is_cuda and x.dtype in ops.FLOAT_DTYPES and LAYER_TAP is None and not self.aqtizer.calibrating()
+        if (ops.pending_redirect() is not None and self.is_conv and x.is_cuda and x.dtype in ops.FLOAT_DTYPES and LAYER_TAP is None and not self.aqtizer.calibrating()
                 and not self._forward_hooks and not self._forward_pre_hooks and not torch.is_grad_enabled()):
             kh, kw = self.w.shape[2], self.w.shape[3]
             st, pd = self.fwd_kwargs["stride"][0], self.fwd_kwargs["padding"][0]
@@ -640,7 +640,7 @@ class QuantLayer(nn.Module):
                 if out is None:                                   # (the FP kernel takes the second copy only)
                     self._fp_natural(x.device)
                     return ops.conv2d_f32w(x, self._wnat_fp[1], self._wnat_fp[2], kh, kw, st, pd, out2=out2)
-                ops.REDIRECT.taken = False
+                ops.pending_redirect().taken = False
         return self(x)
 
     def forward_upsampled(self, x: torch.Tensor, final: bool = False) -> torch.Tensor:
