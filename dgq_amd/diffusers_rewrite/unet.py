@@ -323,7 +323,7 @@ class Transformer2DModel(nn.Module):
         if self.proj_kind != "conv":
             fo = getattr(self.proj_out, "can_fuse_tokens", None)
             if fo is not None and _residual_fusion_on() and fo(h):
-                return self.proj_out.forward_residual_tokens(h, res)   # h + res in proj_out's GEMM epilogue (+ GroupNorm partials)
+                return self.proj_out.forward_residual_tokens(h, res, final=True)   # h + res in proj_out's GEMM epilogue (+ GroupNorm partials)
             h = self.proj_out(h)
         h = h.reshape(b, hh, ww, c).permute(0, 3, 1, 2)      # NHWC storage viewed as NCHW
         if self.proj_kind == "conv":

@@ -729,11 +729,13 @@ class QuantLayer(nn.Module):
         b, n, hh, ww = y.shape
         return _tap(self, y.permute(0, 2, 3, 1).reshape(b, hh * ww, n), x=x, prologue=True)
 
-    def forward_residual_tokens(self, h: torch.Tensor, residual: torch.Tensor) -> torch.Tensor:
-        """Linear(h).reshape(B, H, W, N).permute(0, 3, 1, 2) + residual for tokens h [B, HW, C] and residual [B, N, H, W]."""
+    def forward_residual_tokens(self, h: torch.Tensor, residual: torch.Tensor, final: bool = False) -> torch.Tensor:
+        """Linear(h).reshape(B, H, W, N).permute(0, 3, 1, 2) + residual for tokens h [B, HW, C] and residual [B, N, H, W].
+        final: the result is the calling module's own result (a pending ops.OutputRedirect may place it)."""
         b, n, hh, ww = residual.shape
         x = h.reshape(b, hh, ww, h.shape[-1]).permute(0, 3, 1, 2)
-        y = ops.quant_conv2d(x, self._binding(), 1, 1, 1, 0, residual=residual)
+        o1, o2 = ops.take_redirect(b * hh * ww, n, x.dtype) if (final and LAYER_TAP is None) else (None, None)
+        y = ops.quant_conv2d(x, self._binding(), 1, 1, 1, 0, residual=residual, out=o1, out2=o2)
         yt = y.permute(0, 2, 3, 1).reshape(b, hh * ww, n)
         rt = residual.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1).reshape(b, hh * ww, n)
         out = _tap(self, yt, x=h, prologue=False, residual=rt)
