@@ -34,7 +34,7 @@ SIGNATURES = {
     "dgq_logquant_f32": [_vp, _vp, _i64, _i, _i, _vp, _i, _vp],
     "dgq_attention_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _vp, _i, _vp, _vp, ctypes.c_size_t, _vp],
     "dgq_attention": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _i, _vp, _i, _vp, _vp, ctypes.c_size_t, _vp],
-    "dgq_conv2d_f32w": [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _i, _vp, _vp, _i, _vp, _i, _vp],
+    "dgq_conv2d_f32w": [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _vp],
     "dgq_attention_fuses_fakequant": [_i, _i],
     "dgq_attention_workspace_bytes": [_i, _i, _i, _i, _i],
     "dgq_attention_sync_timeouts": [],

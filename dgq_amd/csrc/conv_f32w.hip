@@ -19,6 +19,7 @@ struct ConvF32Params {
     void* y;             // [M][ldy], y_dtype
     void* y2;            // (or nullptr) a second copy of the rows at pitch ldy2 (the output's slot in a concatenation buffer)
     int ldy2;
+    float* gn_partial;   // (or nullptr; M % 16 == 0) [M/16][N][2] = (mean, M2) per 16-row block and column of the values as stored: dgq_gemm_extra_t.gn_partial
     int x_dtype, y_dtype;
     int B, H, W, C, kh, kw, stride, pad, Ho, Wo, N, K, M, ldy;
 };
@@ -107,6 +108,35 @@ __global__ __launch_bounds__(256) void conv_f32w_kernel(ConvF32Params p) {
         const float v = acc[r] + bias;
         store_any(p.y, p.y_dtype, (int64_t)m * p.ldy + n, v);
         if (p.y2) store_any(p.y2, p.y_dtype, (int64_t)m * p.ldy2 + n, v);
+    }
+    if (p.gn_partial) {
+        // GroupNorm partials of the output (conv_in feeds the first resnet's norm1 and, as a skip, the last up resnet's): a lane holds 8 of
+        // the 16 rows of each of its two 16-row blocks (rows (r & 3) + 4·(lane >> 5) + 8·(r >> 2)), lane ^ 32 the other 8: two-pass
+        // statistics of the 8 stored values, merged with the partner's by Chan's formula (equal counts)
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            float val[8], sum = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                float v = acc[blk * 8 + q] + bias;
+                if (p.y_dtype == DGQ_F16) v = __half2float(__float2half(v));
+                else if (p.y_dtype == DGQ_BF16) v = __bfloat162float(__float2bfloat16(v));
+                val[q] = v;
+                sum += v;
+            }
+            float mean = sum * 0.125f, m2 = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) m2 += (val[q] - mean) * (val[q] - mean);
+            const float om = __shfl_xor(mean, 32, 64), o2 = __shfl_xor(m2, 32, 64);
+            const float dd = om - mean;
+            m2 = m2 + o2 + dd * dd * 4.0f;
+            mean = 0.5f * (mean + om);
+            const int mb = m0 + wm + blk * 16;
+            if ((lane >> 5) == 0 && mb < p.M) {
+                float* q2 = p.gn_partial + ((int64_t)(mb >> 4) * p.N + n) * 2;
+                q2[0] = mean; q2[1] = m2;
+            }
+        }
     }
 }
 
@@ -208,7 +238,7 @@ __global__ __launch_bounds__(256) void conv_f32w_smalln_kernel(ConvF32Params p) 
 
 extern "C" int dgq_conv2d_f32w(const void* x, int x_dtype, int B, int H, int W, int C, int kh, int kw, int stride, int pad,
                                const float* w, const float* bias, int N, void* y, int y_dtype, int ldy,
-                               const float* pre_scale, const float* pre_shift, int pre_act, void* y2, int ldy2, void* stream) {
+                               const float* pre_scale, const float* pre_shift, int pre_act, void* y2, int ldy2, float* gn_partial, void* stream) {
     DGQ_CHECK_ARG(x && w && y, "dgq_conv2d_f32w: null pointer");
     DGQ_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && kh > 0 && kw > 0 && stride > 0 && pad >= 0 && N > 0, "dgq_conv2d_f32w: bad geometry");
     DGQ_CHECK_ARG((x_dtype == DGQ_F32 || x_dtype == DGQ_F16 || x_dtype == DGQ_BF16) && (y_dtype == DGQ_F32 || y_dtype == DGQ_F16 || y_dtype == DGQ_BF16),
@@ -223,6 +253,8 @@ extern "C" int dgq_conv2d_f32w(const void* x, int x_dtype, int B, int H, int W, 
     p.N = N; p.K = kh * kw * C; p.M = B * p.Ho * p.Wo; p.ldy = ldy;
     DGQ_CHECK_ARG(ldy >= N && (!y2 || ldy2 >= N), "dgq_conv2d_f32w: ldy < N");
     p.y2 = y2; p.ldy2 = ldy2;
+    DGQ_CHECK_ARG(!gn_partial || (p.M % 16 == 0 && N > 8), "dgq_conv2d_f32w: GroupNorm partials need M %% 16 == 0 and the tiled kernel (N > 8)");
+    p.gn_partial = gn_partial;
     if (N <= 8) {
         if (N <= 4) hipLaunchKernelGGL(conv_f32w_smalln_kernel<4>, dim3((p.M + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
         else hipLaunchKernelGGL(conv_f32w_smalln_kernel<8>, dim3((p.M + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);

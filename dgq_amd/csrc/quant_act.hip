@@ -714,10 +714,24 @@ static ConvTile conv_tile(int C, int kh, int kw, int stride, int Kp) {
 // Where the path pays (tools/bench_qact_conv.py, profiles/r03_quant_act_conv_block.txt): the tile grid must cover the chip
 // (>= 256 workgroups), i.e. the 64x64-level convolutions and the wide 32x32 ones; on smaller grids the per-row paths, whose
 // workgroups hold four rows, keep more of the chip busy.
+static long conv_tiles(const QuantActParams& p, const ConvTile& t) {
+    return (long)p.B * ((p.Ho + t.th - 1) / t.th) * ((p.Wo + t.tw - 1) / t.tw);
+}
+// ... for a geometry: where the 4 x 4 tile leaves the grid short of the chip (2048 positions: 128 tiles) the 2 x 4 tile — the same patch
+// width, hence the same kpat table — covers it (the 320 -> 640 convolution of SD's 32 x 32 level: 29.8 us on the global-gather path,
+// which the tile rule used to leave it on, against 17 us here)
+static ConvTile conv_tile_geo(const QuantActParams& p) {
+    ConvTile t = conv_tile(p.C, p.kh, p.kw, p.stride, p.Kp);
+    if (t.id == 2 && conv_tiles(p, t) < 256) {
+        const int ph = (2 - 1) * p.stride + p.kh;
+        ConvTile h = {3, 2, 4, t.pw, (size_t)ph * t.pw * p.C * sizeof(float) + ((size_t)p.Kp * 2 + (size_t)(p.Kp >> 5) * 8 + 64)};
+        if (conv_tiles(p, h) >= 256) return h;
+    }
+    return t;
+}
 static bool conv_block_pays(const QuantActParams& p, const ConvTile& t) {
     if (t.id == 0) return false;
-    const long tiles = (long)p.B * ((p.Ho + t.th - 1) / t.th) * ((p.Wo + t.tw - 1) / t.tw);
-    return tiles >= 256 && p.M >= 2048;
+    return conv_tiles(p, t) >= 256 && p.M >= 2048;
 }
 
 extern "C" int dgq_quant_act_conv_tile(int C, int kh, int kw, int stride, int Kp, int* patch_w) {
@@ -750,7 +764,7 @@ static int quant_act_variant(const QuantActParams& p, bool table) {
     // convolutions whose input patch fits the LDS: the block-staged path
     {
         if (p.kpat && taps_ > 1 && p.C % 4 == 0 && ks == 1 && p.pre_act != 2 && !p.ln_gamma &&
-            conv_block_pays(p, conv_tile(p.C, p.kh, p.kw, p.stride, p.Kp)))
+            conv_block_pays(p, conv_tile_geo(p)))
             return 5;
     }
     const bool stage_conv = taps_ > 1 && p.pre_act != 2 && !p.ln_gamma && ks == 1;
@@ -782,7 +796,7 @@ static void launch_quant_act(const QuantActBatch& bt, int n, int variant, bool p
         strip_bytes = std::max(strip_bytes, (size_t)p.kh * p.kw * p.C * sizeof(float));
     }
     if (variant == 5) {
-        const ConvTile t = conv_tile(p0.C, p0.kh, p0.kw, p0.stride, p0.Kp);
+        const ConvTile t = conv_tile_geo(p0);
         const int tiles = p0.B * ((p0.Ho + t.th - 1) / t.th) * ((p0.Wo + t.tw - 1) / t.tw);
         static std::atomic<bool> attr5[64];
         int dev = 0;

@@ -952,7 +952,7 @@ def quant_conv2d(x: torch.Tensor, ab: ActBinding, kh, kw, stride, pad, norm=None
     return out
 
 
-def conv2d_f32w(x: torch.Tensor, w_nat: torch.Tensor, bias, kh, kw, stride, pad, norm=None, out2=None):
+def conv2d_f32w(x: torch.Tensor, w_nat: torch.Tensor, bias, kh, kw, stride, pad, norm=None, out2=None, gn_out=False):
     """Weight-only state: conv2d / linear of UNQUANTISED activations with the dequantised weight, exact fp32 MFMA with the
     im2col folded into the load (dgq_conv2d_f32w).  x logical NCHW (made channels-last) or [..., K] for a Linear layer
     (kh = kw = 1); w_nat [N][kh·kw·C] fp32 with K in (tap, c) order; bias [N] fp32 or None.
@@ -977,10 +977,16 @@ def conv2d_f32w(x: torch.Tensor, w_nat: torch.Tensor, bias, kh, kw, stride, pad,
         Ho = (H + 2 * pad - kh) // stride + 1
         Wo = (W + 2 * pad - kw) // stride + 1
         y = torch.empty((B * Ho * Wo, N), dtype=x.dtype, device=x.device)
+        part = None
+        if gn_out and GN_FROM_GEMM and (Ho * Wo) % 16 == 0 and N % 4 == 0 and N > 8:      # statistics for whoever normalises the output next
+            part = torch.empty((B * Ho * Wo // 16, N, 2), dtype=torch.float32, device=x.device)
         _lib_call("dgq_conv2d_f32w", _lib.ptr(xs), _lib.DTYPE_CODE[x.dtype], B, H, W, C, kh, kw, stride, pad,
                   _lib.ptr(w_nat), _lib.ptr(bias), N, _lib.ptr(y), _lib.DTYPE_CODE[y.dtype], N,
-                  _lib.ptr(sc), _lib.ptr(sh), int(act), _lib.ptr(out2), out2.stride(0) if out2 is not None else 0, _lib.stream())
-        return y.view(B, Ho, Wo, N).permute(0, 3, 1, 2)
+                  _lib.ptr(sc), _lib.ptr(sh), int(act), _lib.ptr(out2), out2.stride(0) if out2 is not None else 0, _lib.ptr(part), _lib.stream())
+        out = y.view(B, Ho, Wo, N).permute(0, 3, 1, 2)
+        if part is not None:
+            out._dgq_gn = dict(parts=[(part, N)], B=B, HW=Ho * Wo, C=N, ver=out._version)
+        return out
     K = x.shape[-1]
     assert w_nat.shape[1] == K and kh == kw == 1, "dgq conv2d_f32w: weight [N][%d] does not match input %s" % (w_nat.shape[1], tuple(x.shape))
     x2 = x.reshape(-1, K)
@@ -989,7 +995,7 @@ def conv2d_f32w(x: torch.Tensor, w_nat: torch.Tensor, bias, kh, kw, stride, pad,
     y = torch.empty((x2.shape[0], N), dtype=x.dtype, device=x.device)
     assert norm is None
     _lib_call("dgq_conv2d_f32w", _lib.ptr(x2), _lib.DTYPE_CODE[x.dtype], x2.shape[0], 1, 1, K, 1, 1, 1, 0,
-              _lib.ptr(w_nat), _lib.ptr(bias), N, _lib.ptr(y), _lib.DTYPE_CODE[y.dtype], N, None, None, 0, None, 0, _lib.stream())
+              _lib.ptr(w_nat), _lib.ptr(bias), N, _lib.ptr(y), _lib.DTYPE_CODE[y.dtype], N, None, None, 0, None, 0, None, _lib.stream())
     return y.view(*x.shape[:-1], N)
 
 

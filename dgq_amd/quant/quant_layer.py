@@ -639,7 +639,7 @@ class QuantLayer(nn.Module):
                 out, out2 = self._take_redirect(x)
                 if out is None:                                   # (the FP kernel takes the second copy only)
                     self._fp_natural(x.device)
-                    return ops.conv2d_f32w(x, self._wnat_fp[1], self._wnat_fp[2], kh, kw, st, pd, out2=out2)
+                    return ops.conv2d_f32w(x, self._wnat_fp[1], self._wnat_fp[2], kh, kw, st, pd, out2=out2, gn_out=True)
                 ops.pending_redirect().taken = False
         return self(x)
 

@@ -41,7 +41,7 @@ extern "C" {
  *        stride, pad; dgq_gemm_conv_act_fuses
  *   121  round 6: dgq_cfg_ddim_step takes the tensors' dtype (void pointers + `dtype`); dgq_attention_workspace_bytes grew by one fp32
  *        part area (key-split launches on 16-bit tensors)
- *   122  round 6: dgq_gemm_extra_t += y2, ldy2; dgq_conv2d_f32w takes y2 / ldy2 */
+ *   122  round 6: dgq_gemm_extra_t += y2, ldy2; dgq_conv2d_f32w takes y2 / ldy2 / gn_partial */
 #define DGQ_ABI_VERSION 122
 int dgq_version(void);
 const char* dgq_last_error(void);
@@ -175,10 +175,11 @@ int dgq_cfg_ddim_step(const void* eps_uncond, const void* eps_cond, const void* 
  * Optional prologue as in dgq_quant_act: pre_scale / pre_shift [B][C] (a GroupNorm folded into the load: x·scale + shift) and
  * pre_act = 1 (SiLU) — conv_out(SiLU(conv_norm_out(x))) of the UNets in one launch.
  * Replaces F.linear / F.conv2d on the dequantised (or, for the FP conv_in / conv_out, the original) weight. 
- * y2 (or NULL), ldy2: a second copy of the output rows, as dgq_gemm_extra_t.y2. */
+ * y2 (or NULL), ldy2: a second copy of the output rows, as dgq_gemm_extra_t.y2; gn_partial (or NULL; M % 16 == 0, N > 8): the
+ * output's GroupNorm partials [M/16][N][2], as dgq_gemm_extra_t.gn_partial. */
 int dgq_conv2d_f32w(const void* x, int x_dtype, int B, int H, int W, int C, int kh, int kw, int stride, int pad,
                     const float* w, const float* bias, int N, void* y, int y_dtype, int ldy,
-                    const float* pre_scale, const float* pre_shift, int pre_act, void* y2, int ldy2, void* stream);
+                    const float* pre_scale, const float* pre_shift, int pre_act, void* y2, int ldy2, float* gn_partial, void* stream);
 
 /* ---- the hot kernel: W4A8 / W8A8 MFMA GEMM with fused dequantisation ------------------------------
  * Replaces F.linear / `w.view(N,-1) @ unfolded` / F.conv2d on fake-quantised operands

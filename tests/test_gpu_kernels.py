@@ -1265,7 +1265,7 @@ def test_output_redirect_into_a_concatenation_buffer(case, dtype, dev):
     if mode is None:
         w = torch.randn(N, C * 9, generator=gen).to(dev) * 0.1
         b = torch.randn(N, generator=gen).to(dev)
-        run = lambda **kw: ops.conv2d_f32w(x, w, b, 3, 3, 1, 1, out2=kw.get("out2"))
+        run = lambda **kw: ops.conv2d_f32w(x, w, b, 3, 3, 1, 1, out2=kw.get("out2"), gn_out=True)
     else:
         w = (torch.randn(N, C, k, k, generator=gen) * 0.05).to(dev)
         wd, wz = synth.channel_minmax(w.cpu(), 4)
@@ -1284,6 +1284,13 @@ def test_output_redirect_into_a_concatenation_buffer(case, dtype, dev):
     torch.cuda.synchronize()
     assert torch.equal(y0, y1) and torch.equal(buf[:, C1:C1 + N].view(B, H, H, N).permute(0, 3, 1, 2), y0)
     assert bool((buf[:, :C1] == 7.0).all()) and bool((buf[:, C1 + N:] == 7.0).all())
+    if mode is None:
+        # ... and the FP kernel's GroupNorm partials of its output (conv_in feeds norm1 of the first resnet) against the statistics pass
+        gam, bet = torch.linspace(0.5, 1.5, N, device=dev), torch.linspace(-0.2, 0.2, N, device=dev)
+        sc, sh = ops.groupnorm_from_partials(ops._gn_of(y1), 32, 1e-5, gam, bet)
+        sc0, sh0 = ops.groupnorm_scale_shift(y1.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1), B, H * H, N, 32, 1e-5, gam, bet)
+        torch.cuda.synchronize()
+        assert rel_l2(sc.cpu(), sc0.cpu()) < 1e-5 and rel_l2(sh.cpu(), sh0.cpu()) < 1e-4
     if mode is not None:
         buf.fill_(7.0)
         y2 = run(out=buf[:, C1:C1 + N])                                # the output itself lives in the buffer
