@@ -562,8 +562,10 @@ class QuantLayer(nn.Module):
                 # step 9.537 vs 9.559 ms with MIOpen)
                 self._fp_natural(x.device)
                 if self.is_conv:
+                    # (gn_out: conv_in's output carries its GroupNorm partials on this path too — with or without an output redirect
+                    # the first resnet's norm1 and the last up resnet's see the same statistics)
                     return ops.conv2d_f32w(x, self._wnat_fp[1], self._wnat_fp[2], self.w.shape[2], self.w.shape[3],
-                                           self.fwd_kwargs["stride"][0], self.fwd_kwargs["padding"][0])
+                                           self.fwd_kwargs["stride"][0], self.fwd_kwargs["padding"][0], gn_out=True)
                 return ops.conv2d_f32w(x, self._wnat_fp[1], self._wnat_fp[2], 1, 1, 1, 0)
             if self.is_conv:
                 return F.conv2d(x, w, b, stride=self.fwd_kwargs["stride"], padding=self.fwd_kwargs["padding"])
