@@ -356,3 +356,56 @@ def test_bench_two_rank_dry_run_under_gloo(tmp_path):
     assert d["config"]["parallelism"].startswith("replicas x2")
     files = [f for f in os.listdir(tmp_path) if f.endswith(".pth")]
     assert len(files) == 1                                   # one ckpt, written by rank 0 only
+
+
+def test_skip_concatenation_in_place_host_logic():
+    """unet._CatInPlace + ops.OutputRedirect on CPU tensors (pure host logic): a producer whose final layer call takes the redirect leaves
+    its rows in the concatenation buffer and `join` returns the buffer itself (no torch.cat); anything that does not take it — or a skip
+    tensor modified afterwards — falls back to torch.cat with the same result.  The kernels' side of it (dgq_gemm_extra_t.y2, strided y):
+    tests/test_gpu_kernels.py::test_output_redirect_into_a_concatenation_buffer."""
+    import types
+    from dgq_amd import ops
+    from dgq_amd.diffusers_rewrite import unet as U
+    B, H, W = 2, 4, 4
+    # two up resnets: the first pops skip 1 (C2 = 6, with h of C1 = 10), the second pops skip 0 (C2 = 4, C1 = 8)
+    mk = lambda c: types.SimpleNamespace(norm1=types.SimpleNamespace(num_channels=c))
+    fake = types.SimpleNamespace(up_blocks=[types.SimpleNamespace(resnets=[mk(16), mk(12)])])
+    g = torch.Generator().manual_seed(0)
+
+    def layer(value, take):
+        """a module's final layer call: stores `value` [B, C, H, W] where a pending redirect asks for it (when `take`)"""
+        M, N = B * H * W, value.shape[1]
+        rows = value.permute(0, 2, 3, 1).reshape(M, N)
+        out, out2 = ops.take_redirect(M, N, value.dtype) if take else (None, None)
+        if out is not None:
+            out.copy_(rows)
+            return out.view(B, H, W, N).permute(0, 3, 1, 2)
+        if out2 is not None:
+            out2.copy_(rows)
+        return value.contiguous(memory_format=torch.channels_last)
+
+    for take_skip, take_h, touch in ((True, True, False), (True, False, False), (False, True, False), (True, True, True)):
+        cat = U._CatInPlace(fake, torch.float32, torch.device("cpu"))
+        s0, s1 = torch.randn(B, 4, H, W, generator=g), torch.randn(B, 6, H, W, generator=g)
+        h1, h0 = torch.randn(B, 10, H, W, generator=g), torch.randn(B, 8, H, W, generator=g)
+        k0 = cat.produce_skip(lambda: layer(s0, take_skip), tuple(s0.shape))
+        k1 = cat.produce_skip(lambda: layer(s1, take_skip), tuple(s1.shape))
+        assert ops.pending_redirect() is None
+        a = cat.produce_h(lambda: layer(h1, take_h))
+        if touch:
+            k1.add_(0.0)                                   # an in-place op on the skip tensor: the copy in the buffer is no longer trusted
+        x1 = cat.join(a)
+        assert torch.equal(x1, torch.cat([h1, k1], dim=1))
+        in_place = take_skip and take_h and not touch
+        assert (x1.data_ptr() == a.data_ptr()) == in_place
+        b = cat.produce_h(lambda: layer(h0, take_h))
+        x0 = cat.join(b)
+        assert torch.equal(x0, torch.cat([h0, k0], dim=1)) and not cat.entries
+    # a redirect whose views do not have the layer's output shape is left alone
+    ops.set_redirect(ops.OutputRedirect(out=torch.empty(5, 3)))
+    try:
+        assert ops.take_redirect(5, 4, torch.float32) == (None, None) and not ops.pending_redirect().taken
+        assert ops.take_redirect(5, 3, torch.float32)[0] is not None and ops.pending_redirect().taken
+        assert ops.take_redirect(5, 3, torch.float32) == (None, None)          # taken once
+    finally:
+        ops.set_redirect(None)
